@@ -1,0 +1,332 @@
+"""ctypes access to the CPU oracle (oracle/librna_oracle.so) and, when built, to the reference's own
+vfh.cpp (oracle/_ref/libref_vfh.so).  TEST INFRASTRUCTURE ONLY -- the product package never imports
+this module.  Built on demand with `make -C oracle`.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "librna_oracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_vfh.so")
+
+
+class Geom(C.Structure):
+    _fields_ = [("len", C.c_double * 2), ("pos", C.c_double * 2), ("res", C.c_double),
+                ("size", C.c_int * 2), ("start", C.c_int * 2)]
+
+
+class SubmapInfo(C.Structure):
+    _fields_ = [("top_left", C.c_int * 2), ("size", C.c_int * 2), ("pos", C.c_double * 2),
+                ("len", C.c_double * 2), ("requested_index", C.c_int * 2)]
+
+
+class Region(C.Structure):
+    _fields_ = [("index", C.c_int * 2), ("size", C.c_int * 2), ("quadrant", C.c_int)]
+
+
+class Ray(C.Structure):
+    _fields_ = [("sx", C.c_double), ("sy", C.c_double), ("ex", C.c_double), ("ey", C.c_double),
+                ("clear_end", C.c_int32), ("_pad", C.c_int32)]
+
+
+RAY_DTYPE = np.dtype([("sx", "<f8"), ("sy", "<f8"), ("ex", "<f8"), ("ey", "<f8"),
+                      ("clear_end", "<i4"), ("_pad", "<i4")])
+
+
+class VfhParams(C.Structure):
+    _fields_ = [("cell_size", C.c_double), ("window_diameter", C.c_int), ("sector_angle", C.c_int),
+                ("safety_dist_0ms", C.c_double), ("safety_dist_1ms", C.c_double),
+                ("max_speed", C.c_int), ("max_speed_narrow_opening", C.c_int),
+                ("max_speed_wide_opening", C.c_int), ("max_acceleration", C.c_int),
+                ("min_turnrate", C.c_int), ("max_turnrate_0ms", C.c_int), ("max_turnrate_1ms", C.c_int),
+                ("min_turn_radius_safety_factor", C.c_double),
+                ("free_space_cutoff_0ms", C.c_double), ("obs_cutoff_0ms", C.c_double),
+                ("free_space_cutoff_1ms", C.c_double), ("obs_cutoff_1ms", C.c_double),
+                ("weight_desired_dir", C.c_double), ("weight_current_dir", C.c_double),
+                ("robot_radius", C.c_double)]
+
+
+class AstarResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("path_len", C.c_int32), ("cost", C.c_int32), ("settled", C.c_int32)]
+
+
+class RrtResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("path_len", C.c_int32), ("tree_size", C.c_int32), ("samples", C.c_int32)]
+
+
+class RandState(C.Structure):
+    _fields_ = [("r", C.c_int32 * 34), ("f", C.c_int), ("b", C.c_int)]
+
+
+Ranges = (C.c_double * 2) * 361
+_lib = None
+_ref = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            build()
+        L = C.CDLL(ORACLE_SO)
+        d2 = C.POINTER(C.c_double)
+        i2 = C.POINTER(C.c_int)
+        fp = C.POINTER(C.c_float)
+        L.og_set_geometry.argtypes = [C.POINTER(Geom)] + [C.c_double] * 5
+        L.og_position_from_index.argtypes = [C.POINTER(Geom), i2, d2]
+        L.og_index_from_position.argtypes = [C.POINTER(Geom), d2, i2]
+        L.og_position_within_map.argtypes = [d2, d2, d2]
+        L.og_index_shift_from_position_shift.argtypes = [d2, C.c_double, i2]
+        L.og_position_shift_from_index_shift.argtypes = [i2, C.c_double, d2]
+        L.og_index_within_range.argtypes = [i2, i2]
+        L.og_wrap_index.argtypes = [C.c_int, C.c_int]
+        L.og_limit_position_to_range.argtypes = [d2, d2, d2]
+        L.og_increment_index.argtypes = [i2, i2, i2]
+        L.og_increment_index_for_submap.argtypes = [i2, i2, i2, i2, i2, i2]
+        L.og_index_from_linear.argtypes = [C.c_size_t, i2, C.c_int, i2]
+        L.og_submap_information.argtypes = [C.POINTER(Geom), d2, d2, C.POINTER(SubmapInfo)]
+        L.og_buffer_regions_for_submap.argtypes = [i2, i2, i2, i2, C.POINTER(Region)]
+        L.og_get_submap.argtypes = [C.POINTER(Geom), fp, d2, d2, C.POINTER(Geom), fp, C.c_int]
+        L.og_move.argtypes = [C.POINTER(Geom), C.POINTER(fp), C.c_int, d2, C.POINTER(Region), i2]
+        L.og_line_cells.argtypes = [C.POINTER(Geom), d2, d2, i2, C.c_int]
+        L.og_line_cells_index.argtypes = [i2, i2, i2, C.c_int]
+        L.og_circle_cells.argtypes = [C.POINTER(Geom), d2, C.c_double, i2, C.c_int]
+        L.og_submap_cells.argtypes = [C.POINTER(Geom), i2, i2, i2, C.c_int]
+        L.og_himm_clear.argtypes = [C.c_float]
+        L.og_himm_clear.restype = C.c_float
+        L.og_himm_mark.argtypes = [C.c_float]
+        L.og_himm_mark.restype = C.c_float
+        L.og_himm_update.argtypes = [C.POINTER(Geom), fp, C.c_void_p, C.c_int, d2]
+        L.og_himm_update.restype = None
+        L.og_ranges_from_submap.argtypes = [C.POINTER(Geom), fp, d2, C.c_double, C.POINTER(Ranges)]
+        L.og_vfh_default_params.argtypes = [C.POINTER(VfhParams)]
+        L.og_vfh_create.argtypes = [C.POINTER(VfhParams)]
+        L.og_vfh_create.restype = C.c_void_p
+        L.og_vfh_destroy.argtypes = [C.c_void_p]
+        L.og_vfh_update.argtypes = [C.c_void_p, C.POINTER(Ranges), C.c_int, C.c_float, C.c_float, C.c_float,
+                                    C.c_double, i2, i2]
+        L.og_vfh_step_pose.argtypes = [C.c_void_p, C.POINTER(Geom), fp, d2, C.c_double, C.c_int, C.c_float,
+                                       C.c_float, C.c_float, C.c_double, i2, i2]
+        L.og_vfh_hist_size.argtypes = [C.c_void_p]
+        for n in ("og_vfh_hist", "og_vfh_origin_hist", "og_vfh_cell_direction", "og_vfh_cell_dist",
+                  "og_vfh_cell_base_mag"):
+            getattr(L, n).argtypes = [C.c_void_p]
+            getattr(L, n).restype = fp
+        L.og_vfh_picked_angle.argtypes = [C.c_void_p]
+        L.og_vfh_picked_angle.restype = C.c_float
+        L.og_vfh_last_picked_angle.argtypes = [C.c_void_p]
+        L.og_vfh_last_picked_angle.restype = C.c_float
+        L.og_vfh_max_speed_for_picked_angle.argtypes = [C.c_void_p]
+        L.og_vfh_num_tables.argtypes = [C.c_void_p]
+        L.og_vfh_cell_sector_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.og_vfh_cell_sector_list.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.og_vfh_cell_sector_list.restype = i2
+        L.og_vfh_min_turning_radius.argtypes = [C.c_void_p, C.c_int]
+        L.og_astar_blocked_mask.argtypes = [fp, C.c_size_t, C.POINTER(C.c_uint8)]
+        L.og_astar_nbr_mask.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+        L.og_astar_query.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.POINTER(AstarResult)]
+        L.og_astar_query.restype = None
+        L.og_graph_astar.argtypes = [C.c_int, d2, C.c_int, i2, fp, C.c_int, C.c_int, i2, C.c_int]
+        L.og_graph_closest_vertex.argtypes = [C.c_int, d2, d2]
+        L.og_reference_graph.argtypes = [d2, i2]
+        L.og_graph_make_plan.argtypes = [d2, d2, d2, C.c_int]
+        L.og_srand.argtypes = [C.POINTER(RandState), C.c_uint]
+        L.og_rand.argtypes = [C.POINTER(RandState)]
+        L.og_if_blocked.argtypes = [C.POINTER(Geom), fp, d2]
+        L.og_rrt_plan.argtypes = [C.POINTER(Geom), fp, d2, d2, C.c_double, C.c_uint, C.c_int, d2, C.c_int,
+                                  C.POINTER(RrtResult)]
+        L.og_rrt_plan.restype = None
+        _lib = L
+    return _lib
+
+
+def ref():
+    """The reference's own vfh.cpp (None when oracle/_ref was never built)."""
+    global _ref
+    if _ref is None:
+        if not os.path.exists(REF_SO):
+            return None
+        R = C.CDLL(REF_SO)
+        R.refvfh_set_clock.argtypes = [C.c_double]
+        R.refvfh_create.argtypes = [C.POINTER(VfhParams)]
+        R.refvfh_create.restype = C.c_void_p
+        R.refvfh_destroy.argtypes = [C.c_void_p]
+        R.refvfh_update.argtypes = [C.c_void_p, C.POINTER(Ranges), C.c_int, C.c_float, C.c_float, C.c_float,
+                                    C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        R.refvfh_hist_size.argtypes = [C.c_void_p]
+        R.refvfh_hist.argtypes = [C.c_void_p]
+        R.refvfh_hist.restype = C.POINTER(C.c_float)
+        R.refvfh_origin_hist.argtypes = [C.c_void_p]
+        R.refvfh_origin_hist.restype = C.POINTER(C.c_float)
+        R.refvfh_picked_angle.argtypes = [C.c_void_p]
+        R.refvfh_picked_angle.restype = C.c_float
+        R.refvfh_num_tables.argtypes = [C.c_void_p]
+        for n in ("refvfh_cell_direction", "refvfh_cell_dist", "refvfh_cell_base_mag"):
+            getattr(R, n).argtypes = [C.c_void_p, C.c_int, C.c_int]
+            getattr(R, n).restype = C.c_float
+        R.refvfh_cell_sector_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        R.refvfh_cell_sector.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        R.refvfh_min_turning_radius.argtypes = [C.c_void_p, C.c_int]
+        _ref = R
+    return _ref
+
+
+# ---------------------------------------------------------------------------------------------
+# numpy-friendly helpers
+# ---------------------------------------------------------------------------------------------
+def d2(x, y):
+    return (C.c_double * 2)(x, y)
+
+
+def i2(a, b):
+    return (C.c_int * 2)(a, b)
+
+
+def make_geom(len_x, len_y, res, px=0.0, py=0.0, start=(0, 0)):
+    g = Geom()
+    lib().og_set_geometry(C.byref(g), len_x, len_y, res, px, py)
+    g.start[0], g.start[1] = start
+    return g
+
+
+def raw_geom(length, pos, res, size, start=(0, 0)):
+    g = Geom()
+    g.len[0], g.len[1] = length
+    g.pos[0], g.pos[1] = pos
+    g.res = res
+    g.size[0], g.size[1] = size
+    g.start[0], g.start[1] = start
+    return g
+
+
+def fptr(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def default_vfh_params():
+    p = VfhParams()
+    lib().og_vfh_default_params(C.byref(p))
+    return p
+
+
+def himm_update(g, layer, rays):
+    """layer: float32 1-D array of rows*cols in column-major order (modified in place)."""
+    assert rays.dtype == RAY_DTYPE
+    lib().og_himm_update(C.byref(g), fptr(layer), rays.ctypes.data, len(rays), None)
+
+
+def ranges_from_submap(g, master, x, y, yaw):
+    r = Ranges()
+    ok = lib().og_ranges_from_submap(C.byref(g), fptr(master), d2(x, y), yaw, C.byref(r))
+    out = np.frombuffer(r, dtype=np.float64).reshape(361, 2)[:, 0].copy()
+    return ok, out
+
+
+def ranges_array(vals):
+    r = Ranges()
+    for i in range(361):
+        r[i][0] = float(vals[i])
+        r[i][1] = 0.0
+    return r
+
+
+class OracleVfh:
+    def __init__(self, params=None):
+        self.p = params or default_vfh_params()
+        self.h = lib().og_vfh_create(C.byref(self.p))
+        self.H = lib().og_vfh_hist_size(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().og_vfh_destroy(self.h)
+            self.h = None
+
+    def update(self, ranges, speed, gdir, gdist, gtol, dt):
+        cs, ct = C.c_int(0), C.c_int(0)
+        r = ranges if isinstance(ranges, Ranges) else ranges_array(ranges)
+        lib().og_vfh_update(self.h, C.byref(r), speed, gdir, gdist, gtol, dt, C.byref(cs), C.byref(ct))
+        return cs.value, ct.value
+
+    def step_pose(self, g, master, x, y, yaw, speed, gdir, gdist, gtol, dt):
+        cs, ct = C.c_int(0), C.c_int(0)
+        lib().og_vfh_step_pose(self.h, C.byref(g), fptr(master), d2(x, y), yaw, speed, gdir, gdist, gtol, dt,
+                               C.byref(cs), C.byref(ct))
+        return cs.value, ct.value
+
+    def hist(self):
+        return np.ctypeslib.as_array(lib().og_vfh_hist(self.h), (self.H,)).copy()
+
+    def origin_hist(self):
+        return np.ctypeslib.as_array(lib().og_vfh_origin_hist(self.h), (self.H,)).copy()
+
+    def picked_angle(self):
+        return lib().og_vfh_picked_angle(self.h)
+
+
+class RefVfh:
+    """The reference's VFH class itself (oracle/_ref)."""
+
+    def __init__(self, params=None):
+        self.p = params or default_vfh_params()
+        self.h = ref().refvfh_create(C.byref(self.p))
+        self.H = ref().refvfh_hist_size(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            ref().refvfh_destroy(self.h)
+            self.h = None
+
+    def update(self, ranges, speed, gdir, gdist, gtol, dt):
+        cs, ct = C.c_int(0), C.c_int(0)
+        r = ranges if isinstance(ranges, Ranges) else ranges_array(ranges)
+        ref().refvfh_update(self.h, C.byref(r), speed, gdir, gdist, gtol, dt, C.byref(cs), C.byref(ct))
+        return cs.value, ct.value
+
+    def hist(self):
+        return np.ctypeslib.as_array(ref().refvfh_hist(self.h), (self.H,)).copy()
+
+    def origin_hist(self):
+        return np.ctypeslib.as_array(ref().refvfh_origin_hist(self.h), (self.H,)).copy()
+
+    def picked_angle(self):
+        return ref().refvfh_picked_angle(self.h)
+
+
+def astar_masks(master, rows, cols):
+    blocked = np.zeros(rows * cols, np.uint8)
+    nbr = np.zeros(rows * cols, np.uint8)
+    u8 = C.POINTER(C.c_uint8)
+    lib().og_astar_blocked_mask(fptr(master), master.size, blocked.ctypes.data_as(u8))
+    lib().og_astar_nbr_mask(blocked.ctypes.data_as(u8), rows, cols, nbr.ctypes.data_as(u8))
+    return blocked, nbr
+
+
+def astar_query(nbr, rows, cols, start, goal, path_cap=None, g_work=None):
+    path_cap = path_cap or rows * cols
+    if g_work is None:
+        g_work = np.empty(rows * cols, np.int32)
+    path = np.empty(path_cap, np.int32)
+    res = AstarResult()
+    lib().og_astar_query(nbr.ctypes.data_as(C.POINTER(C.c_uint8)), rows, cols, int(start), int(goal),
+                         g_work.ctypes.data_as(C.POINTER(C.c_int32)), path.ctypes.data_as(C.POINTER(C.c_int32)),
+                         path_cap, C.byref(res))
+    n = res.path_len if res.status == 0 else 0
+    return res, path[:n].copy(), g_work
+
+
+def rrt_plan(g, master, start, target, tol=0.2, seed=1, max_samples=200000, cap=2048):
+    path = np.zeros(2 * cap, np.float64)
+    res = RrtResult()
+    lib().og_rrt_plan(C.byref(g), fptr(master), d2(*start), d2(*target), tol, seed, max_samples,
+                      path.ctypes.data_as(C.POINTER(C.c_double)), cap, C.byref(res))
+    return res, path[:2 * min(res.path_len, cap)].reshape(-1, 2).copy()

@@ -1,0 +1,197 @@
+"""Oracle self-checks for the parts the reference cannot pin (HIMM, ranges, grid A*, RRT):
+known values worked out from the cited reference lines, libc pinning of the rand() replica, and
+brute-force cross-checks."""
+import ctypes as C
+import heapq
+import math
+
+import numpy as np
+
+import _oracle as O
+
+L = O.lib()
+
+
+# mc/include/move_control/map_updater.h:52-71 ; SURVEY.md Appendix A.2
+def test_himm_cell_ops():
+    nan = float("nan")
+    assert L.og_himm_clear(nan) == 0.0 and L.og_himm_clear(-5.0) == 0.0 and L.og_himm_clear(0.0) == 0.0
+    assert L.og_himm_clear(5.0) == 0.0 and L.og_himm_clear(30.0) == 20.0
+    assert L.og_himm_mark(nan) == 30.0 and L.og_himm_mark(0.0) == 30.0 and L.og_himm_mark(150.0) == 180.0
+    assert L.og_himm_mark(160.0) == 160.0 and L.og_himm_mark(180.0) == 180.0
+    # end cell of a hit ray gets clear then mark: NaN/0/10 -> 30 ; v in [20,160] -> v+20 ; 170 -> 160 ; 180 -> 170
+    for v0, exp in ((nan, 30), (0, 30), (10, 30), (20, 40), (160, 180), (170, 160), (180, 170)):
+        assert L.og_himm_mark(L.og_himm_clear(v0)) == exp
+
+
+def test_himm_ray_order_dependence():
+    g = O.make_geom(2.0, 2.0, 0.05)  # 40 x 40
+    layer = np.full(1600, np.nan, np.float32)
+    rays = np.zeros(2, O.RAY_DTYPE)
+    # ray 0 ends (hit) on a cell, ray 1 passes through the same cell and beyond (clear)
+    rays[0] = (0.0, 0.0, 0.5, 0.0, 0, 0)
+    rays[1] = (0.0, 0.0, 0.9, 0.0, 1, 0)
+    a = layer.copy()
+    O.himm_update(g, a, rays)
+    b = layer.copy()
+    O.himm_update(g, b, rays[::-1].copy())
+    idx = O.i2(0, 0)
+    L.og_index_from_position(C.byref(g), O.d2(0.5, 0.0), idx)
+    lin = idx[0] + idx[1] * 40
+    assert a[lin] == 20.0 and b[lin] == 30.0       # mark then clear = 20 ; clear then mark = 30
+    # cells on the first ray before the end are cleared twice -> 0, the rest of the map stays NaN
+    cells = (C.c_int * 256)()
+    n_long = L.og_line_cells(C.byref(g), O.d2(0.0, 0.0), O.d2(0.9, 0.0), cells, 128)
+    assert np.nansum(a) == 20.0 and np.count_nonzero(~np.isnan(a)) == n_long
+
+
+def test_himm_end_outside_map_is_clipped_not_marked():
+    g = O.make_geom(2.0, 2.0, 0.05)
+    layer = np.full(1600, 50.0, np.float32)
+    rays = np.zeros(1, O.RAY_DTYPE)
+    rays[0] = (0.0, 0.0, 3.0, 0.0, 0, 0)
+    O.himm_update(g, layer, rays)
+    assert np.count_nonzero(layer == 40.0) == 21 and np.count_nonzero(layer > 50.0) == 0
+
+
+# mc/src/steerer.cpp:147-191
+def test_ranges_from_submap_single_obstacle():
+    g = O.make_geom(10.0, 10.0, 0.05)
+    m = np.zeros(200 * 200, np.float32)
+    idx = O.i2(0, 0)
+    L.og_index_from_position(C.byref(g), O.d2(0.5, 0.0), idx)
+    m[idx[0] + idx[1] * 200] = 60.0
+    ok, r = O.ranges_from_submap(g, m, 0.0, 0.0, 0.0)
+    assert ok
+    hit = np.nonzero(r < 5000.0)[0]
+    # obstacle straight ahead of a robot with yaw 0: angle = 0 - 0 + 3.14/2 -> ~89.95 deg => bins 2*89 and 2*90
+    assert list(hit) == [178, 180] or len(hit) == 2
+    p = O.d2(0, 0)
+    L.og_position_from_index(C.byref(g), idx, p)
+    assert abs(r[hit[0]] - math.hypot(p[0], p[1]) * 1000.0) < 1e-9
+    # odd bins are never written (SURVEY A.5 iii)
+    assert np.all(r[1::2] == 5000.0)
+
+
+def test_rand_replica_matches_libc():
+    libc = C.CDLL("libc.so.6")
+    for seed in (1, 2, 12345, 0xFFFFFFFF):
+        libc.srand(C.c_uint(seed))
+        st = O.RandState()
+        L.og_srand(C.byref(st), seed)
+        for _ in range(2000):
+            assert libc.rand() == L.og_rand(C.byref(st))
+
+
+def _dijkstra(nbr, rows, cols, start):
+    DI = [-1, 0, 1, -1, 1, -1, 0, 1]
+    DJ = [-1, -1, -1, 0, 0, 1, 1, 1]
+    W = [1414, 1000, 1414, 1000, 1000, 1414, 1000, 1414]
+    INF = 0x7fffffff
+    d = np.full(rows * cols, INF, np.int64)
+    d[start] = 0
+    pq = [(0, start)]
+    while pq:
+        du, u = heapq.heappop(pq)
+        if du != d[u]:
+            continue
+        i, j = u % rows, u // rows
+        for k in range(8):
+            if nbr[u] >> k & 1:
+                v = (j + DJ[k]) * rows + i + DI[k]
+                if du + W[k] < d[v]:
+                    d[v] = du + W[k]
+                    heapq.heappush(pq, (d[v], v))
+    return d
+
+
+def test_grid_astar_matches_dijkstra_and_contract():
+    rng = np.random.default_rng(3)
+    rows, cols = 48, 40
+    DI = [-1, 0, 1, -1, 1, -1, 0, 1]
+    DJ = [-1, -1, -1, 0, 0, 1, 1, 1]
+    W = [1414, 1000, 1414, 1000, 1000, 1414, 1000, 1414]
+    for trial in range(12):
+        m = np.where(rng.random(rows * cols) < 0.28, 180.0, 0.0).astype(np.float32)
+        m[rng.random(rows * cols) < 0.05] = np.nan  # unknown == free
+        blocked, nbr = O.astar_masks(m, rows, cols)
+        free = np.nonzero(blocked == 0)[0]
+        s, t = rng.choice(free, 2, replace=False)
+        res, path, g = O.astar_query(nbr, rows, cols, s, t)
+        d = _dijkstra(nbr, rows, cols, s)
+        if d[t] == 0x7fffffff:
+            assert res.status == 1
+            continue
+        assert res.status == 0 and res.cost == d[t]
+        # settled count E = |{n : d(n) + h(n) <= d(goal)}|
+        gi, gj = t % rows, t // rows
+        ii, jj = np.arange(rows * cols) % rows, np.arange(rows * cols) // rows
+        dx, dy = np.abs(ii - gi), np.abs(jj - gj)
+        h = 1000 * np.maximum(dx, dy) + 414 * np.minimum(dx, dy)
+        reach = d < 0x7fffffff
+        assert res.settled == int(np.count_nonzero(reach & (d + h <= d[t])))
+        # path: contiguous, legal moves, canonical predecessor (lowest linear index among optimal)
+        assert path[0] == s and path[-1] == t
+        for a, c in zip(path[:-1], path[1:]):
+            ci, cj = c % rows, c // rows
+            cands = []
+            for k in range(8):
+                if nbr[c] >> k & 1:
+                    n = (cj + DJ[k]) * rows + ci + DI[k]
+                    if d[n] + W[k] == d[c]:
+                        cands.append(n)
+            assert a == min(cands)
+
+
+def test_grid_astar_corner_cutting_forbidden_and_trivial_cases():
+    rows = cols = 5
+    m = np.zeros(25, np.float32)
+    m[1 + 0 * 5] = 100.0   # (1,0)
+    m[0 + 1 * 5] = 100.0   # (0,1)
+    blocked, nbr = O.astar_masks(m, rows, cols)
+    res, path, _ = O.astar_query(nbr, rows, cols, 0, 6)   # (0,0) -> (1,1): walled in diagonally
+    assert res.status == 1
+    res, path, _ = O.astar_query(nbr, rows, cols, 6, 6)
+    assert res.status == 0 and list(path) == [6] and res.cost == 0
+    res, path, _ = O.astar_query(nbr, rows, cols, 6, 24)
+    assert res.status == 0 and res.cost == 3 * 1414 and list(path) == [6, 12, 18, 24]
+
+
+# mc/src/astar_planner.cpp:63-145
+def test_reference_waypoint_graph_plan():
+    out = (C.c_double * 64)()
+    n = L.og_graph_make_plan(O.d2(3.0, 0.5), O.d2(19.0, 10.5), out, 32)
+    pts = [(out[2 * k], out[2 * k + 1]) for k in range(n)]
+    assert pts[0] == (3.0, 0.5) and pts[-1] == (19.0, 10.5)
+    assert pts[1] == (4.0, 0.0) and pts[-2] == (20.0, 10.0)
+    # interior points are graph vertices joined by graph edges
+    loc = (C.c_double * 18)()
+    euv = (C.c_int * 20)()
+    L.og_reference_graph(loc, euv)
+    V = [(loc[2 * i], loc[2 * i + 1]) for i in range(9)]
+    E = {(euv[2 * e], euv[2 * e + 1]) for e in range(10)}
+    ids = [V.index(p) for p in pts[1:-1]]
+    for a, b in zip(ids[:-1], ids[1:]):
+        assert (a, b) in E or (b, a) in E
+    # same start and goal vertex -> start, vertex, target
+    n = L.og_graph_make_plan(O.d2(3.0, 0.5), O.d2(4.5, 0.5), out, 32)
+    assert n == 3
+
+
+def test_rrt_reaches_goal_and_is_collision_free():
+    g = O.make_geom(10.0, 10.0, 0.05)
+    m = np.zeros(200 * 200, np.float32)
+    M = m.reshape(200, 200)  # M[j, i]
+    M[90:110, 60:140] = 180.0
+    res, path = O.rrt_plan(g, m, (3.0, 3.0), (-3.0, -3.0), seed=1)
+    assert res.status == 1 and res.path_len == len(path) >= 2
+    assert math.hypot(path[0][0] + 3.0, path[0][1] + 3.0) < 0.2   # goal end first
+    assert tuple(path[-1]) == (3.0, 3.0)
+    for a, b in zip(path[:-1], path[1:]):
+        assert math.hypot(a[0] - b[0], a[1] - b[1]) <= 0.4 + 1e-9
+        assert not L.og_if_blocked(C.byref(g), O.fptr(m), O.d2(*a))
+    # determinism per seed, different seeds differ
+    res2, path2 = O.rrt_plan(g, m, (3.0, 3.0), (-3.0, -3.0), seed=1)
+    assert np.array_equal(path, path2)
+    res3, path3 = O.rrt_plan(g, m, (3.0, 3.0), (-3.0, -3.0), seed=2)
+    assert not np.array_equal(path, path3)
