@@ -1,0 +1,207 @@
+/*
+ * rna.h -- C ABI of the MI355X-native occupancy-grid planning engine (librna.so).
+ *
+ * The reference (jmloveyj/ros_navigation) has no FFI layer: its replan hot path sits behind plain
+ * C++ class methods called by the node mains.  Every entry point below replaces one of those call
+ * sites; the C++ mirror classes in ros_navigation_amd/host/ (same names and argument meaning as
+ * the reference) and the ctypes binding in ros_navigation_amd/capi.py are thin shims over it.
+ * Citations: mc/ = move_control/, gmc/ = grid_map-master/grid_map_core/ in the reference tree.
+ *
+ * Conventions: every call returns 0 (RNA_OK) or a negative rna_status; no exceptions cross the
+ * boundary; buffers are caller-owned; calls on one engine are serialised by the caller (one HIP
+ * stream per engine).  Grids are column-major float32, linear index = i + j*rows, exactly the
+ * Eigen::MatrixXf storage of grid_map::GridMap (gmc/include/grid_map_core/TypeDefs.hpp:16).
+ * "_device" variants take device pointers (inputs/outputs already resident in HBM) and are
+ * asynchronous on the engine's stream; the plain variants take host pointers and return after the
+ * results are back in host memory.
+ */
+#ifndef RNA_H
+#define RNA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RNA_ABI_VERSION 1
+
+typedef enum {
+  RNA_OK = 0,
+  RNA_EINVAL = -1,     /* bad argument */
+  RNA_ENOMEM = -2,     /* device/host allocation failed */
+  RNA_EHIP = -3,       /* HIP runtime error (rna_last_error has the text) */
+  RNA_ECAPACITY = -4,  /* a device work queue overflowed; retry with a larger capacity */
+  RNA_ESTATE = -5,     /* call order (e.g. vfh step before vfh init) */
+  RNA_ENODEVICE = -6   /* no usable gfx950 device */
+} rna_status;
+
+typedef struct rna_engine rna_engine;
+
+/* grid_map::GridMap geometry (gmc/include/grid_map_core/GridMap.hpp:493-516) */
+typedef struct {
+  double length[2];      /* length_   */
+  double position[2];    /* position_ */
+  double resolution;     /* resolution_ */
+  int32_t size[2];       /* size_: rows = Index(0), cols = Index(1) */
+  int32_t start_index[2];/* startIndex_ (circular buffer) */
+} rna_geometry;
+
+/* layers of MapProvider's GridMap (mc/src/map_provider.cpp:17-19, map_updater.h:12-13) */
+typedef enum { RNA_LAYER_MASTER = 0, RNA_LAYER_LASER = 1, RNA_LAYER_RANGE = 2, RNA_NUM_LAYERS = 3 } rna_layer;
+
+/* ---- engine / GridMap container -------------------------------------------------------------- */
+/* GridMap::GridMap + setGeometry (gmc/src/GridMap.cpp:27-70): size = round(length/res), all layers
+ * NaN.  MapProvider::initMap (mc/src/map_provider.cpp:145-149). */
+int rna_create(rna_engine** out, double length_x, double length_y, double resolution,
+               double position_x, double position_y, int device_id);
+void rna_destroy(rna_engine* e);
+const char* rna_last_error(const rna_engine* e);
+int rna_abi_version(void);
+int rna_get_geometry(const rna_engine* e, rna_geometry* out);
+/* GridMap::operator[] / get (gmc/src/GridMap.cpp:125-151): whole-layer copies to/from the host */
+int rna_layer_upload(rna_engine* e, int layer, const float* host, size_t n_cells);
+int rna_layer_download(rna_engine* e, int layer, float* host, size_t n_cells);
+int rna_layer_fill(rna_engine* e, int layer, float value);
+/* device pointer of a layer (rows*cols float32, column-major) for zero-copy producers/consumers */
+void* rna_layer_device_ptr(rna_engine* e, int layer);
+void* rna_stream(rna_engine* e);           /* hipStream_t of this engine */
+int rna_synchronize(rna_engine* e);
+/* GridMap::getIndex / getPosition / isInside (gmc/src/GridMap.cpp:227-240) -- host-side math */
+int rna_get_index(const rna_engine* e, double x, double y, int32_t index[2]);   /* 1 inside, 0 outside */
+int rna_get_position(const rna_engine* e, int32_t i, int32_t j, double position[2]);
+
+/* ---- HIMM map update ------------------------------------------------------------------------- */
+/* RangeSample (mc/include/move_control/map_updater.h:28-32) */
+typedef struct {
+  double sx, sy;        /* start */
+  double ex, ey;        /* end   */
+  int32_t clear_end;    /* ifClearEnd */
+  int32_t _pad;
+} rna_ray;
+/* LaserMapUpdater::updateMap / RangeMapUpdater::updateMap -> MapUpdater::lineOnMap for every
+ * sample in order (mc/src/laser_map_updater.cpp:7-21, map_updater.h:38-71): order-faithful result. */
+int rna_himm_update(rna_engine* e, int layer, const rna_ray* rays_host, int n);
+int rna_himm_update_device(rna_engine* e, int layer, const rna_ray* rays_device, int n);
+/* MapProvider::composeMasterMapFromLayerdMap (mc/src/map_provider.cpp:216-223): master = laser.
+ * mode 0: only the 64x64 tiles the HIMM batches touched since the last compose (fused path);
+ * mode 1: whole-layer copy exactly as the reference does every cycle. */
+int rna_compose_master(rna_engine* e, int mode);
+/* MapProvider::updateMap (mc/src/map_provider.cpp:190-205): laser HIMM batch, then compose(mode) */
+int rna_update_map(rna_engine* e, const rna_ray* rays_host, int n, int compose_mode);
+int rna_update_map_device(rna_engine* e, const rna_ray* rays_device, int n, int compose_mode);
+/* GridMap::move (gmc/src/GridMap.cpp:346-412): recentre the circular buffer, dropped cells -> NaN */
+int rna_move(rna_engine* e, double position_x, double position_y, int* moved);
+
+/* ---- VFH+ local avoidance -------------------------------------------------------------------- */
+/* VFH constructor arguments + SetRobotRadius (mc/include/move_control/vfh.h:185-203,235;
+ * defaults of Steerer::initVfh, mc/src/steerer.cpp:69-121) */
+typedef struct {
+  double cell_size;
+  int32_t window_diameter;
+  int32_t sector_angle;
+  double safety_dist_0ms, safety_dist_1ms;
+  int32_t max_speed, max_speed_narrow_opening, max_speed_wide_opening;
+  int32_t max_acceleration, min_turnrate, max_turnrate_0ms, max_turnrate_1ms;
+  double min_turn_radius_safety_factor;
+  double free_space_cutoff_0ms, obs_cutoff_0ms, free_space_cutoff_1ms, obs_cutoff_1ms;
+  double weight_desired_dir, weight_current_dir;
+  double robot_radius;
+} rna_vfh_params;
+void rna_vfh_default_params(rna_vfh_params* p);
+/* One robot pose + the per-step arguments of VFH::Update_VFH (mc/include/move_control/vfh.h:216-222)
+ * as Steerer::update derives them (mc/src/steerer.cpp:221-263); dt replaces gettimeofday(). */
+typedef struct {
+  double x, y, yaw;            /* MapProvider::getRobotPos(pos, orient) */
+  double dt;                   /* seconds since this robot's previous step */
+  int32_t current_speed;       /* mm/s */
+  float goal_direction;        /* deg, 90 = straight ahead */
+  float goal_distance;         /* mm */
+  float goal_tolerance;        /* mm */
+} rna_pose;
+typedef struct {
+  int32_t chosen_speed;        /* mm/s  */
+  int32_t chosen_turnrate;     /* deg/s */
+  float picked_angle;          /* VFH::GetPickedAngle() */
+  int32_t emergency;           /* 1 when something was inside the safety distance */
+} rna_vfh_out;
+/* VFH::VFH + SetRobotRadius + Init (mc/src/vfh.cpp:53-110,237-416) for `n_robots` independent,
+ * stateful VFH instances (Last_Binary_Hist, Last_Picked_Angle, last_chosen_speed, ...). */
+int rna_vfh_init(rna_engine* e, const rna_vfh_params* p, int n_robots);
+int rna_vfh_reset(rna_engine* e);          /* re-Init every instance's state */
+int rna_vfh_hist_size(const rna_engine* e);
+/* Steerer::getRangesFromSubmap + VFH::Update_VFH for robots [0, n) (mc/src/steerer.cpp:147-191,
+ * 260-263; mc/src/vfh.cpp:480-605).  origin_hist / hist: n x hist_size float32 (may be NULL):
+ * VFH::OriginHist and VFH::Hist after the step. */
+int rna_vfh_step_batch(rna_engine* e, const rna_pose* poses_host, int n, rna_vfh_out* out_host,
+                       float* origin_hist_host, float* hist_host);
+int rna_vfh_step_batch_device(rna_engine* e, const rna_pose* poses_device, int n, rna_vfh_out* out_device,
+                              float* origin_hist_device, float* hist_device);
+/* VFH::Update_VFH fed with caller-provided range scans (double[361][2] per robot, as the reference
+ * signature) instead of the map -- the drop-in for code that owns its own scan (cd/src/vfh_node.cpp). */
+int rna_vfh_update_batch(rna_engine* e, const double* ranges_host /* n*361*2 */, const rna_pose* poses_host,
+                         int n, rna_vfh_out* out_host, float* origin_hist_host, float* hist_host);
+
+/* ---- global planning: grid A* ------------------------------------------------------------------ */
+/* The reference's AStarPlanner::makePlan (mc/src/astar_planner.cpp:63-96) searches a 9-vertex
+ * waypoint graph; BASELINE.json asks for a grid A* over the GridMap, whose contract is defined in
+ * DESIGN.md ("Grid A* contract") and restated by oracle/astar.c. Cells are linear indices. */
+typedef struct { int32_t start, goal; } rna_astar_query;
+typedef struct {
+  int32_t status;      /* 0 found, 1 no path, 2 invalid query, 3 path longer than max_path_len */
+  int32_t path_len;    /* cells, start..goal inclusive */
+  int32_t cost;        /* 1000/1414 integer cost of the path */
+  int32_t expanded;    /* cell expansions the device performed (>= the oracle's settled count) */
+} rna_astar_result;
+/* max_queries: queries searched concurrently (one workgroup + one g-field each; larger batches are
+ * processed in chunks); queue_capacity: entries of each per-query frontier queue; bucket_width: the
+ * f-range (cost units, >= 2828) relaxed together before the search advances; 0 = keep/default. */
+int rna_astar_configure(rna_engine* e, int max_queries, int queue_capacity, int bucket_width);
+int rna_astar_batch(rna_engine* e, const rna_astar_query* queries_host, int n, int32_t* paths_host,
+                    int max_path_len, rna_astar_result* results_host);
+int rna_astar_batch_device(rna_engine* e, const rna_astar_query* queries_device, int n, int32_t* paths_device,
+                           int max_path_len, rna_astar_result* results_device);
+/* E of DESIGN.md's roofline: for each query of the LAST batch (n <= max_queries, i.e. one chunk) the
+ * number of cells with g + h <= f*, counted from the g fields still resident in HBM.  Equals the CPU
+ * oracle's settled count; measurement/test utility, not part of the timed path. */
+int rna_astar_settled_counts(rna_engine* e, int32_t* counts_host, int n);
+/* per-cell traversable-neighbour mask derived from the master layer (rows*cols uint8) */
+int rna_astar_download_nbr_mask(rna_engine* e, uint8_t* host, size_t n_cells);
+
+/* ---- global planning: waypoint-graph A* (the reference's own AStarPlanner) ------------------- */
+/* AStarPlanner::init + makePlan over a caller-supplied graph (astar_planner.cpp:63-145): start and
+ * target positions are snapped to the closest vertex; path = start, vertex locations..., target. */
+int rna_graph_astar_batch(rna_engine* e, int n_vertices, const double* vertex_xy, int n_edges,
+                          const int32_t* edge_uv, const float* edge_weight /* NULL = 0 as the reference */,
+                          const double* start_target_xy /* n*4 */, int n, double* paths_xy /* n*max_len*2 */,
+                          int max_len, int32_t* path_len);
+
+/* ---- global planning: RRT (mc/src/rrt_planner.cpp) -------------------------------------------- */
+typedef struct {
+  double start[2], target[2];
+  double close_tolerance;      /* RrtPlanner ctor default 0.2 */
+  uint32_t seed;               /* srand(seed) of this query's private glibc-compatible rand() */
+  int32_t max_samples;         /* bound for extendTree's while(true) */
+} rna_rrt_query;
+typedef struct { int32_t status, path_len, tree_size, samples; } rna_rrt_result;
+int rna_rrt_batch(rna_engine* e, const rna_rrt_query* queries_host, int n, double* paths_xy_host,
+                  int max_path_len, rna_rrt_result* results_host);
+int rna_rrt_batch_device(rna_engine* e, const rna_rrt_query* queries_device, int n, double* paths_xy_device,
+                         int max_path_len, rna_rrt_result* results_device);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+typedef enum {
+  RNA_K_HIMM_PREP = 0, RNA_K_HIMM_RASTER, RNA_K_HIMM_APPLY, RNA_K_COMPOSE, RNA_K_NBRMASK,
+  RNA_K_VFH_STEP, RNA_K_ASTAR_SEARCH, RNA_K_ASTAR_INIT, RNA_K_RRT, RNA_K_COUNT
+} rna_kernel_id;
+/* when enabled, every launch of the kernels above is bracketed by hipEvents on the engine stream */
+int rna_profile_enable(rna_engine* e, int on);
+int rna_profile_reset(rna_engine* e);
+int rna_profile_get(rna_engine* e, int kernel_id, double* total_ms, int64_t* launches);
+const char* rna_kernel_name(int kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNA_H */

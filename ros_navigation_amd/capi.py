@@ -1,0 +1,341 @@
+"""ctypes binding of the C ABI in include/rna.h (librna.so, built in-tree by csrc/Makefile).
+
+This is plumbing for tests and bench.py: numpy structured arrays mirror the C structs one to one,
+host-pointer calls take numpy arrays, `_device` calls take raw device pointers (e.g.
+``torch.Tensor.data_ptr()``).  There is NO CPU fallback: if librna.so is missing or no gfx950
+device is visible the import / engine creation fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librna.so")
+
+RNA_OK = 0
+STATUS = {0: "RNA_OK", -1: "RNA_EINVAL", -2: "RNA_ENOMEM", -3: "RNA_EHIP", -4: "RNA_ECAPACITY",
+          -5: "RNA_ESTATE", -6: "RNA_ENODEVICE"}
+LAYER_MASTER, LAYER_LASER, LAYER_RANGE = 0, 1, 2
+KERNELS = ["himm_prep", "himm_raster", "himm_apply", "compose_master", "nbr_mask", "vfh_step",
+           "astar_search", "astar_init", "rrt"]
+
+# every symbol include/rna.h declares (tests/test_capi_symbols.py checks the header against this)
+SYMBOLS = [
+    "rna_create", "rna_destroy", "rna_last_error", "rna_abi_version", "rna_get_geometry",
+    "rna_layer_upload", "rna_layer_download", "rna_layer_fill", "rna_layer_device_ptr", "rna_stream",
+    "rna_synchronize", "rna_get_index", "rna_get_position",
+    "rna_himm_update", "rna_himm_update_device", "rna_compose_master", "rna_update_map",
+    "rna_update_map_device", "rna_move",
+    "rna_vfh_default_params", "rna_vfh_init", "rna_vfh_reset", "rna_vfh_hist_size", "rna_vfh_step_batch",
+    "rna_vfh_step_batch_device", "rna_vfh_update_batch",
+    "rna_astar_configure", "rna_astar_batch", "rna_astar_batch_device", "rna_astar_settled_counts",
+    "rna_astar_download_nbr_mask",
+    "rna_graph_astar_batch", "rna_rrt_batch", "rna_rrt_batch_device",
+    "rna_profile_enable", "rna_profile_reset", "rna_profile_get", "rna_kernel_name",
+]
+
+
+class Geometry(C.Structure):
+    _fields_ = [("length", C.c_double * 2), ("position", C.c_double * 2), ("resolution", C.c_double),
+                ("size", C.c_int32 * 2), ("start_index", C.c_int32 * 2)]
+
+
+class VfhParams(C.Structure):
+    _fields_ = [("cell_size", C.c_double), ("window_diameter", C.c_int32), ("sector_angle", C.c_int32),
+                ("safety_dist_0ms", C.c_double), ("safety_dist_1ms", C.c_double),
+                ("max_speed", C.c_int32), ("max_speed_narrow_opening", C.c_int32),
+                ("max_speed_wide_opening", C.c_int32), ("max_acceleration", C.c_int32),
+                ("min_turnrate", C.c_int32), ("max_turnrate_0ms", C.c_int32), ("max_turnrate_1ms", C.c_int32),
+                ("min_turn_radius_safety_factor", C.c_double),
+                ("free_space_cutoff_0ms", C.c_double), ("obs_cutoff_0ms", C.c_double),
+                ("free_space_cutoff_1ms", C.c_double), ("obs_cutoff_1ms", C.c_double),
+                ("weight_desired_dir", C.c_double), ("weight_current_dir", C.c_double),
+                ("robot_radius", C.c_double)]
+
+
+RAY_DTYPE = np.dtype([("sx", "<f8"), ("sy", "<f8"), ("ex", "<f8"), ("ey", "<f8"),
+                      ("clear_end", "<i4"), ("_pad", "<i4")])
+POSE_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("yaw", "<f8"), ("dt", "<f8"),
+                       ("current_speed", "<i4"), ("goal_direction", "<f4"), ("goal_distance", "<f4"),
+                       ("goal_tolerance", "<f4")])
+VFH_OUT_DTYPE = np.dtype([("chosen_speed", "<i4"), ("chosen_turnrate", "<i4"), ("picked_angle", "<f4"),
+                          ("emergency", "<i4")])
+ASTAR_QUERY_DTYPE = np.dtype([("start", "<i4"), ("goal", "<i4")])
+ASTAR_RESULT_DTYPE = np.dtype([("status", "<i4"), ("path_len", "<i4"), ("cost", "<i4"), ("expanded", "<i4")])
+RRT_QUERY_DTYPE = np.dtype([("start", "<f8", (2,)), ("target", "<f8", (2,)), ("close_tolerance", "<f8"),
+                            ("seed", "<u4"), ("max_samples", "<i4")])
+RRT_RESULT_DTYPE = np.dtype([("status", "<i4"), ("path_len", "<i4"), ("tree_size", "<i4"), ("samples", "<i4")])
+
+assert RAY_DTYPE.itemsize == 40 and POSE_DTYPE.itemsize == 48 and VFH_OUT_DTYPE.itemsize == 16
+assert RRT_QUERY_DTYPE.itemsize == 48
+
+_lib = None
+
+
+class RnaError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads librna.so; raises if it has not been built (there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RnaError("librna.so is not built: run `make -C ros_navigation_amd/csrc` (or __graft_entry__.build())")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rna_create.argtypes = [C.POINTER(vp), C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]
+    L.rna_destroy.argtypes = [vp]
+    L.rna_destroy.restype = None
+    L.rna_last_error.argtypes = [vp]
+    L.rna_last_error.restype = C.c_char_p
+    L.rna_get_geometry.argtypes = [vp, C.POINTER(Geometry)]
+    L.rna_layer_upload.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.rna_layer_download.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.rna_layer_fill.argtypes = [vp, C.c_int, C.c_float]
+    L.rna_layer_device_ptr.argtypes = [vp, C.c_int]
+    L.rna_layer_device_ptr.restype = vp
+    L.rna_stream.argtypes = [vp]
+    L.rna_stream.restype = vp
+    L.rna_synchronize.argtypes = [vp]
+    L.rna_get_index.argtypes = [vp, C.c_double, C.c_double, C.POINTER(C.c_int32)]
+    L.rna_get_position.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    L.rna_himm_update.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.rna_himm_update_device.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.rna_compose_master.argtypes = [vp, C.c_int]
+    L.rna_update_map.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.rna_update_map_device.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.rna_move.argtypes = [vp, C.c_double, C.c_double, C.POINTER(C.c_int)]
+    L.rna_vfh_default_params.argtypes = [C.POINTER(VfhParams)]
+    L.rna_vfh_default_params.restype = None
+    L.rna_vfh_init.argtypes = [vp, C.POINTER(VfhParams), C.c_int]
+    L.rna_vfh_reset.argtypes = [vp]
+    L.rna_vfh_hist_size.argtypes = [vp]
+    L.rna_vfh_step_batch.argtypes = [vp, vp, C.c_int, vp, vp, vp]
+    L.rna_vfh_step_batch_device.argtypes = [vp, vp, C.c_int, vp, vp, vp]
+    L.rna_vfh_update_batch.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp]
+    L.rna_astar_configure.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.rna_astar_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
+    L.rna_astar_batch_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
+    L.rna_astar_download_nbr_mask.argtypes = [vp, vp, C.c_size_t]
+    L.rna_astar_settled_counts.argtypes = [vp, vp, C.c_int]
+    L.rna_graph_astar_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, vp]
+    L.rna_rrt_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
+    L.rna_rrt_batch_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
+    L.rna_profile_enable.argtypes = [vp, C.c_int]
+    L.rna_profile_reset.argtypes = [vp]
+    L.rna_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.rna_kernel_name.argtypes = [C.c_int]
+    L.rna_kernel_name.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def default_vfh_params():
+    p = VfhParams()
+    lib().rna_vfh_default_params(C.byref(p))
+    return p
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One rna_engine: a device-resident GridMap (master/laser/range) plus the planners."""
+
+    def __init__(self, length_x, length_y, resolution, pos_x=0.0, pos_y=0.0, device=0):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.rna_create(C.byref(h), length_x, length_y, resolution, pos_x, pos_y, device)
+        if rc != RNA_OK:
+            raise RnaError("rna_create failed: %s" % STATUS.get(rc, rc))
+        self.h = h
+        g = self.geometry()
+        self.rows, self.cols = g.size[0], g.size[1]
+        self.ncell = self.rows * self.cols
+        self.hist_size = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.rna_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != RNA_OK:
+            msg = self._L.rna_last_error(self.h)
+            raise RnaError("%s: %s" % (STATUS.get(rc, rc), msg.decode() if msg else ""))
+
+    # ---- container ----
+    def geometry(self):
+        g = Geometry()
+        self._check(self._L.rna_get_geometry(self.h, C.byref(g)))
+        return g
+
+    def upload(self, layer, a):
+        a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+        self._check(self._L.rna_layer_upload(self.h, layer, _ptr(a), a.size))
+
+    def download(self, layer):
+        a = np.empty(self.ncell, np.float32)
+        self._check(self._L.rna_layer_download(self.h, layer, _ptr(a), a.size))
+        return a
+
+    def fill(self, layer, v):
+        self._check(self._L.rna_layer_fill(self.h, layer, v))
+
+    def layer_ptr(self, layer):
+        return self._L.rna_layer_device_ptr(self.h, layer)
+
+    def synchronize(self):
+        self._check(self._L.rna_synchronize(self.h))
+
+    def get_index(self, x, y):
+        out = (C.c_int32 * 2)()
+        ok = self._L.rna_get_index(self.h, x, y, out)
+        return (out[0], out[1]) if ok == 1 else None
+
+    def get_position(self, i, j):
+        out = (C.c_double * 2)()
+        ok = self._L.rna_get_position(self.h, i, j, out)
+        return (out[0], out[1]) if ok == 1 else None
+
+    def move(self, x, y):
+        m = C.c_int(0)
+        self._check(self._L.rna_move(self.h, x, y, C.byref(m)))
+        return bool(m.value)
+
+    # ---- HIMM ----
+    def himm_update(self, layer, rays):
+        assert rays.dtype == RAY_DTYPE
+        rays = np.ascontiguousarray(rays)
+        self._check(self._L.rna_himm_update(self.h, layer, _ptr(rays), len(rays)))
+
+    def himm_update_device(self, layer, rays_ptr, n):
+        self._check(self._L.rna_himm_update_device(self.h, layer, rays_ptr, n))
+
+    def compose_master(self, mode=0):
+        self._check(self._L.rna_compose_master(self.h, mode))
+
+    def update_map(self, rays, compose_mode=0):
+        assert rays.dtype == RAY_DTYPE
+        rays = np.ascontiguousarray(rays)
+        self._check(self._L.rna_update_map(self.h, _ptr(rays), len(rays), compose_mode))
+
+    def update_map_device(self, rays_ptr, n, compose_mode=0):
+        self._check(self._L.rna_update_map_device(self.h, rays_ptr, n, compose_mode))
+
+    # ---- VFH ----
+    def vfh_init(self, n_robots, params=None):
+        p = params or default_vfh_params()
+        self._check(self._L.rna_vfh_init(self.h, C.byref(p), n_robots))
+        self.hist_size = self._L.rna_vfh_hist_size(self.h)
+        self.n_robots = n_robots
+
+    def vfh_reset(self):
+        self._check(self._L.rna_vfh_reset(self.h))
+
+    def vfh_step(self, poses, want_hist=True):
+        assert poses.dtype == POSE_DTYPE
+        poses = np.ascontiguousarray(poses)
+        n = len(poses)
+        out = np.zeros(n, VFH_OUT_DTYPE)
+        origin = np.zeros((n, self.hist_size), np.float32) if want_hist else None
+        hist = np.zeros((n, self.hist_size), np.float32) if want_hist else None
+        self._check(self._L.rna_vfh_step_batch(self.h, _ptr(poses), n, _ptr(out),
+                                               _ptr(origin) if want_hist else None,
+                                               _ptr(hist) if want_hist else None))
+        return out, origin, hist
+
+    def vfh_step_device(self, poses_ptr, n, out_ptr, origin_ptr=None, hist_ptr=None):
+        self._check(self._L.rna_vfh_step_batch_device(self.h, poses_ptr, n, out_ptr, origin_ptr, hist_ptr))
+
+    def vfh_update(self, ranges, poses):
+        """VFH::Update_VFH on caller-provided scans: ranges is (n, 361, 2) float64."""
+        assert poses.dtype == POSE_DTYPE
+        ranges = np.ascontiguousarray(ranges, dtype=np.float64)
+        n = len(poses)
+        assert ranges.shape == (n, 361, 2)
+        poses = np.ascontiguousarray(poses)
+        out = np.zeros(n, VFH_OUT_DTYPE)
+        origin = np.zeros((n, self.hist_size), np.float32)
+        hist = np.zeros((n, self.hist_size), np.float32)
+        self._check(self._L.rna_vfh_update_batch(self.h, _ptr(ranges), _ptr(poses), n, _ptr(out), _ptr(origin),
+                                                 _ptr(hist)))
+        return out, origin, hist
+
+    # ---- planners ----
+    def astar_configure(self, max_queries=0, queue_capacity=0, bucket_width=0):
+        self._check(self._L.rna_astar_configure(self.h, max_queries, queue_capacity, bucket_width))
+
+    def astar(self, queries, max_path_len):
+        assert queries.dtype == ASTAR_QUERY_DTYPE
+        queries = np.ascontiguousarray(queries)
+        n = len(queries)
+        paths = np.zeros((n, max_path_len), np.int32)
+        res = np.zeros(n, ASTAR_RESULT_DTYPE)
+        self._check(self._L.rna_astar_batch(self.h, _ptr(queries), n, _ptr(paths), max_path_len, _ptr(res)))
+        return res, paths
+
+    def astar_device(self, queries_ptr, n, paths_ptr, max_path_len, results_ptr):
+        self._check(self._L.rna_astar_batch_device(self.h, queries_ptr, n, paths_ptr, max_path_len, results_ptr))
+
+    def astar_settled(self, n):
+        """E per query of the last (single-chunk) batch: |{cells : g + h <= f*}|."""
+        out = np.zeros(n, np.int32)
+        self._check(self._L.rna_astar_settled_counts(self.h, _ptr(out), n))
+        return out
+
+    def nbr_mask(self):
+        a = np.empty(self.ncell, np.uint8)
+        self._check(self._L.rna_astar_download_nbr_mask(self.h, _ptr(a), a.size))
+        return a
+
+    def graph_astar(self, vertex_xy, edge_uv, start_target, edge_weight=None, max_len=None):
+        v = np.ascontiguousarray(vertex_xy, dtype=np.float64).reshape(-1, 2)
+        e = np.ascontiguousarray(edge_uv, dtype=np.int32).reshape(-1, 2)
+        st = np.ascontiguousarray(start_target, dtype=np.float64).reshape(-1, 4)
+        w = None if edge_weight is None else np.ascontiguousarray(edge_weight, dtype=np.float32)
+        n = len(st)
+        max_len = max_len or (len(v) + 2)
+        paths = np.zeros((n, max_len, 2), np.float64)
+        plen = np.zeros(n, np.int32)
+        self._check(self._L.rna_graph_astar_batch(self.h, len(v), _ptr(v), len(e), _ptr(e),
+                                                  _ptr(w) if w is not None else None, _ptr(st), n, _ptr(paths),
+                                                  max_len, _ptr(plen)))
+        return plen, paths
+
+    def rrt(self, queries, max_path_len=2048):
+        assert queries.dtype == RRT_QUERY_DTYPE
+        queries = np.ascontiguousarray(queries)
+        n = len(queries)
+        paths = np.zeros((n, max_path_len, 2), np.float64)
+        res = np.zeros(n, RRT_RESULT_DTYPE)
+        self._check(self._L.rna_rrt_batch(self.h, _ptr(queries), n, _ptr(paths), max_path_len, _ptr(res)))
+        return res, paths
+
+    def rrt_device(self, queries_ptr, n, paths_ptr, max_path_len, results_ptr):
+        self._check(self._L.rna_rrt_batch_device(self.h, queries_ptr, n, paths_ptr, max_path_len, results_ptr))
+
+    # ---- measurement ----
+    def profile(self, on=True):
+        self._check(self._L.rna_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self._L.rna_profile_reset(self.h))
+
+    def profile_get(self):
+        out = {}
+        for i, name in enumerate(KERNELS):
+            ms, cnt = C.c_double(0), C.c_int64(0)
+            self._check(self._L.rna_profile_get(self.h, i, C.byref(ms), C.byref(cnt)))
+            out[name] = (ms.value, cnt.value)
+        return out

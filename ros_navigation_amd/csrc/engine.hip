@@ -1,0 +1,385 @@
+// engine.hip -- engine lifetime, GridMap layers, compose-master, neighbour masks, GridMap::move.
+// Reference call sites replaced (mc/ = move_control, gmc/ = grid_map-master/grid_map_core):
+//   GridMap ctor/setGeometry/operator[]   gmc/src/GridMap.cpp:27-70,125-151
+//   MapProvider::composeMasterMapFromLayerdMap  mc/src/map_provider.cpp:216-223
+//   GridMap::move                          gmc/src/GridMap.cpp:346-412
+#include "engine.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+using namespace rna;
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void fill_f32_kernel(float* __restrict__ p, size_t n, float v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+// master = laser for the tiles whose dirty bit is set (mode 0).  One 256-thread block per tile,
+// lanes run along Index(0), the contiguous dimension of the column-major layer.
+__global__ void compose_dirty_tiles_kernel(float* __restrict__ master, const float* __restrict__ laser,
+                                           const unsigned* __restrict__ dirty, int rows, int cols, int tiles_i) {
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  const int t = tj * tiles_i + ti;
+  if (!((dirty[t >> 5] >> (t & 31)) & 1u)) return;
+  const int i0 = ti * TILE, j0 = tj * TILE;
+  const int li = threadIdx.x & (TILE - 1);
+  for (int c = threadIdx.x >> 6; c < TILE; c += 4) {
+    const int i = i0 + li, j = j0 + c;
+    if (i < rows && j < cols) {
+      const size_t lin = (size_t)j * rows + i;
+      master[lin] = laser[lin];
+    }
+  }
+}
+
+// GlobalPlanner::ifBlocked predicate (mc/include/move_control/map_global_planner.h:47-50):
+// blocked iff the master value is finite-or-inf (not NaN) and > 0.
+__device__ __forceinline__ bool cell_blocked(float v) { return !(v != v) && v > 0.0f; }
+
+// Per-cell 8-bit traversable-neighbour mask (DESIGN.md "Grid A* contract"): bit k <-> neighbour
+// (di,dj) in the order (-1,-1),(0,-1),(1,-1),(-1,0),(1,0),(-1,1),(0,1),(1,1); a diagonal needs the
+// target and both orthogonal cells free.  One block per 64x64 tile with a 1-cell halo in LDS.
+// `all` != 0 recomputes every tile, otherwise only tiles that are dirty or touch a dirty tile.
+__global__ void nbr_mask_tiles_kernel(uint8_t* __restrict__ nbr, const float* __restrict__ master,
+                                      const unsigned* __restrict__ dirty, int all, int rows, int cols,
+                                      int tiles_i, int tiles_j) {
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if (!all) {
+    bool need = false;
+    for (int dj = -1; dj <= 1 && !need; ++dj)
+      for (int di = -1; di <= 1; ++di) {
+        const int a = ti + di, b = tj + dj;
+        if (a < 0 || b < 0 || a >= tiles_i || b >= tiles_j) continue;
+        const int t = b * tiles_i + a;
+        if ((dirty[t >> 5] >> (t & 31)) & 1u) { need = true; break; }
+      }
+    if (!need) return;
+  }
+  __shared__ uint8_t blk[(TILE + 2) * (TILE + 2)];  // [jj][ii], ii fastest; out of map = blocked
+  const int i0 = ti * TILE - 1, j0 = tj * TILE - 1;
+  for (int k = threadIdx.x; k < (TILE + 2) * (TILE + 2); k += blockDim.x) {
+    const int ii = k % (TILE + 2), jj = k / (TILE + 2);
+    const int i = i0 + ii, j = j0 + jj;
+    uint8_t b = 1;
+    if (i >= 0 && j >= 0 && i < rows && j < cols) b = cell_blocked(master[(size_t)j * rows + i]) ? 1 : 0;
+    blk[k] = b;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < TILE * TILE; k += blockDim.x) {
+    const int li = k & (TILE - 1), lj = k >> 6;
+    const int i = ti * TILE + li, j = tj * TILE + lj;
+    if (i >= rows || j >= cols) continue;
+    const uint8_t* c = &blk[(lj + 1) * (TILE + 2) + (li + 1)];
+    constexpr int S = TILE + 2;
+    unsigned m = 0;
+    if (!c[0]) {
+      const bool up = !c[-1], dn = !c[1], lf = !c[-S], rt = !c[S];
+      if (lf && up && !c[-S - 1]) m |= 1u;        // (-1,-1)
+      if (lf) m |= 2u;                            // ( 0,-1)
+      if (lf && dn && !c[-S + 1]) m |= 4u;        // ( 1,-1)
+      if (up) m |= 8u;                            // (-1, 0)
+      if (dn) m |= 16u;                           // ( 1, 0)
+      if (rt && up && !c[S - 1]) m |= 32u;        // (-1, 1)
+      if (rt) m |= 64u;                           // ( 0, 1)
+      if (rt && dn && !c[S + 1]) m |= 128u;       // ( 1, 1)
+    }
+    nbr[(size_t)j * rows + i] = (uint8_t)m;
+  }
+}
+
+// GridMap::clearRows / clearCols on every layer (gmc/src/GridMap.cpp:590-606)
+__global__ void clear_region_kernel(float* __restrict__ p, int rows, int i0, int ni, int j0, int nj) {
+  const size_t n = (size_t)ni * nj;
+  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const float nanv = __int_as_float(0x7fc00000);
+  for (; k < n; k += stride) {
+    const int i = i0 + (int)(k % ni), j = j0 + (int)(k / ni);
+    p[(size_t)j * rows + i] = nanv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int grid_for(size_t n, int block) {
+  size_t b = (n + block - 1) / block;
+  if (b > 8192) b = 8192;
+  if (b == 0) b = 1;
+  return (int)b;
+}
+
+static int fill_layer(rna_engine* e, float* p, float v) {
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(e->ncell, 256)), dim3(256), 0, e->stream, p, e->ncell, v);
+  RNA_HIP(e, hipGetLastError());
+  return RNA_OK;
+}
+
+extern "C" int rna_abi_version(void) { return RNA_ABI_VERSION; }
+
+extern "C" const char* rna_last_error(const rna_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+extern "C" const char* rna_kernel_name(int id) {
+  static const char* names[RNA_K_COUNT] = {"himm_prep", "himm_raster", "himm_apply", "compose_master", "nbr_mask",
+                                           "vfh_step", "astar_search", "astar_init", "rrt"};
+  return (id >= 0 && id < RNA_K_COUNT) ? names[id] : "?";
+}
+
+extern "C" int rna_create(rna_engine** out, double length_x, double length_y, double resolution, double px,
+                          double py, int device_id) {
+  if (!out) return RNA_EINVAL;
+  *out = nullptr;
+  if (!(length_x > 0.0) || !(length_y > 0.0) || !(resolution > 0.0)) return RNA_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RNA_ENODEVICE;
+  if (device_id < 0 || device_id >= ndev) return RNA_EINVAL;
+  rna_engine* e = new rna_engine();
+  e->device = device_id;
+  set_geometry(e->geom, length_x, length_y, resolution, px, py);
+  if (e->geom.size[0] <= 0 || e->geom.size[1] <= 0 ||
+      (double)e->geom.size[0] * (double)e->geom.size[1] > 2.0e9) {
+    delete e;
+    return RNA_EINVAL;
+  }
+  e->ncell = (size_t)e->geom.size[0] * (size_t)e->geom.size[1];
+  e->tiles_i = (e->geom.size[0] + TILE - 1) / TILE;
+  e->tiles_j = (e->geom.size[1] + TILE - 1) / TILE;
+  int rc = RNA_OK;
+  auto bail = [&](int code) { rna_destroy(e); return code; };
+  if (hipSetDevice(device_id) != hipSuccess) return bail(RNA_EHIP);
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(RNA_EHIP);
+  if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) return bail(RNA_EHIP);
+  for (int l = 0; l < RNA_NUM_LAYERS; ++l) {
+    if ((rc = dev_alloc(e, &e->layer[l], e->ncell)) != RNA_OK) return bail(rc);
+    // GridMap::setGeometry -> clearAll(): every layer starts as NaN (gmc/src/GridMap.cpp:62)
+    if ((rc = fill_layer(e, e->layer[l], std::numeric_limits<float>::quiet_NaN())) != RNA_OK) return bail(rc);
+  }
+  const size_t words = ((size_t)e->tiles_i * e->tiles_j + 31) / 32;
+  if ((rc = dev_alloc(e, &e->dirty_tiles, words)) != RNA_OK) return bail(rc);
+  if (hipMemsetAsync(e->dirty_tiles, 0, words * sizeof(unsigned), e->stream) != hipSuccess) return bail(RNA_EHIP);
+  if ((rc = dev_alloc(e, &e->nbr, e->ncell)) != RNA_OK) return bail(rc);
+  e->nbr_all_dirty = true;
+  if (hipStreamSynchronize(e->stream) != hipSuccess) return bail(RNA_EHIP);
+  *out = e;
+  return RNA_OK;
+}
+
+extern "C" void rna_destroy(rna_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  himm_release(e);
+  vfh_release(e);
+  astar_release(e);
+  for (int l = 0; l < RNA_NUM_LAYERS; ++l) dev_free(&e->layer[l]);
+  dev_free(&e->dirty_tiles);
+  dev_free(&e->nbr);
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+extern "C" int rna_get_geometry(const rna_engine* e, rna_geometry* o) {
+  if (!e || !o) return RNA_EINVAL;
+  for (int a = 0; a < 2; ++a) {
+    o->length[a] = e->geom.len[a];
+    o->position[a] = e->geom.pos[a];
+    o->size[a] = e->geom.size[a];
+    o->start_index[a] = e->geom.start[a];
+  }
+  o->resolution = e->geom.res;
+  return RNA_OK;
+}
+
+static void layer_changed(rna_engine* e, int layer) {
+  if (layer == RNA_LAYER_MASTER) e->nbr_all_dirty = true;
+  if (layer == RNA_LAYER_LASER) e->laser_all_dirty = true;
+}
+
+extern "C" int rna_layer_upload(rna_engine* e, int layer, const float* host, size_t n) {
+  if (!e || !host || layer < 0 || layer >= RNA_NUM_LAYERS || n != e->ncell) return RNA_EINVAL;
+  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_HIP(e, hipMemcpyAsync(e->layer[layer], host, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  RNA_HIP(e, hipStreamSynchronize(e->stream));
+  layer_changed(e, layer);
+  return RNA_OK;
+}
+
+extern "C" int rna_layer_download(rna_engine* e, int layer, float* host, size_t n) {
+  if (!e || !host || layer < 0 || layer >= RNA_NUM_LAYERS || n != e->ncell) return RNA_EINVAL;
+  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_HIP(e, hipMemcpyAsync(host, e->layer[layer], n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  RNA_HIP(e, hipStreamSynchronize(e->stream));
+  return RNA_OK;
+}
+
+extern "C" int rna_layer_fill(rna_engine* e, int layer, float value) {
+  if (!e || layer < 0 || layer >= RNA_NUM_LAYERS) return RNA_EINVAL;
+  RNA_HIP(e, hipSetDevice(e->device));
+  int rc = fill_layer(e, e->layer[layer], value);
+  layer_changed(e, layer);
+  return rc;
+}
+
+extern "C" void* rna_layer_device_ptr(rna_engine* e, int layer) {
+  if (!e || layer < 0 || layer >= RNA_NUM_LAYERS) return nullptr;
+  layer_changed(e, layer);  // the caller may write through the pointer
+  return e->layer[layer];
+}
+
+extern "C" void* rna_stream(rna_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+extern "C" int rna_synchronize(rna_engine* e) {
+  if (!e) return RNA_EINVAL;
+  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_HIP(e, hipStreamSynchronize(e->stream));
+  return RNA_OK;
+}
+
+extern "C" int rna_get_index(const rna_engine* e, double x, double y, int32_t index[2]) {
+  if (!e || !index) return RNA_EINVAL;
+  int idx[2];
+  if (!index_from_position(e->geom, x, y, idx)) return 0;
+  index[0] = idx[0];
+  index[1] = idx[1];
+  return 1;
+}
+
+extern "C" int rna_get_position(const rna_engine* e, int32_t i, int32_t j, double p[2]) {
+  if (!e || !p) return RNA_EINVAL;
+  if (i < 0 || j < 0 || i >= e->geom.size[0] || j >= e->geom.size[1]) return 0;
+  const int idx[2] = {i, j};
+  position_from_index(e->geom, idx, p);
+  return 1;
+}
+
+namespace rna {
+
+// Recompute A* neighbour masks where the master layer changed.
+int map_prepare_nbr(rna_engine* e) {
+  if (!e->nbr_all_dirty) return RNA_OK;
+  KernelTimer kt(e, RNA_K_NBRMASK);
+  hipLaunchKernelGGL(nbr_mask_tiles_kernel, dim3(e->tiles_i, e->tiles_j), dim3(256), 0, e->stream, e->nbr,
+                     e->layer[RNA_LAYER_MASTER], e->dirty_tiles, 1, e->geom.size[0], e->geom.size[1], e->tiles_i,
+                     e->tiles_j);
+  RNA_HIP(e, hipGetLastError());
+  e->nbr_all_dirty = false;
+  return RNA_OK;
+}
+
+}  // namespace rna
+
+extern "C" int rna_compose_master(rna_engine* e, int mode) {
+  if (!e || (mode != 0 && mode != 1)) return RNA_EINVAL;
+  RNA_HIP(e, hipSetDevice(e->device));
+  const size_t words = ((size_t)e->tiles_i * e->tiles_j + 31) / 32;
+  const bool full = (mode == 1) || e->laser_all_dirty;
+  {
+    KernelTimer kt(e, RNA_K_COMPOSE);
+    if (full) {
+      RNA_HIP(e, hipMemcpyAsync(e->layer[RNA_LAYER_MASTER], e->layer[RNA_LAYER_LASER], e->ncell * sizeof(float),
+                                hipMemcpyDeviceToDevice, e->stream));
+    } else {
+      hipLaunchKernelGGL(compose_dirty_tiles_kernel, dim3(e->tiles_i, e->tiles_j), dim3(256), 0, e->stream,
+                         e->layer[RNA_LAYER_MASTER], e->layer[RNA_LAYER_LASER], e->dirty_tiles, e->geom.size[0],
+                         e->geom.size[1], e->tiles_i);
+      RNA_HIP(e, hipGetLastError());
+    }
+  }
+  if (e->laser_all_dirty) {
+    // the laser layer was replaced wholesale: nothing is known about which masks are still valid
+    e->nbr_all_dirty = true;
+  } else if (!e->nbr_all_dirty) {
+    // masks were valid before this update: refresh only tiles that are dirty or touch a dirty tile
+    KernelTimer kt(e, RNA_K_NBRMASK);
+    hipLaunchKernelGGL(nbr_mask_tiles_kernel, dim3(e->tiles_i, e->tiles_j), dim3(256), 0, e->stream, e->nbr,
+                       e->layer[RNA_LAYER_MASTER], e->dirty_tiles, 0, e->geom.size[0], e->geom.size[1], e->tiles_i,
+                       e->tiles_j);
+    RNA_HIP(e, hipGetLastError());
+  }
+  RNA_HIP(e, hipMemsetAsync(e->dirty_tiles, 0, words * sizeof(unsigned), e->stream));
+  e->laser_all_dirty = false;
+  return RNA_OK;
+}
+
+// GridMap::move (gmc/src/GridMap.cpp:346-412): shift the circular-buffer origin, NaN the dropped
+// rows/cols of every layer, keep position_ aligned to the grid.
+extern "C" int rna_move(rna_engine* e, double nx, double ny, int* moved) {
+  if (!e) return RNA_EINVAL;
+  RNA_HIP(e, hipSetDevice(e->device));
+  Geom& g = e->geom;
+  const double pshift[2] = {nx - g.pos[0], ny - g.pos[1]};
+  int ishift[2];
+  double aligned[2];
+  for (int a = 0; a < 2; ++a) {  // getIndexShiftFromPositionShift / getPositionShiftFromIndexShift
+    const double t = pshift[a] / g.res;
+    ishift[a] = -(int)(t + 0.5 * (t > 0 ? 1 : -1));
+    aligned[a] = (double)(-ishift[a]) * g.res;
+  }
+  auto clear = [&](int i0, int ni, int j0, int nj) -> int {
+    if (ni <= 0 || nj <= 0) return RNA_OK;
+    for (int l = 0; l < RNA_NUM_LAYERS; ++l) {
+      hipLaunchKernelGGL(clear_region_kernel, dim3(grid_for((size_t)ni * nj, 256)), dim3(256), 0, e->stream,
+                         e->layer[l], g.size[0], i0, ni, j0, nj);
+      RNA_HIP(e, hipGetLastError());
+    }
+    return RNA_OK;
+  };
+  int rc = RNA_OK;
+  for (int a = 0; a < 2 && rc == RNA_OK; ++a) {
+    if (ishift[a] == 0) continue;
+    const int asz = g.size[a];
+    const int ash = ishift[a] < 0 ? -ishift[a] : ishift[a];
+    if (ash >= asz) {
+      rc = clear(0, g.size[0], 0, g.size[1]);
+    } else {
+      const int sign = ishift[a] > 0 ? 1 : -1;
+      const int start_index = g.start[a] - (sign < 0 ? 1 : 0);
+      const int end_index = start_index - sign + ishift[a];
+      const int index = wrap_index(sign > 0 ? start_index : end_index, asz);
+      const int first = (index + ash <= asz) ? ash : asz - index;
+      const int second = ash - first;
+      if (a == 0) {
+        rc = clear(index, first, 0, g.size[1]);
+        if (rc == RNA_OK && second > 0) rc = clear(0, second, 0, g.size[1]);
+      } else {
+        rc = clear(0, g.size[0], index, first);
+        if (rc == RNA_OK && second > 0) rc = clear(0, g.size[0], 0, second);
+      }
+    }
+  }
+  if (rc != RNA_OK) return rc;
+  g.start[0] = wrap_index(g.start[0] + ishift[0], g.size[0]);
+  g.start[1] = wrap_index(g.start[1] + ishift[1], g.size[1]);
+  g.pos[0] += aligned[0];
+  g.pos[1] += aligned[1];
+  if (ishift[0] != 0 || ishift[1] != 0) e->nbr_all_dirty = true;
+  if (moved) *moved = (ishift[0] != 0 || ishift[1] != 0);
+  return RNA_OK;
+}
+
+extern "C" int rna_profile_enable(rna_engine* e, int on) {
+  if (!e) return RNA_EINVAL;
+  e->profiling = on != 0;
+  return RNA_OK;
+}
+
+extern "C" int rna_profile_reset(rna_engine* e) {
+  if (!e) return RNA_EINVAL;
+  for (auto& p : e->prof) p = ProfSlot();
+  return RNA_OK;
+}
+
+extern "C" int rna_profile_get(rna_engine* e, int id, double* total_ms, int64_t* launches) {
+  if (!e || id < 0 || id >= RNA_K_COUNT) return RNA_EINVAL;
+  if (total_ms) *total_ms = e->prof[id].total_ms;
+  if (launches) *launches = e->prof[id].launches;
+  return RNA_OK;
+}

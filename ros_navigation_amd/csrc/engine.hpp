@@ -1,0 +1,149 @@
+// engine.hpp -- internal state of one rna_engine (librna.so).  Not part of the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/rna.h"
+#include "gridmath.hpp"
+
+namespace rna {
+
+constexpr int TILE = 64;  // dirty-tracking / mask tile edge (cells)
+
+struct HimmSlot { int cell; int head; int len; int offset; };
+
+struct HimmScratch {
+  int cap_rays = 0;
+  int n_slots = 0;
+  rna_ray* rays_dev = nullptr;   // staging for host-pointer calls
+  int4* desc = nullptr;          // clipped start/end indices per ray
+  int* ncells = nullptr;         // Bresenham cell count per ray (0 = no cells)
+  int* next = nullptr;           // chain of marks per cell
+  HimmSlot* slots = nullptr;     // open-addressing hash cell -> marks
+  int* seqs = nullptr;           // sorted ray sequence numbers of marks, grouped per cell
+  unsigned* before = nullptr;    // clears that land before mark k
+  unsigned* after = nullptr;     // clears after the last mark of the cell
+  int* total = nullptr;          // allocation cursor into seqs
+  unsigned* mark_bitmap = nullptr;  // 1 bit per cell: cell holds >= 1 mark in the current batch
+};
+
+struct VfhDevice {
+  bool ready = false;
+  rna_vfh_params p{};
+  int n_robots = 0;
+  int W = 0, H = 0, T = 0, CX = 0, CY = 0, NQ = 0, NQF = 0, NW = 0, max_speed = 0;
+  // tables
+  float *cell_dist = nullptr, *cell_base_mag = nullptr, *cell_dir = nullptr;  // [q] in (y outer, x inner) order
+  int* range_idx = nullptr;        // [q] rint(2*dir)
+  unsigned* memb = nullptr;        // [T][H][NW] sector-major membership bit masks over q
+  unsigned* in_circle = nullptr;   // [max_speed+1][2][NW] cell inside right / left blocked circle
+  int* min_turning_radius = nullptr;  // [max_speed+1]
+  // per-robot state
+  float *last_binary = nullptr, *hist = nullptr, *origin = nullptr;
+  float *picked = nullptr, *last_picked = nullptr, *blocked_radius = nullptr;
+  int* last_chosen_speed = nullptr;
+  // staging
+  rna_pose* poses_dev = nullptr;
+  rna_vfh_out* out_dev = nullptr;
+  double* ranges_dev = nullptr;
+};
+
+struct AstarDevice {
+  int max_queries = 0;
+  int queue_cap = 0;
+  int bucket_width = 8000;
+  int32_t* g = nullptr;            // [max_queries][ncell]
+  int2* queues = nullptr;          // [max_queries][3][queue_cap] (cell, g)
+  rna_astar_query* queries_dev = nullptr;
+  rna_astar_result* results_dev = nullptr;
+  int32_t* paths_dev = nullptr;
+  int paths_cap = 0;               // max_queries * max_path_len currently allocated
+  const rna_astar_query* last_queries = nullptr;   // device pointers of the last launched chunk
+  const rna_astar_result* last_results = nullptr;
+  int last_n = 0;
+};
+
+struct ProfSlot { double total_ms = 0; int64_t launches = 0; };
+
+}  // namespace rna
+
+struct rna_engine {
+  rna::Geom geom{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  size_t ncell = 0;
+  float* layer[RNA_NUM_LAYERS] = {nullptr, nullptr, nullptr};
+  int tiles_i = 0, tiles_j = 0;
+  unsigned* dirty_tiles = nullptr;   // bit per TILE x TILE tile: laser changed since last compose
+  bool laser_all_dirty = false;      // laser uploaded/filled: next compose is a whole-layer copy
+  uint8_t* nbr = nullptr;            // A* neighbour masks derived from master
+  bool nbr_all_dirty = true;
+  rna::HimmScratch himm;
+  rna::VfhDevice vfh;
+  rna::AstarDevice astar;
+  bool profiling = false;
+  rna::ProfSlot prof[RNA_K_COUNT];
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+};
+
+namespace rna {
+
+inline int fail(rna_engine* e, int code, const std::string& msg) {
+  if (e) e->err = msg;
+  return code;
+}
+
+#define RNA_HIP(e, call)                                                                      \
+  do {                                                                                        \
+    hipError_t _st = (call);                                                                  \
+    if (_st != hipSuccess)                                                                    \
+      return ::rna::fail((e), RNA_EHIP, std::string(#call) + ": " + hipGetErrorString(_st)); \
+  } while (0)
+
+// Brackets one kernel launch with hipEvents when profiling is on (rna_profile_enable).
+struct KernelTimer {
+  rna_engine* e;
+  int id;
+  KernelTimer(rna_engine* eng, int kid) : e(eng), id(kid) {
+    if (e->profiling) (void)hipEventRecord(e->ev0, e->stream);
+  }
+  ~KernelTimer() {
+    if (e->profiling) {
+      (void)hipEventRecord(e->ev1, e->stream);
+      (void)hipEventSynchronize(e->ev1);
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, e->ev0, e->ev1) == hipSuccess) {
+        e->prof[id].total_ms += ms;
+        e->prof[id].launches += 1;
+      }
+    }
+  }
+};
+
+template <typename T>
+inline int dev_alloc(rna_engine* e, T** p, size_t n) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (n == 0) return RNA_OK;
+  hipError_t st = hipMalloc((void**)p, n * sizeof(T));
+  if (st != hipSuccess) { *p = nullptr; return fail(e, RNA_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(st)); }
+  return RNA_OK;
+}
+
+template <typename T>
+inline void dev_free(T** p) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+}
+
+// module entry points used across translation units
+int himm_release(rna_engine* e);
+int vfh_release(rna_engine* e);
+int astar_release(rna_engine* e);
+int map_prepare_nbr(rna_engine* e);   // make e->nbr consistent with the master layer
+
+}  // namespace rna

@@ -1,0 +1,444 @@
+// planners.hip -- the reference's two global planners, batched: waypoint-graph A* and goal-biased RRT.
+//
+//   AStarPlanner::makePlan / findClosedVertex   mc/src/astar_planner.cpp:63-145 (boost::astar_search,
+//                                               Boost.Graph 1.54 semantics restated, see oracle/astar.c)
+//   RrtPlanner::makePlan/extendTree/sample/findNearNode/backtraceTree   mc/src/rrt_planner.cpp:4-104
+//   GlobalPlanner::ifBlocked/ifFinishPlan + CircleIterator  mc/include/move_control/map_global_planner.h:32-86,
+//                                               gmc/src/iterators/CircleIterator.cpp:16-93
+//
+// RRT layout: one wavefront (64 lanes) per query, four queries per 256-thread workgroup.  The
+// tree (<= 2000 nodes) lives in HBM as SoA doubles; the nearest-node scan strides the tree across
+// the 64 lanes and finishes with a shuffle arg-min that keeps the lowest index on ties (the
+// reference's strict `<` scan); the 0.3 m footprint test spreads the <= 13 x 13 CircleIterator
+// window over the lanes and reduces with a ballot.  Each query owns a glibc-compatible rand()
+// (TYPE_3 additive feedback) in LDS so sample sequences equal srand(seed); rand() on the CPU.
+#include "engine.hpp"
+
+#include <vector>
+
+using namespace rna;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// waypoint-graph A*: one lane per query; graphs are tiny (the reference's has 9 vertices)
+// ------------------------------------------------------------------------------------------------
+constexpr int GRAPH_MAX_V = 256;
+
+struct GraphK {
+  int nv, ne;
+  const double* loc;     // [nv][2]
+  const int* adj_off;    // [nv+1] out-edge lists in add_edge order (listS out-edge container)
+  const int* adj_v;
+  const float* adj_w;
+};
+
+__device__ float graph_heuristic(const GraphK& G, int goal, int u) {  // astar_planner.cpp:16-32
+  const float dx = (float)(G.loc[2 * goal] - G.loc[2 * u]);
+  const float dy = (float)(G.loc[2 * goal + 1] - G.loc[2 * u + 1]);
+  return sqrtf(dx * dx + dy * dy);
+}
+
+__device__ int graph_closest_vertex(const GraphK& G, double x, double y) {  // astar_planner.cpp:129-145
+  float closed = 999.0f;
+  int best = 0;
+  for (int v = 0; v < G.nv; ++v) {
+    const float d = (float)hypot(x - G.loc[2 * v], y - G.loc[2 * v + 1]);
+    if (d < closed) { closed = d; best = v; }
+  }
+  return best;
+}
+
+// d_ary_heap_indirect<Vertex, 4> keyed on f (boost/graph/detail/d_ary_heap.hpp)
+struct DHeap { int* data; int* pos; const float* key; int n; };
+
+__device__ void dheap_up(DHeap& h, int index) {
+  if (index == 0) return;
+  const int moving = h.data[index];
+  const float dist = h.key[moving];
+  int levels = 0, idx = index;
+  while (idx != 0) {
+    const int parent = (idx - 1) / 4;
+    if (dist < h.key[h.data[parent]]) { ++levels; idx = parent; } else break;
+  }
+  idx = index;
+  for (int i = 0; i < levels; ++i) {
+    const int parent = (idx - 1) / 4;
+    h.data[idx] = h.data[parent];
+    h.pos[h.data[idx]] = idx;
+    idx = parent;
+  }
+  h.data[idx] = moving;
+  h.pos[moving] = idx;
+}
+
+__device__ void dheap_down(DHeap& h) {
+  if (h.n == 0) return;
+  int index = 0;
+  const int moving = h.data[0];
+  const float dist = h.key[moving];
+  for (;;) {
+    const int first = index * 4 + 1;
+    if (first >= h.n) break;
+    const int nchild = (first + 4 <= h.n) ? 4 : h.n - first;
+    int best = 0;
+    float best_d = h.key[h.data[first]];
+    for (int i = 1; i < nchild; ++i) {
+      const float d = h.key[h.data[first + i]];
+      if (d < best_d) { best = i; best_d = d; }
+    }
+    if (best_d < dist) {
+      const int ci = first + best;
+      const int tmp = h.data[ci]; h.data[ci] = h.data[index]; h.data[index] = tmp;
+      h.pos[h.data[ci]] = ci;
+      h.pos[h.data[index]] = index;
+      index = ci;
+    } else break;
+  }
+}
+
+__global__ void graph_astar_kernel(GraphK G, const double* __restrict__ start_target, int n,
+                                   float* __restrict__ scratch_f, int* __restrict__ scratch_i,
+                                   double* __restrict__ paths, int max_len, int* __restrict__ path_len) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int nv = G.nv;
+  float* d = scratch_f + (size_t)q * 2 * nv;
+  float* f = d + nv;
+  int* p = scratch_i + (size_t)q * 4 * nv;
+  int* color = p + nv;
+  DHeap h{color + nv, color + 2 * nv, f, 0};
+  const double sx = start_target[4 * q], sy = start_target[4 * q + 1];
+  const double tx = start_target[4 * q + 2], ty = start_target[4 * q + 3];
+  const int start = graph_closest_vertex(G, sx, sy);
+  const int goal = graph_closest_vertex(G, tx, ty);
+  const float FINF = 3.402823466e+38f;  // numeric_limits<float>::max() = astar_search's default "inf"
+  for (int v = 0; v < nv; ++v) { d[v] = FINF; f[v] = FINF; p[v] = v; color[v] = 0; h.pos[v] = -1; }
+  d[start] = 0;
+  f[start] = graph_heuristic(G, goal, start);
+  color[start] = 1;
+  h.data[0] = start; h.pos[start] = 0; h.n = 1;
+  bool found = false;
+  while (h.n) {
+    const int u = h.data[0];
+    h.pos[u] = -1;
+    if (h.n != 1) { h.data[0] = h.data[h.n - 1]; h.pos[h.data[0]] = 0; h.n--; dheap_down(h); }
+    else h.n--;
+    if (u == goal) { found = true; break; }  // astar_goal_visitor::examine_vertex throws found_goal
+    for (int k = G.adj_off[u]; k < G.adj_off[u + 1]; ++k) {
+      const int v = G.adj_v[k];
+      const float w = G.adj_w[k];
+      bool decreased = false;
+      const float d_u = d[u], d_v = d[v];
+      const float cand = (d_u == FINF || w == FINF) ? FINF : d_u + w;   // closed_plus
+      if (cand < d_v) {
+        d[v] = cand;
+        if (d[v] < d_v) { p[v] = u; decreased = true; }
+      } else {
+        const float cand2 = (d_v == FINF || w == FINF) ? FINF : d_v + w;  // undirected branch of relax()
+        if (cand2 < d_u) { d[u] = cand2; if (d[u] < d_u) { p[u] = v; decreased = true; } }
+      }
+      const float fv = (d[v] == FINF) ? FINF : d[v] + graph_heuristic(G, goal, v);
+      if (color[v] == 0) {
+        if (decreased) f[v] = fv;
+        color[v] = 1;
+        h.data[h.n] = v; h.pos[v] = h.n; h.n++; dheap_up(h, h.n - 1);
+      } else if (color[v] == 1) {
+        if (decreased) { f[v] = fv; dheap_up(h, h.pos[v]); }
+      } else if (decreased) {
+        f[v] = fv;
+        h.data[h.n] = v; h.pos[v] = h.n; h.n++; dheap_up(h, h.n - 1);
+        color[v] = 1;
+      }
+    }
+    color[u] = 2;
+  }
+  double* out = paths + (size_t)q * max_len * 2;
+  int len = 0;
+  if (found) {
+    // astar_planner.cpp:80-94 : start, vertex locations (front-inserted walk of p[]), target
+    int nvert = 0;
+    for (int v = goal;; v = p[v]) { ++nvert; if (p[v] == v || nvert > nv) break; }
+    len = nvert + 2;
+    if (len <= max_len) {
+      out[0] = sx; out[1] = sy;
+      int v = goal;
+      for (int k = nvert; k >= 1; --k) { out[2 * k] = G.loc[2 * v]; out[2 * k + 1] = G.loc[2 * v + 1]; v = p[v]; }
+      out[2 * (nvert + 1)] = tx; out[2 * (nvert + 1) + 1] = ty;
+    }
+  }
+  path_len[q] = len;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RRT
+// ------------------------------------------------------------------------------------------------
+constexpr int RRT_ITER = 2000;          // rrt_planner.cpp:6
+constexpr int RRT_WAVES = 4;
+
+struct RandState { int r[31]; int f, b; };
+
+__device__ int rng_next(RandState& s) {  // glibc random_r, TYPE_3
+  const unsigned val = (unsigned)s.r[s.f] + (unsigned)s.r[s.b];
+  s.r[s.f] = (int)val;
+  const int result = (int)(val >> 1);
+  s.f++;
+  if (s.f >= 31) { s.f = 0; s.b++; }
+  else { s.b++; if (s.b >= 31) s.b = 0; }
+  return result;
+}
+
+__device__ void rng_seed(RandState& s, unsigned seed) {  // glibc srandom_r, TYPE_3
+  if (seed == 0) seed = 1;
+  int word = (int)seed;
+  s.r[0] = word;
+  for (int i = 1; i < 31; ++i) {
+    const long long hi = word / 127773, lo = word % 127773;
+    word = (int)(16807 * lo - 2836 * hi);
+    if (word < 0) word += 2147483647;
+    s.r[i] = word;
+  }
+  s.f = 3; s.b = 0;
+  for (int i = 0; i < 310; ++i) (void)rng_next(s);
+}
+
+// GlobalPlanner::ifBlocked (map_global_planner.h:39-54) through CircleIterator (CircleIterator.cpp:16-93):
+// wave-cooperative, returns the same value in every lane.
+__device__ bool wave_if_blocked(const Geom& g, const float* __restrict__ master, double px, double py, int lane) {
+  const double radius = 0.3;
+  const double r2 = radius * radius;  // pow(radius, 2)
+  double tl[2] = {px + radius, py + radius};
+  double br[2] = {px - radius, py - radius};
+  limit_position_to_range(g, tl);
+  limit_position_to_range(g, br);
+  int s[2] = {0, 0}, t[2] = {0, 0}, su[2], tu[2];
+  index_from_position(g, tl[0], tl[1], s);
+  index_from_position(g, br[0], br[1], t);
+  unwrap_index(g, s, su);
+  unwrap_index(g, t, tu);
+  const int ni = tu[0] - su[0] + 1, nj = tu[1] - su[1] + 1;
+  bool hit = false;
+  const int total = (ni > 0 && nj > 0) ? ni * nj : 0;
+  for (int k = lane; k < total; k += 64) {
+    const int u[2] = {su[0] + k % ni, su[1] + k / ni};
+    int bi[2];
+    buffer_index(g, u, bi);
+    double p[2];
+    position_from_index(g, bi, p);
+    const double dx = p[0] - px, dy = p[1] - py;
+    if (dx * dx + dy * dy <= r2) {
+      const float v = master[(size_t)bi[1] * g.size[0] + bi[0]];
+      if (!(v != v) && v > 0.0f) hit = true;
+    }
+  }
+  return __ballot(hit) != 0ULL;
+}
+
+__global__ void __launch_bounds__(64 * RRT_WAVES)
+rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __restrict__ queries, int n,
+           double* __restrict__ tree_x, double* __restrict__ tree_y, int* __restrict__ tree_parent,
+           double* __restrict__ paths, int max_path_len, rna_rrt_result* __restrict__ results) {
+  __shared__ RandState s_rng[RRT_WAVES];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int q = blockIdx.x * RRT_WAVES + wave;
+  if (q >= n) return;
+  const rna_rrt_query qu = queries[q];
+  double* tx = tree_x + (size_t)q * RRT_ITER;
+  double* ty = tree_y + (size_t)q * RRT_ITER;
+  int* tp = tree_parent + (size_t)q * RRT_ITER;
+  RandState& rs = s_rng[wave];
+  if (lane == 0) rng_seed(rs, qu.seed);
+  __builtin_amdgcn_wave_barrier();
+
+  const double strideStep = 0.4;   // rrt_planner.h:23 ; targetTendency_ is int(0.5) == 0 (rrt_planner.h:24,32)
+  const bool target_inside = position_within_map(g, qu.target[0], qu.target[1]);
+  const double pbx = g.pos[0] + g.len[0] / 2, pby = g.pos[1] + g.len[1] / 2;
+  const double mbx = g.pos[0] - g.len[0] / 2, mby = g.pos[1] - g.len[1] / 2;
+
+  double nx = qu.start[0], ny = qu.start[1];
+  int nparent = -1;
+  int n_tree = 0, samples = 0;
+  bool finished = false, aborted = false;
+
+  for (int it = 0; it < RRT_ITER && !aborted; ++it) {
+    if (lane == 0) { tx[n_tree] = nx; ty[n_tree] = ny; tp[n_tree] = nparent; }
+    n_tree++;
+    __threadfence_block();
+    bool fin;  // ifFinishPlan, map_global_planner.h:32-37,56-86
+    if (target_inside) fin = hypot(nx - qu.target[0], ny - qu.target[1]) < qu.close_tolerance;
+    else fin = ((pbx - nx) < qu.close_tolerance) || ((pby - ny) < qu.close_tolerance) ||
+               ((nx - mbx) < qu.close_tolerance) || ((ny - mby) < qu.close_tolerance);
+    if (fin) { finished = true; break; }
+
+    for (;;) {  // extendTree, rrt_planner.cpp:26-59
+      if (samples >= qu.max_samples) { aborted = true; break; }
+      samples++;
+      int r0 = 0, r1 = 0, r2 = 0;
+      if (lane == 0) {
+        r0 = rng_next(rs);
+        if (r0 % 10 > 3) { r1 = rng_next(rs); r2 = rng_next(rs); }
+      }
+      r0 = __shfl(r0, 0); r1 = __shfl(r1, 0); r2 = __shfl(r2, 0);
+      double rx, ry;
+      if (r0 % 10 > 3) {  // sample(), rrt_planner.cpp:61-68
+        const int ridx[2] = {r1 % g.size[0], r2 % g.size[1]};
+        double p[2];
+        position_from_index(g, ridx, p);
+        rx = p[0]; ry = p[1];
+      } else {
+        rx = qu.target[0]; ry = qu.target[1];
+      }
+      // findNearNode, rrt_planner.cpp:70-89 : strict < keeps the lowest index among equals
+      double best = 9999.0;
+      int best_i = 0x7fffffff;
+      for (int i = lane; i < n_tree; i += 64) {
+        const double d = hypot(rx - tx[i], ry - ty[i]);
+        if (d < best) { best = d; best_i = i; }
+      }
+      for (int o = 32; o >= 1; o >>= 1) {
+        const double ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(best_i, o);
+        if (ob < best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+      }
+      const int near = (best_i == 0x7fffffff) ? 0 : best_i;
+      const double npx = tx[near], npy = ty[near];
+      double wx, wy;
+      if (hypot(npx - rx, npy - ry) < strideStep) { wx = rx; wy = ry; }
+      else {
+        const double a = atan2(ry - npy, rx - npx);
+        wx = npx + strideStep * cos(a);
+        wy = npy + strideStep * sin(a);
+      }
+      if (!wave_if_blocked(g, master, wx, wy, lane)) { nx = wx; ny = wy; nparent = near; break; }
+    }
+  }
+
+  // backtraceTree, rrt_planner.cpp:91-104 : goal -> start
+  int len = 0;
+  if (!aborted && n_tree > 0) {
+    double* out = paths + (size_t)q * max_path_len * 2;
+    int i = n_tree - 1;
+    for (;;) {
+      if (lane == 0 && len < max_path_len) { out[2 * len] = tx[i]; out[2 * len + 1] = ty[i]; }
+      len++;
+      const int par = tp[i];
+      if (par == -1) break;
+      i = par;
+    }
+  }
+  if (lane == 0) results[q] = rna_rrt_result{aborted ? -1 : (finished ? 1 : 0), len, n_tree, samples};
+}
+
+}  // namespace
+
+extern "C" int rna_graph_astar_batch(rna_engine* e, int nv, const double* vertex_xy, int ne, const int32_t* edge_uv,
+                                     const float* edge_weight, const double* start_target_xy, int n, double* paths_xy,
+                                     int max_len, int32_t* path_len) {
+  if (!e || nv <= 0 || nv > GRAPH_MAX_V || ne < 0 || !vertex_xy || (ne > 0 && !edge_uv) || n < 0 || max_len < 3 ||
+      (n > 0 && (!start_target_xy || !paths_xy || !path_len)))
+    return RNA_EINVAL;
+  if (n == 0) return RNA_OK;
+  for (int k = 0; k < 2 * ne; ++k)
+    if (edge_uv[k] < 0 || edge_uv[k] >= nv) return RNA_EINVAL;
+  RNA_HIP(e, hipSetDevice(e->device));
+  // out-edge lists in add_edge order: add_edge(u,v) appends to u's list and to v's list
+  std::vector<int> off(nv + 1, 0), fill(nv, 0), adj_v(2 * ne + 1);
+  std::vector<float> adj_w(2 * ne + 1);
+  for (int k = 0; k < ne; ++k) { off[edge_uv[2 * k] + 1]++; off[edge_uv[2 * k + 1] + 1]++; }
+  for (int v = 0; v < nv; ++v) off[v + 1] += off[v];
+  for (int k = 0; k < ne; ++k) {
+    const int u = edge_uv[2 * k], v = edge_uv[2 * k + 1];
+    const float w = edge_weight ? edge_weight[k] : 0.0f;  // add_edge without a property: weight 0 (astar_planner.cpp:116-125)
+    adj_v[off[u] + fill[u]] = v; adj_w[off[u] + fill[u]++] = w;
+    adj_v[off[v] + fill[v]] = u; adj_w[off[v] + fill[v]++] = w;
+  }
+  double *d_loc = nullptr, *d_st = nullptr, *d_paths = nullptr;
+  int *d_off = nullptr, *d_adjv = nullptr, *d_si = nullptr, *d_len = nullptr;
+  float *d_adjw = nullptr, *d_sf = nullptr;
+  int rc = RNA_OK;
+  auto cleanup = [&]() {
+    dev_free(&d_loc); dev_free(&d_st); dev_free(&d_paths); dev_free(&d_off); dev_free(&d_adjv); dev_free(&d_si);
+    dev_free(&d_len); dev_free(&d_adjw); dev_free(&d_sf);
+  };
+#define GA_TRY(x) do { rc = (x); if (rc != RNA_OK) { cleanup(); return rc; } } while (0)
+#define GA_HIP(x) do { if ((x) != hipSuccess) { cleanup(); return fail(e, RNA_EHIP, #x); } } while (0)
+  GA_TRY(dev_alloc(e, &d_loc, (size_t)2 * nv));
+  GA_TRY(dev_alloc(e, &d_st, (size_t)4 * n));
+  GA_TRY(dev_alloc(e, &d_paths, (size_t)2 * max_len * n));
+  GA_TRY(dev_alloc(e, &d_off, (size_t)nv + 1));
+  GA_TRY(dev_alloc(e, &d_adjv, adj_v.size()));
+  GA_TRY(dev_alloc(e, &d_adjw, adj_w.size()));
+  GA_TRY(dev_alloc(e, &d_sf, (size_t)2 * nv * n));
+  GA_TRY(dev_alloc(e, &d_si, (size_t)4 * nv * n));
+  GA_TRY(dev_alloc(e, &d_len, (size_t)n));
+  GA_HIP(hipMemcpyAsync(d_loc, vertex_xy, sizeof(double) * 2 * nv, hipMemcpyHostToDevice, e->stream));
+  GA_HIP(hipMemcpyAsync(d_st, start_target_xy, sizeof(double) * 4 * n, hipMemcpyHostToDevice, e->stream));
+  GA_HIP(hipMemcpyAsync(d_off, off.data(), sizeof(int) * (nv + 1), hipMemcpyHostToDevice, e->stream));
+  GA_HIP(hipMemcpyAsync(d_adjv, adj_v.data(), sizeof(int) * adj_v.size(), hipMemcpyHostToDevice, e->stream));
+  GA_HIP(hipMemcpyAsync(d_adjw, adj_w.data(), sizeof(float) * adj_w.size(), hipMemcpyHostToDevice, e->stream));
+  GraphK G{nv, ne, d_loc, d_off, d_adjv, d_adjw};
+  hipLaunchKernelGGL(graph_astar_kernel, dim3((n + 63) / 64), dim3(64), 0, e->stream, G, d_st, n, d_sf, d_si,
+                     d_paths, max_len, d_len);
+  GA_HIP(hipGetLastError());
+  GA_HIP(hipMemcpyAsync(paths_xy, d_paths, sizeof(double) * 2 * max_len * n, hipMemcpyDeviceToHost, e->stream));
+  GA_HIP(hipMemcpyAsync(path_len, d_len, sizeof(int) * n, hipMemcpyDeviceToHost, e->stream));
+  GA_HIP(hipStreamSynchronize(e->stream));
+#undef GA_TRY
+#undef GA_HIP
+  cleanup();
+  return RNA_OK;
+}
+
+static int rrt_launch(rna_engine* e, const rna_rrt_query* q_dev, int n, double* paths_dev, int max_len,
+                      rna_rrt_result* res_dev, double** tx, double** ty, int** tp) {
+  int rc;
+  if ((rc = dev_alloc(e, tx, (size_t)n * RRT_ITER)) != RNA_OK) return rc;
+  if ((rc = dev_alloc(e, ty, (size_t)n * RRT_ITER)) != RNA_OK) return rc;
+  if ((rc = dev_alloc(e, tp, (size_t)n * RRT_ITER)) != RNA_OK) return rc;
+  KernelTimer kt(e, RNA_K_RRT);
+  hipLaunchKernelGGL(rrt_kernel, dim3((n + RRT_WAVES - 1) / RRT_WAVES), dim3(64 * RRT_WAVES), 0, e->stream, e->geom,
+                     e->layer[RNA_LAYER_MASTER], q_dev, n, *tx, *ty, *tp, paths_dev, max_len, res_dev);
+  RNA_HIP(e, hipGetLastError());
+  return RNA_OK;
+}
+
+extern "C" int rna_rrt_batch_device(rna_engine* e, const rna_rrt_query* queries, int n, double* paths_xy,
+                                    int max_path_len, rna_rrt_result* results) {
+  if (!e || n < 0 || max_path_len <= 0 || (n > 0 && (!queries || !paths_xy || !results))) return RNA_EINVAL;
+  if (n == 0) return RNA_OK;
+  RNA_HIP(e, hipSetDevice(e->device));
+  double *tx = nullptr, *ty = nullptr;
+  int* tp = nullptr;
+  int rc = rrt_launch(e, queries, n, paths_xy, max_path_len, results, &tx, &ty, &tp);
+  if (rc == RNA_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(e, RNA_EHIP, "rrt sync");
+  dev_free(&tx); dev_free(&ty); dev_free(&tp);
+  return rc;
+}
+
+extern "C" int rna_rrt_batch(rna_engine* e, const rna_rrt_query* queries_host, int n, double* paths_xy_host,
+                             int max_path_len, rna_rrt_result* results_host) {
+  if (!e || n < 0 || max_path_len <= 0 || (n > 0 && (!queries_host || !paths_xy_host || !results_host)))
+    return RNA_EINVAL;
+  if (n == 0) return RNA_OK;
+  RNA_HIP(e, hipSetDevice(e->device));
+  rna_rrt_query* dq = nullptr;
+  rna_rrt_result* dr = nullptr;
+  double *dp = nullptr, *tx = nullptr, *ty = nullptr;
+  int* tp = nullptr;
+  int rc = RNA_OK;
+  auto cleanup = [&]() { dev_free(&dq); dev_free(&dr); dev_free(&dp); dev_free(&tx); dev_free(&ty); dev_free(&tp); };
+  if ((rc = dev_alloc(e, &dq, (size_t)n)) != RNA_OK || (rc = dev_alloc(e, &dr, (size_t)n)) != RNA_OK ||
+      (rc = dev_alloc(e, &dp, (size_t)n * max_path_len * 2)) != RNA_OK) { cleanup(); return rc; }
+  if (hipMemcpyAsync(dq, queries_host, sizeof(rna_rrt_query) * n, hipMemcpyHostToDevice, e->stream) != hipSuccess) {
+    cleanup(); return fail(e, RNA_EHIP, "rrt H2D");
+  }
+  rc = rrt_launch(e, dq, n, dp, max_path_len, dr, &tx, &ty, &tp);
+  if (rc == RNA_OK) {
+    if (hipMemcpyAsync(results_host, dr, sizeof(rna_rrt_result) * n, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        hipMemcpyAsync(paths_xy_host, dp, sizeof(double) * 2 * max_path_len * n, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess)
+      rc = fail(e, RNA_EHIP, "rrt D2H");
+  }
+  cleanup();
+  return rc;
+}

@@ -1,0 +1,662 @@
+// vfh.hip -- batched VFH+ steps on gfx950: Steerer::getRangesFromSubmap + VFH::Update_VFH for many
+// independent robots per launch.
+//
+// Reference path replaced (mc/ = move_control in the reference):
+//   Steerer::getRangesFromSubmap           mc/src/steerer.cpp:147-191
+//   MapProvider::getSubMap / getSubmap     mc/src/map_provider.cpp:93-100, gmc/src/GridMap.cpp:287-339
+//   VFH::Init tables                       mc/src/vfh.cpp:237-416,144-166
+//   VFH::Update_VFH and its stages         mc/src/vfh.cpp:480-605,986-1261
+//
+// Layout: one 128-thread workgroup (two wavefronts) per robot.  The 1.5 m window (<= 31 x 31 cells)
+// is read straight from the master layer with lanes along Index(0) (contiguous in the column-major
+// layer); the 361-bin min-range scan lives in LDS as IEEE-double bit patterns reduced with LDS
+// atomicMin (all distances are positive, so the unsigned order is the numeric order); cell
+// magnitudes and a non-zero bit mask are staged in LDS; every histogram sector is owned by one lane
+// that adds its cells in the reference's (y outer, x inner) order through a precomputed
+// sector-major membership bit mask, which makes OriginHist bit-identical to the sequential CPU sum.
+// phi_left/phi_right of the masked histogram are order-free min/max reductions (see comment there).
+// All tables that need libm (atanf, asinf, pow, tan, hypotf) are built on the host at init with the
+// same calls the reference makes, so the device never re-derives them.
+#include "engine.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+using namespace rna;
+
+namespace {
+
+constexpr int VFH_THREADS = 128;
+constexpr int MAX_W = 64;
+constexpr int MAX_NQ = (MAX_W / 2 + 1) * MAX_W;   // 2112
+constexpr int MAX_NW = (MAX_NQ + 31) / 32;        // 66
+constexpr int MAX_H = 128;
+
+struct VfhK {
+  int W, H, T, CX, CY, YH, NQ, NQF, NW, max_speed, sector_angle;
+  float cell_width, robot_radius, sd0, sd1, bl0, bh0, bl1, bh1, U1, U2;
+  int current_max_speed, max_speed_narrow, max_speed_wide, max_accel, mt0, mt1;
+  const float *cell_dist, *cell_base_mag, *cell_dir;
+  const int* range_idx;
+  const unsigned *memb, *in_circle;
+  const int* mtr;
+  const float* bcr;
+  float *last_binary, *hist, *origin, *picked, *last_picked, *blocked_radius;
+  int *last_chosen_speed, *max_speed_picked;
+};
+
+// ---- small pieces of vfh.cpp that are pure arithmetic (usable on host and device) --------------
+RNA_HD int k_max_turnrate(int mt0, int mt1, int speed) {  // vfh.cpp:130-138
+  int val = (mt0 - (int)(speed * (mt0 - mt1) / 1000.0));
+  return val < 0 ? 0 : val;
+}
+RNA_HD int k_safety_dist(float sd0, float sd1, int speed) {  // vfh.cpp:194-205
+  int val = (int)(sd0 + (int)(speed * (sd1 - sd0) / 1000.0));
+  return val < 0 ? 0 : val;
+}
+RNA_HD float k_delta_angle(float a1, float a2) {  // vfh.cpp:673-686
+  float diff = a2 - a1;
+  if (diff > 180) diff -= 360;
+  else if (diff < -180) diff += 360;
+  return diff;
+}
+// glibc 2.35 hypotf() is (float)sqrt((double)x*x + (double)y*y); restated so host tables and the
+// device agree bit for bit (checked against libm in tests/test_host_tables.py)
+RNA_HD float k_hypotf(float x, float y) { return (float)sqrt((double)x * (double)x + (double)y * (double)y); }
+
+// angles::normalize_angle_positive (ROS `angles` package)
+__device__ __forceinline__ double normalize_angle_positive(double a) {
+  return fmod(fmod(a, 2.0 * M_PI) + 2.0 * M_PI, 2.0 * M_PI);
+}
+
+__global__ void __launch_bounds__(VFH_THREADS)
+vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose* __restrict__ poses,
+                const double* __restrict__ ext_ranges, rna_vfh_out* __restrict__ out,
+                float* __restrict__ origin_out, float* __restrict__ hist_out) {
+  __shared__ unsigned long long rng[361];
+  __shared__ float mag[MAX_NQ];
+  __shared__ unsigned nz[MAX_NW];
+  __shared__ float s_hist[MAX_H];
+  __shared__ unsigned s_phi_right, s_phi_left;
+  __shared__ int s_emergency;
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const rna_pose pose = poses[b];
+
+  // ---------------- ranges (steerer.cpp:147-191) ----------------
+  for (int i = tid; i < 361; i += VFH_THREADS)
+    rng[i] = ext_ranges ? (unsigned long long)__double_as_longlong(ext_ranges[((size_t)b * 361 + i) * 2])
+                        : (unsigned long long)__double_as_longlong(5000.0);
+  for (int i = tid; i < K.NW; i += VFH_THREADS) nz[i] = 0;
+  if (tid == 0) { s_phi_right = 0u; s_phi_left = __float_as_uint(180.0f); s_emergency = 0; }
+  __syncthreads();
+
+  if (!ext_ranges) {
+    const double rp[2] = {pose.x, pose.y};
+    const double rl[2] = {1.5, 1.5};
+    SubmapInfo sm;
+    if (submap_information(g, rp, rl, sm)) {  // getSubMap failure leaves every range at 5000
+      int tl_u[2];
+      unwrap_index(g, sm.top_left, tl_u);
+      const int sr = sm.size[0], sc = sm.size[1];
+      const double offx = sm.pos[0] + (0.5 * sm.len[0] - 0.5 * g.res);
+      const double offy = sm.pos[1] + (0.5 * sm.len[1] - 0.5 * g.res);
+      for (int lin = tid; lin < sr * sc; lin += VFH_THREADS) {
+        const int i = lin % sr, j = lin / sr;  // GridMapIterator order; lanes run along Index(0)
+        const int u[2] = {tl_u[0] + i, tl_u[1] + j};
+        int bi[2];
+        buffer_index(g, u, bi);
+        const float value = master[(size_t)bi[1] * g.size[0] + bi[0]];
+        if (value != value) continue;
+        if (value <= 3) continue;
+        const double px = offx + g.res * (double)(-i);
+        const double py = offy + g.res * (double)(-j);
+        const double angle = atan2(py - pose.y, px - pose.x);
+        const double deg = normalize_angle_positive(angle - pose.yaw + 3.14 / 2) * 180.0 / M_PI;
+        if (deg > 180) continue;
+        const int fl = (int)floor(deg), ce = (int)ceil(deg);
+        const double dx = pose.x - px, dy = pose.y - py;
+        const double distance = sqrt(dx * dx + dy * dy) * 1000.0;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(distance);
+        atomicMin(&rng[fl * 2], bits);
+        atomicMin(&rng[ce * 2], bits);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- Update_VFH prologue (vfh.cpp:490-515) ----------------
+  const float desired_angle = pose.goal_direction;
+  const float dist_to_goal = pose.goal_distance;
+  const float goal_tol = pose.goal_tolerance;
+  const int last_speed = K.last_chosen_speed[b];
+  int speed = pose.current_speed < 0 ? 0 : pose.current_speed;
+  if (speed < last_speed) speed = last_speed;
+  const int tspeed = speed > K.max_speed ? K.max_speed : speed;  // table index (reference: OOB read)
+
+  // ---------------- Calculate_Cells_Mag (vfh.cpp:986-1049) ----------------
+  const float r_safe = K.robot_radius + (float)k_safety_dist(K.sd0, K.sd1, speed);
+  for (int q = tid; q < K.NQ; q += VFH_THREADS) {
+    float m = 0.0f;
+    if (q < K.NQF) {
+      const float cd = K.cell_dist[q];
+      const double range = __longlong_as_double((long long)rng[K.range_idx[q]]);
+      if ((cd + K.cell_width / 2.0) > range) {
+        const int x = q % K.W, y = q / K.W;
+        if (cd < r_safe && !(x == K.CX && y == K.CY)) s_emergency = 1;
+        m = K.cell_base_mag[q];
+      }
+    }
+    mag[q] = m;
+    if (m != 0.0f) atomicOr(&nz[q >> 5], 1u << (q & 31));
+  }
+  __syncthreads();
+  const bool emergency = s_emergency != 0;
+
+  float* origin = K.origin + (size_t)b * K.H;
+  float* hist = K.hist + (size_t)b * K.H;
+  float* last_binary = K.last_binary + (size_t)b * K.H;
+
+  if (emergency) {
+    // vfh.cpp:1070-1077 and :533-540 : OriginHist all 1, Hist untouched
+    if (tid < K.H) origin[tid] = 1.0f;
+  } else {
+    // ---------------- Build_Primary_Polar_Histogram (vfh.cpp:1057-1095) ----------------
+    int speed_index = (int)floorf(((float)speed / (float)K.current_max_speed) * K.T);  // vfh.cpp:175-186
+    if (speed_index >= K.T) speed_index = K.T - 1;
+    if (tid < K.H) {
+      const unsigned* mb = K.memb + ((size_t)speed_index * K.H + tid) * K.NW;
+      float sum = 0.0f;
+      for (int w = 0; w < K.NW; ++w) {
+        unsigned bits = mb[w] & nz[w];
+        while (bits) {  // ascending q == the reference's (y outer, x inner) order
+          const int bit = __ffs(bits) - 1;
+          bits &= bits - 1;
+          sum += mag[w * 32 + bit];
+        }
+      }
+      origin[tid] = sum;
+      // ---------------- Build_Binary_Polar_Histogram (vfh.cpp:1102-1121, 214-231) ----------------
+      const float hi = (float)(K.bh0 - (speed * (K.bh0 - K.bh1) / 1000.0));
+      const float lo = (float)(K.bl0 - (speed * (K.bl0 - K.bl1) / 1000.0));
+      float h;
+      if (sum > hi) h = 1.0f;
+      else if (sum < lo) h = 0.0f;
+      else h = last_binary[tid];
+      last_binary[tid] = h;
+      s_hist[tid] = h;
+    }
+    // ---------------- Build_Masked_Polar_Histogram (vfh.cpp:1131-1213) ----------------
+    // The reference walks the occupied front cells sequentially, raising phi_right / lowering
+    // phi_left.  Front cells have directions in (0,180): a cell updates phi_right iff it lies right
+    // of straight-ahead (Delta(dir,90) > 0), inside the right blocked circle and dir >= phi_right,
+    // so the final phi_right is the MAX direction of those cells (and symmetrically phi_left the
+    // MIN on the left side) -- independent of the visiting order.  Circle membership is a host table.
+    {
+      const unsigned* inr = K.in_circle + ((size_t)tspeed * 2 + 0) * K.NW;
+      const unsigned* inl = K.in_circle + ((size_t)tspeed * 2 + 1) * K.NW;
+      for (int q = tid; q < K.NQF; q += VFH_THREADS) {
+        if (mag[q] == 0.0f) continue;
+        const float dir = K.cell_dir[q];
+        const unsigned bit = 1u << (q & 31);
+        if (k_delta_angle(dir, 90.0f) > 0) {
+          if ((inr[q >> 5] & bit) && dir >= 0.0f && dir < 90.0f) atomicMax(&s_phi_right, __float_as_uint(dir));
+        } else {
+          if ((inl[q >> 5] & bit) && dir <= 180.0f) atomicMin(&s_phi_left, __float_as_uint(dir));
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < K.H) {
+      const float phi_right = __uint_as_float(s_phi_right), phi_left = __uint_as_float(s_phi_left);
+      const float angle = (float)(tid * K.sector_angle);
+      const float h = s_hist[tid];
+      float nh;
+      if ((h == 0) && (((k_delta_angle(angle, phi_right) <= 0) && (k_delta_angle(angle, 90.0f) >= 0)) ||
+                       ((k_delta_angle(angle, phi_left) >= 0) && (k_delta_angle(angle, 90.0f) <= 0))))
+        nh = 0.0f;
+      else
+        nh = 1.0f;
+      s_hist[tid] = nh;
+      hist[tid] = nh;
+    }
+  }
+  __syncthreads();
+
+  // ---------------- serial tail on one lane ----------------
+  if (tid == 0) {
+    float picked = K.picked[b];
+    float last_picked = K.last_picked[b];
+    int max_speed_for_picked = K.max_speed_picked[b];
+    float blocked_radius = K.blocked_radius[b];
+    const int H = K.H, SA = K.sector_angle;
+
+    if (emergency) {
+      picked = last_picked;
+      max_speed_for_picked = 0;
+      last_picked = picked;
+    } else {
+      blocked_radius = K.bcr[tspeed];
+      // ---------------- Select_Direction (vfh.cpp:755-870) ----------------
+      int start = -1;
+      for (int i = 0; i < H / 2; i++)
+        if (s_hist[i] == 1) { start = i; break; }
+      if (start == -1) {
+        picked = desired_angle;
+        last_picked = picked;
+        max_speed_for_picked = K.current_max_speed;
+      } else {
+        // candidates are weighed as they are generated: Select_Candidate_Angle keeps the first
+        // minimum (strict <), vfh.cpp:715-749
+        int ncand = 0;
+        float best_angle = 90.0f, min_weight = 10000000.0f;
+        int best_speed = max_speed_for_picked;
+        auto consider = [&](float a, int sp) {
+          const float weight = K.U1 * fabsf(k_delta_angle(desired_angle, a)) +
+                               K.U2 * fabsf(k_delta_angle(last_picked, a));
+          if (weight < min_weight) { min_weight = weight; best_angle = a; best_speed = sp; }
+          ++ncand;
+        };
+        const int cms = K.current_max_speed;
+        const int sp_narrow = cms < K.max_speed_narrow ? cms : K.max_speed_narrow;
+        const int sp_wide = cms < K.max_speed_wide ? cms : K.max_speed_wide;
+        int left = 1, b1 = 0;
+        for (int i = start; i <= (start + H); i++) {
+          const float hv = s_hist[i % H];
+          if ((hv == 0) && left) { b1 = (i % H) * SA; left = 0; }
+          if ((hv == 1) && !left) {
+            int b2 = ((i % H) - 1) * SA;
+            if (b2 < 0) b2 += 360;
+            left = 1;
+            const float angle = k_delta_angle((float)b1, (float)b2);
+            if (fabsf(angle) < 10) continue;
+            if (fabsf(angle) < 80) {
+              consider((float)(b1 + (b2 - b1) / 2.0), sp_narrow);
+            } else {
+              consider((float)(b1 + (b2 - b1) / 2.0), cms);
+              const float c2 = (float)((b1 + 40) % 360);
+              consider(c2, sp_wide);
+              float c3 = (float)(b2 - 40);
+              if (c3 < 0) c3 += 360;
+              consider(c3, sp_wide);
+              if ((k_delta_angle(desired_angle, c2) < 0) && (k_delta_angle(desired_angle, c3) > 0))
+                consider(desired_angle, sp_wide);
+            }
+          }
+        }
+        if (ncand == 0) {
+          picked = last_picked;
+          max_speed_for_picked = 0;
+          last_picked = picked;
+        } else {
+          picked = best_angle;
+          max_speed_for_picked = best_speed;
+          last_picked = picked;
+        }
+      }
+    }
+
+    // ---------------- speed (vfh.cpp:571-599) ----------------
+    int speed_incr;
+    if ((pose.dt > 0.3) || (pose.dt < 0)) speed_incr = 10;
+    else speed_incr = (int)(K.max_accel * pose.dt);
+
+    {  // Cant_Turn_To_Goal (vfh.cpp:612-654)
+      const float goal_x = (float)(dist_to_goal * cos(desired_angle * M_PI / 180));
+      const float goal_y = (float)(dist_to_goal * sin(desired_angle * M_PI / 180));
+      bool cant = false;
+      float dc = k_hypotf(goal_x - blocked_radius, goal_y);
+      if (dc + goal_tol < blocked_radius) cant = true;
+      if (!cant) {
+        dc = k_hypotf(-goal_x - blocked_radius, goal_y);
+        if (dc + goal_tol < blocked_radius) cant = true;
+      }
+      if (cant) speed_incr = -speed_incr;
+    }
+    int chosen_speed = last_speed + speed_incr;
+    if (max_speed_for_picked < chosen_speed) chosen_speed = max_speed_for_picked;
+
+    // ---------------- Set_Motion (vfh.cpp:1222-1261) ----------------
+    const int maxturn = k_max_turnrate(K.mt0, K.mt1, speed);
+    int turnrate;
+    if (chosen_speed <= 0) {
+      turnrate = maxturn;
+      chosen_speed = 0;
+    } else if ((picked > 270) && (picked < 360)) {
+      turnrate = -1 * maxturn;
+    } else if ((picked < 270) && (picked > 180)) {
+      turnrate = maxturn;
+    } else {
+      turnrate = (int)rint(((float)(picked - 90) / 75.0) * maxturn);
+      if (turnrate > maxturn) turnrate = maxturn;
+      else if (turnrate < (-1 * maxturn)) turnrate = -1 * maxturn;
+    }
+
+    K.picked[b] = picked;
+    K.last_picked[b] = last_picked;
+    K.max_speed_picked[b] = max_speed_for_picked;
+    K.blocked_radius[b] = blocked_radius;
+    K.last_chosen_speed[b] = chosen_speed;
+    rna_vfh_out o;
+    o.chosen_speed = chosen_speed;
+    o.chosen_turnrate = turnrate;
+    o.picked_angle = picked;
+    o.emergency = emergency ? 1 : 0;
+    out[b] = o;
+  }
+  __syncthreads();
+  if (tid < K.H) {
+    if (origin_out) origin_out[(size_t)b * K.H + tid] = origin[tid];
+    if (hist_out) hist_out[(size_t)b * K.H + tid] = hist[tid];
+  }
+}
+
+__global__ void vfh_reset_kernel(VfhK K, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * K.H) {  // vfh.cpp:258-262
+    K.hist[i] = 0.0f;
+    K.origin[i] = 0.0f;
+    K.last_binary[i] = 1.0f;
+  }
+  if (i < n) {  // vfh.cpp:92-95
+    K.picked[i] = 90.0f;
+    K.last_picked[i] = 90.0f;
+    K.blocked_radius[i] = 0.0f;   // uninitialised in the reference until the first normal step
+    K.last_chosen_speed[i] = 0;
+    K.max_speed_picked[i] = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host: VFH::VFH + VFH::Init tables (vfh.cpp:53-110,144-166,237-416)
+// ------------------------------------------------------------------------------------------------
+struct HostTables {
+  int W, H, T, CX, CY, YH, NQ, NQF, NW, max_speed;
+  std::vector<float> cell_dist, cell_base_mag, cell_dir;
+  std::vector<int> range_idx;
+  std::vector<unsigned> memb, in_circle;
+  std::vector<int> mtr;
+  std::vector<float> bcr;
+};
+
+float sector_to_dir(float sector, float dir) {  // the four wrap-aware differences of vfh.cpp:343-381
+  if ((sector - dir) > 180) return dir - (sector - 360);
+  if ((dir - sector) > 180) return sector - (dir + 360);
+  return dir - sector;
+}
+
+bool build_tables(const rna_vfh_params& p, HostTables& t) {
+  const float CELL_WIDTH = (float)p.cell_size;
+  const float SD0 = (float)p.safety_dist_0ms, SD1 = (float)p.safety_dist_1ms;
+  const float ROBOT_RADIUS = (float)p.robot_radius;
+  const int W = p.window_diameter, SA = p.sector_angle, MAX_SPEED = p.max_speed;
+  if (W < 2 || W > MAX_W || SA < 1 || MAX_SPEED < 1 || MAX_SPEED > 100000) return false;
+  t.W = W;
+  t.T = (SD0 == SD1) ? 1 : 20;  // vfh.cpp:100-109
+  t.CX = t.CY = (int)floor(W / 2.0);
+  t.H = (int)rint(360.0 / SA);
+  if (t.H > MAX_H || t.H != 360 / SA) return false;
+  t.YH = (int)ceil(W / 2.0);
+  t.NQ = (t.YH + 1) * W;
+  t.NQF = t.YH * W;
+  t.NW = (t.NQ + 31) / 32;
+  t.max_speed = MAX_SPEED;
+  if (t.YH + 1 > W) return false;
+  const int H = t.H, T = t.T, CX = t.CX, CY = t.CY;
+
+  // Min_Turning_Radius (SetCurrentMaxSpeed, vfh.cpp:144-166) and per-speed blocked circles
+  t.mtr.resize(MAX_SPEED + 1);
+  t.bcr.resize(MAX_SPEED + 1);
+  for (int x = 0; x <= MAX_SPEED; x++) {
+    const double dx = (double)x / 1e6;
+    const double dtheta = ((M_PI / 180) * (double)(k_max_turnrate(p.max_turnrate_0ms, p.max_turnrate_1ms, x))) / 1000.0;
+    t.mtr[x] = (int)(((dx / tan(dtheta)) * 1000.0) * p.min_turn_radius_safety_factor);
+    t.bcr[x] = t.mtr[x] + ROBOT_RADIUS + k_safety_dist(SD0, SD1, x);  // vfh.cpp:1148
+  }
+
+  t.cell_dist.assign(t.NQ, 0.f);
+  t.cell_base_mag.assign(t.NQ, 0.f);
+  t.cell_dir.assign(t.NQ, 0.f);
+  t.range_idx.assign(t.NQ, 0);
+  t.memb.assign((size_t)T * H * t.NW, 0u);
+  t.in_circle.assign((size_t)(MAX_SPEED + 1) * 2 * t.NW, 0u);
+
+  for (int x = 0; x < W; x++) {
+    for (int y = 0; y <= t.YH; y++) {
+      const int q = y * W + x;
+      const float dist = (float)(sqrt(pow((double)(CX - x), 2.0) + pow((double)(CY - y), 2.0)) * CELL_WIDTH);
+      const float base = (float)(15 * pow((3000.0 - dist), 4.0) / 100000000.0);
+      float d = 0.0f;
+      if (x < CX) {
+        if (y < CY) { d = atanf((float)(CY - y) / (float)(CX - x)); d = (float)(d * (360.0 / 6.28)); d = (float)(180.0 - d); }
+        else if (y == CY) d = 180.0f;
+        else { d = atanf((float)(y - CY) / (float)(CX - x)); d = (float)(d * (360.0 / 6.28)); d = (float)(180.0 + d); }
+      } else if (x == CX) {
+        d = (y < CY) ? 90.0f : (y == CY ? -1.0f : 270.0f);
+      } else {
+        if (y < CY) { d = atanf((float)(CY - y) / (float)(x - CX)); d = (float)(d * (360.0 / 6.28)); }
+        else if (y == CY) d = 0.0f;
+        else { d = atanf((float)(y - CY) / (float)(x - CX)); d = (float)(d * (360.0 / 6.28)); d = (float)(360.0 - d); }
+      }
+      t.cell_dist[q] = dist;
+      t.cell_base_mag[q] = base;
+      t.cell_dir[q] = d;
+      if (y < t.YH) {
+        const int ri = (int)rint(d * 2.0);  // vfh.cpp:1018
+        if (ri < 0 || ri > 360) return false;  // cannot happen for front cells (y < CY or odd-W centre row)
+        t.range_idx[q] = ri;
+      }
+      for (int tb = 0; tb < T; tb++) {
+        const int max_speed_this_table = (int)(((float)(tb + 1) / (float)T) * (float)MAX_SPEED);
+        float enlarge;
+        if (dist > 0) {
+          const float r = ROBOT_RADIUS + k_safety_dist(SD0, SD1, max_speed_this_table);
+          enlarge = (float)((float)asinf(r / dist) * (180 / M_PI));
+        } else {
+          enlarge = 0;
+        }
+        const float plus_dir = d + enlarge, neg_dir = d - enlarge;
+        for (int i = 0; i < (360 / SA); i++) {
+          const float plus_sector = (i + 1) * (float)SA, neg_sector = i * (float)SA;
+          const float nn = sector_to_dir(neg_sector, neg_dir), pn = sector_to_dir(plus_sector, neg_dir);
+          const float pp = sector_to_dir(plus_sector, plus_dir), np = sector_to_dir(neg_sector, plus_dir);
+          bool plus_dir_bw = false, neg_dir_bw = false, around = false;
+          if ((nn >= 0) && (pn <= 0)) neg_dir_bw = true;
+          if ((np >= 0) && (pp <= 0)) plus_dir_bw = true;
+          if ((nn <= 0) && (np >= 0)) around = true;
+          if ((pn <= 0) && (pp >= 0)) plus_dir_bw = true;
+          if (plus_dir_bw || neg_dir_bw || around) t.memb[((size_t)tb * H + i) * t.NW + (q >> 5)] |= 1u << (q & 31);
+        }
+      }
+      if (y < t.YH) {  // blocked-circle membership per speed (vfh.cpp:1140-1189)
+        for (int s = 0; s <= MAX_SPEED; s++) {
+          const float cxr = CX + (t.mtr[s] / (float)CELL_WIDTH);
+          const float cxl = CX - (t.mtr[s] / (float)CELL_WIDTH);
+          const float cy = (float)CY;
+          const float dr = k_hypotf(cxr - x, cy - y) * CELL_WIDTH;
+          const float dl = k_hypotf(cxl - x, cy - y) * CELL_WIDTH;
+          if (dr < t.bcr[s]) t.in_circle[((size_t)s * 2 + 0) * t.NW + (q >> 5)] |= 1u << (q & 31);
+          if (dl < t.bcr[s]) t.in_circle[((size_t)s * 2 + 1) * t.NW + (q >> 5)] |= 1u << (q & 31);
+        }
+      }
+    }
+  }
+  return true;
+}
+
+template <typename T>
+int upload(rna_engine* e, T** dst, const std::vector<T>& src) {
+  int rc = dev_alloc(e, dst, src.size());
+  if (rc != RNA_OK) return rc;
+  RNA_HIP(e, hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, e->stream));
+  return RNA_OK;
+}
+
+VfhK make_k(const rna_engine* e) {
+  const VfhDevice& v = e->vfh;
+  VfhK K{};
+  K.W = v.W; K.H = v.H; K.T = v.T; K.CX = v.CX; K.CY = v.CY; K.YH = v.NQF / v.W; K.NQ = v.NQ; K.NQF = v.NQF;
+  K.NW = v.NW; K.max_speed = v.max_speed; K.sector_angle = v.p.sector_angle;
+  K.cell_width = (float)v.p.cell_size; K.robot_radius = (float)v.p.robot_radius;
+  K.sd0 = (float)v.p.safety_dist_0ms; K.sd1 = (float)v.p.safety_dist_1ms;
+  K.bl0 = (float)v.p.free_space_cutoff_0ms; K.bh0 = (float)v.p.obs_cutoff_0ms;
+  K.bl1 = (float)v.p.free_space_cutoff_1ms; K.bh1 = (float)v.p.obs_cutoff_1ms;
+  K.U1 = (float)v.p.weight_desired_dir; K.U2 = (float)v.p.weight_current_dir;
+  K.current_max_speed = v.p.max_speed; K.max_speed_narrow = v.p.max_speed_narrow_opening;
+  K.max_speed_wide = v.p.max_speed_wide_opening; K.max_accel = v.p.max_acceleration;
+  K.mt0 = v.p.max_turnrate_0ms; K.mt1 = v.p.max_turnrate_1ms;
+  K.cell_dist = v.cell_dist; K.cell_base_mag = v.cell_base_mag; K.cell_dir = v.cell_dir; K.range_idx = v.range_idx;
+  K.memb = v.memb; K.in_circle = v.in_circle; K.mtr = v.min_turning_radius; K.bcr = v.blocked_radius + v.n_robots;
+  K.last_binary = v.last_binary; K.hist = v.hist; K.origin = v.origin; K.picked = v.picked;
+  K.last_picked = v.last_picked; K.blocked_radius = v.blocked_radius; K.last_chosen_speed = v.last_chosen_speed;
+  K.max_speed_picked = v.last_chosen_speed + v.n_robots;
+  return K;
+}
+
+int ensure_staging(rna_engine* e, bool ranges) {
+  VfhDevice& v = e->vfh;
+  int rc;
+  if (!v.poses_dev) {
+    if ((rc = dev_alloc(e, &v.poses_dev, (size_t)v.n_robots)) != RNA_OK) return rc;
+    if ((rc = dev_alloc(e, &v.out_dev, (size_t)v.n_robots)) != RNA_OK) return rc;
+  }
+  if (ranges && !v.ranges_dev)
+    if ((rc = dev_alloc(e, &v.ranges_dev, (size_t)v.n_robots * 361 * 2)) != RNA_OK) return rc;
+  return RNA_OK;
+}
+
+int launch_step(rna_engine* e, const rna_pose* poses_dev, const double* ranges_dev, int n, rna_vfh_out* out_dev,
+                float* origin_dev, float* hist_dev) {
+  KernelTimer kt(e, RNA_K_VFH_STEP);
+  hipLaunchKernelGGL(vfh_step_kernel, dim3(n), dim3(VFH_THREADS), 0, e->stream, make_k(e), e->geom,
+                     e->layer[RNA_LAYER_MASTER], poses_dev, ranges_dev, out_dev, origin_dev, hist_dev);
+  RNA_HIP(e, hipGetLastError());
+  return RNA_OK;
+}
+
+}  // namespace
+
+namespace rna {
+int vfh_release(rna_engine* e) {
+  VfhDevice& v = e->vfh;
+  dev_free(&v.cell_dist); dev_free(&v.cell_base_mag); dev_free(&v.cell_dir); dev_free(&v.range_idx);
+  dev_free(&v.memb); dev_free(&v.in_circle); dev_free(&v.min_turning_radius);
+  dev_free(&v.last_binary); dev_free(&v.hist); dev_free(&v.origin); dev_free(&v.picked); dev_free(&v.last_picked);
+  dev_free(&v.blocked_radius); dev_free(&v.last_chosen_speed);
+  dev_free(&v.poses_dev); dev_free(&v.out_dev); dev_free(&v.ranges_dev);
+  v.ready = false;
+  return RNA_OK;
+}
+}  // namespace rna
+
+extern "C" void rna_vfh_default_params(rna_vfh_params* p) {  // Steerer::initVfh, steerer.cpp:69-121
+  if (!p) return;
+  p->cell_size = 100; p->window_diameter = 30; p->sector_angle = 5;
+  p->safety_dist_0ms = 10; p->safety_dist_1ms = 50;
+  p->max_speed = 200; p->max_speed_narrow_opening = 200; p->max_speed_wide_opening = 300;
+  p->max_acceleration = 200; p->min_turnrate = 40; p->max_turnrate_0ms = 40; p->max_turnrate_1ms = 40;
+  p->min_turn_radius_safety_factor = 1.0;
+  p->free_space_cutoff_0ms = 2000000.0; p->obs_cutoff_0ms = 4000000.0;
+  p->free_space_cutoff_1ms = 2000000.0; p->obs_cutoff_1ms = 4000000.0;
+  p->weight_desired_dir = 10.0; p->weight_current_dir = 1.0;
+  p->robot_radius = 178.0;
+}
+
+extern "C" int rna_vfh_init(rna_engine* e, const rna_vfh_params* p, int n_robots) {
+  if (!e || !p || n_robots <= 0) return RNA_EINVAL;
+  RNA_HIP(e, hipSetDevice(e->device));
+  HostTables t;
+  if (!build_tables(*p, t)) return fail(e, RNA_EINVAL, "rna_vfh_init: unsupported VFH parameters");
+  RNA_HIP(e, hipStreamSynchronize(e->stream));
+  vfh_release(e);
+  VfhDevice& v = e->vfh;
+  v.p = *p;
+  v.n_robots = n_robots;
+  v.W = t.W; v.H = t.H; v.T = t.T; v.CX = t.CX; v.CY = t.CY; v.NQ = t.NQ; v.NQF = t.NQF; v.NW = t.NW;
+  v.max_speed = t.max_speed;
+  int rc;
+  if ((rc = upload(e, &v.cell_dist, t.cell_dist)) != RNA_OK) return rc;
+  if ((rc = upload(e, &v.cell_base_mag, t.cell_base_mag)) != RNA_OK) return rc;
+  if ((rc = upload(e, &v.cell_dir, t.cell_dir)) != RNA_OK) return rc;
+  if ((rc = upload(e, &v.range_idx, t.range_idx)) != RNA_OK) return rc;
+  if ((rc = upload(e, &v.memb, t.memb)) != RNA_OK) return rc;
+  if ((rc = upload(e, &v.in_circle, t.in_circle)) != RNA_OK) return rc;
+  if ((rc = upload(e, &v.min_turning_radius, t.mtr)) != RNA_OK) return rc;
+  const size_t nh = (size_t)n_robots * t.H;
+  if ((rc = dev_alloc(e, &v.last_binary, nh)) != RNA_OK) return rc;
+  if ((rc = dev_alloc(e, &v.hist, nh)) != RNA_OK) return rc;
+  if ((rc = dev_alloc(e, &v.origin, nh)) != RNA_OK) return rc;
+  if ((rc = dev_alloc(e, &v.picked, (size_t)n_robots)) != RNA_OK) return rc;
+  if ((rc = dev_alloc(e, &v.last_picked, (size_t)n_robots)) != RNA_OK) return rc;
+  // blocked_radius: [n_robots] per-robot state followed by the [max_speed+1] per-speed table
+  if ((rc = dev_alloc(e, &v.blocked_radius, (size_t)n_robots + t.bcr.size())) != RNA_OK) return rc;
+  RNA_HIP(e, hipMemcpyAsync(v.blocked_radius + n_robots, t.bcr.data(), t.bcr.size() * sizeof(float),
+                            hipMemcpyHostToDevice, e->stream));
+  // last_chosen_speed: [n_robots] followed by Max_Speed_For_Picked_Angle [n_robots]
+  if ((rc = dev_alloc(e, &v.last_chosen_speed, (size_t)2 * n_robots)) != RNA_OK) return rc;
+  RNA_HIP(e, hipStreamSynchronize(e->stream));  // host vectors go out of scope
+  v.ready = true;
+  return rna_vfh_reset(e);
+}
+
+extern "C" int rna_vfh_reset(rna_engine* e) {
+  if (!e) return RNA_EINVAL;
+  if (!e->vfh.ready) return fail(e, RNA_ESTATE, "rna_vfh_reset before rna_vfh_init");
+  RNA_HIP(e, hipSetDevice(e->device));
+  const int n = e->vfh.n_robots;
+  const int threads = n * e->vfh.H;
+  hipLaunchKernelGGL(vfh_reset_kernel, dim3((threads + 255) / 256), dim3(256), 0, e->stream, make_k(e), n);
+  RNA_HIP(e, hipGetLastError());
+  RNA_HIP(e, hipStreamSynchronize(e->stream));
+  return RNA_OK;
+}
+
+extern "C" int rna_vfh_hist_size(const rna_engine* e) { return (e && e->vfh.ready) ? e->vfh.H : RNA_ESTATE; }
+
+extern "C" int rna_vfh_step_batch_device(rna_engine* e, const rna_pose* poses, int n, rna_vfh_out* out,
+                                         float* origin_hist, float* hist) {
+  if (!e || !poses || !out || n < 0) return RNA_EINVAL;
+  if (!e->vfh.ready) return fail(e, RNA_ESTATE, "rna_vfh_step_batch before rna_vfh_init");
+  if (n > e->vfh.n_robots) return fail(e, RNA_EINVAL, "more poses than VFH instances");
+  if (n == 0) return RNA_OK;
+  RNA_HIP(e, hipSetDevice(e->device));
+  return launch_step(e, poses, nullptr, n, out, origin_hist, hist);
+}
+
+static int step_host(rna_engine* e, const double* ranges_host, const rna_pose* poses_host, int n,
+                     rna_vfh_out* out_host, float* origin_host, float* hist_host) {
+  if (!e || !poses_host || !out_host || n < 0) return RNA_EINVAL;
+  if (!e->vfh.ready) return fail(e, RNA_ESTATE, "VFH step before rna_vfh_init");
+  VfhDevice& v = e->vfh;
+  if (n > v.n_robots) return fail(e, RNA_EINVAL, "more poses than VFH instances");
+  if (n == 0) return RNA_OK;
+  RNA_HIP(e, hipSetDevice(e->device));
+  int rc = ensure_staging(e, ranges_host != nullptr);
+  if (rc != RNA_OK) return rc;
+  RNA_HIP(e, hipMemcpyAsync(v.poses_dev, poses_host, (size_t)n * sizeof(rna_pose), hipMemcpyHostToDevice, e->stream));
+  if (ranges_host)
+    RNA_HIP(e, hipMemcpyAsync(v.ranges_dev, ranges_host, (size_t)n * 361 * 2 * sizeof(double), hipMemcpyHostToDevice,
+                              e->stream));
+  rc = launch_step(e, v.poses_dev, ranges_host ? v.ranges_dev : nullptr, n, v.out_dev, nullptr, nullptr);
+  if (rc != RNA_OK) return rc;
+  RNA_HIP(e, hipMemcpyAsync(out_host, v.out_dev, (size_t)n * sizeof(rna_vfh_out), hipMemcpyDeviceToHost, e->stream));
+  if (origin_host)
+    RNA_HIP(e, hipMemcpyAsync(origin_host, v.origin, (size_t)n * v.H * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  if (hist_host)
+    RNA_HIP(e, hipMemcpyAsync(hist_host, v.hist, (size_t)n * v.H * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  RNA_HIP(e, hipStreamSynchronize(e->stream));
+  return RNA_OK;
+}
+
+extern "C" int rna_vfh_step_batch(rna_engine* e, const rna_pose* poses_host, int n, rna_vfh_out* out_host,
+                                  float* origin_hist_host, float* hist_host) {
+  return step_host(e, nullptr, poses_host, n, out_host, origin_hist_host, hist_host);
+}
+
+extern "C" int rna_vfh_update_batch(rna_engine* e, const double* ranges_host, const rna_pose* poses_host, int n,
+                                    rna_vfh_out* out_host, float* origin_hist_host, float* hist_host) {
+  if (!ranges_host) return RNA_EINVAL;
+  return step_host(e, ranges_host, poses_host, n, out_host, origin_hist_host, hist_host);
+}

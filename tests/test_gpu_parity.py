@@ -1,0 +1,330 @@
+"""GPU parity tests: the HIP path (through the C ABI in include/rna.h) against the CPU oracle on the
+same seeded inputs, and against the committed golden vectors generated from the reference.
+Bit-exact for cells/indices/paths/integers and for the VFH histogram floats; RRT waypoints (double
+positions built from device atan2/cos/sin) within 1e-9 m."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "vfh_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def R():
+    import ros_navigation_amd as R
+    R.capi.lib()  # fails loudly when librna.so is missing -- there is no fallback
+    return R
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def same_f32(a, b):
+    """bitwise equality, all NaNs treated as equal"""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(bits(a)[~np.isnan(a)], bits(b)[~np.isnan(b)])
+
+
+# ------------------------------------------------------------------------------------------------
+# container
+# ------------------------------------------------------------------------------------------------
+def test_layers_geometry_roundtrip(R):
+    e = R.Engine(10.0, 7.5, 0.05, 1.25, -2.5)
+    g = O.make_geom(10.0, 7.5, 0.05, 1.25, -2.5)
+    assert (e.rows, e.cols) == (g.size[0], g.size[1]) == (200, 150)
+    assert np.all(np.isnan(e.download(R.capi.LAYER_MASTER)))  # setGeometry -> NaN
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=e.ncell).astype(np.float32)
+    e.upload(R.capi.LAYER_RANGE, a)
+    assert np.array_equal(e.download(R.capi.LAYER_RANGE), a)
+    for _ in range(200):
+        x, y = rng.uniform(-5, 8), rng.uniform(-8, 3)
+        out = O.i2(0, 0)
+        ok = O.lib().og_index_from_position(C.byref(g), O.d2(x, y), out)
+        got = e.get_index(x, y)
+        assert (got is not None) == bool(ok)
+        if ok:
+            assert got == (out[0], out[1])
+            p = O.d2(0, 0)
+            O.lib().og_position_from_index(C.byref(g), out, p)
+            assert e.get_position(*got) == (p[0], p[1])
+    e.close()
+
+
+def test_move_matches_oracle(R):
+    e = R.Engine(8.1, 5.1, 1.0)
+    g = O.make_geom(8.1, 5.1, 1.0)
+    a = np.arange(40, dtype=np.float32)
+    for l in range(3):
+        e.upload(l, a)
+    ref = a.copy()
+    ptrs = (C.POINTER(C.c_float) * 1)(O.fptr(ref))
+    regs = (O.Region * 4)()
+    mv = C.c_int(0)
+    for target in ((-3.0, -2.0), (-2.0, 1.0), (4.4, 0.4), (40.0, 0.0)):
+        O.lib().og_move(C.byref(g), ptrs, 1, O.d2(*target), regs, C.byref(mv))
+        assert e.move(*target) == bool(mv.value)
+        gg = e.geometry()
+        assert tuple(gg.start_index) == tuple(g.start) and tuple(gg.position) == tuple(g.pos)
+        assert same_f32(e.download(R.capi.LAYER_LASER), ref)
+    e.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# HIMM
+# ------------------------------------------------------------------------------------------------
+def random_rays(rng, n, half, hit=0.7, outside=0.2):
+    r = np.zeros(n, O.RAY_DTYPE)
+    ox, oy = rng.uniform(-half, half, n), rng.uniform(-half, half, n)
+    th, ln = rng.uniform(-np.pi, np.pi, n), rng.uniform(0.0, 1.5 * half, n)
+    far = rng.random(n) < outside
+    ox[far] *= 2.5
+    r["sx"], r["sy"] = ox, oy
+    r["ex"], r["ey"] = ox + ln * np.cos(th), oy + ln * np.sin(th)
+    r["clear_end"] = (rng.random(n) >= hit).astype(np.int32)
+    return r
+
+
+@pytest.mark.parametrize("seed,n", [(0, 1), (1, 50), (2, 3000), (3, 20000)])
+def test_himm_matches_oracle(R, seed, n):
+    rng = np.random.default_rng(seed)
+    e = R.Engine(6.4, 4.8, 0.05)  # 128 x 96
+    g = O.make_geom(6.4, 4.8, 0.05)
+    init = rng.choice(np.array([np.nan, 0, 10, 50, 150, 160, 170, 180, 7.5, -3, 1e3], np.float32), e.ncell)
+    e.upload(R.capi.LAYER_LASER, init)
+    rays = random_rays(rng, n, 3.0)
+    # many rays ending in the same few cells (a wall seen by consecutive beams): ordering of marks
+    k = max(1, n // 4)
+    rays["ex"][:k] = 1.0 + rng.integers(0, 3, k) * 0.05
+    rays["ey"][:k] = 0.5
+    rays["clear_end"][:k] = 0
+    ref = init.copy()
+    for lo in range(0, n, 7000):  # several batches in sequence
+        chunk = rays[lo:lo + 7000]
+        O.himm_update(g, ref, chunk)
+        e.himm_update(R.capi.LAYER_LASER, chunk.view(R.capi.RAY_DTYPE))
+    assert same_f32(e.download(R.capi.LAYER_LASER), ref)
+    e.close()
+
+
+def test_himm_zero_length_and_outside_rays(R):
+    e = R.Engine(2.0, 2.0, 0.05)
+    g = O.make_geom(2.0, 2.0, 0.05)
+    rays = np.zeros(6, O.RAY_DTYPE)
+    rays[0] = (0.3, 0.3, 0.3, 0.3, 0, 0)      # zero length inside: one cell cleared then marked
+    rays[1] = (5.0, 5.0, 5.0, 5.0, 0, 0)      # zero length outside
+    rays[2] = (-8.0, 8.0, 8.0, 8.0, 1, 0)     # misses the map
+    rays[3] = (0.0, 0.0, 3.0, 0.0, 0, 0)      # end outside: clipped, no mark
+    rays[4] = (3.0, 3.0, 0.0, 0.0, 0, 0)      # start outside
+    rays[5] = (0.999, 0.999, -0.999, -0.999, 1, 0)
+    ref = np.full(1600, np.nan, np.float32)
+    O.himm_update(g, ref, rays)
+    e.himm_update(R.capi.LAYER_LASER, rays.view(R.capi.RAY_DTYPE))
+    assert same_f32(e.download(R.capi.LAYER_LASER), ref)
+    e.close()
+
+
+def test_update_map_compose_modes(R):
+    rng = np.random.default_rng(5)
+    for mode in (0, 1):
+        e = R.Engine(12.8, 12.8, 0.05)  # 256 x 256 -> 4 x 4 tiles
+        g = O.make_geom(12.8, 12.8, 0.05)
+        laser = np.full(e.ncell, np.nan, np.float32)
+        for step in range(3):
+            rays = random_rays(rng, 400, 2.0 + step, outside=0.0)
+            O.himm_update(g, laser, rays)
+            e.update_map(rays.view(R.capi.RAY_DTYPE), compose_mode=mode)
+            assert same_f32(e.download(R.capi.LAYER_LASER), laser)
+            assert same_f32(e.download(R.capi.LAYER_MASTER), laser)  # master = laser (map_provider.cpp:221)
+            _, nbr = O.astar_masks(laser, e.rows, e.cols)
+            assert np.array_equal(e.nbr_mask(), nbr)
+        e.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# VFH
+# ------------------------------------------------------------------------------------------------
+def check_vfh_vs_oracle(R, e, g, master, poses, steps, params=None):
+    n = len(poses)
+    oracles = [O.OracleVfh(params) for _ in range(n)]
+    rng = np.random.default_rng(99)
+    for s in range(steps):
+        out, origin, hist = e.vfh_step(poses)
+        for k in range(n):
+            p = poses[k]
+            cs, ct = oracles[k].step_pose(g, master, p["x"], p["y"], p["yaw"], int(p["current_speed"]),
+                                          p["goal_direction"], p["goal_distance"], p["goal_tolerance"], float(p["dt"]))
+            assert (out["chosen_speed"][k], out["chosen_turnrate"][k]) == (cs, ct), (s, k)
+            assert bits(origin[k]).tobytes() == bits(oracles[k].origin_hist()).tobytes(), (s, k)
+            assert bits(hist[k]).tobytes() == bits(oracles[k].hist()).tobytes(), (s, k)
+            assert np.float32(out["picked_angle"][k]) == np.float32(oracles[k].picked_angle()), (s, k)
+        # robots move a little and change their state between steps
+        poses["x"] += rng.uniform(-0.05, 0.05, n)
+        poses["y"] += rng.uniform(-0.05, 0.05, n)
+        poses["yaw"] += rng.uniform(-0.2, 0.2, n)
+        poses["current_speed"] = out["chosen_speed"]
+        poses["goal_direction"] = rng.uniform(0, 360, n).astype(np.float32)
+
+
+def test_vfh_step_matches_oracle_on_sparse_map(R):
+    e = R.Engine(20.0, 20.0, 0.05)  # 400 x 400
+    g = O.make_geom(20.0, 20.0, 0.05)
+    master = R.synth.occupancy_sparse(e.rows, e.cols, seed=1)
+    e.upload(R.capi.LAYER_MASTER, master)
+    poses = R.synth.poses(96, 20.0, 20.0, seed=1)
+    e.vfh_init(len(poses))
+    check_vfh_vs_oracle(R, e, g, master, poses, steps=6)
+    e.close()
+
+
+def test_vfh_step_dense_walls_edges_and_w60(R):
+    e = R.Engine(12.0, 12.0, 0.05)
+    g = O.make_geom(12.0, 12.0, 0.05)
+    master = R.synth.obstacles_rect(e.rows, e.cols, density=0.12, seed=7, side=(2, 12))
+    e.upload(R.capi.LAYER_MASTER, master)
+    poses = R.synth.poses(64, 12.0, 12.0, seed=3, margin=0.2, speed=60)   # windows clipped at the map edge
+    poses["x"][0], poses["y"][0] = 30.0, 0.0                                # robot outside the map
+    e.vfh_init(len(poses))
+    check_vfh_vs_oracle(R, e, g, master, poses.copy(), steps=5)
+    p = O.default_vfh_params()
+    p.window_diameter, p.robot_radius, p.safety_dist_0ms, p.safety_dist_1ms = 60, 300.0, 100.0, 100.0
+    p.max_turnrate_0ms, p.max_turnrate_1ms = 80, 40
+    rp = R.capi.default_vfh_params()
+    for f, _ in rp._fields_:
+        setattr(rp, f, getattr(p, f))
+    e.vfh_init(len(poses), rp)
+    check_vfh_vs_oracle(R, e, g, master, poses.copy(), steps=4, params=p)
+    e.close()
+
+
+@pytest.mark.parametrize("pi", [0, 1])
+def test_vfh_update_matches_reference_golden(R, pi):
+    """Update_VFH on caller-provided scans against vectors produced by the reference's own vfh.cpp."""
+    z = np.load(GOLD)
+    pre = "p%d_" % pi
+    rp = R.capi.default_vfh_params()
+    for (name, ctype), v in zip(rp._fields_, z[pre + "params"]):
+        setattr(rp, name, int(v) if "int" in ctype.__name__ else float(v))
+    Rg = z[pre + "ranges_even"]
+    n_seq, n_step = Rg.shape[:2]
+    e = R.Engine(4.0, 4.0, 0.05)
+    e.vfh_init(n_seq, rp)
+    for k in range(n_step):
+        ranges = np.full((n_seq, 361, 2), 5000.0)
+        ranges[:, 0::2, 0] = Rg[:, k]
+        poses = np.zeros(n_seq, R.capi.POSE_DTYPE)
+        poses["dt"] = z[pre + "dt"][:, k]
+        poses["current_speed"] = z[pre + "speed"][:, k]
+        poses["goal_direction"] = z[pre + "goal_dir"][:, k]
+        poses["goal_distance"] = z[pre + "goal_dist"][:, k]
+        poses["goal_tolerance"] = z[pre + "goal_tol"][:, k]
+        out, origin, hist = e.vfh_update(ranges, poses)
+        assert np.array_equal(out["chosen_speed"], z[pre + "chosen_speed"][:, k]), k
+        assert np.array_equal(out["chosen_turnrate"], z[pre + "chosen_turnrate"][:, k]), k
+        assert bits(origin).tobytes() == bits(z[pre + "origin_hist"][:, k]).tobytes(), k
+        assert bits(hist).tobytes() == bits(z[pre + "hist"][:, k]).tobytes(), k
+        assert bits(out["picked_angle"]).tobytes() == bits(z[pre + "picked"][:, k]).tobytes(), k
+    e.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# grid A*
+# ------------------------------------------------------------------------------------------------
+def check_astar(R, e, master, queries, max_len, **cfg):
+    if cfg:
+        e.astar_configure(**cfg)
+    res, paths = e.astar(queries, max_len)
+    settled = e.astar_settled(len(queries))
+    _, nbr = O.astar_masks(master, e.rows, e.cols)
+    assert np.array_equal(e.nbr_mask(), nbr)
+    gw = np.empty(e.ncell, np.int32)
+    total_settled = 0
+    for k, q in enumerate(queries):
+        ores, opath, _ = O.astar_query(nbr, e.rows, e.cols, q["start"], q["goal"], g_work=gw)
+        assert res["status"][k] == ores.status, (k, q)
+        if ores.status == 0:
+            assert res["cost"][k] == ores.cost and res["path_len"][k] == ores.path_len, (k, q)
+            assert np.array_equal(paths[k, :ores.path_len], opath), (k, q)
+            assert res["expanded"][k] >= ores.settled
+            assert settled[k] == ores.settled, (k, q)   # the whole settled g field agrees with the oracle
+            total_settled += ores.settled
+    return res, total_settled
+
+
+@pytest.mark.parametrize("rows,cols,density,seed", [(64, 64, 0.25, 1), (200, 120, 0.3, 2), (512, 512, 0.3, 3)])
+def test_astar_paths_bit_identical(R, rows, cols, density, seed):
+    e = R.Engine(rows * 0.05, cols * 0.05, 0.05)
+    assert (e.rows, e.cols) == (rows, cols)
+    master = R.synth.obstacles_rect(rows, cols, density=density, seed=seed, side=(2, max(4, rows // 10)))
+    master[np.random.default_rng(seed).random(rows * cols) < 0.03] = np.nan  # unknown cells are free
+    e.upload(R.capi.LAYER_MASTER, master)
+    q = R.synth.astar_queries(40, master, rows, cols, seed=seed)
+    rng = np.random.default_rng(seed)
+    q["start"][:6] = rng.integers(0, rows * cols, 6)     # arbitrary cells: blocked / disconnected cases
+    q["goal"][6] = q["start"][6]                          # trivial query
+    for bw in (2828, 8000, 50000):
+        check_astar(R, e, master, q, rows * cols, bucket_width=bw)
+    e.close()
+
+
+def test_astar_invalid_and_short_buffer(R):
+    e = R.Engine(3.2, 3.2, 0.05)
+    master = np.zeros(e.ncell, np.float32)
+    e.upload(R.capi.LAYER_MASTER, master)
+    q = np.zeros(3, R.capi.ASTAR_QUERY_DTYPE)
+    q[0] = (-1, 5)
+    q[1] = (0, e.ncell)
+    q[2] = (0, e.ncell - 1)
+    res, paths = e.astar(q, 16)
+    assert list(res["status"]) == [2, 2, 3] and res["path_len"][2] == 64
+    e.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own planners
+# ------------------------------------------------------------------------------------------------
+def test_graph_astar_matches_oracle(R):
+    e = R.Engine(2.0, 2.0, 0.05)
+    loc = (C.c_double * 18)()
+    euv = (C.c_int * 20)()
+    O.lib().og_reference_graph(loc, euv)
+    V = np.array(loc).reshape(9, 2)
+    E = np.array(euv, np.int32).reshape(10, 2)
+    rng = np.random.default_rng(4)
+    st = rng.uniform(-2, 24, (64, 4))
+    st[:, 1] = rng.uniform(-2, 12, 64)
+    st[:, 3] = rng.uniform(-2, 12, 64)
+    plen, paths = e.graph_astar(V, E, st)
+    out = (C.c_double * 64)()
+    for k in range(64):
+        n = O.lib().og_graph_make_plan(O.d2(st[k, 0], st[k, 1]), O.d2(st[k, 2], st[k, 3]), out, 32)
+        assert plen[k] == n
+        assert np.array_equal(paths[k, :n].reshape(-1), np.array(out[:2 * n]))
+    e.close()
+
+
+def test_rrt_matches_oracle(R):
+    e = R.Engine(10.0, 10.0, 0.05)
+    g = O.make_geom(10.0, 10.0, 0.05)
+    master = R.synth.obstacles_rect(e.rows, e.cols, density=0.08, seed=3, side=(4, 24))
+    e.upload(R.capi.LAYER_MASTER, master)
+    q = R.synth.rrt_queries(24, master, e.rows, e.cols, e.get_position, seed=3)
+    q["target"][0] = (40.0, 0.0)          # target outside the map: plan to the boundary
+    q["max_samples"][1] = 3               # sample budget exhausted
+    res, paths = e.rrt(q)
+    for k in range(len(q)):
+        ores, opath = O.rrt_plan(g, master, tuple(q["start"][k]), tuple(q["target"][k]), tol=0.2,
+                                 seed=int(q["seed"][k]), max_samples=int(q["max_samples"][k]))
+        assert (res["status"][k], res["path_len"][k], res["tree_size"][k], res["samples"][k]) == \
+               (ores.status, ores.path_len, ores.tree_size, ores.samples), k
+        n = ores.path_len
+        assert np.allclose(paths[k, :n], opath, rtol=0, atol=1e-9), k
+    e.close()
