@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- replan cycles/sec (HIMM + VFH+ + A*) on a 4096 x 4096 grid, BASELINE.json's metric.
+
+One "step" = one pass of the hot path over one batch of synthetic input, all resident in HBM:
+    HIMM ray batch (64 robot origins x 1563 rays) on the laser layer + fused compose-master
+    -> VFH+ step for 256 robot poses -> grid A* for 256 (start, goal) queries.
+A "replan cycle" is one (pose -> VFH command, start/goal -> A* path) pair served against the map
+that has received its HIMM batch, so one step = 256 cycles with the ray batch amortised over them
+(SURVEY.md section 8d).  N > 1: one process per GPU, each with its own replicated grid and its own
+shard of poses/queries (weak scaling, no data-path collective); value = all ranks' cycles / max time.
+
+Prints ONE JSON line on rank 0 (see the task contract) including
+  roofline:     dominant kernel (astar_search) algorithmic GB/s vs the 8 TB/s HBM peak
+  cpu_baseline: the CPU oracle ("port") timed on a bounded sample of the same workload, 1 core
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+ASTAR_BYTES_PER_SETTLED = 44   # 8 neighbour occupancy reads x 4 B + 12 B g/parent/flag RMW
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--grid", type=int, default=4096)
+    ap.add_argument("--queries", type=int, default=256, help="A* queries == VFH poses per step (cycles per step)")
+    ap.add_argument("--ray-poses", type=int, default=64)
+    ap.add_argument("--rays-per-pose", type=int, default=1563)
+    ap.add_argument("--bucket-width", type=int, default=0)
+    ap.add_argument("--queue-capacity", type=int, default=0)
+    ap.add_argument("--max-path", type=int, default=32768)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, R, master, rays, poses, queries, rows, cols, length):
+    """Oracle (CPU restatement of the reference path) on a bounded sample; 1 thread."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    g = O.make_geom(length, length, 0.05)
+    laser = master.copy()
+    t0 = time.perf_counter()
+    O.himm_update(g, laser, rays.view(O.RAY_DTYPE))
+    mast = laser.copy()  # compose: master = laser (whole-layer copy, as the reference does)
+    t_himm = time.perf_counter() - t0
+    n_vfh = min(len(poses), 256)
+    vs = [O.OracleVfh() for _ in range(n_vfh)]
+    t0 = time.perf_counter()
+    for k in range(n_vfh):
+        p = poses[k]
+        vs[k].step_pose(g, mast, p["x"], p["y"], p["yaw"], int(p["current_speed"]), p["goal_direction"],
+                        p["goal_distance"], p["goal_tolerance"], float(p["dt"]))
+    t_vfh = (time.perf_counter() - t0) / n_vfh
+    _, nbr = O.astar_masks(mast, rows, cols)
+    gw = np.empty(rows * cols, np.int32)
+    t_a, n_a, settled = 0.0, 0, 0
+    while n_a < len(queries) and (n_a < 2 or t_a < args.cpu_seconds):
+        q = queries[n_a]
+        t0 = time.perf_counter()
+        res, _, _ = O.astar_query(nbr, rows, cols, q["start"], q["goal"], path_cap=rows * cols, g_work=gw)
+        t_a += time.perf_counter() - t0
+        settled += res.settled
+        n_a += 1
+    per_cycle = t_himm / len(queries) + t_vfh + t_a / n_a
+    return {"value": 1.0 / per_cycle, "unit": "replan cycles/s", "cores": 1, "kind": "port",
+            "sample": "oracle (C, -O2, 1 thread): full %d-ray HIMM batch + compose (%.3f s, amortised over %d cycles), "
+                      "%d VFH+ poses (%.1f us each), first %d A* queries (%.2f s each, %.0f cells settled each)"
+                      % (len(rays), t_himm, len(queries), n_vfh, t_vfh * 1e6, n_a, t_a / n_a, settled / n_a)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import ros_navigation_amd as R
+
+    n = args.grid
+    length = n * 0.05
+    e = R.Engine(length, length, 0.05, device=local_rank)
+    assert (e.rows, e.cols) == (n, n)
+    # map: config 3's obstacle field (seed 2) is the laser layer the HIMM batches work on
+    master = R.synth.obstacles_rect(n, n, density=0.30, seed=2)
+    e.upload(R.capi.LAYER_LASER, master)
+    e.compose_master(1)
+    rays = R.synth.rays(args.ray_poses, args.rays_per_pose, length, length, seed=4 + rank)
+    poses = R.synth.poses(args.queries, length, length, seed=1 + rank)
+    queries = R.synth.astar_queries(args.queries, master, n, n, seed=2 + rank)
+    nq = args.queries
+
+    dev = torch.device("cuda", local_rank)
+
+    def to_dev(a):
+        return torch.from_numpy(np.frombuffer(a.tobytes(), dtype=np.uint8).copy()).to(dev)
+
+    d_rays, d_poses, d_queries = to_dev(rays), to_dev(poses), to_dev(queries)
+    d_vfh_out = torch.zeros(nq * R.capi.VFH_OUT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    d_paths = torch.zeros(nq * args.max_path, dtype=torch.int32, device=dev)
+    d_results = torch.zeros(nq * 4, dtype=torch.int32, device=dev)
+    e.vfh_init(nq)
+    e.astar_configure(max_queries=nq, queue_capacity=args.queue_capacity, bucket_width=args.bucket_width)
+    torch.cuda.synchronize()
+
+    def step():
+        e.update_map_device(d_rays.data_ptr(), len(rays), compose_mode=0)
+        e.vfh_step_device(d_poses.data_ptr(), nq, d_vfh_out.data_ptr())
+        e.astar_device(d_queries.data_ptr(), nq, d_paths.data_ptr(), args.max_path, d_results.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    e.synchronize()
+    torch.cuda.synchronize()
+    res = d_results.cpu().numpy().reshape(nq, 4)
+    if (res[:, 0] < 0).any():
+        raise SystemExit("A* frontier queue overflow during warm-up: pass a larger --queue-capacity")
+
+    e.profile(True)
+    e.profile_reset()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    e.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    prof = e.profile_get()
+    e.profile(False)
+
+    res = d_results.cpu().numpy().reshape(nq, 4)
+    found = int((res[:, 0] == 0).sum())
+    if (res[:, 0] < 0).any() or (res[:, 0] == 3).any():
+        raise SystemExit("A* batch did not complete (status %s)" % sorted(set(res[:, 0].tolist())))
+    settled = e.astar_settled(nq)          # E per query of the last launch, from the resident g fields
+
+    t_max = elapsed
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_max = float(t.item())
+
+    if rank == 0:
+        cycles = nq * args.steps * world
+        ms_search = prof["astar_search"][0] / max(1, prof["astar_search"][1])
+        alg_bytes = float(settled.astype(np.int64).sum()) * ASTAR_BYTES_PER_SETTLED
+        achieved = alg_bytes / (ms_search * 1e-3) / 1e9 if ms_search > 0 else 0.0
+        out = {
+            "metric": "replan cycles/sec (HIMM+VFH++A*) on %dx%d grid" % (n, n),
+            "value": cycles / t_max, "unit": "replan cycles/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "full replan loop on %dx%d f32 grid (res 0.05 m): %d-ray HIMM batch + fused "
+                                   "compose -> %d VFH+ poses -> %d grid-A* queries per step; 30%% rectangle "
+                                   "obstacles (seed 2)" % (n, n, len(rays), nq, nq),
+                       "cycles_per_step": nq, "rays_per_step": int(len(rays)), "astar_paths_found": found,
+                       "astar_bucket_width": args.bucket_width or 8000, "parallelism": "query-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "astar_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "settled_cells_per_launch": int(settled.sum()),
+                         "avg_launch_ms": ms_search, "launches": prof["astar_search"][1]},
+            "kernel_ms_per_step": {k: (v[0] / args.steps) for k, v in prof.items() if v[1]},
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args, R, master, rays, poses, queries, n, n, length)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    e.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,7 +95,7 @@ astar_search_kernel(const uint8_t* __restrict__ nbr, int rows, int cols, const r
       const int ci = cell % rows, cj = cell / rows;
       if (gv + octile(ci, cj, gi, gj) > best) continue;
       ++my_expanded;
-      if (cell == qu.goal) continue;
+      if (cell == qu.goal) { atomicMin(&s_best, gv); continue; }  // (also covers start == goal)
       const unsigned m = nbr[cell];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {

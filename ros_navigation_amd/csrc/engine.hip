@@ -154,7 +154,6 @@ extern "C" int rna_create(rna_engine** out, double length_x, double length_y, do
   auto bail = [&](int code) { rna_destroy(e); return code; };
   if (hipSetDevice(device_id) != hipSuccess) return bail(RNA_EHIP);
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(RNA_EHIP);
-  if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) return bail(RNA_EHIP);
   for (int l = 0; l < RNA_NUM_LAYERS; ++l) {
     if ((rc = dev_alloc(e, &e->layer[l], e->ncell)) != RNA_OK) return bail(rc);
     // GridMap::setGeometry -> clearAll(): every layer starts as NaN (gmc/src/GridMap.cpp:62)
@@ -180,8 +179,9 @@ extern "C" void rna_destroy(rna_engine* e) {
   for (int l = 0; l < RNA_NUM_LAYERS; ++l) dev_free(&e->layer[l]);
   dev_free(&e->dirty_tiles);
   dev_free(&e->nbr);
-  if (e->ev0) (void)hipEventDestroy(e->ev0);
-  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  (void)profile_flush(e);
+  for (hipEvent_t ev : e->free_events) (void)hipEventDestroy(ev);
+  e->free_events.clear();
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -261,6 +261,22 @@ extern "C" int rna_get_position(const rna_engine* e, int32_t i, int32_t j, doubl
 }
 
 namespace rna {
+
+int profile_flush(rna_engine* e) {
+  if (e->pending_events == 0) return RNA_OK;
+  RNA_HIP(e, hipStreamSynchronize(e->stream));
+  for (auto& slot : e->prof) {
+    for (auto& pr : slot.pending) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { slot.total_ms += ms; slot.launches += 1; }
+      e->free_events.push_back(pr.first);
+      e->free_events.push_back(pr.second);
+    }
+    slot.pending.clear();
+  }
+  e->pending_events = 0;
+  return RNA_OK;
+}
 
 // Recompute A* neighbour masks where the master layer changed.
 int map_prepare_nbr(rna_engine* e) {
@@ -373,12 +389,18 @@ extern "C" int rna_profile_enable(rna_engine* e, int on) {
 
 extern "C" int rna_profile_reset(rna_engine* e) {
   if (!e) return RNA_EINVAL;
-  for (auto& p : e->prof) p = ProfSlot();
+  RNA_HIP(e, hipSetDevice(e->device));
+  int rc = profile_flush(e);
+  if (rc != RNA_OK) return rc;
+  for (auto& p : e->prof) { p.total_ms = 0; p.launches = 0; }
   return RNA_OK;
 }
 
 extern "C" int rna_profile_get(rna_engine* e, int id, double* total_ms, int64_t* launches) {
   if (!e || id < 0 || id >= RNA_K_COUNT) return RNA_EINVAL;
+  RNA_HIP(e, hipSetDevice(e->device));
+  int rc = profile_flush(e);
+  if (rc != RNA_OK) return rc;
   if (total_ms) *total_ms = e->prof[id].total_ms;
   if (launches) *launches = e->prof[id].launches;
   return RNA_OK;
