@@ -116,7 +116,7 @@ def main():
     d_rays, d_poses, d_queries = to_dev(rays), to_dev(poses), to_dev(queries)
     d_vfh_out = torch.zeros(nq * R.capi.VFH_OUT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     d_paths = torch.zeros(nq * args.max_path, dtype=torch.int32, device=dev)
-    d_results = torch.zeros(nq * 4, dtype=torch.int32, device=dev)
+    d_results = torch.zeros(nq * 6, dtype=torch.int32, device=dev)
     e.vfh_init(nq)
     e.astar_configure(max_queries=nq, queue_capacity=args.queue_capacity, bucket_width=args.bucket_width)
     torch.cuda.synchronize()
@@ -134,7 +134,7 @@ def main():
         step()
     e.synchronize()
     torch.cuda.synchronize()
-    res = d_results.cpu().numpy().reshape(nq, 4)
+    res = d_results.cpu().numpy().reshape(nq, 6)
     if (res[:, 0] < 0).any():
         raise SystemExit("A* frontier queue overflow during warm-up: pass a larger --queue-capacity")
 
@@ -152,7 +152,7 @@ def main():
     prof = e.profile_get()
     e.profile(False)
 
-    res = d_results.cpu().numpy().reshape(nq, 4)
+    res = d_results.cpu().numpy().reshape(nq, 6)
     found = int((res[:, 0] == 0).sum())
     if (res[:, 0] < 0).any() or (res[:, 0] == 3).any():
         raise SystemExit("A* batch did not complete (status %s)" % sorted(set(res[:, 0].tolist())))

@@ -149,10 +149,13 @@ int rna_vfh_update_batch(rna_engine* e, const double* ranges_host /* n*361*2 */,
  * DESIGN.md ("Grid A* contract") and restated by oracle/astar.c. Cells are linear indices. */
 typedef struct { int32_t start, goal; } rna_astar_query;
 typedef struct {
-  int32_t status;      /* 0 found, 1 no path, 2 invalid query, 3 path longer than max_path_len */
+  int32_t status;      /* 0 found, 1 no path, 2 invalid query, 3 path longer than max_path_len,
+                          4 path cost beyond the 24-bit g range (>= 16.7e6), RNA_ECAPACITY queue overflow */
   int32_t path_len;    /* cells, start..goal inclusive */
   int32_t cost;        /* 1000/1414 integer cost of the path */
   int32_t expanded;    /* cell expansions the device performed (>= the oracle's settled count) */
+  int32_t rounds;      /* frontier rounds (workgroup barriers pairs) the search took */
+  int32_t buckets;     /* f-buckets visited */
 } rna_astar_result;
 /* max_queries: queries searched concurrently (one workgroup + one g-field each; larger batches are
  * processed in chunks); queue_capacity: entries of each per-query frontier queue; bucket_width: the

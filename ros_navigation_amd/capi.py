@@ -62,7 +62,8 @@ POSE_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("yaw", "<f8"), ("dt", "<f8")
 VFH_OUT_DTYPE = np.dtype([("chosen_speed", "<i4"), ("chosen_turnrate", "<i4"), ("picked_angle", "<f4"),
                           ("emergency", "<i4")])
 ASTAR_QUERY_DTYPE = np.dtype([("start", "<i4"), ("goal", "<i4")])
-ASTAR_RESULT_DTYPE = np.dtype([("status", "<i4"), ("path_len", "<i4"), ("cost", "<i4"), ("expanded", "<i4")])
+ASTAR_RESULT_DTYPE = np.dtype([("status", "<i4"), ("path_len", "<i4"), ("cost", "<i4"), ("expanded", "<i4"),
+                               ("rounds", "<i4"), ("buckets", "<i4")])
 RRT_QUERY_DTYPE = np.dtype([("start", "<f8", (2,)), ("target", "<f8", (2,)), ("close_tolerance", "<f8"),
                             ("seed", "<u4"), ("max_samples", "<i4")])
 RRT_RESULT_DTYPE = np.dtype([("status", "<i4"), ("path_len", "<i4"), ("tree_size", "<i4"), ("samples", "<i4")])

@@ -1,4 +1,4 @@
-// astar.hip -- batched grid A* on gfx950 (one workgroup per query) + the reference's waypoint-graph A*.
+// astar.hip -- batched grid A* on gfx950 (one workgroup per query).
 //
 // Grid A* (DESIGN.md "Grid A* contract", restated by oracle/astar.c).  The reference has no grid
 // search (AStarPlanner::makePlan walks a 9-vertex graph, mc/src/astar_planner.cpp:63-127); the
@@ -9,29 +9,39 @@
 //   * bucketed parallel frontier ("delta-stepping" on f = g + h): cells whose f lies in the current
 //     bucket [k*B, (k+1)*B) are relaxed to a fixed point in rounds, then the search advances.  With
 //     B >= 2828 (the largest f increase of one step) a relaxation only ever targets the current or
-//     the next bucket, so three queues per query suffice: cur (this round), nxt (same bucket, next
-//     round), far (next bucket).
-//   * g lives in HBM (int32 per cell, one field per concurrent query) and is relaxed with
-//     atomicMin; queue entries carry (cell, g) so stale entries are dropped when popped;
-//   * queue tails are LDS counters; one 1024-thread workgroup (16 wavefronts) per query keeps the
-//     whole round -- pop, 8 neighbour relaxations, push -- behind two workgroup barriers;
-//   * pruning: once the goal has a finite g, candidates with f > g(goal) are dropped;
-//   * the path is rebuilt by one wavefront: lane k tests neighbour k, ballot + ffs picks the
+//     the next bucket: an LDS-resident double-buffered frontier (cur / nxt) plus one "far" queue in
+//     HBM suffice.
+//   * one search field per concurrent query in HBM, one 32-bit word per cell = (g << 8) | mask,
+//     where mask is the cell's 8-bit traversable-neighbour mask.  atomicMin on the word is atomicMin
+//     on g.  A single CU sustains only ~1 scattered memory lane-op per 4 cycles (measured,
+//     scripts/ubench_atomics.hip), so the expansion is built around FEW, WIDE accesses: the 3x3
+//     neighbourhood is three 12-byte buffer loads (one per column, lanes of a column are contiguous
+//     in the column-major field), which deliver the staleness probe, the cell's own mask and all
+//     eight neighbour values at once; an atomicMin is then issued only for neighbours it can improve.
+//   * queue entries carry (cell, g); a popped entry whose g no longer matches the field is stale and
+//     is dropped;  pruning: once the goal has a finite g, candidates with f > g(goal) are dropped;
+//   * the path is rebuilt by one wavefront: lane k probes neighbour k, ballot + ffs picks the
 //     lowest-index optimal predecessor.
+// g is 24 bits: path cost < 16 777 215 (about 16 700 straight cells); longer searches fail loudly
+// with status 4.
 #include "engine.hpp"
 
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 using namespace rna;
 
 namespace {
 
-constexpr int ASTAR_THREADS = 1024;
 constexpr int COST_S = 1000, COST_D = 1414;
-constexpr int INF = 0x7fffffff;
+constexpr int INF = 0x7fffffff;          // "no path" cost in results
+constexpr unsigned G_INF = 0xFFFFFFu;    // unreached cell in the packed field
+constexpr int LQ_CAP = 8192;             // entries of each LDS frontier queue (2 x 64 KiB)
+
+typedef int v3i __attribute__((ext_vector_type(3)));
 
 __device__ __forceinline__ int octile(int i, int j, int gi, int gj) {
   const int dx = abs(i - gi), dy = abs(j - gj);
@@ -39,100 +49,164 @@ __device__ __forceinline__ int octile(int i, int j, int gi, int gj) {
   return COST_S * mx + (COST_D - COST_S) * mn;
 }
 
-__global__ void astar_fill_kernel(int4* __restrict__ p, size_t n4) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const int4 v = make_int4(INF, INF, INF, INF);
-  for (; i < n4; i += stride) p[i] = v;
+__device__ __forceinline__ unsigned field_load(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L2-served (sc1)
 }
 
-__global__ void __launch_bounds__(ASTAR_THREADS)
-astar_search_kernel(const uint8_t* __restrict__ nbr, int rows, int cols, const rna_astar_query* __restrict__ queries,
-                    int32_t* __restrict__ g_all, size_t g_stride, int2* __restrict__ queues, int queue_cap,
-                    int bucket_width, int32_t* __restrict__ paths, int max_path_len,
-                    rna_astar_result* __restrict__ results) {
-  __shared__ int s_cur_n, s_nxt_n, s_far_n, s_best, s_overflow, s_expanded, s_state, s_bucket;
-  __shared__ int s_sel[3];  // which physical queue plays cur / nxt / far
+// field[q][c] = (G_INF << 8) | nbr[c] for the n concurrent queries: 4 cells per thread, 16-byte stores
+__global__ void astar_init_kernel(const uint8_t* __restrict__ nbr, unsigned* __restrict__ field, size_t stride,
+                                  int n, size_t ncell) {
+  const size_t n4 = ncell / 4;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n4; i += step) {
+    const uchar4 m = reinterpret_cast<const uchar4*>(nbr)[i];
+    const uint4 v = make_uint4(0xFFFFFF00u | m.x, 0xFFFFFF00u | m.y, 0xFFFFFF00u | m.z, 0xFFFFFF00u | m.w);
+    for (int q = 0; q < n; ++q) reinterpret_cast<uint4*>(field + (size_t)q * stride)[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (ncell & 3)) {
+    const size_t c = n4 * 4 + threadIdx.x;
+    for (int q = 0; q < n; ++q) field[(size_t)q * stride + c] = 0xFFFFFF00u | nbr[c];
+  }
+}
+
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
+astar_search_kernel(int rows, int cols, const rna_astar_query* __restrict__ queries, unsigned* __restrict__ field_all,
+                    size_t field_stride, int2* __restrict__ queues, int queue_cap, int bucket_width,
+                    int32_t* __restrict__ paths, int max_path_len, rna_astar_result* __restrict__ results) {
+  __shared__ int2 l_q[2][LQ_CAP];  // frontier of the current bucket: (cell, g); overflow spills to HBM
+  __shared__ int s_n[2];           // entries pushed into frontier queue b (LDS part + spill part)
+  __shared__ int s_far_n, s_best, s_overflow, s_expanded, s_state, s_bucket, s_rounds, s_bucket0;
+  __shared__ int s_cur;            // which LDS queue is being popped
+  __shared__ int s_lds_n, s_glob_n;  // entries to pop this round from LDS / from the HBM source
+  __shared__ int s_sel[3];         // HBM buffers playing: spill of cur, spill of nxt, far
+  __shared__ int s_len;
+#ifdef RNA_ASTAR_DEBUG
+  __shared__ int s_dbg_iters, s_dbg_pops, s_dbg_glob;
+  if (threadIdx.x == 0) { s_dbg_iters = 0; s_dbg_pops = 0; s_dbg_glob = 0; }
+#endif
   const int q = blockIdx.x;
   const int tid = threadIdx.x;
   const rna_astar_query qu = queries[q];
-  int32_t* g = g_all + (size_t)q * g_stride;
+  unsigned* field = field_all + (size_t)q * field_stride;
   int2* qbase = queues + (size_t)q * 3 * queue_cap;
   const int ncell = rows * cols;
 
   const bool valid = qu.start >= 0 && qu.goal >= 0 && qu.start < ncell && qu.goal < ncell;
   if (!valid) {
-    if (tid == 0) results[q] = rna_astar_result{2, 0, INF, 0};
+    if (tid == 0) results[q] = rna_astar_result{2, 0, INF, 0, 0, 0};
     return;
   }
   const int gi = qu.goal % rows, gj = qu.goal / rows;
-  const int off[8] = {-1 - rows, -rows, 1 - rows, -1, 1, rows - 1, rows, rows + 1};
+  // wave-uniform buffer descriptor starting ONE WORD BEFORE this query's field (fields are padded),
+  // so the 12-byte load at byte offset 4*c covers cells c-1, c, c+1; out-of-range loads return 0
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(field - 1, 0, (ncell + 2) * 4, 0x00020000);
 
   if (tid == 0) {
     s_sel[0] = 0; s_sel[1] = 1; s_sel[2] = 2;
-    s_cur_n = 1; s_nxt_n = 0; s_far_n = 0;
+    s_n[0] = 0; s_n[1] = 0; s_cur = 0; s_lds_n = 1; s_glob_n = 0;
+    s_far_n = 0;
     s_best = INF; s_overflow = 0; s_expanded = 0; s_state = 0;
     const int f0 = octile(qu.start % rows, qu.start / rows, gi, gj);
     s_bucket = f0 / bucket_width;
-    __hip_atomic_store(&g[qu.start], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    qbase[0] = make_int2(qu.start, 0);
+    s_bucket0 = s_bucket;
+    s_rounds = 0;
+    const unsigned w0 = field_load(&field[qu.start]);
+    __hip_atomic_store(&field[qu.start], w0 & 0xffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // g = 0
+    l_q[0][0] = make_int2(qu.start, 0);
   }
   __syncthreads();
 
   int my_expanded = 0;
   for (;;) {
-    const int n = s_cur_n;
-    const int2* cur = qbase + (size_t)s_sel[0] * queue_cap;
-    int2* nxt = qbase + (size_t)s_sel[1] * queue_cap;
+    const int cb = s_cur, nb = cb ^ 1;
+    const int lds_n = s_lds_n, glob_n = s_glob_n;
+    const int2* gsrc = qbase + (size_t)s_sel[0] * queue_cap;
+    int2* spill = qbase + (size_t)s_sel[1] * queue_cap;
     int2* far = qbase + (size_t)s_sel[2] * queue_cap;
     const int best = s_best;
     const long long bucket_end = ((long long)s_bucket + 1) * bucket_width;  // exclusive
-    for (int e = tid; e < n; e += ASTAR_THREADS) {
-      const int2 ent = cur[e];
-      const int cell = ent.x, gv = ent.y;
-      // stale entry: the cell was improved after this entry was queued
-      if (__hip_atomic_load(&g[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gv) continue;
+
+    auto expand = [&](const int cell, const int gv) {
       const int ci = cell % rows, cj = cell / rows;
-      if (gv + octile(ci, cj, gi, gj) > best) continue;
+      if (gv + octile(ci, cj, gi, gj) > best) return;
+      if (cell == qu.goal) { atomicMin(&s_best, gv); ++my_expanded; return; }  // (also covers start == goal)
+      // 3x3 neighbourhood = three 12-byte loads: rows (i-1, i, i+1) of columns j-1, j, j+1
+      const int base = cell * 4;
+      const v3i c0 = __builtin_amdgcn_raw_buffer_load_b96(rsrc, base - rows * 4, 0, 16);
+      const v3i c1 = __builtin_amdgcn_raw_buffer_load_b96(rsrc, base, 0, 16);
+      const v3i c2 = __builtin_amdgcn_raw_buffer_load_b96(rsrc, base + rows * 4, 0, 16);
+      const unsigned centre = (unsigned)c1.y;
+      if ((int)(centre >> 8) != gv) return;  // stale: the cell was improved after this entry was queued
       ++my_expanded;
-      if (cell == qu.goal) { atomicMin(&s_best, gv); continue; }  // (also covers start == goal)
-      const unsigned m = nbr[cell];
+      const unsigned m = centre & 0xffu;
+      const unsigned w[8] = {(unsigned)c0.x, (unsigned)c0.y, (unsigned)c0.z, (unsigned)c1.x,
+                             (unsigned)c1.z, (unsigned)c2.x, (unsigned)c2.y, (unsigned)c2.z};
+      const int off[8] = {-1 - rows, -rows, 1 - rows, -1, 1, rows - 1, rows, rows + 1};
+      unsigned old[8], nw[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {  // issue every useful relaxation before consuming any result
+        const int ng = gv + ((k == 1 || k == 3 || k == 4 || k == 6) ? COST_S : COST_D);
+        nw[k] = ((unsigned)ng << 8) | (w[k] & 0xffu);
+        old[k] = 0;
+        if (((m >> k) & 1u) && (unsigned)ng < (w[k] >> 8)) old[k] = atomicMin(&field[cell + off[k]], nw[k]);
+      }
+      const int best_now = s_best;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        if (!((m >> k) & 1u)) continue;
+        if (nw[k] >= old[k]) continue;  // not issued (old = 0) or lost the race
+        const int ng = (int)(nw[k] >> 8);
         const int nc = cell + off[k];
-        const int ng = gv + ((k == 1 || k == 3 || k == 4 || k == 6) ? COST_S : COST_D);
-        const int old = atomicMin(&g[nc], ng);
-        if (ng >= old) continue;
         const int ni = ci + ((k == 0 || k == 3 || k == 5) ? -1 : ((k == 2 || k == 4 || k == 7) ? 1 : 0));
         const int nj = cj + (k < 3 ? -1 : (k > 4 ? 1 : 0));
         const int fn = ng + octile(ni, nj, gi, gj);
-        if (fn > s_best) continue;
+        if (fn > best_now) continue;
+        if (ng >= (int)G_INF - 2 * COST_D) { s_overflow = 2; continue; }  // 24-bit g exhausted
         if (nc == qu.goal) atomicMin(&s_best, ng);
         if (fn < bucket_end) {
-          const int pos = atomicAdd(&s_nxt_n, 1);
-          if (pos < queue_cap) nxt[pos] = make_int2(nc, ng); else s_overflow = 1;
+          const int pos = atomicAdd(&s_n[nb], 1);
+          if (pos < LQ_CAP) l_q[nb][pos] = make_int2(nc, ng);
+          else if (pos - LQ_CAP < queue_cap) spill[pos - LQ_CAP] = make_int2(nc, ng);
+          else s_overflow = 1;
         } else {
           const int pos = atomicAdd(&s_far_n, 1);
           if (pos < queue_cap) far[pos] = make_int2(nc, ng); else s_overflow = 1;
         }
       }
+    };
+    for (int e = tid; e < lds_n; e += THREADS) {     // LDS-resident part of the frontier
+      const int2 ent = l_q[cb][e];
+      expand(ent.x, ent.y);
+    }
+    for (int e = tid; e < glob_n; e += THREADS) {    // spilled part / a freshly opened bucket (HBM)
+      const int2 ent = gsrc[e];
+      expand(ent.x, ent.y);
     }
     __syncthreads();
     if (tid == 0) {
+      s_rounds += 1;
+#ifdef RNA_ASTAR_DEBUG
+      s_dbg_iters += (lds_n + glob_n + THREADS - 1) / THREADS; s_dbg_pops += lds_n + glob_n; if (glob_n) s_dbg_glob += 1;
+#endif
+      const int nn = s_n[nb];
       if (s_overflow) {
-        s_state = 3;
-      } else if (s_nxt_n > 0) {            // same bucket, next round
+        s_state = 2 + s_overflow;          // 3 queue overflow, 4 cost overflow
+      } else if (nn > 0) {                 // same bucket, next round: pop what was just pushed
+        s_cur = nb;
+        s_lds_n = nn < LQ_CAP ? nn : LQ_CAP;
+        s_glob_n = nn - s_lds_n;
+        s_n[cb] = 0;
         const int t = s_sel[0]; s_sel[0] = s_sel[1]; s_sel[1] = t;
-        s_cur_n = s_nxt_n; s_nxt_n = 0;
       } else {
         // bucket k is at its fixed point: every cell with f < (k+1)*B has its exact g.
         const long long done_below = ((long long)s_bucket + 1) * bucket_width;
         if (s_best != INF && (long long)s_best < done_below) s_state = 1;       // goal settled, ties included
         else if (s_far_n == 0) s_state = (s_best != INF) ? 1 : 2;              // frontier exhausted
-        else {
+        else {                             // advance: the far queue (HBM) becomes the frontier
           const int t = s_sel[0]; s_sel[0] = s_sel[2]; s_sel[2] = t;
-          s_cur_n = s_far_n; s_far_n = 0; s_bucket += 1;
+          s_lds_n = 0; s_glob_n = s_far_n; s_far_n = 0; s_bucket += 1;
+          s_n[0] = 0; s_n[1] = 0;
         }
       }
     }
@@ -143,34 +217,35 @@ astar_search_kernel(const uint8_t* __restrict__ nbr, int rows, int cols, const r
   __syncthreads();
 
   const int state = s_state;
+  const int n_buckets = s_bucket - s_bucket0 + 1;
   if (state != 1) {
-    if (tid == 0) results[q] = rna_astar_result{state == 3 ? (int)RNA_ECAPACITY : 1, 0, INF, s_expanded};
+    const int status = state == 3 ? (int)RNA_ECAPACITY : (state == 4 ? 4 : 1);
+    if (tid == 0) results[q] = rna_astar_result{status, 0, INF, s_expanded, s_rounds, n_buckets};
     return;
   }
 
-  // ---- canonical backtrace by the first wavefront; reversed path staged in queue 0 ----
+  // ---- canonical backtrace by the first wavefront; reversed path staged in the queue memory ----
   int* rev = reinterpret_cast<int*>(qbase);
   const int rev_cap = 3 * queue_cap * 2;
-  __shared__ int s_len;
   if (tid < 64) {
     int c = qu.goal;
     int len = 0;
     bool ok = true;
+    const int k = tid & 7;
+    const int w = (k == 1 || k == 3 || k == 4 || k == 6) ? COST_S : COST_D;
+    const int offk = (k == 0 ? -1 - rows : k == 1 ? -rows : k == 2 ? 1 - rows : k == 3 ? -1 : k == 4 ? 1
+                      : k == 5 ? rows - 1 : k == 6 ? rows : rows + 1);
     for (;;) {
       if (tid == 0 && len < rev_cap) rev[len] = c;
       ++len;
       if (c == qu.start) break;
       if (len > ncell) { ok = false; break; }
-      const unsigned m = nbr[c];
-      const int gc = __hip_atomic_load(&g[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      bool hit = false;
-      int nc = -1;
-      if (tid < 8 && ((m >> tid) & 1u)) {
-        nc = c + off[tid];
-        const int gn = __hip_atomic_load(&g[nc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int w = (tid == 1 || tid == 3 || tid == 4 || tid == 6) ? COST_S : COST_D;
-        hit = (gn != INF) && (gn + w == gc);
-      }
+      // lane k probes neighbour k; g(c), its mask and the eight g(n) arrive in one round trip
+      const int nc = c + offk;
+      const bool inb = nc >= 0 && nc < ncell;
+      const unsigned wc = field_load(&field[c]);
+      const unsigned wn = field_load(&field[inb ? nc : c]);
+      const bool hit = tid < 8 && ((wc >> k) & 1u) && ((wn >> 8) != G_INF) && ((wn >> 8) + (unsigned)w == (wc >> 8));
       const unsigned long long mask = __ballot(hit);
       if (!mask) { ok = false; break; }
       const int lane = __ffsll((long long)mask) - 1;
@@ -181,22 +256,25 @@ astar_search_kernel(const uint8_t* __restrict__ nbr, int rows, int cols, const r
   __syncthreads();
   const int len = s_len;
   if (len < 0) {
-    if (tid == 0) results[q] = rna_astar_result{1, 0, INF, s_expanded};
+    if (tid == 0) results[q] = rna_astar_result{1, 0, INF, s_expanded, s_rounds, n_buckets};
     return;
   }
   if (len > max_path_len || len > rev_cap) {
-    if (tid == 0) results[q] = rna_astar_result{3, len, s_best, s_expanded};
+    if (tid == 0) results[q] = rna_astar_result{3, len, s_best, s_expanded, s_rounds, n_buckets};
     return;
   }
   int32_t* path = paths + (size_t)q * max_path_len;
-  for (int k = tid; k < len; k += ASTAR_THREADS) path[k] = rev[len - 1 - k];
-  if (tid == 0) results[q] = rna_astar_result{0, len, s_best, s_expanded};
+  for (int i = tid; i < len; i += THREADS) path[i] = rev[len - 1 - i];
+#ifdef RNA_ASTAR_DEBUG
+  if (tid == 0) { results[q] = rna_astar_result{0, s_dbg_glob, s_dbg_pops, s_expanded, s_rounds, s_dbg_iters}; return; }
+#endif
+  if (tid == 0) results[q] = rna_astar_result{0, len, s_best, s_expanded, s_rounds, n_buckets};
 }
 
-// |{n : g(n) + h(n) <= f*}| per query, from the resident g fields (measurement utility)
+// |{n : g(n) + h(n) <= f*}| per query, from the resident fields (measurement utility)
 __global__ void astar_settled_kernel(int rows, int cols, const rna_astar_query* __restrict__ queries,
-                                     const rna_astar_result* __restrict__ results, const int32_t* __restrict__ g_all,
-                                     size_t g_stride, int32_t* __restrict__ counts) {
+                                     const rna_astar_result* __restrict__ results, const unsigned* __restrict__ field_all,
+                                     size_t field_stride, int32_t* __restrict__ counts) {
   __shared__ int s_cnt;
   const int q = blockIdx.x;
   if (threadIdx.x == 0) s_cnt = 0;
@@ -206,11 +284,11 @@ __global__ void astar_settled_kernel(int rows, int cols, const rna_astar_query* 
   if (r.status == 0 || r.status == 3) {
     const int goal = queries[q].goal;
     const int gi = goal % rows, gj = goal / rows;
-    const int32_t* g = g_all + (size_t)q * g_stride;
+    const unsigned* field = field_all + (size_t)q * field_stride;
     const int ncell = rows * cols;
     for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
-      const int gv = g[c];
-      if (gv != INF && gv + octile(c % rows, c / rows, gi, gj) <= r.cost) ++cnt;
+      const unsigned gv = field[c] >> 8;
+      if (gv != G_INF && (int)gv + octile(c % rows, c / rows, gi, gj) <= r.cost) ++cnt;
     }
   }
   atomicAdd(&s_cnt, cnt);
@@ -222,6 +300,7 @@ int ensure_config(rna_engine* e) {
   AstarDevice& a = e->astar;
   if (a.g) return RNA_OK;
   if (a.max_queries <= 0) a.max_queries = 256;
+  if (const char* t = getenv("RNA_ASTAR_THREADS")) a.threads = atoi(t);  // tuning knob: 256 / 512 / 1024
   if (a.queue_cap <= 0) {
     // a bucket's queue holds the cells whose f falls into one bucket_width band of the search
     // ellipse (plus duplicates); 64 x (rows + cols) entries is a wide margin, checked at run time
@@ -233,10 +312,13 @@ int ensure_config(rna_engine* e) {
   // shrink the concurrent-query count until the g fields fit in free HBM (leave 25 % headroom)
   size_t free_b = 0, total_b = 0;
   RNA_HIP(e, hipMemGetInfo(&free_b, &total_b));
-  const size_t per_query = e->ncell * sizeof(int32_t) + (size_t)3 * a.queue_cap * sizeof(int2);
+  if (e->ncell >= (1ull << 30)) return fail(e, RNA_EINVAL, "grid A*: more than 2^30 cells");
+  const size_t per_query = (e->ncell + 128) * sizeof(int32_t) + (size_t)3 * a.queue_cap * sizeof(int2);
   while (a.max_queries > 1 && (double)per_query * a.max_queries > 0.75 * (double)free_b) a.max_queries /= 2;
   int rc;
-  if ((rc = dev_alloc(e, &a.g, e->ncell * (size_t)a.max_queries + 4)) != RNA_OK) return rc;
+  // each query's field is padded (the 3-cell column loads reach one word past either end) and 16-byte aligned
+  a.field_stride = ((e->ncell + 64 + 63) / 64) * 64;   // keeps every field 256-byte aligned
+  if ((rc = dev_alloc(e, &a.g, a.field_stride * (size_t)a.max_queries + 128)) != RNA_OK) return rc;
   if ((rc = dev_alloc(e, &a.queues, (size_t)3 * a.queue_cap * a.max_queries)) != RNA_OK) return rc;
   if ((rc = dev_alloc(e, &a.queries_dev, (size_t)a.max_queries)) != RNA_OK) return rc;
   if ((rc = dev_alloc(e, &a.results_dev, (size_t)a.max_queries)) != RNA_OK) return rc;
@@ -246,19 +328,21 @@ int ensure_config(rna_engine* e) {
 int launch_chunk(rna_engine* e, const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len,
                  rna_astar_result* res_dev) {
   AstarDevice& a = e->astar;
+  unsigned* field = reinterpret_cast<unsigned*>(a.g) + 64;
   {
     KernelTimer kt(e, RNA_K_ASTAR_INIT);
-    // g fields of the n concurrent queries are contiguous; the allocation carries 4 spare words so
-    // the last int4 store may run past the used part
-    const size_t n4 = (e->ncell * (size_t)n + 3) / 4;
-    hipLaunchKernelGGL(astar_fill_kernel, dim3(8192), dim3(256), 0, e->stream, reinterpret_cast<int4*>(a.g), n4);
+    hipLaunchKernelGGL(astar_init_kernel, dim3(4096), dim3(256), 0, e->stream, e->nbr, field, a.field_stride, n, e->ncell);
     RNA_HIP(e, hipGetLastError());
   }
   {
     KernelTimer kt(e, RNA_K_ASTAR_SEARCH);
-    hipLaunchKernelGGL(astar_search_kernel, dim3(n), dim3(ASTAR_THREADS), 0, e->stream, e->nbr, e->geom.size[0],
-                       e->geom.size[1], q_dev, a.g, e->ncell, a.queues, a.queue_cap, a.bucket_width, paths_dev,
-                       max_len, res_dev);
+#define RNA_LAUNCH_SEARCH(T)                                                                                   \
+  hipLaunchKernelGGL(astar_search_kernel<T>, dim3(n), dim3(T), 0, e->stream, e->geom.size[0], e->geom.size[1], \
+                     q_dev, field, a.field_stride, a.queues, a.queue_cap, a.bucket_width, paths_dev, max_len, res_dev)
+    if (a.threads == 256) RNA_LAUNCH_SEARCH(256);
+    else if (a.threads == 1024) RNA_LAUNCH_SEARCH(1024);
+    else RNA_LAUNCH_SEARCH(512);
+#undef RNA_LAUNCH_SEARCH
     RNA_HIP(e, hipGetLastError());
   }
   a.last_queries = q_dev;
@@ -366,7 +450,7 @@ extern "C" int rna_astar_settled_counts(rna_engine* e, int32_t* counts_host, int
   int rc = dev_alloc(e, &d_counts, (size_t)n);
   if (rc != RNA_OK) return rc;
   hipLaunchKernelGGL(astar_settled_kernel, dim3(n), dim3(1024), 0, e->stream, e->geom.size[0], e->geom.size[1],
-                     a.last_queries, a.last_results, a.g, e->ncell, d_counts);
+                     a.last_queries, a.last_results, reinterpret_cast<const unsigned*>(a.g) + 64, a.field_stride, d_counts);
   hipError_t st = hipGetLastError();
   if (st == hipSuccess) st = hipMemcpyAsync(counts_host, d_counts, sizeof(int32_t) * n, hipMemcpyDeviceToHost, e->stream);
   if (st == hipSuccess) st = hipStreamSynchronize(e->stream);

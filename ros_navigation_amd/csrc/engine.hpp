@@ -57,7 +57,9 @@ struct AstarDevice {
   int max_queries = 0;
   int queue_cap = 0;
   int bucket_width = 8000;
-  int32_t* g = nullptr;            // [max_queries][ncell]
+  int threads = 1024;              // workgroup size of the search kernel (256 / 512 / 1024)
+  int32_t* g = nullptr;            // [max_queries][field_stride] packed (g << 8) | mask search fields
+  size_t field_stride = 0;         // words per query field incl. padding
   int2* queues = nullptr;          // [max_queries][3][queue_cap] (cell, g)
   rna_astar_query* queries_dev = nullptr;
   rna_astar_result* results_dev = nullptr;
