@@ -19,6 +19,9 @@ import os
 import sys
 import time
 
+# pipelined A* batches run on several HIP streams; give the runtime enough hardware queues
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -40,6 +43,7 @@ def parse():
     ap.add_argument("--bucket-width", type=int, default=0)
     ap.add_argument("--queue-capacity", type=int, default=0)
     ap.add_argument("--max-path", type=int, default=32768)
+    ap.add_argument("--pipeline", type=int, default=4, help="A* batches in flight (rna_astar_set_pipeline_depth)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
@@ -100,10 +104,15 @@ def main():
     e = R.Engine(length, length, 0.05, device=local_rank)
     assert (e.rows, e.cols) == (n, n)
     # map: config 3's obstacle field (seed 2) is the laser layer the HIMM batches work on
-    master = R.synth.obstacles_rect(n, n, density=0.30, seed=2)
-    e.upload(R.capi.LAYER_LASER, master)
+    master0 = R.synth.obstacles_rect(n, n, density=0.30, seed=2)
+    e.upload(R.capi.LAYER_LASER, master0)
     e.compose_master(1)
     rays = R.synth.rays(args.ray_poses, args.rays_per_pose, length, length, seed=4 + rank)
+    # untimed setup: the map receives the ray batch once, so that the (start, goal) pairs are drawn
+    # from cells that stay free while the same batch is re-applied every step (ray end points are
+    # marked as obstacles by HIMM; a query ending on one would be a trivial "no path")
+    e.update_map(rays, compose_mode=0)
+    master = e.download(R.capi.LAYER_MASTER)
     poses = R.synth.poses(args.queries, length, length, seed=1 + rank)
     queries = R.synth.astar_queries(args.queries, master, n, n, seed=2 + rank)
     nq = args.queries
@@ -115,26 +124,34 @@ def main():
 
     d_rays, d_poses, d_queries = to_dev(rays), to_dev(poses), to_dev(queries)
     d_vfh_out = torch.zeros(nq * R.capi.VFH_OUT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    d_paths = torch.zeros(nq * args.max_path, dtype=torch.int32, device=dev)
-    d_results = torch.zeros(nq * 6, dtype=torch.int32, device=dev)
+    # one output set per batch that may be in flight (pipelined searches write them asynchronously)
+    d_paths = [torch.zeros(nq * args.max_path, dtype=torch.int32, device=dev) for _ in range(args.pipeline)]
+    d_results = [torch.zeros(nq * 6, dtype=torch.int32, device=dev) for _ in range(args.pipeline)]
     e.vfh_init(nq)
+    e.astar_pipeline_depth(args.pipeline)
     e.astar_configure(max_queries=nq, queue_capacity=args.queue_capacity, bucket_width=args.bucket_width)
     torch.cuda.synchronize()
 
+    step_no = [0]
+
     def step():
+        b = step_no[0] % args.pipeline
+        step_no[0] += 1
         e.update_map_device(d_rays.data_ptr(), len(rays), compose_mode=0)
         e.vfh_step_device(d_poses.data_ptr(), nq, d_vfh_out.data_ptr())
-        e.astar_device(d_queries.data_ptr(), nq, d_paths.data_ptr(), args.max_path, d_results.data_ptr())
+        e.astar_device(d_queries.data_ptr(), nq, d_paths[b].data_ptr(), args.max_path, d_results[b].data_ptr())
+        return b
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    last = 0
     for _ in range(args.warmup):
-        step()
+        last = step()
     e.synchronize()
     torch.cuda.synchronize()
-    res = d_results.cpu().numpy().reshape(nq, 6)
+    res = d_results[last].cpu().numpy().reshape(nq, 6)
     if (res[:, 0] < 0).any():
         raise SystemExit("A* frontier queue overflow during warm-up: pass a larger --queue-capacity")
 
@@ -144,7 +161,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        last = step()
     e.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -152,7 +169,7 @@ def main():
     prof = e.profile_get()
     e.profile(False)
 
-    res = d_results.cpu().numpy().reshape(nq, 6)
+    res = d_results[last].cpu().numpy().reshape(nq, 6)
     found = int((res[:, 0] == 0).sum())
     if (res[:, 0] < 0).any() or (res[:, 0] == 3).any():
         raise SystemExit("A* batch did not complete (status %s)" % sorted(set(res[:, 0].tolist())))
@@ -178,7 +195,7 @@ def main():
                                    "compose -> %d VFH+ poses -> %d grid-A* queries per step; 30%% rectangle "
                                    "obstacles (seed 2)" % (n, n, len(rays), nq, nq),
                        "cycles_per_step": nq, "rays_per_step": int(len(rays)), "astar_paths_found": found,
-                       "astar_bucket_width": args.bucket_width or 8000, "parallelism": "query-sharded x%d" % world},
+                       "astar_bucket_width": args.bucket_width or 8000, "astar_pipeline_depth": args.pipeline, "parallelism": "query-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "astar_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "settled_cells_per_launch": int(settled.sum()),

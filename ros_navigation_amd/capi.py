@@ -29,7 +29,7 @@ SYMBOLS = [
     "rna_update_map_device", "rna_move",
     "rna_vfh_default_params", "rna_vfh_init", "rna_vfh_reset", "rna_vfh_hist_size", "rna_vfh_step_batch",
     "rna_vfh_step_batch_device", "rna_vfh_update_batch",
-    "rna_astar_configure", "rna_astar_batch", "rna_astar_batch_device", "rna_astar_settled_counts",
+    "rna_astar_configure", "rna_astar_set_pipeline_depth", "rna_astar_batch", "rna_astar_batch_device", "rna_astar_settled_counts",
     "rna_astar_download_nbr_mask",
     "rna_graph_astar_batch", "rna_rrt_batch", "rna_rrt_batch_device",
     "rna_profile_enable", "rna_profile_reset", "rna_profile_get", "rna_kernel_name",
@@ -118,6 +118,7 @@ def lib():
     L.rna_vfh_step_batch_device.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.rna_vfh_update_batch.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp]
     L.rna_astar_configure.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.rna_astar_set_pipeline_depth.argtypes = [vp, C.c_int]
     L.rna_astar_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
     L.rna_astar_batch_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
     L.rna_astar_download_nbr_mask.argtypes = [vp, vp, C.c_size_t]
@@ -276,6 +277,9 @@ class Engine:
     # ---- planners ----
     def astar_configure(self, max_queries=0, queue_capacity=0, bucket_width=0):
         self._check(self._L.rna_astar_configure(self.h, max_queries, queue_capacity, bucket_width))
+
+    def astar_pipeline_depth(self, depth):
+        self._check(self._L.rna_astar_set_pipeline_depth(self.h, depth))
 
     def astar(self, queries, max_path_len):
         assert queries.dtype == ASTAR_QUERY_DTYPE

@@ -115,8 +115,15 @@ astar_search_kernel(int rows, int cols, const rna_astar_query* __restrict__ quer
     const unsigned w0 = field_load(&field[qu.start]);
     __hip_atomic_store(&field[qu.start], w0 & 0xffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // g = 0
     l_q[0][0] = make_int2(qu.start, 0);
+    // a goal without a single traversable neighbour (blocked, or walled in) cannot be reached:
+    // answer "no path" without flooding the whole connected component
+    if (qu.goal != qu.start && (field_load(&field[qu.goal]) & 0xffu) == 0u) s_state = 2;
   }
   __syncthreads();
+  if (s_state == 2) {
+    if (tid == 0) results[q] = rna_astar_result{1, 0, INF, 0, 0, 0};
+    return;
+  }
 
   int my_expanded = 0;
   for (;;) {
@@ -298,9 +305,11 @@ __global__ void astar_settled_kernel(int rows, int cols, const rna_astar_query* 
 
 int ensure_config(rna_engine* e) {
   AstarDevice& a = e->astar;
-  if (a.g) return RNA_OK;
+  if (a.g[0]) return RNA_OK;
   if (a.max_queries <= 0) a.max_queries = 256;
   if (const char* t = getenv("RNA_ASTAR_THREADS")) a.threads = atoi(t);  // tuning knob: 256 / 512 / 1024
+  if (a.depth < 1) a.depth = 1;
+  if (a.depth > AstarDevice::MAX_DEPTH) a.depth = AstarDevice::MAX_DEPTH;
   if (a.queue_cap <= 0) {
     // a bucket's queue holds the cells whose f falls into one bucket_width band of the search
     // ellipse (plus duplicates); 64 x (rows + cols) entries is a wide margin, checked at run time
@@ -309,45 +318,72 @@ int ensure_config(rna_engine* e) {
     if (c > (1 << 22)) c = 1 << 22;
     a.queue_cap = (int)c;
   }
-  // shrink the concurrent-query count until the g fields fit in free HBM (leave 25 % headroom)
+  if (e->ncell >= (1ull << 30)) return fail(e, RNA_EINVAL, "grid A*: more than 2^30 cells");
+  // fit into free HBM (25 % headroom): first fewer pipeline stages, then fewer concurrent queries
   size_t free_b = 0, total_b = 0;
   RNA_HIP(e, hipMemGetInfo(&free_b, &total_b));
-  if (e->ncell >= (1ull << 30)) return fail(e, RNA_EINVAL, "grid A*: more than 2^30 cells");
   const size_t per_query = (e->ncell + 128) * sizeof(int32_t) + (size_t)3 * a.queue_cap * sizeof(int2);
-  while (a.max_queries > 1 && (double)per_query * a.max_queries > 0.75 * (double)free_b) a.max_queries /= 2;
+  while (a.depth > 1 && (double)per_query * a.max_queries * a.depth > 0.75 * (double)free_b) a.depth -= 1;
+  while (a.max_queries > 1 && (double)per_query * a.max_queries * a.depth > 0.75 * (double)free_b) a.max_queries /= 2;
   int rc;
-  // each query's field is padded (the 3-cell column loads reach one word past either end) and 16-byte aligned
-  a.field_stride = ((e->ncell + 64 + 63) / 64) * 64;   // keeps every field 256-byte aligned
-  if ((rc = dev_alloc(e, &a.g, a.field_stride * (size_t)a.max_queries + 128)) != RNA_OK) return rc;
-  if ((rc = dev_alloc(e, &a.queues, (size_t)3 * a.queue_cap * a.max_queries)) != RNA_OK) return rc;
+  // each query's field is padded (the 3-cell column loads reach one word past either end) and 256-byte aligned
+  a.field_stride = ((e->ncell + 64 + 63) / 64) * 64;
+  for (int d = 0; d < a.depth; ++d) {
+    if ((rc = dev_alloc(e, &a.g[d], a.field_stride * (size_t)a.max_queries + 128)) != RNA_OK) return rc;
+    if ((rc = dev_alloc(e, &a.queues[d], (size_t)3 * a.queue_cap * a.max_queries)) != RNA_OK) return rc;
+    if (a.depth > 1) {
+      RNA_HIP(e, hipStreamCreateWithFlags(&a.side[d], hipStreamNonBlocking));
+      RNA_HIP(e, hipEventCreateWithFlags(&a.done[d], hipEventDisableTiming));
+    }
+    a.busy[d] = false;
+  }
+  if (a.depth > 1) RNA_HIP(e, hipEventCreateWithFlags(&a.ev_init, hipEventDisableTiming));
+  a.launches = 0;
   if ((rc = dev_alloc(e, &a.queries_dev, (size_t)a.max_queries)) != RNA_OK) return rc;
   if ((rc = dev_alloc(e, &a.results_dev, (size_t)a.max_queries)) != RNA_OK) return rc;
   return RNA_OK;
 }
 
+// One batch (<= max_queries): field init on the engine stream (it reads the neighbour masks, which
+// the next map update may overwrite), then the search on this pipeline stage's own stream.
 int launch_chunk(rna_engine* e, const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len,
-                 rna_astar_result* res_dev) {
+                 rna_astar_result* res_dev, int* slot_out) {
   AstarDevice& a = e->astar;
-  unsigned* field = reinterpret_cast<unsigned*>(a.g) + 64;
+  const int slot = (int)(a.launches % (unsigned long long)a.depth);
+  unsigned* field = reinterpret_cast<unsigned*>(a.g[slot]) + 64;
+  hipStream_t search_stream = a.depth > 1 ? a.side[slot] : e->stream;
+  if (a.depth > 1 && a.busy[slot]) RNA_HIP(e, hipStreamWaitEvent(e->stream, a.done[slot], 0));  // stage is free again
   {
     KernelTimer kt(e, RNA_K_ASTAR_INIT);
     hipLaunchKernelGGL(astar_init_kernel, dim3(4096), dim3(256), 0, e->stream, e->nbr, field, a.field_stride, n, e->ncell);
     RNA_HIP(e, hipGetLastError());
   }
+  if (a.depth > 1) {
+    RNA_HIP(e, hipEventRecord(a.ev_init, e->stream));
+    RNA_HIP(e, hipStreamWaitEvent(search_stream, a.ev_init, 0));
+  }
   {
-    KernelTimer kt(e, RNA_K_ASTAR_SEARCH);
-#define RNA_LAUNCH_SEARCH(T)                                                                                   \
-  hipLaunchKernelGGL(astar_search_kernel<T>, dim3(n), dim3(T), 0, e->stream, e->geom.size[0], e->geom.size[1], \
-                     q_dev, field, a.field_stride, a.queues, a.queue_cap, a.bucket_width, paths_dev, max_len, res_dev)
+    KernelTimer kt(e, RNA_K_ASTAR_SEARCH, search_stream);
+#define RNA_LAUNCH_SEARCH(T)                                                                                        \
+  hipLaunchKernelGGL(astar_search_kernel<T>, dim3(n), dim3(T), 0, search_stream, e->geom.size[0], e->geom.size[1], \
+                     q_dev, field, a.field_stride, a.queues[slot], a.queue_cap, a.bucket_width, paths_dev, max_len, \
+                     res_dev)
     if (a.threads == 256) RNA_LAUNCH_SEARCH(256);
-    else if (a.threads == 1024) RNA_LAUNCH_SEARCH(1024);
-    else RNA_LAUNCH_SEARCH(512);
+    else if (a.threads == 512) RNA_LAUNCH_SEARCH(512);
+    else RNA_LAUNCH_SEARCH(1024);
 #undef RNA_LAUNCH_SEARCH
     RNA_HIP(e, hipGetLastError());
   }
+  if (a.depth > 1) {
+    RNA_HIP(e, hipEventRecord(a.done[slot], search_stream));
+    a.busy[slot] = true;
+  }
+  a.launches += 1;
   a.last_queries = q_dev;
   a.last_results = res_dev;
   a.last_n = n;
+  a.last_slot = slot;
+  if (slot_out) *slot_out = slot;
   return RNA_OK;
 }
 
@@ -356,7 +392,15 @@ int launch_chunk(rna_engine* e, const rna_astar_query* q_dev, int n, int32_t* pa
 namespace rna {
 int astar_release(rna_engine* e) {
   AstarDevice& a = e->astar;
-  dev_free(&a.g); dev_free(&a.queues); dev_free(&a.queries_dev); dev_free(&a.results_dev); dev_free(&a.paths_dev);
+  (void)sync_all(e);
+  for (int d = 0; d < AstarDevice::MAX_DEPTH; ++d) {
+    dev_free(&a.g[d]); dev_free(&a.queues[d]);
+    if (a.side[d]) { (void)hipStreamDestroy(a.side[d]); a.side[d] = nullptr; }
+    if (a.done[d]) { (void)hipEventDestroy(a.done[d]); a.done[d] = nullptr; }
+    a.busy[d] = false;
+  }
+  if (a.ev_init) { (void)hipEventDestroy(a.ev_init); a.ev_init = nullptr; }
+  dev_free(&a.queries_dev); dev_free(&a.results_dev); dev_free(&a.paths_dev);
   a.paths_cap = 0;
   a.last_queries = nullptr; a.last_results = nullptr; a.last_n = 0;
   return RNA_OK;
@@ -370,9 +414,23 @@ extern "C" int rna_astar_configure(rna_engine* e, int max_queries, int queue_cap
   RNA_HIP(e, hipStreamSynchronize(e->stream));
   AstarDevice& a = e->astar;
   if (max_queries || queue_capacity) astar_release(e);
+  if (const char* d = getenv("RNA_ASTAR_PIPELINE")) {  // pipeline stages (1 = searches run on the engine stream)
+    const int dd = atoi(d);
+    if (dd >= 1 && dd != a.depth) { astar_release(e); a.depth = dd; }
+  }
   if (max_queries) a.max_queries = max_queries;
   if (queue_capacity) a.queue_cap = queue_capacity;
   if (bucket_width) a.bucket_width = bucket_width;
+  return RNA_OK;
+}
+
+extern "C" int rna_astar_set_pipeline_depth(rna_engine* e, int depth) {
+  if (!e || depth < 1 || depth > AstarDevice::MAX_DEPTH) return RNA_EINVAL;
+  RNA_HIP(e, hipSetDevice(e->device));
+  if (depth != e->astar.depth) {
+    astar_release(e);
+    e->astar.depth = depth;
+  }
   return RNA_OK;
 }
 
@@ -389,7 +447,7 @@ extern "C" int rna_astar_batch_device(rna_engine* e, const rna_astar_query* quer
   const int chunk = e->astar.max_queries;
   for (int o = 0; o < n; o += chunk) {
     const int m = std::min(chunk, n - o);
-    rc = launch_chunk(e, queries + o, m, paths + (size_t)o * max_path_len, max_path_len, results + o);
+    rc = launch_chunk(e, queries + o, m, paths + (size_t)o * max_path_len, max_path_len, results + o, nullptr);
     if (rc != RNA_OK) return rc;
   }
   return RNA_OK;
@@ -417,8 +475,10 @@ extern "C" int rna_astar_batch(rna_engine* e, const rna_astar_query* queries_hos
     const int m = std::min(chunk, n - o);
     RNA_HIP(e, hipMemcpyAsync(a.queries_dev, queries_host + o, (size_t)m * sizeof(rna_astar_query),
                               hipMemcpyHostToDevice, e->stream));
-    rc = launch_chunk(e, a.queries_dev, m, a.paths_dev, max_path_len, a.results_dev);
+    int slot = 0;
+    rc = launch_chunk(e, a.queries_dev, m, a.paths_dev, max_path_len, a.results_dev, &slot);
     if (rc != RNA_OK) return rc;
+    if (a.depth > 1) RNA_HIP(e, hipStreamWaitEvent(e->stream, a.done[slot], 0));
     RNA_HIP(e, hipMemcpyAsync(results_host + o, a.results_dev, (size_t)m * sizeof(rna_astar_result),
                               hipMemcpyDeviceToHost, e->stream));
     RNA_HIP(e, hipMemcpyAsync(paths_host + (size_t)o * max_path_len, a.paths_dev,
@@ -444,13 +504,14 @@ extern "C" int rna_astar_download_nbr_mask(rna_engine* e, uint8_t* host, size_t 
 extern "C" int rna_astar_settled_counts(rna_engine* e, int32_t* counts_host, int n) {
   if (!e || !counts_host || n <= 0) return RNA_EINVAL;
   AstarDevice& a = e->astar;
-  if (!a.g || !a.last_queries || n != a.last_n) return fail(e, RNA_ESTATE, "no resident A* batch of that size");
+  if (!a.g[0] || !a.last_queries || n != a.last_n) return fail(e, RNA_ESTATE, "no resident A* batch of that size");
   RNA_HIP(e, hipSetDevice(e->device));
   int32_t* d_counts = nullptr;
-  int rc = dev_alloc(e, &d_counts, (size_t)n);
+  int rc = sync_all(e);
   if (rc != RNA_OK) return rc;
+  if ((rc = dev_alloc(e, &d_counts, (size_t)n)) != RNA_OK) return rc;
   hipLaunchKernelGGL(astar_settled_kernel, dim3(n), dim3(1024), 0, e->stream, e->geom.size[0], e->geom.size[1],
-                     a.last_queries, a.last_results, reinterpret_cast<const unsigned*>(a.g) + 64, a.field_stride, d_counts);
+                     a.last_queries, a.last_results, reinterpret_cast<const unsigned*>(a.g[a.last_slot]) + 64, a.field_stride, d_counts);
   hipError_t st = hipGetLastError();
   if (st == hipSuccess) st = hipMemcpyAsync(counts_host, d_counts, sizeof(int32_t) * n, hipMemcpyDeviceToHost, e->stream);
   if (st == hipSuccess) st = hipStreamSynchronize(e->stream);

@@ -172,7 +172,7 @@ extern "C" int rna_create(rna_engine** out, double length_x, double length_y, do
 extern "C" void rna_destroy(rna_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->stream) (void)sync_all(e);
   himm_release(e);
   vfh_release(e);
   astar_release(e);
@@ -239,8 +239,7 @@ extern "C" void* rna_stream(rna_engine* e) { return e ? (void*)e->stream : nullp
 extern "C" int rna_synchronize(rna_engine* e) {
   if (!e) return RNA_EINVAL;
   RNA_HIP(e, hipSetDevice(e->device));
-  RNA_HIP(e, hipStreamSynchronize(e->stream));
-  return RNA_OK;
+  return sync_all(e);
 }
 
 extern "C" int rna_get_index(const rna_engine* e, double x, double y, int32_t index[2]) {
@@ -262,9 +261,17 @@ extern "C" int rna_get_position(const rna_engine* e, int32_t i, int32_t j, doubl
 
 namespace rna {
 
+int sync_all(rna_engine* e) {
+  RNA_HIP(e, hipStreamSynchronize(e->stream));
+  for (int d = 0; d < AstarDevice::MAX_DEPTH; ++d)
+    if (e->astar.side[d]) RNA_HIP(e, hipStreamSynchronize(e->astar.side[d]));
+  return RNA_OK;
+}
+
 int profile_flush(rna_engine* e) {
   if (e->pending_events == 0) return RNA_OK;
-  RNA_HIP(e, hipStreamSynchronize(e->stream));
+  int src = sync_all(e);
+  if (src != RNA_OK) return src;
   for (auto& slot : e->prof) {
     for (auto& pr : slot.pending) {
       float ms = 0;

@@ -58,9 +58,19 @@ struct AstarDevice {
   int queue_cap = 0;
   int bucket_width = 8000;
   int threads = 1024;              // workgroup size of the search kernel (256 / 512 / 1024)
-  int32_t* g = nullptr;            // [max_queries][field_stride] packed (g << 8) | mask search fields
+  // Pipelined batches: `depth` independent sets of search fields + queues, each with its own HIP
+  // stream, so the tail of batch k (few long queries) overlaps the head of batch k+1.
+  static constexpr int MAX_DEPTH = 8;
+  int depth = 2;
+  int32_t* g[MAX_DEPTH] = {};      // [max_queries][field_stride] packed (g << 8) | mask search fields
+  int2* queues[MAX_DEPTH] = {};    // [max_queries][3][queue_cap] (cell, g)
+  hipStream_t side[MAX_DEPTH] = {};
+  hipEvent_t done[MAX_DEPTH] = {}; // search of the batch that last used this set has finished
+  bool busy[MAX_DEPTH] = {};
+  hipEvent_t ev_init = nullptr;
+  unsigned long long launches = 0;
+  int last_slot = 0;
   size_t field_stride = 0;         // words per query field incl. padding
-  int2* queues = nullptr;          // [max_queries][3][queue_cap] (cell, g)
   rna_astar_query* queries_dev = nullptr;
   rna_astar_result* results_dev = nullptr;
   int32_t* paths_dev = nullptr;
@@ -128,16 +138,17 @@ struct KernelTimer {
     else if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
     return ev;
   }
-  KernelTimer(rna_engine* eng, int kid) : e(eng), id(kid) {
+  hipStream_t st;
+  KernelTimer(rna_engine* eng, int kid, hipStream_t stream = nullptr) : e(eng), id(kid), st(stream ? stream : eng->stream) {
     if (!e->profiling) return;
     if (e->pending_events > 16384) (void)profile_flush(e);
     a = take(e);
     b = take(e);
-    if (a) (void)hipEventRecord(a, e->stream);
+    if (a) (void)hipEventRecord(a, st);
   }
   ~KernelTimer() {
     if (!e->profiling || !a || !b) return;
-    (void)hipEventRecord(b, e->stream);
+    (void)hipEventRecord(b, st);
     e->prof[id].pending.emplace_back(a, b);
     e->pending_events += 2;
   }
@@ -162,5 +173,6 @@ int himm_release(rna_engine* e);
 int vfh_release(rna_engine* e);
 int astar_release(rna_engine* e);
 int map_prepare_nbr(rna_engine* e);   // make e->nbr consistent with the master layer
+int sync_all(rna_engine* e);          // main stream + every A* side stream
 
 }  // namespace rna
