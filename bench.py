@@ -84,20 +84,25 @@ def cpu_baseline(args, R, master, rays, poses, queries, rows, cols, length):
                       % (len(rays), t_himm, len(queries), n_vfh, t_vfh * 1e6, n_a, t_a / n_a, settled / n_a)}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (None when absent)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
-    import torch.distributed as dist
+    import ros_navigation_amd as R
+    from ros_navigation_amd import dist as D
+    rank, local_rank, world = D.env_rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    import ros_navigation_amd as R
+    dist = D.init("nccl", torch.device("cuda", local_rank)) if world > 1 else None
 
     n = args.grid
     length = n * 0.05
@@ -107,15 +112,17 @@ def main():
     master0 = R.synth.obstacles_rect(n, n, density=0.30, seed=2)
     e.upload(R.capi.LAYER_LASER, master0)
     e.compose_master(1)
-    rays = R.synth.rays(args.ray_poses, args.rays_per_pose, length, length, seed=4 + rank)
+    rays = R.synth.rays(args.ray_poses, args.rays_per_pose, length, length, seed=4)  # same batch on every replica
     # untimed setup: the map receives the ray batch once, so that the (start, goal) pairs are drawn
     # from cells that stay free while the same batch is re-applied every step (ray end points are
     # marked as obstacles by HIMM; a query ending on one would be a trivial "no path")
     e.update_map(rays, compose_mode=0)
     master = e.download(R.capi.LAYER_MASTER)
-    poses = R.synth.poses(args.queries, length, length, seed=1 + rank)
-    queries = R.synth.astar_queries(args.queries, master, n, n, seed=2 + rank)
-    nq = args.queries
+    # weak scaling: the global batch holds `queries` cycles per GPU; each rank serves its own shard
+    lo, hi = D.shard_bounds(args.queries * world, rank, world)
+    poses = R.synth.poses(args.queries * world, length, length, seed=1)[lo:hi]
+    queries = R.synth.astar_queries(args.queries * world, master, n, n, seed=2)[lo:hi]
+    nq = hi - lo
 
     dev = torch.device("cuda", local_rank)
 
@@ -175,14 +182,10 @@ def main():
         raise SystemExit("A* batch did not complete (status %s)" % sorted(set(res[:, 0].tolist())))
     settled = e.astar_settled(nq)          # E per query of the last launch, from the resident g fields
 
-    t_max = elapsed
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_max = float(t.item())
+    t_max = D.max_over_ranks(elapsed, dev) if world > 1 else elapsed
 
     if rank == 0:
-        cycles = nq * args.steps * world
+        cycles = args.queries * world * args.steps
         ms_search = prof["astar_search"][0] / max(1, prof["astar_search"][1])
         alg_bytes = float(settled.astype(np.int64).sum()) * ASTAR_BYTES_PER_SETTLED
         achieved = alg_bytes / (ms_search * 1e-3) / 1e9 if ms_search > 0 else 0.0
@@ -197,7 +200,9 @@ def main():
                        "cycles_per_step": nq, "rays_per_step": int(len(rays)), "astar_paths_found": found,
                        "astar_bucket_width": args.bucket_width or 8000, "astar_pipeline_depth": args.pipeline, "parallelism": "query-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "astar_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("astar_search_kernel<1024>"),
+                         "traffic_source": "profiles/r01_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                           "of this command (2*FETCH+WRITE)*1024 B per launch, see MI355X_MICROARCH.md",
                          "algorithmic_bytes_per_launch": alg_bytes, "settled_cells_per_launch": int(settled.sum()),
                          "avg_launch_ms": ms_search, "launches": prof["astar_search"][1]},
             "kernel_ms_per_step": {k: (v[0] / args.steps) for k, v in prof.items() if v[1]},

@@ -1,0 +1,304 @@
+// move_control_amd.hpp -- C++ host-side mirror of the reference's planner-facing classes, implemented
+// over the C ABI of include/rna.h (librna.so).  Header-only, ROS-free, C++11.
+//
+// Same names, argument meaning and error behaviour as the reference so that the node code of
+// move_control (nav_graph_node.cpp, nav_node.cpp, steerer.cpp) can switch by changing includes:
+//
+//   grid_map::Position / Index / Length / Size   gmc/include/grid_map_core/TypeDefs.hpp:16-25
+//   grid_map::GridMap (subset used by mc/)        gmc/include/grid_map_core/GridMap.hpp:39-520
+//   move_control::VFH                             mc/include/move_control/vfh.h:182-361
+//   move_control::MapProvider (update/compose/getMap/getSubMap core, no ROS I/O)
+//                                                 mc/include/move_control/map_provider.h:21-29
+//   move_control::AStarPlanner                    mc/include/move_control/astar_planner.h:30-44
+//   move_control::GridAStarPlanner                (new: grid A* of BASELINE.json, same makePlan shape)
+//   move_control::RrtPlanner                      mc/include/move_control/rrt_planner.h:7-41
+//
+// (mc/ = move_control, gmc/ = grid_map-master/grid_map_core in the reference tree.)
+// Data lives on the GPU inside one rna_engine; these classes own no algorithmic code.
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rna.h"
+
+namespace grid_map {
+
+// Minimal stand-ins for the Eigen typedefs of TypeDefs.hpp (x()/y()/operator[] like Eigen::Vector2d)
+struct Position {
+  double v[2];
+  Position() : v{0, 0} {}
+  Position(double x, double y) : v{x, y} {}
+  double& operator[](int i) { return v[i]; }
+  double operator[](int i) const { return v[i]; }
+  double& operator()(int i) { return v[i]; }
+  double operator()(int i) const { return v[i]; }
+  double x() const { return v[0]; }
+  double y() const { return v[1]; }
+};
+typedef Position Length;
+struct Index {
+  int v[2];
+  Index() : v{0, 0} {}
+  Index(int i, int j) : v{i, j} {}
+  int& operator[](int i) { return v[i]; }
+  int operator[](int i) const { return v[i]; }
+  int& operator()(int i) { return v[i]; }
+  int operator()(int i) const { return v[i]; }
+};
+typedef Index Size;
+
+inline void rna_check(int rc, rna_engine* e, const char* what) {
+  if (rc != RNA_OK) throw std::runtime_error(std::string(what) + ": " + (e ? rna_last_error(e) : "rna error"));
+}
+
+// GridMap: geometry + the three layers MapProvider uses ("master", "laser", "range"), resident in HBM.
+class GridMap {
+ public:
+  GridMap() : e_(nullptr) {}
+  ~GridMap() { if (e_) rna_destroy(e_); }
+  GridMap(const GridMap&) = delete;
+  GridMap& operator=(const GridMap&) = delete;
+
+  // GridMap::setGeometry (gmc/src/GridMap.cpp:51-70)
+  void setGeometry(const Length& length, double resolution, const Position& position = Position(0.0, 0.0), int device = 0) {
+    if (e_) { rna_destroy(e_); e_ = nullptr; }
+    int rc = rna_create(&e_, length[0], length[1], resolution, position[0], position[1], device);
+    if (rc != RNA_OK) throw std::runtime_error("GridMap::setGeometry: rna_create failed (no MI355X / bad geometry)");
+  }
+  static int layerId(const std::string& layer) {
+    if (layer == "master") return RNA_LAYER_MASTER;
+    if (layer == "laser") return RNA_LAYER_LASER;
+    if (layer == "range") return RNA_LAYER_RANGE;
+    // GridMap::get throws std::out_of_range for unknown layers (gmc/src/GridMap.cpp:125-141)
+    throw std::out_of_range("GridMap::get(...) : No map layer '" + layer + "' available.");
+  }
+  bool exists(const std::string& layer) const { return layer == "master" || layer == "laser" || layer == "range"; }
+  rna_geometry geometry() const { rna_geometry g; rna_check(rna_get_geometry(e_, &g), e_, "geometry"); return g; }
+  Length getLength() const { rna_geometry g = geometry(); return Length(g.length[0], g.length[1]); }
+  Position getPosition() const { rna_geometry g = geometry(); return Position(g.position[0], g.position[1]); }
+  Size getSize() const { rna_geometry g = geometry(); return Size(g.size[0], g.size[1]); }
+  double getResolution() const { return geometry().resolution; }
+  // getIndex / getPosition / isInside (gmc/src/GridMap.cpp:227-240)
+  bool getIndex(const Position& p, Index& idx) const {
+    int32_t o[2];
+    if (rna_get_index(e_, p[0], p[1], o) != 1) return false;
+    idx = Index(o[0], o[1]);
+    return true;
+  }
+  bool getPosition(const Index& idx, Position& p) const {
+    double o[2];
+    if (rna_get_position(e_, idx[0], idx[1], o) != 1) return false;
+    p = Position(o[0], o[1]);
+    return true;
+  }
+  bool isInside(const Position& p) const { Index i; return getIndex(p, i); }
+  bool move(const Position& p) { int moved = 0; rna_check(rna_move(e_, p[0], p[1], &moved), e_, "move"); return moved != 0; }
+  // whole-layer access (column-major, linear = i + j*rows) replacing operator[] copies
+  void set(const std::string& layer, const std::vector<float>& data) {
+    rna_check(rna_layer_upload(e_, layerId(layer), data.data(), data.size()), e_, "GridMap::set");
+  }
+  std::vector<float> get(const std::string& layer) const {
+    rna_geometry g = geometry();
+    std::vector<float> out((size_t)g.size[0] * g.size[1]);
+    rna_check(rna_layer_download(e_, layerId(layer), out.data(), out.size()), e_, "GridMap::get");
+    return out;
+  }
+  rna_engine* engine() const { return e_; }
+
+ private:
+  rna_engine* e_;
+};
+
+}  // namespace grid_map
+
+namespace move_control {
+
+using grid_map::GridMap;
+using grid_map::Length;
+using grid_map::Position;
+
+// MapUpdater::RangeSample (mc/include/move_control/map_updater.h:28-32)
+struct RangeSample {
+  Position start, end;
+  bool ifClearEnd;
+};
+
+// The compute core of MapProvider (mc/src/map_provider.cpp:190-223): buffered samples are applied
+// in arrival order (laser_map_updater.cpp:7-21) and master is composed from the laser layer.
+class MapProvider {
+ public:
+  explicit MapProvider(Length mapLength = Length(30, 30), double resolution = 0.05, int device = 0) {
+    map_.setGeometry(mapLength, resolution, Position(0.0, 0.0), device);  // initParameter/initMap, :130-149
+  }
+  void bufferSample(const RangeSample& s) {  // LaserMapUpdater::bufferIncomingMsg's push_back, :63-72
+    rna_ray r;
+    r.sx = s.start[0]; r.sy = s.start[1]; r.ex = s.end[0]; r.ey = s.end[1];
+    r.clear_end = s.ifClearEnd ? 1 : 0; r._pad = 0;
+    buffer_.push_back(r);
+  }
+  // MapProvider::updateMap: drain the buffer through HIMM, then compose master (fused, dirty tiles)
+  void updateMap(bool wholeLayerCopy = false) {
+    grid_map::rna_check(rna_update_map(map_.engine(), buffer_.data(), (int)buffer_.size(), wholeLayerCopy ? 1 : 0),
+                        map_.engine(), "MapProvider::updateMap");
+    buffer_.clear();
+  }
+  GridMap& getMap() { return map_; }
+  bool ifCloseToPostion(const Position& robot, const Position& pos, double tolerance) const {  // :102-111
+    return std::hypot(pos[0] - robot[0], pos[1] - robot[1]) < tolerance;
+  }
+
+ private:
+  GridMap map_;
+  std::vector<rna_ray> buffer_;
+};
+
+// VFH with the reference's constructor signature and Update_VFH contract (vfh.h:185-253).  One
+// instance drives `robots` independent stateful VFH instances on the GPU (robots = 1 is the drop-in).
+class VFH {
+ public:
+  VFH(double cell_size, int window_diameter, int sector_angle, double safety_dist_0ms, double safety_dist_1ms,
+      int max_speed, int max_speed_narrow_opening, int max_speed_wide_opening, int max_acceleration, int min_turnrate,
+      int max_turnrate_0ms, int max_turnrate_1ms, double min_turn_radius_safety_factor, double free_space_cutoff_0ms,
+      double obs_cutoff_0ms, double free_space_cutoff_1ms, double obs_cutoff_1ms, double weight_desired_dir,
+      double weight_current_dir)
+      : map_(nullptr), robots_(1), picked_(90.0f) {
+    p_.cell_size = cell_size; p_.window_diameter = window_diameter; p_.sector_angle = sector_angle;
+    p_.safety_dist_0ms = safety_dist_0ms; p_.safety_dist_1ms = safety_dist_1ms; p_.max_speed = max_speed;
+    p_.max_speed_narrow_opening = max_speed_narrow_opening; p_.max_speed_wide_opening = max_speed_wide_opening;
+    p_.max_acceleration = max_acceleration; p_.min_turnrate = min_turnrate; p_.max_turnrate_0ms = max_turnrate_0ms;
+    p_.max_turnrate_1ms = max_turnrate_1ms; p_.min_turn_radius_safety_factor = min_turn_radius_safety_factor;
+    p_.free_space_cutoff_0ms = free_space_cutoff_0ms; p_.obs_cutoff_0ms = obs_cutoff_0ms;
+    p_.free_space_cutoff_1ms = free_space_cutoff_1ms; p_.obs_cutoff_1ms = obs_cutoff_1ms;
+    p_.weight_desired_dir = weight_desired_dir; p_.weight_current_dir = weight_current_dir;
+    p_.robot_radius = 0.0;
+    Hist = nullptr; OriginHist = nullptr;
+  }
+  void SetRobotRadius(float robot_radius) { p_.robot_radius = robot_radius; }
+  // Init() needs the map the instance works on (the reference passes ranges in; here the engine
+  // also offers the fused map -> ranges -> VFH path)
+  int Init(GridMap& map, int robots = 1) {
+    map_ = &map; robots_ = robots;
+    grid_map::rna_check(rna_vfh_init(map.engine(), &p_, robots), map.engine(), "VFH::Init");
+    hist_.assign((size_t)robots * getHistSize(), 0.0f);
+    origin_.assign((size_t)robots * getHistSize(), 0.0f);
+    Hist = hist_.data(); OriginHist = origin_.data();
+    return 1;
+  }
+  // VFH::Update_VFH (vfh.h:216-222); dt = seconds since the previous call (the reference reads gettimeofday)
+  int Update_VFH(double laser_ranges[361][2], int current_speed, float goal_direction, float goal_distance,
+                 float goal_distance_tolerance, int& chosen_speed, int& chosen_turnrate, double dt = 0.2) {
+    rna_pose pose = {0, 0, 0, dt, current_speed, goal_direction, goal_distance, goal_distance_tolerance};
+    rna_vfh_out out;
+    grid_map::rna_check(rna_vfh_update_batch(map_->engine(), &laser_ranges[0][0], &pose, 1, &out, origin_.data(), hist_.data()),
+                        map_->engine(), "VFH::Update_VFH");
+    chosen_speed = out.chosen_speed; chosen_turnrate = out.chosen_turnrate; picked_ = out.picked_angle;
+    return 1;
+  }
+  // Steerer::update's getRangesFromSubmap + Update_VFH for a batch of robot poses (steerer.cpp:221-270)
+  int Update_VFH(const std::vector<rna_pose>& poses, std::vector<rna_vfh_out>& out) {
+    out.resize(poses.size());
+    grid_map::rna_check(rna_vfh_step_batch(map_->engine(), poses.data(), (int)poses.size(), out.data(), origin_.data(), hist_.data()),
+                        map_->engine(), "VFH::Update_VFH(batch)");
+    if (!out.empty()) picked_ = out[0].picked_angle;
+    return 1;
+  }
+  float GetPickedAngle() const { return picked_; }
+  int getHistSize() const { return rna_vfh_hist_size(map_->engine()); }
+  int getSectorAngle() const { return p_.sector_angle; }
+  float* Hist;        // public as in the reference (vfh.h:239-244); refreshed by every Update_VFH
+  float* OriginHist;
+
+ private:
+  rna_vfh_params p_;
+  GridMap* map_;
+  int robots_;
+  float picked_;
+  std::vector<float> hist_, origin_;
+};
+
+// AStarPlanner::makePlan over the reference's hard-coded waypoint graph (astar_planner.cpp:63-127)
+class AStarPlanner {
+ public:
+  explicit AStarPlanner(GridMap& map) : map_(map) {  // init(), :98-127
+    const int m = 8, n = 5;
+    const double L[9][2] = {{0.5 * m, 0.0 * n}, {1.5 * m, 0.0 * n}, {2.5 * m, 0.0 * n}, {2.5 * m, 1.0 * n}, {1.5 * m, 1.0 * n},
+                            {0.5 * m, 1.0 * n}, {0.5 * m, 2.0 * n}, {1.5 * m, 2.0 * n}, {2.5 * m, 2.0 * n}};
+    const int E[10][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}, {4, 5}, {5, 6}, {6, 7}, {7, 8}, {0, 5}, {3, 8}};
+    for (auto& l : L) { locations_.push_back(l[0]); locations_.push_back(l[1]); }
+    for (auto& ed : E) { edges_.push_back(ed[0]); edges_.push_back(ed[1]); }
+  }
+  // appends to `path` (start, vertex locations..., target); leaves it untouched when no route exists
+  bool makePlan(Position& start, Position& target, std::vector<Position>& path) {
+    const double st[4] = {start[0], start[1], target[0], target[1]};
+    std::vector<double> out(2 * 16);
+    int32_t len = 0;
+    grid_map::rna_check(rna_graph_astar_batch(map_.engine(), 9, locations_.data(), 10, edges_.data(), nullptr, st, 1,
+                                              out.data(), 16, &len), map_.engine(), "AStarPlanner::makePlan");
+    for (int k = 0; k < len; ++k) path.push_back(Position(out[2 * k], out[2 * k + 1]));
+    return len > 0;
+  }
+
+ private:
+  GridMap& map_;
+  std::vector<double> locations_;
+  std::vector<int32_t> edges_;
+};
+
+// Grid A* over the GridMap's master layer (BASELINE.json's planner): same makePlan shape.
+class GridAStarPlanner {
+ public:
+  explicit GridAStarPlanner(GridMap& map) : map_(map) {}
+  bool makePlan(Position& start, Position& target, std::vector<Position>& path) {
+    grid_map::Index s, t;
+    if (!map_.getIndex(start, s) || !map_.getIndex(target, t)) return false;
+    const int rows = map_.getSize()[0];
+    rna_astar_query q = {s[0] + s[1] * rows, t[0] + t[1] * rows};
+    std::vector<int32_t> cells(1 << 16);
+    rna_astar_result r;
+    grid_map::rna_check(rna_astar_batch(map_.engine(), &q, 1, cells.data(), (int)cells.size(), &r), map_.engine(),
+                        "GridAStarPlanner::makePlan");
+    if (r.status != 0) return false;
+    for (int k = 0; k < r.path_len; ++k) {
+      Position p;
+      map_.getPosition(grid_map::Index(cells[k] % rows, cells[k] / rows), p);
+      path.push_back(p);
+    }
+    return true;
+  }
+
+ private:
+  GridMap& map_;
+};
+
+// RrtPlanner(GridMap&, start, target, closeTolerance).makePlan(path) (rrt_planner.h:17-28): clears
+// then fills `path` goal -> start; returns false (with the best-effort path) after 2000 iterations.
+class RrtPlanner {
+ public:
+  RrtPlanner(GridMap& map, Position& start, Position& target, double closeTolerance = 0.2, unsigned seed = 1)
+      : map_(map), start_(start), target_(target), tol_(closeTolerance), seed_(seed) {}
+  bool makePlan(std::vector<Position>& path) {
+    rna_rrt_query q;
+    q.start[0] = start_[0]; q.start[1] = start_[1]; q.target[0] = target_[0]; q.target[1] = target_[1];
+    q.close_tolerance = tol_; q.seed = seed_; q.max_samples = 1000000;
+    std::vector<double> out(2 * 2048);
+    rna_rrt_result r;
+    grid_map::rna_check(rna_rrt_batch(map_.engine(), &q, 1, out.data(), 2048, &r), map_.engine(), "RrtPlanner::makePlan");
+    path.clear();
+    for (int k = 0; k < r.path_len && k < 2048; ++k) path.push_back(Position(out[2 * k], out[2 * k + 1]));
+    return r.status == 1;
+  }
+
+ private:
+  GridMap& map_;
+  Position start_, target_;
+  double tol_;
+  unsigned seed_;
+};
+
+}  // namespace move_control

@@ -1,0 +1,121 @@
+// GPU test of the C++ host mirror (ros_navigation_amd/host/move_control_amd.hpp): the calls read like
+// the reference's node code (mc/src/nav_graph_node.cpp, steerer.cpp), results are checked against
+// the CPU oracle.  Built and run by tests/test_host_mirror.py.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../oracle/rna_oracle.h"
+#include "../../ros_navigation_amd/host/move_control_amd.hpp"
+
+using namespace grid_map;
+using namespace move_control;
+
+#define CHECK(c) do { if (!(c)) { std::printf("FAILED line %d: %s\n", __LINE__, #c); return 1; } } while (0)
+
+static bool same_bits(float a, float b) { return (std::isnan(a) && std::isnan(b)) || std::memcmp(&a, &b, 4) == 0; }
+
+int main() {
+  // ---- MapProvider: buffered range samples -> HIMM -> master (map_provider.cpp:190-223) ----
+  MapProvider provider(Length(12.8, 12.8));
+  GridMap& map = provider.getMap();
+  og_geom g;
+  og_set_geometry(&g, 12.8, 12.8, 0.05, 0.0, 0.0);
+  CHECK(map.getSize()[0] == g.size[0] && map.getSize()[1] == g.size[1]);
+  std::vector<float> ref((size_t)g.size[0] * g.size[1], NAN);
+  std::vector<og_ray> rays;
+  std::srand(7);
+  for (int k = 0; k < 800; ++k) {
+    const double a = 6.283 * std::rand() / RAND_MAX, l = 0.5 + 4.0 * std::rand() / RAND_MAX;
+    RangeSample s;
+    s.start = Position(1.0, -0.5);
+    s.end = Position(1.0 + l * std::cos(a), -0.5 + l * std::sin(a));
+    s.ifClearEnd = (k % 5 == 0);
+    provider.bufferSample(s);
+    og_ray r = {s.start[0], s.start[1], s.end[0], s.end[1], s.ifClearEnd ? 1 : 0, 0};
+    rays.push_back(r);
+  }
+  provider.updateMap();
+  og_himm_update(&g, ref.data(), rays.data(), (int)rays.size(), nullptr);
+  std::vector<float> master = map.get("master");
+  for (size_t i = 0; i < ref.size(); ++i) CHECK(same_bits(master[i], ref[i]));
+  bool threw = false;
+  try { map.get("elevation"); } catch (const std::out_of_range&) { threw = true; }
+  CHECK(threw);  // unknown layer -> std::out_of_range as GridMap::get
+
+  // ---- VFH with the Steerer's parameters (steerer.cpp:69-132) ----
+  VFH vfh(100, 30, 5, 10, 50, 200, 200, 300, 200, 40, 40, 40, 1.0, 2000000.0, 4000000.0, 2000000.0, 4000000.0, 10.0, 1.0);
+  vfh.SetRobotRadius(178.0);
+  vfh.Init(map);
+  og_vfh_params op;
+  og_vfh_default_params(&op);
+  og_vfh* ov = og_vfh_create(&op);
+  double ranges[361][2];
+  for (int step = 0; step < 5; ++step) {
+    for (int i = 0; i < 361; ++i) { ranges[i][0] = 5000.0; ranges[i][1] = 0; }
+    for (int i = 60 + 10 * step; i < 120; i += 2) ranges[i][0] = 700.0 + 13.0 * i;
+    int cs = 0, ct = 0, ocs = 0, oct = 0;
+    vfh.Update_VFH(ranges, 50 * step, 80.0f + 10 * step, 2500.0f, 250.0f, cs, ct, 0.2);
+    og_vfh_update(ov, ranges, 50 * step, 80.0f + 10 * step, 2500.0f, 250.0f, 0.2, &ocs, &oct);
+    CHECK(cs == ocs && ct == oct);
+    CHECK(vfh.GetPickedAngle() == og_vfh_picked_angle(ov));
+    for (int s = 0; s < vfh.getHistSize(); ++s) {
+      CHECK(same_bits(vfh.Hist[s], og_vfh_hist(ov)[s]));
+      CHECK(same_bits(vfh.OriginHist[s], og_vfh_origin_hist(ov)[s]));
+    }
+  }
+  og_vfh_destroy(ov);
+
+  // ---- planners ----
+  Position start(-5.0, -5.0), target(5.5, 4.0);
+  std::vector<Position> path;
+  GridAStarPlanner grid_planner(map);
+  CHECK(grid_planner.makePlan(start, target, path));
+  {
+    std::vector<uint8_t> blocked(ref.size()), nbr(ref.size());
+    og_astar_blocked_mask(ref.data(), ref.size(), blocked.data());
+    og_astar_nbr_mask(blocked.data(), g.size[0], g.size[1], nbr.data());
+    int si[2], ti[2];
+    const double sp[2] = {start[0], start[1]}, tp[2] = {target[0], target[1]};
+    og_index_from_position(&g, sp, si);
+    og_index_from_position(&g, tp, ti);
+    std::vector<int32_t> gw(ref.size()), op_(ref.size());
+    og_astar_result r;
+    og_astar_query(nbr.data(), g.size[0], g.size[1], si[0] + si[1] * g.size[0], ti[0] + ti[1] * g.size[0], gw.data(),
+                   op_.data(), (int)op_.size(), &r);
+    CHECK(r.status == 0 && (size_t)r.path_len == path.size());
+    for (int k = 0; k < r.path_len; ++k) {
+      const int idx[2] = {op_[k] % g.size[0], op_[k] / g.size[0]};
+      double p[2];
+      og_position_from_index(&g, idx, p);
+      CHECK(p[0] == path[k][0] && p[1] == path[k][1]);
+    }
+  }
+  AStarPlanner graph_planner(map);
+  Position gs(3.0, 0.5), gt(19.0, 10.5);
+  std::vector<Position> gpath;
+  CHECK(graph_planner.makePlan(gs, gt, gpath));
+  {
+    double out[64];
+    const double a[2] = {gs[0], gs[1]}, b[2] = {gt[0], gt[1]};
+    const int n = og_graph_make_plan(a, b, out, 32);
+    CHECK((size_t)n == gpath.size());
+    for (int k = 0; k < n; ++k) CHECK(out[2 * k] == gpath[k][0] && out[2 * k + 1] == gpath[k][1]);
+  }
+  RrtPlanner rrt(map, start, target);
+  std::vector<Position> rpath;
+  const bool rrt_ok = rrt.makePlan(rpath);
+  {
+    std::vector<double> out(2 * 2048);
+    og_rrt_result r;
+    const double a[2] = {start[0], start[1]}, b[2] = {target[0], target[1]};
+    og_rrt_plan(&g, ref.data(), a, b, 0.2, 1, 1000000, out.data(), 2048, &r);
+    CHECK(rrt_ok == (r.status == 1) && (size_t)r.path_len == rpath.size());
+    for (int k = 0; k < r.path_len; ++k)
+      CHECK(std::fabs(out[2 * k] - rpath[k][0]) < 1e-9 && std::fabs(out[2 * k + 1] - rpath[k][1]) < 1e-9);
+  }
+  std::printf("host mirror OK (%zu grid-A* cells, %zu graph waypoints, %zu RRT waypoints)\n", path.size(), gpath.size(), rpath.size());
+  return 0;
+}
