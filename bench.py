@@ -96,6 +96,9 @@ def pmc_traffic(kernel):
 def main():
     args = parse()
     import torch
+    from ros_navigation_amd import capi as _capi
+    if os.environ.get("RNA_LIB"):  # developer switch: alternative build of librna.so
+        _capi.LIB_PATH = os.path.join(os.path.dirname(_capi.LIB_PATH), os.environ["RNA_LIB"])
     import ros_navigation_amd as R
     from ros_navigation_amd import dist as D
     rank, local_rank, world = D.env_rank_world()

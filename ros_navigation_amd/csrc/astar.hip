@@ -39,7 +39,10 @@ namespace {
 constexpr int COST_S = 1000, COST_D = 1414;
 constexpr int INF = 0x7fffffff;          // "no path" cost in results
 constexpr unsigned G_INF = 0xFFFFFFu;    // unreached cell in the packed field
-constexpr int LQ_CAP = 8192;             // entries of each LDS frontier queue (2 x 64 KiB)
+#ifndef RNA_ASTAR_LQ_CAP
+#define RNA_ASTAR_LQ_CAP 4096
+#endif
+constexpr int LQ_CAP = RNA_ASTAR_LQ_CAP;   // entries of each LDS frontier queue (2 queues x 8 B x LQ_CAP)
 
 typedef int v3i __attribute__((ext_vector_type(3)));
 

@@ -57,7 +57,7 @@ struct AstarDevice {
   int max_queries = 0;
   int queue_cap = 0;
   int bucket_width = 8000;
-  int threads = 1024;              // workgroup size of the search kernel (256 / 512 / 1024)
+  int threads = 512;               // workgroup size of the search kernel (256 / 512 / 1024)
   // Pipelined batches: `depth` independent sets of search fields + queues, each with its own HIP
   // stream, so the tail of batch k (few long queries) overlaps the head of batch k+1.
   static constexpr int MAX_DEPTH = 8;
