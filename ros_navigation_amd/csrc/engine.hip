@@ -26,7 +26,7 @@ __global__ void compose_dirty_tiles_kernel(float* __restrict__ master, const flo
                                            const unsigned* __restrict__ dirty, int rows, int cols, int tiles_i) {
   const int ti = blockIdx.x, tj = blockIdx.y;
   const int t = tj * tiles_i + ti;
-  if (!((dirty[t >> 5] >> (t & 31)) & 1u)) return;
+  if (!reinterpret_cast<const unsigned char*>(dirty)[t]) return;
   const int i0 = ti * TILE, j0 = tj * TILE;
   const int li = threadIdx.x & (TILE - 1);
   for (int c = threadIdx.x >> 6; c < TILE; c += 4) {
@@ -57,7 +57,7 @@ __global__ void nbr_mask_tiles_kernel(uint8_t* __restrict__ nbr, const float* __
         const int a = ti + di, b = tj + dj;
         if (a < 0 || b < 0 || a >= tiles_i || b >= tiles_j) continue;
         const int t = b * tiles_i + a;
-        if ((dirty[t >> 5] >> (t & 31)) & 1u) { need = true; break; }
+        if (reinterpret_cast<const unsigned char*>(dirty)[t]) { need = true; break; }
       }
     if (!need) return;
   }
@@ -159,7 +159,7 @@ extern "C" int rna_create(rna_engine** out, double length_x, double length_y, do
     // GridMap::setGeometry -> clearAll(): every layer starts as NaN (gmc/src/GridMap.cpp:62)
     if ((rc = fill_layer(e, e->layer[l], std::numeric_limits<float>::quiet_NaN())) != RNA_OK) return bail(rc);
   }
-  const size_t words = ((size_t)e->tiles_i * e->tiles_j + 31) / 32;
+  const size_t words = ((size_t)e->tiles_i * e->tiles_j + 3) / 4;  // one byte per tile, rounded to words
   if ((rc = dev_alloc(e, &e->dirty_tiles, words)) != RNA_OK) return bail(rc);
   if (hipMemsetAsync(e->dirty_tiles, 0, words * sizeof(unsigned), e->stream) != hipSuccess) return bail(RNA_EHIP);
   if ((rc = dev_alloc(e, &e->nbr, e->ncell)) != RNA_OK) return bail(rc);
@@ -302,7 +302,7 @@ int map_prepare_nbr(rna_engine* e) {
 extern "C" int rna_compose_master(rna_engine* e, int mode) {
   if (!e || (mode != 0 && mode != 1)) return RNA_EINVAL;
   RNA_HIP(e, hipSetDevice(e->device));
-  const size_t words = ((size_t)e->tiles_i * e->tiles_j + 31) / 32;
+  const size_t words = ((size_t)e->tiles_i * e->tiles_j + 3) / 4;  // one byte per tile, rounded to words
   const bool full = (mode == 1) || e->laser_all_dirty;
   {
     KernelTimer kt(e, RNA_K_COMPOSE);

@@ -95,7 +95,7 @@ struct rna_engine {
   size_t ncell = 0;
   float* layer[RNA_NUM_LAYERS] = {nullptr, nullptr, nullptr};
   int tiles_i = 0, tiles_j = 0;
-  unsigned* dirty_tiles = nullptr;   // bit per TILE x TILE tile: laser changed since last compose
+  unsigned* dirty_tiles = nullptr;   // one BYTE per TILE x TILE tile: laser changed since last compose
   bool laser_all_dirty = false;      // laser uploaded/filled: next compose is a whole-layer copy
   uint8_t* nbr = nullptr;            // A* neighbour masks derived from master
   bool nbr_all_dirty = true;

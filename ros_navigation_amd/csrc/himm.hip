@@ -178,9 +178,10 @@ __global__ void himm_raster_kernel(int rows, const int4* __restrict__ desc, cons
     const int cell = j * rows + i;
     const int tile = (j >> 6) * tiles_i + (i >> 6);
     if (tile != last_tile) {
-      const unsigned bit = 1u << (tile & 31);
-      if (!(__hip_atomic_load(&dirty_tiles[tile >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit))
-        atomicOr(&dirty_tiles[tile >> 5], bit);
+      // one byte per tile, plain load + plain store of the same value by every first toucher: no
+      // atomics (a bit-packed atomicOr here serialised the whole batch on four cache lines)
+      volatile unsigned char* flag = reinterpret_cast<volatile unsigned char*>(dirty_tiles) + tile;
+      if (!*flag) *flag = 1;
       last_tile = tile;
     }
     if ((mark_bitmap[cell >> 5] >> (cell & 31)) & 1u) {
@@ -228,7 +229,7 @@ __global__ void himm_apply_kernel(int rows, const HimmSlot* __restrict__ slots, 
   atomicAnd(&mark_bitmap[sl.cell >> 5], ~(1u << (sl.cell & 31)));  // leave the bitmap all-zero
   const int i = sl.cell % rows, j = sl.cell / rows;
   const int tile = (j >> 6) * tiles_i + (i >> 6);
-  atomicOr(&dirty_tiles[tile >> 5], 1u << (tile & 31));
+  reinterpret_cast<volatile unsigned char*>(dirty_tiles)[tile] = 1;
 }
 
 int ensure_scratch(rna_engine* e, int n) {
