@@ -1,0 +1,115 @@
+"""Per-row measurements of SURVEY.md section 8 on one MI355X (not the headline bench): each hot-path
+kernel on BASELINE.json's config for it, inputs resident in HBM, HIP-event timed, with the
+algorithmic-byte roofline of SURVEY.md 8d.  Writes one JSON object to stdout.
+
+    python scripts/bench_rows.py > profiles/r01_rows.json
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+torch.cuda.init()
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ros_navigation_amd as R  # noqa: E402
+
+PEAK = 8000.0  # GB/s
+out = {}
+
+
+def dev(a):
+    return torch.from_numpy(np.frombuffer(a.tobytes(), dtype=np.uint8).copy()).cuda()
+
+
+def timed(e, fn, reps):
+    fn()
+    e.synchronize()
+    e.profile(True)
+    e.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    e.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    prof = {k: v[0] / max(1, v[1]) for k, v in e.profile_get().items() if v[1]}
+    e.profile(False)
+    return wall, prof
+
+
+# ---- config 2: 1024^2 grid, 72-sector VFH+, 1024 poses ---------------------------------------------
+n = 1024
+e = R.Engine(n * 0.05, n * 0.05, 0.05)
+e.upload(R.capi.LAYER_MASTER, R.synth.occupancy_sparse(n, n, seed=1))
+poses = R.synth.poses(1024, n * 0.05, n * 0.05, seed=1)
+e.vfh_init(len(poses))
+d_poses, d_out = dev(poses), torch.zeros(len(poses) * 16, dtype=torch.uint8, device="cuda")
+wall, prof = timed(e, lambda: e.vfh_step_device(d_poses.data_ptr(), len(poses), d_out.data_ptr()), 50)
+bytes_pose = 4 * 31 * 31 + 2 * 72 * 4 + 32
+gbs = len(poses) * bytes_pose / (prof["vfh_step"] * 1e-3) / 1e9
+out["config2_vfh"] = dict(workload="1024x1024 grid, 1024 poses, Steerer VFH params", poses_per_s=len(poses) / wall,
+                          kernel_ms=prof["vfh_step"], algorithmic_bytes_per_pose=bytes_pose, achieved_gbs=gbs, frac=gbs / PEAK)
+e.close()
+
+# ---- HIMM: 100k-ray batch (config 5's ray batch) on 4096^2 ------------------------------------------
+n = 4096
+L = n * 0.05
+e = R.Engine(L, L, 0.05)
+master = R.synth.obstacles_rect(n, n, density=0.30, seed=2)
+e.upload(R.capi.LAYER_LASER, master)
+rays = R.synth.rays(64, 1563, L, L, seed=4)
+d_rays = dev(rays)
+for _ in range(3):
+    e.update_map_device(d_rays.data_ptr(), len(rays), 0)
+wall, prof = timed(e, lambda: e.update_map_device(d_rays.data_ptr(), len(rays), 0), 20)
+ln = np.hypot(rays["ex"] - rays["sx"], rays["ey"] - rays["sy"]) / 0.05
+alg = float((8 * ln + 8 * (rays["clear_end"] == 0) + 40).sum())
+k_ms = sum(prof.get(k, 0.0) for k in ("himm_prep", "himm_raster", "himm_apply"))
+out["himm_batch"] = dict(workload="100032 rays (64 origins x 1563, 1-6 m) on 4096x4096, fused compose (dirty tiles)",
+                         rays_per_s=len(rays) / wall, kernels_ms=prof, algorithmic_bytes=alg,
+                         achieved_gbs=alg / (k_ms * 1e-3) / 1e9, frac=alg / (k_ms * 1e-3) / 1e9 / PEAK)
+wall1, prof1 = timed(e, lambda: e.update_map_device(d_rays.data_ptr(), len(rays), 1), 10)
+out["himm_batch"]["compose_full_copy_ms"] = prof1.get("compose_master")
+out["himm_batch"]["compose_full_copy_gbs"] = 8.0 * n * n / (prof1.get("compose_master", 1) * 1e-3) / 1e9
+
+# ---- config 3: 4096^2, 256 A* queries (static map), unpipelined launch ------------------------------
+m1 = e.download(R.capi.LAYER_MASTER)
+q = R.synth.astar_queries(256, m1, n, n, seed=2)
+d_q = dev(q)
+d_paths = torch.zeros(256 * 32768, dtype=torch.int32, device="cuda")
+d_res = torch.zeros(256 * 6, dtype=torch.int32, device="cuda")
+e.astar_pipeline_depth(1)
+e.astar_configure(max_queries=256)
+wall, prof = timed(e, lambda: e.astar_device(d_q.data_ptr(), 256, d_paths.data_ptr(), 32768, d_res.data_ptr()), 5)
+settled = e.astar_settled(256)
+alg = float(settled.astype(np.int64).sum()) * 44
+out["config3_astar"] = dict(workload="4096x4096, 256 queries, one launch (pipeline depth 1)", queries_per_s=256 / wall,
+                            search_ms=prof["astar_search"], init_ms=prof["astar_init"], settled_cells=int(settled.sum()),
+                            algorithmic_bytes=alg, achieved_gbs=alg / (prof["astar_search"] * 1e-3) / 1e9,
+                            frac=alg / (prof["astar_search"] * 1e-3) / 1e9 / PEAK,
+                            init_gbs=256 * 4.0 * n * n / (prof["astar_init"] * 1e-3) / 1e9)
+e.close()
+
+# ---- config 4: RRT, 512 queries (one GPU's share of 4096) on 2048^2 ---------------------------------
+n = 2048
+e = R.Engine(n * 0.05, n * 0.05, 0.05)
+master = R.synth.obstacles_rect(n, n, density=0.30, seed=3)
+e.upload(R.capi.LAYER_MASTER, master)
+q = R.synth.rrt_queries(512, master, n, n, e.get_position, seed=3, max_samples=100000)
+t0 = time.perf_counter()
+res, paths = e.rrt(q)
+wall = time.perf_counter() - t0
+e.profile(True)
+e.profile_reset()
+res, paths = e.rrt(q)
+prof = e.profile_get()
+nodes = int(res["tree_size"].sum())
+alg = float((24.0 * res["tree_size"].astype(np.float64) ** 2 / 2 + 452.0 * res["samples"]).sum())
+out["config4_rrt"] = dict(workload="2048x2048, 512 queries (per-GPU share of 4096), <= 2000 nodes each",
+                          queries_per_s=512 / (prof["rrt"][0] * 1e-3), kernel_ms=prof["rrt"][0], reached=int((res["status"] == 1).sum()),
+                          tree_nodes=nodes, samples=int(res["samples"].sum()), algorithmic_bytes=alg,
+                          achieved_gbs=alg / (prof["rrt"][0] * 1e-3) / 1e9)
+e.close()
+print(json.dumps(out, indent=1))

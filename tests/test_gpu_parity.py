@@ -328,3 +328,92 @@ def test_rrt_matches_oracle(R):
         n = ores.path_len
         assert np.allclose(paths[k, :n], opath, rtol=0, atol=1e-9), k
     e.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# circular buffer (GridMap::move) and degenerate inputs
+# ------------------------------------------------------------------------------------------------
+def test_himm_and_vfh_on_a_moved_map(R):
+    """After GridMap::move the buffer start index is non-zero: index<->position math wraps
+    (gmc/src/GridMapMath.cpp:70-81,467-476); LineIterator walks buffer indices without unwrapping
+    (reference behaviour, restated by the oracle) and getSubmap gathers across the seam."""
+    e = R.Engine(12.8, 9.6, 0.05)
+    g = O.make_geom(12.8, 9.6, 0.05)
+    rng = np.random.default_rng(11)
+    laser = R.synth.occupancy_sparse(e.rows, e.cols, seed=5, occupied=0.03)
+    for l in range(3):
+        e.upload(l, laser)
+    ref = laser.copy()
+    ptrs = (C.POINTER(C.c_float) * 1)(O.fptr(ref))
+    regs = (O.Region * 4)()
+    mv = C.c_int(0)
+    O.lib().og_move(C.byref(g), ptrs, 1, O.d2(1.37, -0.82), regs, C.byref(mv))
+    assert e.move(1.37, -0.82) and tuple(e.geometry().start_index) == tuple(g.start) != (0, 0)
+    rays = random_rays(rng, 1500, 3.0, outside=0.1)
+    rays["sx"] += 1.37
+    rays["ex"] += 1.37
+    rays["sy"] -= 0.82
+    rays["ey"] -= 0.82
+    O.himm_update(g, ref, rays)
+    e.himm_update(R.capi.LAYER_LASER, rays.view(R.capi.RAY_DTYPE))
+    assert same_f32(e.download(R.capi.LAYER_LASER), ref)
+    e.compose_master(1)
+    poses = R.synth.poses(48, 12.8, 9.6, seed=9, margin=0.3)
+    poses["x"] += 1.37
+    poses["y"] -= 0.82
+    e.vfh_init(len(poses))
+    check_vfh_vs_oracle(R, e, g, ref, poses, steps=3)
+    q = np.zeros(1, R.capi.ASTAR_QUERY_DTYPE)
+    with pytest.raises(R.RnaError):       # grid A* refuses a moved map instead of planning across the seam
+        e.astar(q, 64)
+    e.close()
+
+
+def test_empty_batches_are_noops(R):
+    e = R.Engine(3.2, 3.2, 0.05)
+    e.himm_update(R.capi.LAYER_LASER, np.zeros(0, R.capi.RAY_DTYPE))
+    e.update_map(np.zeros(0, R.capi.RAY_DTYPE))
+    e.vfh_init(4)
+    out, origin, hist = e.vfh_step(np.zeros(0, R.capi.POSE_DTYPE))
+    assert len(out) == 0
+    res, paths = e.astar(np.zeros(0, R.capi.ASTAR_QUERY_DTYPE), 8)
+    assert len(res) == 0
+    res, paths = e.rrt(np.zeros(0, R.capi.RRT_QUERY_DTYPE))
+    assert len(res) == 0
+    assert np.all(np.isnan(e.download(R.capi.LAYER_MASTER)))
+    with pytest.raises(R.RnaError):
+        e.vfh_step(np.zeros(5, R.capi.POSE_DTYPE))     # more poses than VFH instances
+    e.close()
+
+
+def test_astar_large_grid_properties(R):
+    """BASELINE.json's full size (4096 x 4096): properties that need no oracle run -- every path is a
+    chain of legal 8-connected moves over free cells whose 1000/1414 cost equals the reported cost,
+    the reverse query has the same cost, and two bucket widths give identical paths."""
+    n = 4096
+    e = R.Engine(n * 0.05, n * 0.05, 0.05)
+    master = R.synth.obstacles_rect(n, n, density=0.30, seed=2)
+    e.upload(R.capi.LAYER_MASTER, master)
+    q = R.synth.astar_queries(24, master, n, n, seed=5)
+    rq = q.copy()
+    rq["start"], rq["goal"] = q["goal"], q["start"]
+    e.astar_configure(max_queries=24, bucket_width=8000)
+    res, paths = e.astar(q, 32768)
+    rres, _ = e.astar(rq, 32768)
+    e.astar_configure(bucket_width=3000)
+    res2, paths2 = e.astar(q, 32768)
+    nbr = e.nbr_mask()
+    assert np.all(res["status"] == 0) and np.array_equal(res["cost"], rres["cost"])
+    assert np.array_equal(res["cost"], res2["cost"]) and np.array_equal(res["path_len"], res2["path_len"])
+    off = np.array([-1 - n, -n, 1 - n, -1, 1, n - 1, n, n + 1])
+    cost = np.array([1414, 1000, 1414, 1000, 1000, 1414, 1000, 1414])
+    for k in range(len(q)):
+        p = paths[k, :res["path_len"][k]].astype(np.int64)
+        assert np.array_equal(p, paths2[k, :res2["path_len"][k]])
+        assert p[0] == q["start"][k] and p[-1] == q["goal"][k]
+        d = p[1:] - p[:-1]
+        kk = np.searchsorted(off, d)
+        assert np.all(off[np.clip(kk, 0, 7)] == d)                      # only the 8 neighbour offsets
+        assert np.all((nbr[p[:-1]] >> kk) & 1)                          # each move allowed by the mask
+        assert int(cost[kk].sum()) == res["cost"][k]
+    e.close()
