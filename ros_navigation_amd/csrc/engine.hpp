@@ -64,6 +64,11 @@ struct AstarDevice {
   int depth = 2;
   int32_t* g[MAX_DEPTH] = {};      // [max_queries][field_stride] packed (g << 8) | mask search fields
   int2* queues[MAX_DEPTH] = {};    // [max_queries][3][queue_cap] (cell, g)
+  unsigned* pend[MAX_DEPTH] = {};  // tile kernel: two pending bitmaps per query
+  int32_t* rev[MAX_DEPTH] = {};    // tile kernel: reversed-path staging per query
+  size_t pend_stride = 0;
+  int rev_cap = 16800;             // g < 2^24 at >= 1000 per step bounds a path to 16 777 cells
+  int mode = 0;                    // 0 = frontier kernel (astar.hip), 1 = tile-synchronous kernel (astar_tile.hip)
   hipStream_t side[MAX_DEPTH] = {};
   hipEvent_t done[MAX_DEPTH] = {}; // search of the batch that last used this set has finished
   bool busy[MAX_DEPTH] = {};
@@ -174,5 +179,14 @@ int vfh_release(rna_engine* e);
 int astar_release(rna_engine* e);
 int map_prepare_nbr(rna_engine* e);   // make e->nbr consistent with the master layer
 int sync_all(rna_engine* e);          // main stream + every A* side stream
+// tile-synchronous A* (astar_tile.hip)
+size_t tsa_field_words(const rna_engine* e);
+size_t tsa_pend_words(const rna_engine* e);
+bool tsa_supported(const rna_engine* e);
+int tsa_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init, unsigned* field,
+               size_t field_stride, unsigned* pend, size_t pend_stride, int32_t* rev, int rev_cap,
+               const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len, rna_astar_result* res_dev);
+int tsa_settled(rna_engine* e, const unsigned* field, size_t field_stride, const rna_astar_query* q,
+                const rna_astar_result* r, int n, int32_t* d_counts);
 
 }  // namespace rna

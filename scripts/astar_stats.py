@@ -2,6 +2,8 @@
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ros_navigation_amd import capi as _capi
+if os.environ.get("RNA_LIB"): _capi.LIB_PATH = os.path.join(os.path.dirname(_capi.LIB_PATH), os.environ["RNA_LIB"])
 import ros_navigation_amd as R
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
