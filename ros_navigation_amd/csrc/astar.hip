@@ -311,8 +311,8 @@ int ensure_config(rna_engine* e) {
   if (a.g[0]) return RNA_OK;
   if (a.max_queries <= 0) a.max_queries = 256;
   if (const char* t = getenv("RNA_ASTAR_THREADS")) a.threads = atoi(t);  // tuning knob: 256 / 512 / 1024
-  if (const char* k = getenv("RNA_ASTAR_KERNEL")) a.mode = (k[0] == 't') ? 1 : 0;  // "tile" | "frontier"
-  if (a.mode == 1 && !tsa_supported(e)) a.mode = 0;
+  if (const char* k = getenv("RNA_ASTAR_KERNEL")) a.mode = (k[0] == 'p') ? 2 : ((k[0] == 't') ? 1 : 0);  // persistent | tile | frontier
+  if (a.mode != 0 && !tsa_supported(e)) a.mode = 0;
   if (a.depth < 1) a.depth = 1;
   if (a.depth > AstarDevice::MAX_DEPTH) a.depth = AstarDevice::MAX_DEPTH;
   if (a.queue_cap <= 0) {
@@ -327,9 +327,9 @@ int ensure_config(rna_engine* e) {
   // fit into free HBM (25 % headroom): first fewer pipeline stages, then fewer concurrent queries
   size_t free_b = 0, total_b = 0;
   RNA_HIP(e, hipMemGetInfo(&free_b, &total_b));
-  const size_t field_words = a.mode == 1 ? tsa_field_words(e) : e->ncell;
+  const size_t field_words = a.mode != 0 ? tsa_field_words(e) : e->ncell;
   const size_t per_query = (field_words + 128) * sizeof(int32_t) +
-                           (a.mode == 1 ? tsa_pend_words(e) * 4 + (size_t)a.rev_cap * 4 : (size_t)3 * a.queue_cap * sizeof(int2));
+                           (a.mode != 0 ? tsa_pend_words(e) * 4 + (size_t)a.rev_cap * 4 : (size_t)3 * a.queue_cap * sizeof(int2));
   while (a.depth > 1 && (double)per_query * a.max_queries * a.depth > 0.75 * (double)free_b) a.depth -= 1;
   while (a.max_queries > 1 && (double)per_query * a.max_queries * a.depth > 0.75 * (double)free_b) a.max_queries /= 2;
   int rc;
@@ -338,9 +338,15 @@ int ensure_config(rna_engine* e) {
   a.pend_stride = ((tsa_pend_words(e) + 63) / 64) * 64;
   for (int d = 0; d < a.depth; ++d) {
     if ((rc = dev_alloc(e, &a.g[d], a.field_stride * (size_t)a.max_queries + 128)) != RNA_OK) return rc;
-    if (a.mode == 1) {
+    if (a.mode != 0) {
       if ((rc = dev_alloc(e, &a.pend[d], a.pend_stride * (size_t)a.max_queries)) != RNA_OK) return rc;
       if ((rc = dev_alloc(e, &a.rev[d], (size_t)a.rev_cap * a.max_queries)) != RNA_OK) return rc;
+      if (a.mode == 2) {
+        size_t s1 = 0, s2 = 0;
+        char* st = nullptr;
+        if ((rc = dev_alloc(e, &st, tsa_persist_state_bytes(e, a.max_queries, &s1, &s2))) != RNA_OK) return rc;
+        a.pstate[d] = st;
+      }
     } else {
       if ((rc = dev_alloc(e, &a.queues[d], (size_t)3 * a.queue_cap * a.max_queries)) != RNA_OK) return rc;
     }
@@ -366,7 +372,12 @@ int launch_chunk(rna_engine* e, const rna_astar_query* q_dev, int n, int32_t* pa
   unsigned* field = reinterpret_cast<unsigned*>(a.g[slot]) + 64;
   hipStream_t search_stream = a.depth > 1 ? a.side[slot] : e->stream;
   if (a.depth > 1 && a.busy[slot]) RNA_HIP(e, hipStreamWaitEvent(e->stream, a.done[slot], 0));  // stage is free again
-  if (a.mode == 1) {
+  if (a.mode == 2) {
+    int rc = tsa_persist_launch(e, e->stream, search_stream, a.depth > 1 ? a.ev_init : nullptr, field, a.field_stride,
+                                a.pend[slot], a.pend_stride, a.pstate[slot], a.max_queries, a.rev[slot], a.rev_cap, q_dev, n,
+                                paths_dev, max_len, res_dev);
+    if (rc != RNA_OK) return rc;
+  } else if (a.mode == 1) {
     int rc = tsa_launch(e, e->stream, search_stream, a.depth > 1 ? a.ev_init : nullptr, field, a.field_stride, a.pend[slot],
                         a.pend_stride, a.rev[slot], a.rev_cap, q_dev, n, paths_dev, max_len, res_dev);
     if (rc != RNA_OK) return rc;
@@ -414,6 +425,7 @@ int astar_release(rna_engine* e) {
   (void)sync_all(e);
   for (int d = 0; d < AstarDevice::MAX_DEPTH; ++d) {
     dev_free(&a.g[d]); dev_free(&a.queues[d]); dev_free(&a.pend[d]); dev_free(&a.rev[d]);
+    if (a.pstate[d]) { (void)hipFree(a.pstate[d]); a.pstate[d] = nullptr; }
     if (a.side[d]) { (void)hipStreamDestroy(a.side[d]); a.side[d] = nullptr; }
     if (a.done[d]) { (void)hipEventDestroy(a.done[d]); a.done[d] = nullptr; }
     a.busy[d] = false;
@@ -529,7 +541,7 @@ extern "C" int rna_astar_settled_counts(rna_engine* e, int32_t* counts_host, int
   int rc = sync_all(e);
   if (rc != RNA_OK) return rc;
   if ((rc = dev_alloc(e, &d_counts, (size_t)n)) != RNA_OK) return rc;
-  if (a.mode == 1)
+  if (a.mode != 0)
     (void)tsa_settled(e, reinterpret_cast<const unsigned*>(a.g[a.last_slot]) + 64, a.field_stride, a.last_queries,
                       a.last_results, n, d_counts);
   else

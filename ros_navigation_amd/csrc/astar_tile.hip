@@ -77,6 +77,218 @@ struct TsaWave {
                                      // job, bit2 interior cell improved beyond the current bucket
 };
 
+// One tile job, executed by one wavefront (lane = this wave's lane id).  `sch` supplies the
+// scheduler-specific pieces: best() / improve_best(g) (upper bound on f*), act_cur(tile) /
+// act_far(tile) (a tile received pending cells for the current / the next bucket), overflow().
+// Returns the number of cell expansions.
+template <class Sched>
+__device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, const int t, const int rows, const int cols,
+                                       const int tiles_i, const int tiles_j, unsigned* __restrict__ field,
+                                       unsigned* __restrict__ pend_cur, unsigned* __restrict__ pend_far,
+                                       const long long bucket_end, const int gi, const int gj) {
+  const unsigned long long lane_lt = (1ull << lane) - 1ull;
+  int expanded = 0;
+  const int ti = t % tiles_i, tj = t / tiles_i;
+  const int i0 = ti * TS, j0 = tj * TS;
+  unsigned* ftile = field + ((size_t)t << 10);
+
+  // 1. grab-and-clear the pending bits of this tile (lane = column jl)
+  unsigned seed = 0u;
+  if (lane < TS) seed = atomicExch(&pend_cur[(size_t)t * TS + lane], 0u);
+  for (int w = lane; w < (TW * TW + 4) / 4; w += 64) reinterpret_cast<unsigned*>(W.flags)[w] = 0u;
+  // 2. tile + halo -> LDS (after the pending bits: every grabbed bit's value is already in L2)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    unsigned tv[TILE_WORDS / 64];   // issue all 16 coalesced loads, then one wait, then the LDS stores
+#pragma unroll
+    for (int r = 0; r < TILE_WORDS / 64; ++r) tv[r] = ld_l2(&ftile[r * 64 + lane]);
+#pragma unroll
+    for (int r = 0; r < TILE_WORDS / 64; ++r) {
+      const int l = r * 64 + lane;
+      W.tile[((l >> 5) + 1) * TW + (l & 31) + 1] = tv[r];
+    }
+  }
+  {
+    // halo: left/right neighbour columns (contiguous), top/bottom rows (strided), 4 corners
+    const int h = lane & 31;
+    const bool second = lane >= 32;
+    // columns: tile (ti, tj-1) column 31 -> LDS jl=-1 ; tile (ti, tj+1) column 0 -> LDS jl=32
+    {
+      const int ntj = second ? tj + 1 : tj - 1;
+      unsigned v = 0xFFFFFF00u;
+      if (ntj >= 0 && ntj < tiles_j) v = ld_l2(&field[((size_t)(ntj * tiles_i + ti) << 10) + ((second ? 0 : 31) << 5) + h]);
+      W.tile[(second ? TS + 1 : 0) * TW + h + 1] = v;
+    }
+    // rows: tile (ti-1, tj) row 31 -> LDS il=-1 ; tile (ti+1, tj) row 0 -> LDS il=32
+    {
+      const int nti = second ? ti + 1 : ti - 1;
+      unsigned v = 0xFFFFFF00u;
+      if (nti >= 0 && nti < tiles_i) v = ld_l2(&field[((size_t)(tj * tiles_i + nti) << 10) + (h << 5) + (second ? 0 : 31)]);
+      W.tile[(h + 1) * TW + (second ? TS + 1 : 0)] = v;
+    }
+    if (lane < 4) {
+      const int di = (lane & 1) ? 1 : -1, dj = (lane & 2) ? 1 : -1;
+      const int nti = ti + di, ntj = tj + dj;
+      unsigned v = 0xFFFFFF00u;
+      if (nti >= 0 && nti < tiles_i && ntj >= 0 && ntj < tiles_j)
+        v = ld_l2(&field[((size_t)(ntj * tiles_i + nti) << 10) + ((dj > 0 ? 0 : 31) << 5) + (di > 0 ? 0 : 31)]);
+      W.tile[(dj > 0 ? TS + 1 : 0) * TW + (di > 0 ? TS + 1 : 0)] = v;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+  // 3. seed the local queue from the pending bits
+  int head = 0, tail = 0;   // wave-uniform
+  {
+    unsigned bits = seed;   // lane jl holds the bits (il) of its column
+    for (;;) {
+      const bool has = bits != 0u;
+      const unsigned long long m = __ballot(has);
+      if (!m) break;
+      if (has) {
+        const int il = __ffs(bits) - 1;
+        bits &= bits - 1;
+        const int p = (lane + 1) * TW + il + 1;
+        const int pos = tail + __popcll(m & lane_lt);
+        W.lq[pos & (LQ - 1)] = (unsigned short)p;
+        W.flags[p] = 1;
+      }
+      tail += __popcll(m);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // 4. relax to the tile-local fixed point of the current bucket.  One lane per popped cell; the
+  //    eight directions are visited one after the other.  Within one direction all lanes target
+  //    DIFFERENT cells (target = own cell + the same offset), so the min-update of a neighbour and
+  //    the test-and-set of its in-queue flag are plain LDS reads and writes -- no LDS atomics
+  //    (ds_min_rtn on 16 waves turned out to be the bottleneck of an earlier version).
+  const int best_in = sch.best();
+  while (tail != head) {
+    const int n = tail - head;
+    const int take = n < 64 ? n : 64;
+    const bool act = lane < take;
+    const int p = act ? (int)W.lq[(head + lane) & (LQ - 1)] : (TW + 1);
+    head += take;
+    const unsigned cw = W.tile[p];
+    if (act) W.flags[p] &= (unsigned char)~1u;   // popped: may be queued again
+    const int g = (int)(cw >> 8);
+    const int pil = p % TW - 1, pjl = p / TW - 1;
+    const int ci = i0 + pil, cj = j0 + pjl;
+    const int sb = sch.best();
+    const int best_now = best_in < sb ? best_in : sb;
+    bool ok = act && g + tsa_octile(ci, cj, gi, gj) <= best_now;
+    if (ok) {
+      ++expanded;
+      if (ci == gi && cj == gj) { sch.improve_best(g); ok = false; }
+    }
+    const unsigned m = ok ? (cw & 0xffu) : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int di = (k == 0 || k == 3 || k == 5) ? -1 : ((k == 2 || k == 4 || k == 7) ? 1 : 0);
+      const int dj = k < 3 ? -1 : (k > 4 ? 1 : 0);
+      const int np_ = p + di + dj * TW;
+      const int ng = g + ((k == 1 || k == 3 || k == 4 || k == 6) ? COST_S : COST_D);
+      bool doit = false;
+      if ((m >> k) & 1u) {
+        const unsigned nwv = W.tile[np_];
+        const unsigned fl = W.flags[np_];
+        if ((unsigned)ng < (nwv >> 8)) {
+          W.tile[np_] = ((unsigned)ng << 8) | (nwv & 0xffu);
+          const int ni = ci + di, nj = cj + dj;
+          const int fn = ng + tsa_octile(ni, nj, gi, gj);
+          if (ng >= (int)G_INF - 2 * COST_D) sch.overflow();            // 24-bit g exhausted
+          else {
+            if (ni == gi && nj == gj) sch.improve_best(ng);
+            if (fn <= best_now) {
+              const int nil = pil + di, njl = pjl + dj;
+              if (nil < 0 || nil >= TS || njl < 0 || njl >= TS) W.flags[np_] = (unsigned char)(fl | 2u);  // halo
+              else if (fn >= bucket_end) W.flags[np_] = (unsigned char)(fl | 4u);                          // next bucket
+              else if (!(fl & 1u)) { W.flags[np_] = (unsigned char)(fl | 1u); doit = true; }
+            }
+          }
+        }
+      }
+      const unsigned long long bm = __ballot(doit);
+      if (doit) W.lq[(tail + __popcll(bm & lane_lt)) & (LQ - 1)] = (unsigned short)np_;
+      tail += __popcll(bm);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // 5. write back.  Inner 30 x 30 cells are private to this tile: coalesced stores.  Edge ring:
+  //    atomicMin (a neighbouring tile's job may have improved them in HBM meanwhile).
+#pragma unroll
+  for (int r = 0; r < TILE_WORDS / 64; ++r) {
+    const int l = r * 64 + lane;
+    const int il = l & 31, jl = l >> 5;
+    const unsigned v = W.tile[(jl + 1) * TW + il + 1];
+    if (il == 0 || il == TS - 1 || jl == 0 || jl == TS - 1) {
+      if ((v >> 8) != G_INF) (void)atomicMin(&ftile[l], v);
+    } else {
+      ftile[l] = v;
+    }
+  }
+  //    far-bucket cells of this tile: column jl -> one pending word (bit il)
+  {
+    bool anyfar = false;
+#pragma unroll 4
+    for (int r = 0; r < TS / 2; ++r) {
+      const int jl = 2 * r + (lane >> 5), il = lane & 31;
+      const bool f = (W.flags[(jl + 1) * TW + il + 1] & 4u) != 0u;
+      const unsigned long long bm = __ballot(f);
+      const unsigned word = (unsigned)(bm >> (lane & 32));
+      if ((lane & 31) == 0 && word) { atomicOr(&pend_far[(size_t)t * TS + jl], word); }
+      anyfar |= bm != 0ull;
+    }
+    if (anyfar && lane == 0) sch.act_far(t);
+  }
+  //    improved halo cells -> their tiles (value first, then the pending bit, then the activation)
+  for (int hh = lane; hh < 4 * TW; hh += 64) {
+    // ring positions: hh in [0,TW): jl=-1 row; [TW,2TW): jl=32 row; [2TW,3TW): il=-1 col; [3TW,4TW): il=32 col
+    const int side = hh / TW, u = hh % TW;
+    int pil, pjl;
+    if (side == 0) { pjl = -1; pil = u - 1; }
+    else if (side == 1) { pjl = TS; pil = u - 1; }
+    else if (side == 2) { pil = -1; pjl = u - 1; }
+    else { pil = TS; pjl = u - 1; }
+    if (side >= 2 && (pjl < 0 || pjl >= TS)) continue;   // corners are covered by the row sides
+    const int p = (pjl + 1) * TW + pil + 1;
+    if (!(W.flags[p] & 2u)) continue;
+    const int ni = i0 + pil, nj = j0 + pjl;
+    if (ni < 0 || nj < 0 || ni >= rows || nj >= cols) continue;
+    const unsigned v = W.tile[p];
+    const size_t nidx = tm_index(ni, nj, tiles_i);
+    const unsigned old = atomicMin(&field[nidx], v);
+    if (v < old) {
+      const int nt = (int)(nidx >> 10);
+      const int fn = (int)(v >> 8) + tsa_octile(ni, nj, gi, gj);
+      const bool far = fn >= bucket_end;
+      atomicOr(&(far ? pend_far : pend_cur)[(size_t)nt * TS + (nj & 31)], 1u << (ni & 31));
+      // the value and its pending bit must be performed at L2 before the tile can be scheduled
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (far) sch.act_far(nt); else sch.act_cur(nt);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_wave_barrier();
+  return expanded;
+}
+
+// scheduler state of the one-workgroup-per-query kernel lives in LDS
+struct TsaLocalSched {
+  int* best_;
+  int* state_;
+  unsigned* act_cur_;
+  unsigned* act_far_;
+  __device__ __forceinline__ int best() const { return *reinterpret_cast<volatile int*>(best_); }
+  __device__ __forceinline__ void improve_best(int g) { atomicMin(best_, g); }
+  __device__ __forceinline__ void overflow() { *state_ = 4; }
+  __device__ __forceinline__ void act_cur(int t) { atomicOr(&act_cur_[t >> 5], 1u << (t & 31)); }
+  __device__ __forceinline__ void act_far(int t) { atomicOr(&act_far_[t >> 5], 1u << (t & 31)); }
+};
+
 __global__ void __launch_bounds__(TSA_THREADS)
 tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_query* __restrict__ queries,
                   unsigned* __restrict__ field_all, size_t field_stride, unsigned* __restrict__ pend_all,
@@ -131,12 +343,7 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
 
   TsaWave& W = s_w[wv];
   int my_expanded = 0;
-#ifdef RNA_TSA_DEBUG
-  __shared__ int s_dbg_jobs, s_dbg_iters; __shared__ long long s_dbg_t[4];
-  if (tid == 0) { s_dbg_jobs = 0; s_dbg_iters = 0; s_dbg_t[0] = s_dbg_t[1] = s_dbg_t[2] = s_dbg_t[3] = 0; }
-  long long d_t[4] = {0, 0, 0, 0}; int d_jobs = 0, d_iters = 0;
-#endif
-  const unsigned long long lane_lt = (1ull << lane) - 1ull;
+  TsaLocalSched sch{&s_best, &s_state, s_act[0], s_act[1]};
 
   for (;;) {
     // ---- build this round's job list from the active-tile bitset ----
@@ -197,232 +404,16 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
       job = __shfl(job, 0);
       if (job >= njobs) break;
       const int t = s_jobs[job];
-#ifdef RNA_TSA_DEBUG
-      const long long t0 = wall_clock64(); ++d_jobs;
-#endif
-      const int ti = t % tiles_i, tj = t / tiles_i;
-      const int i0 = ti * TS, j0 = tj * TS;
-      unsigned* ftile = field + ((size_t)t << 10);
-
-      // 1. grab-and-clear the pending bits of this tile (lane = column jl)
-      unsigned seed = 0u;
-      if (lane < TS) seed = atomicExch(&pend_cur[(size_t)t * TS + lane], 0u);
-      for (int w = lane; w < (TW * TW + 4) / 4; w += 64) reinterpret_cast<unsigned*>(W.flags)[w] = 0u;
-      // 2. tile + halo -> LDS (after the pending bits: every grabbed bit's value is already in L2)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      {
-        unsigned tv[TILE_WORDS / 64];   // issue all 16 coalesced loads, then one wait, then the LDS stores
-#pragma unroll
-        for (int r = 0; r < TILE_WORDS / 64; ++r) tv[r] = ld_l2(&ftile[r * 64 + lane]);
-#pragma unroll
-        for (int r = 0; r < TILE_WORDS / 64; ++r) {
-          const int l = r * 64 + lane;
-          W.tile[((l >> 5) + 1) * TW + (l & 31) + 1] = tv[r];
-        }
-      }
-      {
-        // halo: left/right neighbour columns (contiguous), top/bottom rows (strided), 4 corners
-        const int h = lane & 31;
-        const bool second = lane >= 32;
-        // columns: tile (ti, tj-1) column 31 -> LDS jl=-1 ; tile (ti, tj+1) column 0 -> LDS jl=32
-        {
-          const int ntj = second ? tj + 1 : tj - 1;
-          unsigned v = 0xFFFFFF00u;
-          if (ntj >= 0 && ntj < tiles_j) v = ld_l2(&field[((size_t)(ntj * tiles_i + ti) << 10) + ((second ? 0 : 31) << 5) + h]);
-          W.tile[(second ? TS + 1 : 0) * TW + h + 1] = v;
-        }
-        // rows: tile (ti-1, tj) row 31 -> LDS il=-1 ; tile (ti+1, tj) row 0 -> LDS il=32
-        {
-          const int nti = second ? ti + 1 : ti - 1;
-          unsigned v = 0xFFFFFF00u;
-          if (nti >= 0 && nti < tiles_i) v = ld_l2(&field[((size_t)(tj * tiles_i + nti) << 10) + (h << 5) + (second ? 0 : 31)]);
-          W.tile[(h + 1) * TW + (second ? TS + 1 : 0)] = v;
-        }
-        if (lane < 4) {
-          const int di = (lane & 1) ? 1 : -1, dj = (lane & 2) ? 1 : -1;
-          const int nti = ti + di, ntj = tj + dj;
-          unsigned v = 0xFFFFFF00u;
-          if (nti >= 0 && nti < tiles_i && ntj >= 0 && ntj < tiles_j)
-            v = ld_l2(&field[((size_t)(ntj * tiles_i + nti) << 10) + ((dj > 0 ? 0 : 31) << 5) + (di > 0 ? 0 : 31)]);
-          W.tile[(dj > 0 ? TS + 1 : 0) * TW + (di > 0 ? TS + 1 : 0)] = v;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-
-#ifdef RNA_TSA_DEBUG
-      const long long t1 = wall_clock64();
-#endif
-      // 3. seed the local queue from the pending bits
-      int head = 0, tail = 0;   // wave-uniform
-      {
-        unsigned bits = seed;   // lane jl holds the bits (il) of its column
-        for (;;) {
-          const bool has = bits != 0u;
-          const unsigned long long m = __ballot(has);
-          if (!m) break;
-          if (has) {
-            const int il = __ffs(bits) - 1;
-            bits &= bits - 1;
-            const int p = (lane + 1) * TW + il + 1;
-            const int pos = tail + __popcll(m & lane_lt);
-            W.lq[pos & (LQ - 1)] = (unsigned short)p;
-            W.flags[p] = 1;
-          }
-          tail += __popcll(m);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-
-      // 4. relax to the tile-local fixed point of the current bucket.  One lane per popped cell; the
-      //    eight directions are visited one after the other.  Within one direction all lanes target
-      //    DIFFERENT cells (target = own cell + the same offset), so the min-update of a neighbour and
-      //    the test-and-set of its in-queue flag are plain LDS reads and writes -- no LDS atomics
-      //    (ds_min_rtn on 16 waves turned out to be the bottleneck of an earlier version).
-      const int best_in = s_best;
-      while (tail != head) {
-        const int n = tail - head;
-        const int take = n < 64 ? n : 64;
-#ifdef RNA_TSA_DEBUG
-        ++d_iters;
-#endif
-        const bool act = lane < take;
-        const int p = act ? (int)W.lq[(head + lane) & (LQ - 1)] : (TW + 1);
-        head += take;
-        const unsigned cw = W.tile[p];
-        if (act) W.flags[p] &= (unsigned char)~1u;   // popped: may be queued again
-        const int g = (int)(cw >> 8);
-        const int pil = p % TW - 1, pjl = p / TW - 1;
-        const int ci = i0 + pil, cj = j0 + pjl;
-        const int sb = s_best;
-        const int best_now = best_in < sb ? best_in : sb;
-        bool ok = act && g + tsa_octile(ci, cj, gi, gj) <= best_now;
-        if (ok) {
-          ++my_expanded;
-          if (ci == gi && cj == gj) { atomicMin(&s_best, g); ok = false; }
-        }
-        const unsigned m = ok ? (cw & 0xffu) : 0u;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int di = (k == 0 || k == 3 || k == 5) ? -1 : ((k == 2 || k == 4 || k == 7) ? 1 : 0);
-          const int dj = k < 3 ? -1 : (k > 4 ? 1 : 0);
-          const int np_ = p + di + dj * TW;
-          const int ng = g + ((k == 1 || k == 3 || k == 4 || k == 6) ? COST_S : COST_D);
-          bool doit = false;
-          if ((m >> k) & 1u) {
-            const unsigned nwv = W.tile[np_];
-            const unsigned fl = W.flags[np_];
-            if ((unsigned)ng < (nwv >> 8)) {
-              W.tile[np_] = ((unsigned)ng << 8) | (nwv & 0xffu);
-              const int ni = ci + di, nj = cj + dj;
-              const int fn = ng + tsa_octile(ni, nj, gi, gj);
-              if (ng >= (int)G_INF - 2 * COST_D) s_state = 4;            // 24-bit g exhausted
-              else {
-                if (ni == gi && nj == gj) atomicMin(&s_best, ng);
-                if (fn <= best_now) {
-                  const int nil = pil + di, njl = pjl + dj;
-                  if (nil < 0 || nil >= TS || njl < 0 || njl >= TS) W.flags[np_] = (unsigned char)(fl | 2u);  // halo
-                  else if (fn >= bucket_end) W.flags[np_] = (unsigned char)(fl | 4u);                          // next bucket
-                  else if (!(fl & 1u)) { W.flags[np_] = (unsigned char)(fl | 1u); doit = true; }
-                }
-              }
-            }
-          }
-          const unsigned long long bm = __ballot(doit);
-          if (doit) W.lq[(tail + __popcll(bm & lane_lt)) & (LQ - 1)] = (unsigned short)np_;
-          tail += __popcll(bm);
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-
-#ifdef RNA_TSA_DEBUG
-      const long long t2 = wall_clock64();
-#endif
-      // 5. write back.  Inner 30 x 30 cells are private to this tile: coalesced stores.  Edge ring:
-      //    atomicMin (a neighbouring tile's job may have improved them in HBM meanwhile).
-#pragma unroll
-      for (int r = 0; r < TILE_WORDS / 64; ++r) {
-        const int l = r * 64 + lane;
-        const int il = l & 31, jl = l >> 5;
-        const unsigned v = W.tile[(jl + 1) * TW + il + 1];
-        if (il == 0 || il == TS - 1 || jl == 0 || jl == TS - 1) {
-          if ((v >> 8) != G_INF) (void)atomicMin(&ftile[l], v);
-        } else {
-          ftile[l] = v;
-        }
-      }
-      //    far-bucket cells of this tile: column jl -> one pending word (bit il)
-      {
-        bool anyfar = false;
-#pragma unroll 4
-        for (int r = 0; r < TS / 2; ++r) {
-          const int jl = 2 * r + (lane >> 5), il = lane & 31;
-          const bool f = (W.flags[(jl + 1) * TW + il + 1] & 4u) != 0u;
-          const unsigned long long bm = __ballot(f);
-          const unsigned word = (unsigned)(bm >> (lane & 32));
-          if ((lane & 31) == 0 && word) { atomicOr(&pend_far[(size_t)t * TS + jl], word); }
-          anyfar |= bm != 0ull;
-        }
-        if (anyfar && lane == 0) atomicOr(&s_act[1][t >> 5], 1u << (t & 31));
-      }
-      //    improved halo cells -> their tiles (value first, then the pending bit, then the activation)
-      for (int hh = lane; hh < 4 * TW; hh += 64) {
-        // ring positions: hh in [0,TW): jl=-1 row; [TW,2TW): jl=32 row; [2TW,3TW): il=-1 col; [3TW,4TW): il=32 col
-        const int side = hh / TW, u = hh % TW;
-        int pil, pjl;
-        if (side == 0) { pjl = -1; pil = u - 1; }
-        else if (side == 1) { pjl = TS; pil = u - 1; }
-        else if (side == 2) { pil = -1; pjl = u - 1; }
-        else { pil = TS; pjl = u - 1; }
-        if (side >= 2 && (pjl < 0 || pjl >= TS)) continue;   // corners are covered by the row sides
-        const int p = (pjl + 1) * TW + pil + 1;
-        if (!(W.flags[p] & 2u)) continue;
-        const int ni = i0 + pil, nj = j0 + pjl;
-        if (ni < 0 || nj < 0 || ni >= rows || nj >= cols) continue;
-        const unsigned v = W.tile[p];
-        const size_t nidx = tm_index(ni, nj, tiles_i);
-        const unsigned old = atomicMin(&field[nidx], v);
-        if (v < old) {
-          const int nt = (int)(nidx >> 10);
-          const int fn = (int)(v >> 8) + tsa_octile(ni, nj, gi, gj);
-          const bool far = fn >= bucket_end;
-          atomicOr(&(far ? pend_far : pend_cur)[(size_t)nt * TS + (nj & 31)], 1u << (ni & 31));
-          atomicOr(&s_act[far ? 1 : 0][nt >> 5], 1u << (nt & 31));
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-#ifdef RNA_TSA_DEBUG
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const long long t3 = wall_clock64();
-      d_t[0] += t1 - t0; d_t[1] += t2 - t1; d_t[2] += t3 - t2;
-#endif
+      my_expanded += tsa_job(sch, W, lane, t, rows, cols, tiles_i, tiles_j, field, pend_cur, pend_far, bucket_end, gi, gj);
     }
-#ifdef RNA_TSA_DEBUG
-    const long long tb0 = wall_clock64();
-#endif
     // all stores / atomics of this round are performed before any wave loads tiles in the next one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int stop = __syncthreads_or(s_state == 4);
-#ifdef RNA_TSA_DEBUG
-    d_t[3] += wall_clock64() - tb0;
-#endif
     if (tid == 0) s_rounds += 1;
     if (stop) break;
   }
   atomicAdd(&s_expanded, my_expanded);
-#ifdef RNA_TSA_DEBUG
-  if (lane == 0) { atomicAdd(&s_dbg_jobs, d_jobs); atomicAdd(&s_dbg_iters, d_iters);
-    if (wv == 0) { s_dbg_t[0] = d_t[0]; s_dbg_t[1] = d_t[1]; s_dbg_t[2] = d_t[2]; s_dbg_t[3] = d_t[3]; } }
-#endif
   __syncthreads();
-#ifdef RNA_TSA_DEBUG
-  if (tid == 0 && s_state == 1) {
-    // status=jobs, path_len=local iterations (all waves), cost/expanded/rounds/buckets = wave-0 time (10 ns ticks): load, local, writeback, barrier-wait
-    results[q] = rna_astar_result{s_dbg_jobs, s_dbg_iters, (int)s_dbg_t[0], (int)s_dbg_t[1], (int)s_dbg_t[2], (int)s_dbg_t[3]};
-    paths[(size_t)q * max_path_len] = s_rounds; paths[(size_t)q * max_path_len + 1] = s_expanded;
-  }
-  if (s_state == 1) return;
-#endif
 
   const int state = s_state;
   const int n_buckets = s_bucket - s_bucket0 + 1;
@@ -501,6 +492,346 @@ __global__ void tsa_settled_kernel(int rows, int cols, int tiles_i, int tiles_j,
   if (threadIdx.x == 0) counts[q] = s_cnt;
 }
 
+// =================================================================================================
+// Persistent, cross-CU scheduler ("TSA-P"): every wavefront of the whole GPU is a worker that pulls
+// (query, tile) jobs from a queue.  A long query is therefore served by many CUs at once and the
+// batch is load-balanced at tile granularity -- the one-workgroup-per-query kernels above finish
+// only when their slowest query does (the mean query is 5x shorter than the longest one).
+//
+//  * Queries are bound to the XCD whose worker first picks them and all their jobs stay on that
+//    XCD's queue: a query's field, pending bitmaps and tile states are then only touched through ONE
+//    L2 (L2s of different XCDs are not coherent); L1 is bypassed with sc1 loads and every hand-over
+//    is "s_waitcnt vmcnt(0), then a device-scope atomic".  The XCD id is read from HW_REG_XCC_ID, so
+//    nothing depends on the block -> XCD placement.
+//  * Tile state machine (2 bits per tile): IDLE -> QUEUED -> RUNNING -> IDLE, or RUNNING ->
+//    RUNNING_DIRTY (re-activated while in flight) -> QUEUED.  A tile is never run by two waves.
+//  * outstanding[q] counts queued + running jobs of the current bucket; the wave that brings it to 0
+//    owns the query alone and either finishes it or opens the next bucket (tiles flagged in far_act).
+//  * No worker ever waits for a particular other worker: it waits for queue entries, which any
+//    resident worker of that XCD can produce/consume, so co-residency of the grid is not required.
+//    Every spin is bounded; on timeout the abort flag ends the launch and the host reports it.
+// =================================================================================================
+constexpr int TSA_QN = 1 << 16;         // ring entries per XCD
+constexpr unsigned TSA_NOJOB = 0xFFFFFFFFu;
+constexpr int TSA_SPIN_LIMIT = 1 << 22;
+
+struct TsaQ {   // per-query state (one 64-byte line)
+  int best, bucket, bucket0, role, outstanding, status, xcc, expanded, jobs, overflow, start, goal, pad[4];
+};
+struct TsaCtl {
+  int next_query, remaining, abort, n, pad[12];
+  unsigned head[8][16];   // one 64-byte line per XCD
+  unsigned tail[8][16];
+};
+
+__device__ __forceinline__ int ld_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_i32(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_u64(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_u64(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int read_xcc_id() {
+  int x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return x & 7;
+}
+
+// bounded MPMC ring: entry = (sequence << 32) | job; slot i starts with sequence i
+__device__ bool tsa_enqueue(TsaCtl* ctl, unsigned long long* ring, int x, unsigned job) {
+  const unsigned pos = atomicAdd(&ctl->tail[x][0], 1u);
+  unsigned long long* slot = &ring[(size_t)x * TSA_QN + (pos & (TSA_QN - 1))];
+  for (int spin = 0;; ++spin) {
+    if ((unsigned)(ld_u64(slot) >> 32) == pos) break;          // slot is free for this lap
+    if (spin > TSA_SPIN_LIMIT || ((spin & 1023) == 1023 && ld_i32(&ctl->abort))) { atomicCAS(&ctl->abort, 0, 1); return false; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  st_u64(slot, ((unsigned long long)(pos + 1u) << 32) | job);  // one 64-bit store publishes job + sequence
+  return true;
+}
+// Ticket dequeue: one atomicAdd takes the next position of this XCD's ring, then the worker waits
+// for that slot to be published (a CAS-on-head dequeue collapsed under 512 contending wavefronts).
+// Returns TSA_NOJOB only when the launch is over (no query left unfinished) or aborted.
+__device__ unsigned tsa_dequeue(TsaCtl* ctl, unsigned long long* ring, int x) {
+  const unsigned pos = atomicAdd(&ctl->head[x][0], 1u);
+  unsigned long long* slot = &ring[(size_t)x * TSA_QN + (pos & (TSA_QN - 1))];
+  for (int spin = 0;; ++spin) {
+    const unsigned long long v = ld_u64(slot);
+    if ((unsigned)(v >> 32) == pos + 1u) {
+      st_u64(slot, (unsigned long long)(pos + (unsigned)TSA_QN) << 32);   // free the slot for the next lap
+      return (unsigned)v;
+    }
+    if ((spin & 15) == 15) {
+      if (ld_i32(&ctl->remaining) <= 0 || ld_i32(&ctl->abort)) return TSA_NOJOB;
+      if (spin > 400000) { atomicCAS(&ctl->abort, 0, 5); return TSA_NOJOB; }   // ~5 s without work
+    }
+    if (spin < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);
+  }
+}
+
+struct TsaGlobalSched {
+  TsaQ* qs;
+  TsaCtl* ctl;
+  unsigned long long* ring;
+  unsigned* tstate;     // 2 bits per tile of this query
+  unsigned* far_act;    // bit per tile: has next-bucket pending cells
+  int q, xcc, best_cache;
+  __device__ __forceinline__ int best() const { return best_cache; }
+  __device__ __forceinline__ void improve_best(int g) { atomicMin(&qs->best, g); if (g < best_cache) best_cache = g; }
+  __device__ __forceinline__ void overflow() { st_i32(&qs->overflow, 1); }
+  __device__ __forceinline__ void act_far(int t) { atomicOr(&far_act[t >> 5], 1u << (t & 31)); }
+  __device__ void act_cur(int t) {
+    unsigned* w = &tstate[t >> 4];
+    const int sh = (t & 15) * 2;
+    for (int spin = 0; spin < TSA_SPIN_LIMIT; ++spin) {
+      const unsigned old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned st = (old >> sh) & 3u;
+      if (st == 1u || st == 3u) return;                               // already scheduled to run (again)
+      const unsigned nw = (st == 0u) ? (old | (1u << sh)) : (old | (3u << sh));   // IDLE->QUEUED, RUNNING->RUNNING_DIRTY
+      if (atomicCAS(w, old, nw) == old) {
+        if (st == 0u) {
+          atomicAdd(&qs->outstanding, 1);                            // count the job BEFORE it becomes visible
+          tsa_enqueue(ctl, ring, xcc, ((unsigned)q << 16) | (unsigned)t);
+        }
+        return;
+      }
+    }
+    atomicCAS(&ctl->abort, 0, 2);
+  }
+};
+
+struct TsaPersistArgs {
+  int rows, cols, tiles_i, tiles_j, n, bucket_width;
+  const rna_astar_query* queries;
+  unsigned* field; size_t field_stride;
+  unsigned* pend; size_t pend_stride;
+  TsaQ* qstate; TsaCtl* ctl; unsigned long long* ring;
+  unsigned* tstate; size_t tstate_stride;
+  unsigned* far_act; size_t far_stride;
+};
+
+__global__ void tsa_persist_init_kernel(TsaPersistArgs A) {
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t w = gid; w < (size_t)A.n * A.tstate_stride; w += step) A.tstate[w] = 0u;
+  for (size_t w = gid; w < (size_t)A.n * A.far_stride; w += step) A.far_act[w] = 0u;
+  for (size_t w = gid; w < (size_t)8 * TSA_QN; w += step) A.ring[w] = (unsigned long long)(w & (TSA_QN - 1)) << 32;
+  for (size_t w = gid; w < (size_t)A.n * (sizeof(TsaQ) / 4); w += step)
+    reinterpret_cast<int*>(A.qstate)[w] = ((w % (sizeof(TsaQ) / 4)) == 5) ? -2 : 0;   // status = -2: not started
+  if (gid == 0) {
+    A.ctl->next_query = 0; A.ctl->remaining = A.n; A.ctl->abort = 0; A.ctl->n = A.n;
+    for (int x = 0; x < 8; ++x) { A.ctl->head[x][0] = 0u; A.ctl->tail[x][0] = 0u; }
+  }
+}
+
+__global__ void __launch_bounds__(TSA_THREADS) tsa_persist_kernel(TsaPersistArgs A) {
+  __shared__ TsaWave s_w[TSA_WAVES];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  TsaWave& W = s_w[wv];
+  const int xcc = read_xcc_id();
+  const int ntile = A.tiles_i * A.tiles_j;
+  const int nt_words = (ntile + 31) >> 5;
+  const size_t pend_words = (size_t)ntile * TS;
+  for (;;) {
+    // ---- unstarted queries first: the worker that starts a query binds it to its own XCD ----
+    int qn = -1;
+    if (lane == 0 && ld_i32(&A.ctl->next_query) < A.n) {
+      qn = atomicAdd(&A.ctl->next_query, 1);
+      if (qn >= A.n) qn = -1;
+    }
+    qn = __shfl(qn, 0);
+    if (qn >= 0) {
+      if (lane == 0) {
+        TsaQ* qs = &A.qstate[qn];
+        const rna_astar_query qu = A.queries[qn];
+        const int ncell = A.rows * A.cols;
+        unsigned* field = A.field + (size_t)qn * A.field_stride;
+        int status = -1;
+        if (!(qu.start >= 0 && qu.goal >= 0 && qu.start < ncell && qu.goal < ncell)) status = 2;
+        else {
+          const int si = qu.start % A.rows, sj = qu.start / A.rows, gi = qu.goal % A.rows, gj = qu.goal / A.rows;
+          const int b0 = tsa_octile(si, sj, gi, gj) / A.bucket_width;
+          qs->best = INF; qs->bucket = b0; qs->bucket0 = b0; qs->role = 0; qs->outstanding = 1; qs->xcc = xcc;
+          qs->expanded = 0; qs->jobs = 0; qs->overflow = 0; qs->start = qu.start; qs->goal = qu.goal;
+          if (qu.goal != qu.start && (ld_l2(&field[tm_index(gi, gj, A.tiles_i)]) & 0xffu) == 0u) status = 1;  // walled-in goal
+          else {
+            const size_t ws = tm_index(si, sj, A.tiles_i);
+            const unsigned w0 = ld_l2(&field[ws]);
+            __hip_atomic_store(&field[ws], w0 & 0xffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // g(start) = 0
+            const int ts = (sj >> 5) * A.tiles_i + (si >> 5);
+            unsigned* pend0 = A.pend + (size_t)qn * A.pend_stride;
+            atomicOr(&pend0[(size_t)ts * TS + (sj & 31)], 1u << (si & 31));
+            atomicOr(&(A.tstate + (size_t)qn * A.tstate_stride)[ts >> 4], 1u << ((ts & 15) * 2));     // QUEUED
+            st_i32(&qs->status, -1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tsa_enqueue(A.ctl, A.ring, xcc, ((unsigned)qn << 16) | (unsigned)ts);
+          }
+        }
+        if (status >= 0) {
+          st_i32(&qs->status, status);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          atomicSub(&A.ctl->remaining, 1);
+        }
+      }
+      continue;
+    }
+    // ---- next job of this XCD (blocks until one is published or the launch is over) ----
+    unsigned job = TSA_NOJOB;
+    if (lane == 0) job = tsa_dequeue(A.ctl, A.ring, xcc);
+    job = __shfl(job, 0);
+    if (job == TSA_NOJOB) break;
+
+    // ---- run one tile job ----
+    const int q = (int)(job >> 16), t = (int)(job & 0xffffu);
+    TsaQ* qs = &A.qstate[q];
+    unsigned* tstate = A.tstate + (size_t)q * A.tstate_stride;
+    unsigned* far_act = A.far_act + (size_t)q * A.far_stride;
+    unsigned* tw = &tstate[t >> 4];
+    const int sh = (t & 15) * 2;
+    if (lane == 0) {   // QUEUED -> RUNNING
+      for (int spin = 0;; ++spin) {
+        const unsigned old = __hip_atomic_load(tw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (((old >> sh) & 3u) == 1u && atomicCAS(tw, old, (old & ~(3u << sh)) | (2u << sh)) == old) break;
+        if (spin > TSA_SPIN_LIMIT) { atomicCAS(&A.ctl->abort, 0, 3); break; }
+      }
+    }
+    const int bucket = ld_i32(&qs->bucket), role = ld_i32(&qs->role);
+    const int goal = ld_i32(&qs->goal);
+    const int gi = goal % A.rows, gj = goal / A.rows;
+    unsigned* field = A.field + (size_t)q * A.field_stride;
+    unsigned* pend0 = A.pend + (size_t)q * A.pend_stride;
+    TsaGlobalSched sch{qs, A.ctl, A.ring, tstate, far_act, q, xcc, ld_i32(&qs->best)};
+    const long long bucket_end = ((long long)bucket + 1) * A.bucket_width;
+    int exp = tsa_job(sch, W, lane, t, A.rows, A.cols, A.tiles_i, A.tiles_j, field, pend0 + (size_t)role * pend_words,
+                      pend0 + (size_t)(role ^ 1) * pend_words, bucket_end, gi, gj);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // everything this job wrote is at L2 before the tile is released
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) exp += __shfl_xor(exp, o);
+    int last = 0;
+    if (lane == 0) {
+      atomicAdd(&qs->expanded, exp);
+      atomicAdd(&qs->jobs, 1);
+      for (int spin = 0;; ++spin) {
+        const unsigned old = __hip_atomic_load(tw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned st = (old >> sh) & 3u;
+        if (st == 2u) {            // RUNNING -> IDLE
+          if (atomicCAS(tw, old, old & ~(3u << sh)) == old) { last = (atomicSub(&qs->outstanding, 1) == 1); break; }
+        } else if (st == 3u) {     // re-activated while running: RUNNING_DIRTY -> QUEUED, same job count
+          if (atomicCAS(tw, old, (old & ~(3u << sh)) | (1u << sh)) == old) { tsa_enqueue(A.ctl, A.ring, xcc, job); break; }
+        }
+        if (spin > TSA_SPIN_LIMIT) { atomicCAS(&A.ctl->abort, 0, 4); break; }
+      }
+    }
+    last = __shfl(last, 0);
+    if (!last) continue;
+
+    // ---- this wave emptied the bucket: it owns the query alone until it enqueues new jobs ----
+    const int best = ld_i32(&qs->best);
+    const long long done_below = ((long long)bucket + 1) * A.bucket_width;
+    int status = -1;
+    if (ld_i32(&qs->overflow)) status = 4;
+    else if (best != INF && (long long)best < done_below) status = 0;   // goal settled, ties included
+    else {
+      unsigned* scratch = W.tile;   // grabbed far bits (nt_words <= TW*TW)
+      int cnt = 0;
+      for (int w = lane; w < nt_words; w += 64) {
+        const unsigned bits = atomicExch(&far_act[w], 0u);
+        scratch[w] = bits;
+        cnt += __popc(bits);
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+      if (cnt == 0) status = (best != INF) ? 0 : 1;   // nothing left anywhere
+      else {
+        if (lane == 0) { st_i32(&qs->bucket, bucket + 1); st_i32(&qs->role, role ^ 1); st_i32(&qs->outstanding, cnt); }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // pass 1: every tile of the new bucket becomes QUEUED before the first job is visible (a job
+        // that is already running may otherwise activate -- and enqueue -- one of them a second time)
+        for (int w = lane; w < nt_words; w += 64) {
+          unsigned bits = scratch[w];
+          while (bits) {
+            const int b = __ffs(bits) - 1;
+            bits &= bits - 1;
+            const int tt = (w << 5) + b;
+            atomicOr(&tstate[tt >> 4], 1u << ((tt & 15) * 2));   // IDLE -> QUEUED (all tiles are idle here)
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // pass 2: publish the jobs
+        for (int w = lane; w < nt_words; w += 64) {
+          unsigned bits = scratch[w];
+          while (bits) {
+            const int b = __ffs(bits) - 1;
+            bits &= bits - 1;
+            tsa_enqueue(A.ctl, A.ring, xcc, ((unsigned)q << 16) | (unsigned)((w << 5) + b));
+          }
+        }
+      }
+    }
+    if (status >= 0 && lane == 0) {
+      st_i32(&qs->status, status);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      atomicSub(&A.ctl->remaining, 1);
+    }
+  }
+}
+
+// canonical backtrace + result records for the persistent scheduler: one wavefront per query
+__global__ void tsa_backtrace_kernel(int rows, int cols, int tiles_i, const unsigned* __restrict__ field_all, size_t field_stride,
+                                     const TsaQ* __restrict__ qstate, const TsaCtl* __restrict__ ctl, int32_t* __restrict__ paths,
+                                     int max_path_len, int32_t* __restrict__ rev_all, int rev_cap,
+                                     rna_astar_result* __restrict__ results) {
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const TsaQ qs = qstate[q];
+  const unsigned* field = field_all + (size_t)q * field_stride;
+  const int n_buckets = qs.bucket - qs.bucket0 + 1;
+  if (ctl->abort || qs.status < 0) {   // scheduler timeout: report it as a capacity/scheduling failure
+    if (tid == 0) results[q] = rna_astar_result{(int)RNA_ECAPACITY, ctl->abort, qs.status, qs.expanded, qs.jobs, qs.outstanding};
+    return;
+  }
+  if (qs.status != 0) {
+    if (tid == 0) results[q] = rna_astar_result{qs.status, 0, INF, qs.expanded, qs.jobs, qs.status == 2 ? 0 : n_buckets};
+    return;
+  }
+  const int ncell = rows * cols;
+  const int si = qs.start % rows, sj = qs.start / rows, gi = qs.goal % rows, gj = qs.goal / rows;
+  int* rev = rev_all + (size_t)q * rev_cap;
+  int ci = gi, cj = gj, len = 0;
+  bool ok = true;
+  const int k = tid & 7;
+  const int w = (k == 1 || k == 3 || k == 4 || k == 6) ? COST_S : COST_D;
+  const int di = (k == 0 || k == 3 || k == 5) ? -1 : ((k == 2 || k == 4 || k == 7) ? 1 : 0);
+  const int dj = k < 3 ? -1 : (k > 4 ? 1 : 0);
+  for (;;) {
+    if (tid == 0 && len < rev_cap) rev[len] = cj * rows + ci;
+    ++len;
+    if (ci == si && cj == sj) break;
+    if (len > ncell) { ok = false; break; }
+    const int ni = ci + di, nj = cj + dj;
+    const bool inb = ni >= 0 && nj >= 0 && ni < rows && nj < cols;
+    const unsigned wc = field[tm_index(ci, cj, tiles_i)];
+    const unsigned wn = field[inb ? tm_index(ni, nj, tiles_i) : tm_index(ci, cj, tiles_i)];
+    const bool hit = tid < 8 && inb && ((wc >> k) & 1u) && ((wn >> 8) != G_INF) && ((wn >> 8) + (unsigned)w == (wc >> 8));
+    const unsigned long long mask = __ballot(hit);
+    if (!mask) { ok = false; break; }
+    const int src = __ffsll((long long)mask) - 1;
+    ci = __shfl(ni, src);
+    cj = __shfl(nj, src);
+  }
+  if (!ok) { if (tid == 0) results[q] = rna_astar_result{1, 0, INF, qs.expanded, qs.jobs, n_buckets}; return; }
+  if (len > max_path_len || len > rev_cap) {
+    if (tid == 0) results[q] = rna_astar_result{3, len, qs.best, qs.expanded, qs.jobs, n_buckets};
+    return;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int32_t* path = paths + (size_t)q * max_path_len;
+  for (int i = tid; i < len; i += 64) path[i] = rev[len - 1 - i];
+  if (tid == 0) results[q] = rna_astar_result{0, len, qs.best, qs.expanded, qs.jobs, n_buckets};
+}
+
 // ---- host entry points used by astar.hip ----
 size_t tsa_field_words(const rna_engine* e) {
   const size_t ti = (e->geom.size[0] + TS - 1) / TS, tj = (e->geom.size[1] + TS - 1) / TS;
@@ -546,6 +877,60 @@ int tsa_settled(rna_engine* e, const unsigned* field, size_t field_stride, const
   hipLaunchKernelGGL(tsa_settled_kernel, dim3(n), dim3(1024), 0, e->stream, rows, cols, ti, tj, q, r, field, field_stride,
                      d_counts);
   RNA_HIP(e, hipGetLastError());
+  return RNA_OK;
+}
+
+
+size_t tsa_persist_state_bytes(const rna_engine* e, int max_queries, size_t* tstate_stride, size_t* far_stride) {
+  const size_t ti = (e->geom.size[0] + TS - 1) / TS, tj = (e->geom.size[1] + TS - 1) / TS;
+  const size_t ntile = ti * tj;
+  *tstate_stride = ((ntile + 15) / 16 + 15) / 16 * 16;
+  *far_stride = ((ntile + 31) / 32 + 15) / 16 * 16;
+  return sizeof(TsaCtl) + (size_t)max_queries * sizeof(TsaQ) + (size_t)8 * TSA_QN * 8 +
+         (size_t)max_queries * (*tstate_stride + *far_stride) * 4;
+}
+
+// persistent launch: init (field + scheduler state) on init_stream, then the worker grid and the
+// backtrace on search_stream.  `state` is one allocation laid out as ctl | qstate | ring | tstate | far_act.
+int tsa_persist_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init, unsigned* field,
+                       size_t field_stride, unsigned* pend, size_t pend_stride, void* state, int max_queries, int32_t* rev,
+                       int rev_cap, const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len,
+                       rna_astar_result* res_dev) {
+  const int rows = e->geom.size[0], cols = e->geom.size[1];
+  const int ti = (rows + TS - 1) / TS, tj = (cols + TS - 1) / TS;
+  if (n > 32767 || (size_t)ti * tj > 65536) return fail(e, RNA_EINVAL, "persistent A*: too many queries or tiles");
+  TsaPersistArgs A{};
+  A.rows = rows; A.cols = cols; A.tiles_i = ti; A.tiles_j = tj; A.n = n; A.bucket_width = e->astar.bucket_width;
+  A.queries = q_dev; A.field = field; A.field_stride = field_stride; A.pend = pend; A.pend_stride = pend_stride;
+  size_t ts_stride = 0, far_stride = 0;
+  (void)tsa_persist_state_bytes(e, max_queries, &ts_stride, &far_stride);
+  char* base = static_cast<char*>(state);
+  A.ctl = reinterpret_cast<TsaCtl*>(base); base += sizeof(TsaCtl);
+  A.qstate = reinterpret_cast<TsaQ*>(base); base += (size_t)max_queries * sizeof(TsaQ);
+  A.ring = reinterpret_cast<unsigned long long*>(base); base += (size_t)8 * TSA_QN * 8;
+  A.tstate = reinterpret_cast<unsigned*>(base); A.tstate_stride = ts_stride; base += (size_t)max_queries * ts_stride * 4;
+  A.far_act = reinterpret_cast<unsigned*>(base); A.far_stride = far_stride;
+  {
+    KernelTimer kt(e, RNA_K_ASTAR_INIT, init_stream);
+    hipLaunchKernelGGL(tsa_init_kernel, dim3(4096), dim3(256), 0, init_stream, e->nbr, rows, cols, ti, tj, field,
+                       field_stride, pend, pend_stride, n);
+    hipLaunchKernelGGL(tsa_persist_init_kernel, dim3(512), dim3(256), 0, init_stream, A);
+    RNA_HIP(e, hipGetLastError());
+  }
+  if (ev_init) {
+    RNA_HIP(e, hipEventRecord(ev_init, init_stream));
+    RNA_HIP(e, hipStreamWaitEvent(search_stream, ev_init, 0));
+  }
+  {
+    KernelTimer kt(e, RNA_K_ASTAR_SEARCH, search_stream);
+    int cus = 0;
+    RNA_HIP(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+    if (cus <= 0) cus = 256;
+    hipLaunchKernelGGL(tsa_persist_kernel, dim3(cus), dim3(TSA_THREADS), 0, search_stream, A);
+    hipLaunchKernelGGL(tsa_backtrace_kernel, dim3(n), dim3(64), 0, search_stream, rows, cols, ti, field, field_stride,
+                       A.qstate, A.ctl, paths_dev, max_len, rev, rev_cap, res_dev);
+    RNA_HIP(e, hipGetLastError());
+  }
   return RNA_OK;
 }
 

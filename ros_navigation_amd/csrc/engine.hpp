@@ -68,7 +68,8 @@ struct AstarDevice {
   int32_t* rev[MAX_DEPTH] = {};    // tile kernel: reversed-path staging per query
   size_t pend_stride = 0;
   int rev_cap = 16800;             // g < 2^24 at >= 1000 per step bounds a path to 16 777 cells
-  int mode = 0;                    // 0 = frontier kernel (astar.hip), 1 = tile-synchronous kernel (astar_tile.hip)
+  int mode = 0;                    // 0 = frontier kernel (astar.hip), 1 = tile kernel, 2 = persistent cross-CU tile scheduler
+  void* pstate[MAX_DEPTH] = {};    // mode 2: scheduler state (control block, per-query state, job rings, tile states)
   hipStream_t side[MAX_DEPTH] = {};
   hipEvent_t done[MAX_DEPTH] = {}; // search of the batch that last used this set has finished
   bool busy[MAX_DEPTH] = {};
@@ -186,6 +187,11 @@ bool tsa_supported(const rna_engine* e);
 int tsa_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init, unsigned* field,
                size_t field_stride, unsigned* pend, size_t pend_stride, int32_t* rev, int rev_cap,
                const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len, rna_astar_result* res_dev);
+size_t tsa_persist_state_bytes(const rna_engine* e, int max_queries, size_t* tstate_stride, size_t* far_stride);
+int tsa_persist_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init, unsigned* field,
+                       size_t field_stride, unsigned* pend, size_t pend_stride, void* state, int max_queries, int32_t* rev,
+                       int rev_cap, const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len,
+                       rna_astar_result* res_dev);
 int tsa_settled(rna_engine* e, const unsigned* field, size_t field_stride, const rna_astar_query* q,
                 const rna_astar_result* r, int n, int32_t* d_counts);
 
