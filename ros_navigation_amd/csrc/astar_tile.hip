@@ -17,6 +17,8 @@
 // the schedule runs every bucket to its fixed point, so at termination g is exact for f <= f*, which
 // is all the canonical backtrace reads (DESIGN.md "Grid A* contract").
 #include "engine.hpp"
+#include <algorithm>
+#include <vector>
 
 using namespace rna;
 
@@ -27,6 +29,9 @@ constexpr int TW = TS + 2;             // LDS row pitch incl. halo
 constexpr int TILE_WORDS = TS * TS;    // 1024
 #ifndef RNA_TSA_WAVES
 #define RNA_TSA_WAVES 16
+#endif
+#ifndef RNA_TSA_POLL_SLEEP
+#define RNA_TSA_POLL_SLEEP 32
 #endif
 #ifndef RNA_TSA_UNR
 #define RNA_TSA_UNR 1
@@ -70,11 +75,28 @@ __global__ void tsa_init_kernel(const uint8_t* __restrict__ nbr, int rows, int c
   for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < pw; w += step) pend[w] = 0u;
 }
 
+#ifdef RNA_TSA_STATS
+// developer build: phase timers (100 MHz wall clock ticks summed over all jobs), printed by the host
+__device__ unsigned long long g_tsa_stat[16];
+#define TSA_T(var) const unsigned long long var = wall_clock64()
+#define TSA_ACC(slot, t0, t1) tsa_acc[slot] += (unsigned long long)((t1) - (t0))
+#define TSA_CNT(slot, v) tsa_acc[slot] += (unsigned long long)(v)
+#define TSA_ACC_PARAM , unsigned long long* tsa_acc
+#define TSA_ACC_ARG , tsa_acc
+#else
+#define TSA_ACC_PARAM
+#define TSA_ACC_ARG
+#define TSA_T(var)
+#define TSA_ACC(slot, t0, t1)
+#define TSA_CNT(slot, v)
+#endif
+
 struct TsaWave {
-  unsigned tile[TW * TW];        // (g << 8) | mask, halo included; index (jl+1)*TW + (il+1)
+  unsigned tile[TW * TW];        // (g << 8) | job flags, halo included; index (jl+1)*TW + (il+1).  Flags: bit0 in
+                                 // the local queue, bit1 halo cell improved by this job, bit2 interior cell
+                                 // improved beyond the current bucket
   unsigned short lq[LQ];         // local queue of LDS positions
-  unsigned char flags[TW * TW + 4];  // per LDS position: bit0 in the local queue, bit1 halo cell improved by this
-                                     // job, bit2 interior cell improved beyond the current bucket
+  unsigned char mask[TW * TW + 4];   // neighbour mask of every position (the low byte of the field word)
 };
 
 // One tile job, executed by one wavefront (lane = this wave's lane id).  `sch` supplies the
@@ -85,27 +107,30 @@ template <class Sched>
 __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, const int t, const int rows, const int cols,
                                        const int tiles_i, const int tiles_j, unsigned* __restrict__ field,
                                        unsigned* __restrict__ pend_cur, unsigned* __restrict__ pend_far,
-                                       const long long bucket_end, const int gi, const int gj) {
+                                       const long long bucket_end, const int gi, const int gj TSA_ACC_PARAM) {
   const unsigned long long lane_lt = (1ull << lane) - 1ull;
   int expanded = 0;
   const int ti = t % tiles_i, tj = t / tiles_i;
   const int i0 = ti * TS, j0 = tj * TS;
   unsigned* ftile = field + ((size_t)t << 10);
 
+  TSA_T(t_a);
   // 1. grab-and-clear the pending bits of this tile (lane = column jl)
   unsigned seed = 0u;
   if (lane < TS) seed = atomicExch(&pend_cur[(size_t)t * TS + lane], 0u);
-  for (int w = lane; w < (TW * TW + 4) / 4; w += 64) reinterpret_cast<unsigned*>(W.flags)[w] = 0u;
   // 2. tile + halo -> LDS (after the pending bits: every grabbed bit's value is already in L2)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   {
     unsigned tv[TILE_WORDS / 64];   // issue all 16 coalesced loads, then one wait, then the LDS stores
 #pragma unroll
     for (int r = 0; r < TILE_WORDS / 64; ++r) tv[r] = ld_l2(&ftile[r * 64 + lane]);
+    // cell r*64 + lane sits 2r rows below cell `lane`: one base address + compile-time offsets
+    unsigned* tp = &W.tile[((lane >> 5) + 1) * TW + (lane & 31) + 1];
+    unsigned char* mp = &W.mask[((lane >> 5) + 1) * TW + (lane & 31) + 1];
 #pragma unroll
     for (int r = 0; r < TILE_WORDS / 64; ++r) {
-      const int l = r * 64 + lane;
-      W.tile[((l >> 5) + 1) * TW + (l & 31) + 1] = tv[r];
+      tp[r * 2 * TW] = tv[r] & 0xFFFFFF00u;
+      mp[r * 2 * TW] = (unsigned char)tv[r];
     }
   }
   {
@@ -117,14 +142,18 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
       const int ntj = second ? tj + 1 : tj - 1;
       unsigned v = 0xFFFFFF00u;
       if (ntj >= 0 && ntj < tiles_j) v = ld_l2(&field[((size_t)(ntj * tiles_i + ti) << 10) + ((second ? 0 : 31) << 5) + h]);
-      W.tile[(second ? TS + 1 : 0) * TW + h + 1] = v;
+      const int pos = (second ? TS + 1 : 0) * TW + h + 1;
+      W.tile[pos] = v & 0xFFFFFF00u;
+      W.mask[pos] = (unsigned char)v;
     }
     // rows: tile (ti-1, tj) row 31 -> LDS il=-1 ; tile (ti+1, tj) row 0 -> LDS il=32
     {
       const int nti = second ? ti + 1 : ti - 1;
       unsigned v = 0xFFFFFF00u;
       if (nti >= 0 && nti < tiles_i) v = ld_l2(&field[((size_t)(tj * tiles_i + nti) << 10) + (h << 5) + (second ? 0 : 31)]);
-      W.tile[(h + 1) * TW + (second ? TS + 1 : 0)] = v;
+      const int pos = (h + 1) * TW + (second ? TS + 1 : 0);
+      W.tile[pos] = v & 0xFFFFFF00u;
+      W.mask[pos] = (unsigned char)v;
     }
     if (lane < 4) {
       const int di = (lane & 1) ? 1 : -1, dj = (lane & 2) ? 1 : -1;
@@ -132,12 +161,16 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
       unsigned v = 0xFFFFFF00u;
       if (nti >= 0 && nti < tiles_i && ntj >= 0 && ntj < tiles_j)
         v = ld_l2(&field[((size_t)(ntj * tiles_i + nti) << 10) + ((dj > 0 ? 0 : 31) << 5) + (di > 0 ? 0 : 31)]);
-      W.tile[(dj > 0 ? TS + 1 : 0) * TW + (di > 0 ? TS + 1 : 0)] = v;
+      const int pos = (dj > 0 ? TS + 1 : 0) * TW + (di > 0 ? TS + 1 : 0);
+      W.tile[pos] = v & 0xFFFFFF00u;
+      W.mask[pos] = (unsigned char)v;
     }
   }
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
+  TSA_T(t_b);
+  TSA_ACC(0, t_a, t_b);
   // 3. seed the local queue from the pending bits
   int head = 0, tail = 0;   // wave-uniform
   {
@@ -152,7 +185,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
         const int p = (lane + 1) * TW + il + 1;
         const int pos = tail + __popcll(m & lane_lt);
         W.lq[pos & (LQ - 1)] = (unsigned short)p;
-        W.flags[p] = 1;
+        W.tile[p] |= 1u;
       }
       tail += __popcll(m);
     }
@@ -162,72 +195,79 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
   // 4. relax to the tile-local fixed point of the current bucket.  One lane per popped cell; the
   //    eight directions are visited one after the other.  Within one direction all lanes target
   //    DIFFERENT cells (target = own cell + the same offset), so the min-update of a neighbour and
-  //    the test-and-set of its in-queue flag are plain LDS reads and writes -- no LDS atomics
-  //    (ds_min_rtn on 16 waves turned out to be the bottleneck of an earlier version).
+  //    the test-and-set of its in-queue flag are one plain LDS read and one plain LDS write of the
+  //    same word -- no LDS atomics (ds_min_rtn on 16 waves was the bottleneck of an earlier version)
+  //    and no divergent branches.  All f-tests (prune against the upper bound, defer to the next
+  //    bucket) happen once per POPPED cell, so the direction body is only compare / select / store.
   const int best_in = sch.best();
+  const int bend = bucket_end > (long long)INF ? INF : (int)bucket_end;
+  const int goal_p = (gi >= i0 && gi < i0 + TS && gj >= j0 && gj < j0 + TS) ? (gj - j0 + 1) * TW + (gi - i0 + 1) : -1;
+  bool ovf = false;
   while (tail != head) {
     const int n = tail - head;
     const int take = n < 64 ? n : 64;
     const bool act = lane < take;
     const int p = act ? (int)W.lq[(head + lane) & (LQ - 1)] : (TW + 1);
     head += take;
+    TSA_CNT(8, 1);
+    TSA_CNT(9, take);
     const unsigned cw = W.tile[p];
-    if (act) W.flags[p] &= (unsigned char)~1u;   // popped: may be queued again
+    const unsigned mk = W.mask[p];
     const int g = (int)(cw >> 8);
     const int pil = p % TW - 1, pjl = p / TW - 1;
-    const int ci = i0 + pil, cj = j0 + pjl;
+    const unsigned ax = (unsigned)abs(i0 + pil - gi), ay = (unsigned)abs(j0 + pjl - gj);
+    const int fc = g + (int)(__umul24(ax > ay ? ax : ay, COST_S) + __umul24(ax > ay ? ay : ax, COST_D - COST_S));
     const int sb = sch.best();
     const int best_now = best_in < sb ? best_in : sb;
-    bool ok = act && g + tsa_octile(ci, cj, gi, gj) <= best_now;
+    const bool live = act && fc <= best_now;      // else pruned: f > upper bound on f*
+    const bool later = live && fc >= bend;        // belongs to a later bucket: flag it, do not expand
+    if (act) W.tile[p] = (cw & ~1u) | (later ? 4u : 0u);   // popped: may be queued again
+    bool ok = live && !later;
     if (ok) {
       ++expanded;
-      if (ci == gi && cj == gj) { sch.improve_best(g); ok = false; }
+      if (p == goal_p) { sch.improve_best(g); ok = false; }
+      else if (g >= (int)G_INF - 3 * COST_D) { ovf = true; ok = false; }   // 24-bit g exhausted
     }
-    const unsigned m = ok ? (cw & 0xffu) : 0u;
+    const unsigned m = ok ? mk : 0u;
+    const unsigned gs = ((unsigned)(g + COST_S) << 8), gd = ((unsigned)(g + COST_D) << 8);
+    const bool il_lo = pil == 0, il_hi = pil == TS - 1, jl_lo = pjl == 0, jl_hi = pjl == TS - 1;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int di = (k == 0 || k == 3 || k == 5) ? -1 : ((k == 2 || k == 4 || k == 7) ? 1 : 0);
       const int dj = k < 3 ? -1 : (k > 4 ? 1 : 0);
       const int np_ = p + di + dj * TW;
-      const int ng = g + ((k == 1 || k == 3 || k == 4 || k == 6) ? COST_S : COST_D);
-      bool doit = false;
-      if ((m >> k) & 1u) {
-        const unsigned nwv = W.tile[np_];
-        const unsigned fl = W.flags[np_];
-        if ((unsigned)ng < (nwv >> 8)) {
-          W.tile[np_] = ((unsigned)ng << 8) | (nwv & 0xffu);
-          const int ni = ci + di, nj = cj + dj;
-          const int fn = ng + tsa_octile(ni, nj, gi, gj);
-          if (ng >= (int)G_INF - 2 * COST_D) sch.overflow();            // 24-bit g exhausted
-          else {
-            if (ni == gi && nj == gj) sch.improve_best(ng);
-            if (fn <= best_now) {
-              const int nil = pil + di, njl = pjl + dj;
-              if (nil < 0 || nil >= TS || njl < 0 || njl >= TS) W.flags[np_] = (unsigned char)(fl | 2u);  // halo
-              else if (fn >= bucket_end) W.flags[np_] = (unsigned char)(fl | 4u);                          // next bucket
-              else if (!(fl & 1u)) { W.flags[np_] = (unsigned char)(fl | 1u); doit = true; }
-            }
-          }
-        }
-      }
+      const unsigned ng8 = (k == 1 || k == 3 || k == 4 || k == 6) ? gs : gd;
+      const unsigned nwv = W.tile[np_];
+      const bool improve = ((m >> k) & 1u) && (ng8 | 0xffu) < nwv;     // <=> g + w < g(neighbour)
+      const bool halo = (di < 0 && il_lo) || (di > 0 && il_hi) || (dj < 0 && jl_lo) || (dj > 0 && jl_hi);
+      if (improve) W.tile[np_] = ng8 | (nwv & 7u) | (halo ? 2u : 1u);
+      const bool doit = improve && !halo && !(nwv & 1u);
       const unsigned long long bm = __ballot(doit);
       if (doit) W.lq[(tail + __popcll(bm & lane_lt)) & (LQ - 1)] = (unsigned short)np_;
       tail += __popcll(bm);
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (ovf) sch.overflow();
 
+  TSA_T(t_c);
+  TSA_ACC(1, t_b, t_c);
   // 5. write back.  Inner 30 x 30 cells are private to this tile: coalesced stores.  Edge ring:
   //    atomicMin (a neighbouring tile's job may have improved them in HBM meanwhile).
+  {
+    const unsigned* tp = &W.tile[((lane >> 5) + 1) * TW + (lane & 31) + 1];
+    const unsigned char* mp = &W.mask[((lane >> 5) + 1) * TW + (lane & 31) + 1];
+    const int il = lane & 31;
+    const bool edge_col = il == 0 || il == TS - 1;
 #pragma unroll
-  for (int r = 0; r < TILE_WORDS / 64; ++r) {
-    const int l = r * 64 + lane;
-    const int il = l & 31, jl = l >> 5;
-    const unsigned v = W.tile[(jl + 1) * TW + il + 1];
-    if (il == 0 || il == TS - 1 || jl == 0 || jl == TS - 1) {
-      if ((v >> 8) != G_INF) (void)atomicMin(&ftile[l], v);
-    } else {
-      ftile[l] = v;
+    for (int r = 0; r < TILE_WORDS / 64; ++r) {
+      const unsigned v = (tp[r * 2 * TW] & 0xFFFFFF00u) | mp[r * 2 * TW];
+      const bool edge = edge_col || (r == 0 && lane < 32) || (r == TILE_WORDS / 64 - 1 && lane >= 32);
+      if (edge) {
+        if ((v >> 8) != G_INF) (void)atomicMin(&ftile[r * 64 + lane], v);
+      } else {
+        ftile[r * 64 + lane] = v;
+      }
     }
   }
   //    far-bucket cells of this tile: column jl -> one pending word (bit il)
@@ -236,7 +276,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
 #pragma unroll 4
     for (int r = 0; r < TS / 2; ++r) {
       const int jl = 2 * r + (lane >> 5), il = lane & 31;
-      const bool f = (W.flags[(jl + 1) * TW + il + 1] & 4u) != 0u;
+      const bool f = (W.tile[(jl + 1) * TW + il + 1] & 4u) != 0u;
       const unsigned long long bm = __ballot(f);
       const unsigned word = (unsigned)(bm >> (lane & 32));
       if ((lane & 31) == 0 && word) { atomicOr(&pend_far[(size_t)t * TS + jl], word); }
@@ -244,6 +284,8 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
     }
     if (anyfar && lane == 0) sch.act_far(t);
   }
+  TSA_T(t_d);
+  TSA_ACC(2, t_c, t_d);
   //    improved halo cells -> their tiles (value first, then the pending bit, then the activation)
   for (int hh = lane; hh < 4 * TW; hh += 64) {
     // ring positions: hh in [0,TW): jl=-1 row; [TW,2TW): jl=32 row; [2TW,3TW): il=-1 col; [3TW,4TW): il=32 col
@@ -255,15 +297,18 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
     else { pil = TS; pjl = u - 1; }
     if (side >= 2 && (pjl < 0 || pjl >= TS)) continue;   // corners are covered by the row sides
     const int p = (pjl + 1) * TW + pil + 1;
-    if (!(W.flags[p] & 2u)) continue;
+    const unsigned tw_ = W.tile[p];
+    if (!(tw_ & 2u)) continue;
     const int ni = i0 + pil, nj = j0 + pjl;
     if (ni < 0 || nj < 0 || ni >= rows || nj >= cols) continue;
-    const unsigned v = W.tile[p];
+    const unsigned v = (tw_ & 0xFFFFFF00u) | W.mask[p];
     const size_t nidx = tm_index(ni, nj, tiles_i);
+    const int fn = (int)(v >> 8) + tsa_octile(ni, nj, gi, gj);
+    if (fn > sch.best()) continue;                         // pruned: f > upper bound on f*
+    if (ni == gi && nj == gj) sch.improve_best((int)(v >> 8));
     const unsigned old = atomicMin(&field[nidx], v);
     if (v < old) {
       const int nt = (int)(nidx >> 10);
-      const int fn = (int)(v >> 8) + tsa_octile(ni, nj, gi, gj);
       const bool far = fn >= bucket_end;
       atomicOr(&(far ? pend_far : pend_cur)[(size_t)nt * TS + (nj & 31)], 1u << (ni & 31));
       // the value and its pending bit must be performed at L2 before the tile can be scheduled
@@ -273,6 +318,8 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_wave_barrier();
+  TSA_T(t_e);
+  TSA_ACC(3, t_d, t_e);
   return expanded;
 }
 
@@ -343,6 +390,9 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
 
   TsaWave& W = s_w[wv];
   int my_expanded = 0;
+#ifdef RNA_TSA_STATS
+  unsigned long long tsa_acc[16] = {};
+#endif
   TsaLocalSched sch{&s_best, &s_state, s_act[0], s_act[1]};
 
   for (;;) {
@@ -404,7 +454,7 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
       job = __shfl(job, 0);
       if (job >= njobs) break;
       const int t = s_jobs[job];
-      my_expanded += tsa_job(sch, W, lane, t, rows, cols, tiles_i, tiles_j, field, pend_cur, pend_far, bucket_end, gi, gj);
+      my_expanded += tsa_job(sch, W, lane, t, rows, cols, tiles_i, tiles_j, field, pend_cur, pend_far, bucket_end, gi, gj TSA_ACC_ARG);
     }
     // all stores / atomics of this round are performed before any wave loads tiles in the next one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -538,10 +588,13 @@ __device__ __forceinline__ int read_xcc_id() {
   return x & 7;
 }
 
-// bounded MPMC ring: entry = (sequence << 32) | job; slot i starts with sequence i
+// Consecutive ring positions are spread 264 B apart (odd multiplier = bijection on the ring): the
+// waiting workers of an XCD then poll different L2 channels instead of one cache line.
+__device__ __forceinline__ unsigned tsa_slot(unsigned pos) { return (pos * 33u) & (unsigned)(TSA_QN - 1); }
+// bounded MPMC ring: entry = (sequence << 32) | job; the slot of position i starts with sequence i
 __device__ bool tsa_enqueue(TsaCtl* ctl, unsigned long long* ring, int x, unsigned job) {
   const unsigned pos = atomicAdd(&ctl->tail[x][0], 1u);
-  unsigned long long* slot = &ring[(size_t)x * TSA_QN + (pos & (TSA_QN - 1))];
+  unsigned long long* slot = &ring[(size_t)x * TSA_QN + tsa_slot(pos)];
   for (int spin = 0;; ++spin) {
     if ((unsigned)(ld_u64(slot) >> 32) == pos) break;          // slot is free for this lap
     if (spin > TSA_SPIN_LIMIT || ((spin & 1023) == 1023 && ld_i32(&ctl->abort))) { atomicCAS(&ctl->abort, 0, 1); return false; }
@@ -555,7 +608,7 @@ __device__ bool tsa_enqueue(TsaCtl* ctl, unsigned long long* ring, int x, unsign
 // Returns TSA_NOJOB only when the launch is over (no query left unfinished) or aborted.
 __device__ unsigned tsa_dequeue(TsaCtl* ctl, unsigned long long* ring, int x) {
   const unsigned pos = atomicAdd(&ctl->head[x][0], 1u);
-  unsigned long long* slot = &ring[(size_t)x * TSA_QN + (pos & (TSA_QN - 1))];
+  unsigned long long* slot = &ring[(size_t)x * TSA_QN + tsa_slot(pos)];
   for (int spin = 0;; ++spin) {
     const unsigned long long v = ld_u64(slot);
     if ((unsigned)(v >> 32) == pos + 1u) {
@@ -566,7 +619,7 @@ __device__ unsigned tsa_dequeue(TsaCtl* ctl, unsigned long long* ring, int x) {
       if (ld_i32(&ctl->remaining) <= 0 || ld_i32(&ctl->abort)) return TSA_NOJOB;
       if (spin > 400000) { atomicCAS(&ctl->abort, 0, 5); return TSA_NOJOB; }   // ~5 s without work
     }
-    if (spin < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);
+    if (spin < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(RNA_TSA_POLL_SLEEP);
   }
 }
 
@@ -616,7 +669,8 @@ __global__ void tsa_persist_init_kernel(TsaPersistArgs A) {
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (size_t w = gid; w < (size_t)A.n * A.tstate_stride; w += step) A.tstate[w] = 0u;
   for (size_t w = gid; w < (size_t)A.n * A.far_stride; w += step) A.far_act[w] = 0u;
-  for (size_t w = gid; w < (size_t)8 * TSA_QN; w += step) A.ring[w] = (unsigned long long)(w & (TSA_QN - 1)) << 32;
+  for (size_t w = gid; w < (size_t)8 * TSA_QN; w += step)
+    A.ring[(w & ~(size_t)(TSA_QN - 1)) + tsa_slot((unsigned)w & (TSA_QN - 1))] = (unsigned long long)(w & (TSA_QN - 1)) << 32;
   for (size_t w = gid; w < (size_t)A.n * (sizeof(TsaQ) / 4); w += step)
     reinterpret_cast<int*>(A.qstate)[w] = ((w % (sizeof(TsaQ) / 4)) == 5) ? -2 : 0;   // status = -2: not started
   if (gid == 0) {
@@ -633,6 +687,9 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_persist_kernel(TsaPersistArgs
   const int ntile = A.tiles_i * A.tiles_j;
   const int nt_words = (ntile + 31) >> 5;
   const size_t pend_words = (size_t)ntile * TS;
+#ifdef RNA_TSA_STATS
+  unsigned long long tsa_acc[16] = {};
+#endif
   for (;;) {
     // ---- unstarted queries first: the worker that starts a query binds it to its own XCD ----
     int qn = -1;
@@ -654,6 +711,9 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_persist_kernel(TsaPersistArgs
           const int b0 = tsa_octile(si, sj, gi, gj) / A.bucket_width;
           qs->best = INF; qs->bucket = b0; qs->bucket0 = b0; qs->role = 0; qs->outstanding = 1; qs->xcc = xcc;
           qs->expanded = 0; qs->jobs = 0; qs->overflow = 0; qs->start = qu.start; qs->goal = qu.goal;
+#ifdef RNA_TSA_STATS
+          qs->pad[0] = (int)(wall_clock64() & 0x7fffffff);
+#endif
           if (qu.goal != qu.start && (ld_l2(&field[tm_index(gi, gj, A.tiles_i)]) & 0xffu) == 0u) status = 1;  // walled-in goal
           else {
             const size_t ws = tm_index(si, sj, A.tiles_i);
@@ -678,9 +738,13 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_persist_kernel(TsaPersistArgs
     }
     // ---- next job of this XCD (blocks until one is published or the launch is over) ----
     unsigned job = TSA_NOJOB;
+    TSA_T(t_w0);
     if (lane == 0) job = tsa_dequeue(A.ctl, A.ring, xcc);
     job = __shfl(job, 0);
+    TSA_T(t_w1);
+    TSA_ACC(4, t_w0, t_w1);
     if (job == TSA_NOJOB) break;
+    TSA_CNT(7, 1);
 
     // ---- run one tile job ----
     const int q = (int)(job >> 16), t = (int)(job & 0xffffu);
@@ -704,7 +768,7 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_persist_kernel(TsaPersistArgs
     TsaGlobalSched sch{qs, A.ctl, A.ring, tstate, far_act, q, xcc, ld_i32(&qs->best)};
     const long long bucket_end = ((long long)bucket + 1) * A.bucket_width;
     int exp = tsa_job(sch, W, lane, t, A.rows, A.cols, A.tiles_i, A.tiles_j, field, pend0 + (size_t)role * pend_words,
-                      pend0 + (size_t)(role ^ 1) * pend_words, bucket_end, gi, gj);
+                      pend0 + (size_t)(role ^ 1) * pend_words, bucket_end, gi, gj TSA_ACC_ARG);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // everything this job wrote is at L2 before the tile is released
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) exp += __shfl_xor(exp, o);
@@ -724,6 +788,8 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_persist_kernel(TsaPersistArgs
       }
     }
     last = __shfl(last, 0);
+    TSA_T(t_w2);
+    TSA_ACC(5, t_w1, t_w2);
     if (!last) continue;
 
     // ---- this wave emptied the bucket: it owns the query alone until it enqueues new jobs ----
@@ -772,11 +838,19 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_persist_kernel(TsaPersistArgs
       }
     }
     if (status >= 0 && lane == 0) {
+#ifdef RNA_TSA_STATS
+      qs->pad[1] = (int)(wall_clock64() & 0x7fffffff);
+#endif
       st_i32(&qs->status, status);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       atomicSub(&A.ctl->remaining, 1);
     }
+    TSA_T(t_w3);
+    TSA_ACC(6, t_w2, t_w3);
   }
+#ifdef RNA_TSA_STATS
+  if (lane == 0) for (int k = 0; k < 10; ++k) atomicAdd(&g_tsa_stat[k], tsa_acc[k]);
+#endif
 }
 
 // canonical backtrace + result records for the persistent scheduler: one wavefront per query
@@ -926,11 +1000,35 @@ int tsa_persist_launch(rna_engine* e, hipStream_t init_stream, hipStream_t searc
     int cus = 0;
     RNA_HIP(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
     if (cus <= 0) cus = 256;
+    if (const char* m = getenv("RNA_TSA_BLOCKS_PER_CU")) cus *= std::max(1, atoi(m));
     hipLaunchKernelGGL(tsa_persist_kernel, dim3(cus), dim3(TSA_THREADS), 0, search_stream, A);
     hipLaunchKernelGGL(tsa_backtrace_kernel, dim3(n), dim3(64), 0, search_stream, rows, cols, ti, field, field_stride,
                        A.qstate, A.ctl, paths_dev, max_len, rev, rev_cap, res_dev);
     RNA_HIP(e, hipGetLastError());
   }
+#ifdef RNA_TSA_STATS
+  {
+    RNA_HIP(e, hipStreamSynchronize(search_stream));
+    unsigned long long st[16];
+    RNA_HIP(e, hipMemcpyFromSymbol(st, HIP_SYMBOL(g_tsa_stat), sizeof(st)));
+    static const unsigned long long zero[16] = {};
+    RNA_HIP(e, hipMemcpyToSymbol(HIP_SYMBOL(g_tsa_stat), zero, sizeof(zero)));
+    std::vector<TsaQ> qh(n);
+    RNA_HIP(e, hipMemcpy(qh.data(), A.qstate, (size_t)n * sizeof(TsaQ), hipMemcpyDeviceToHost));
+    int t0 = 0x7fffffff;
+    for (auto& qq : qh) if (qq.status != 2 && qq.pad[0] < t0) t0 = qq.pad[0];
+    std::vector<double> fin;
+    for (auto& qq : qh) if (qq.status != 2) fin.push_back((qq.pad[1] - t0) * 1e-5);
+    std::sort(fin.begin(), fin.end());
+    const double jobs = (double)st[7];
+    fprintf(stderr, "[tsa stats] jobs %.0f | per job us: load %.2f relax %.2f wb %.2f handover %.2f finish %.2f advance %.2f | wait total %.1f ms-waves | relax iters/job %.1f cells/iter %.1f\n",
+            jobs, st[0] * 0.01 / jobs, st[1] * 0.01 / jobs, st[2] * 0.01 / jobs, st[3] * 0.01 / jobs, (st[5] - st[0] - st[1] - st[2] - st[3]) * 0.01 / jobs,
+            st[6] * 0.01 / jobs, st[4] * 1e-5, st[8] / jobs, st[9] / (double)std::max<unsigned long long>(1, st[8]));
+    if (!fin.empty())
+      fprintf(stderr, "[tsa stats] query finish ms: p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f | busy wave-ms %.1f\n", fin[fin.size() / 10],
+              fin[fin.size() / 2], fin[fin.size() * 9 / 10], fin[fin.size() * 99 / 100], fin.back(), (st[5] + st[6]) * 1e-5);
+  }
+#endif
   return RNA_OK;
 }
 

@@ -17,10 +17,14 @@ e.profile(True)
 for bw in widths:
     e.astar_configure(max_queries=nq, bucket_width=bw)
     e.astar(q, 32768)
+    times = []
+    for rep in range(int(os.environ.get("REPS", "7"))):
+        e.profile_reset()
+        res, paths = e.astar(q, 32768)
+        times.append(e.profile_get()["astar_search"][0])
     e.profile_reset()
-    t0 = time.perf_counter()
     res, paths = e.astar(q, 32768)
-    dt = time.perf_counter() - t0
+    print("bw=%d search ms over %d launches: min %.1f median %.1f max %.1f" % (bw, len(times), min(times), float(np.median(times)), max(times)))
     settled = e.astar_settled(nq)
     prof = e.profile_get()
     ok = res["status"] == 0
