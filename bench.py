@@ -201,7 +201,7 @@ def main():
                                    "compose -> %d VFH+ poses -> %d grid-A* queries per step; 30%% rectangle "
                                    "obstacles (seed 2)" % (n, n, len(rays), nq, nq),
                        "cycles_per_step": nq, "rays_per_step": int(len(rays)), "astar_paths_found": found,
-                       "astar_bucket_width": args.bucket_width or 8000, "astar_pipeline_depth": args.pipeline, "parallelism": "query-sharded x%d" % world},
+                       "astar_bucket_width": args.bucket_width or 16000, "astar_pipeline_depth": args.pipeline, "parallelism": "query-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "astar_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("astar_search_kernel<1024>"),
                          "traffic_source": "profiles/r01_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "

@@ -311,7 +311,7 @@ int ensure_config(rna_engine* e) {
   if (a.g[0]) return RNA_OK;
   if (a.max_queries <= 0) a.max_queries = 256;
   if (const char* t = getenv("RNA_ASTAR_THREADS")) a.threads = atoi(t);  // tuning knob: 256 / 512 / 1024
-  if (const char* k = getenv("RNA_ASTAR_KERNEL")) a.mode = (k[0] == 'p') ? 2 : ((k[0] == 't') ? 1 : 0);  // persistent | tile | frontier
+  if (const char* k = getenv("RNA_ASTAR_KERNEL")) a.mode = (k[0] == 'p') ? 2 : ((k[0] == 'f') ? 0 : 1);  // persist | frontier | tile (default)
   if (a.mode != 0 && !tsa_supported(e)) a.mode = 0;
   if (a.depth < 1) a.depth = 1;
   if (a.depth > AstarDevice::MAX_DEPTH) a.depth = AstarDevice::MAX_DEPTH;

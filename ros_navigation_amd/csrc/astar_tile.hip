@@ -342,7 +342,7 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
                   size_t pend_stride, int bucket_width, int32_t* __restrict__ paths, int max_path_len,
                   int32_t* __restrict__ rev_all, int rev_cap, rna_astar_result* __restrict__ results) {
   __shared__ TsaWave s_w[TSA_WAVES];
-  __shared__ unsigned s_act[2][TSA_MAX_TILE_WORDS];   // active tiles: [0] current bucket (next round), [1] next bucket
+  extern __shared__ unsigned s_dyn[];   // active-tile bitsets, sized by the launch: 2 x ((ntile + 31) / 32) words
   __shared__ unsigned short s_jobs[TSA_JOBS];
   __shared__ int s_njobs, s_first_fail, s_job_next, s_best, s_state, s_bucket, s_bucket0, s_rounds, s_role, s_expanded, s_len;
 
@@ -352,6 +352,7 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
   const int ncell = rows * cols;
   const int ntile = tiles_i * tiles_j;
   const int nt_words = (ntile + 31) >> 5;
+  unsigned* const s_act[2] = {s_dyn, s_dyn + nt_words};   // [0] current bucket (next round), [1] next bucket
   unsigned* field = field_all + (size_t)q * field_stride;
   unsigned* pend0 = pend_all + (size_t)q * pend_stride;   // two bitmaps of ntile*32 words each
   const size_t pend_words = (size_t)ntile * TS;
@@ -937,7 +938,7 @@ int tsa_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream
   }
   {
     KernelTimer kt(e, RNA_K_ASTAR_SEARCH, search_stream);
-    hipLaunchKernelGGL(tsa_search_kernel, dim3(n), dim3(TSA_THREADS), 0, search_stream, rows, cols, ti, tj, q_dev, field,
+    hipLaunchKernelGGL(tsa_search_kernel, dim3(n), dim3(TSA_THREADS), (size_t)2 * ((ti * tj + 31) / 32) * sizeof(unsigned), search_stream, rows, cols, ti, tj, q_dev, field,
                        field_stride, pend, pend_stride, e->astar.bucket_width, paths_dev, max_len, rev, rev_cap, res_dev);
     RNA_HIP(e, hipGetLastError());
   }

@@ -56,7 +56,7 @@ struct VfhDevice {
 struct AstarDevice {
   int max_queries = 0;
   int queue_cap = 0;
-  int bucket_width = 8000;
+  int bucket_width = 16000;
   int threads = 512;               // workgroup size of the search kernel (256 / 512 / 1024)
   // Pipelined batches: `depth` independent sets of search fields + queues, each with its own HIP
   // stream, so the tail of batch k (few long queries) overlaps the head of batch k+1.
@@ -68,7 +68,7 @@ struct AstarDevice {
   int32_t* rev[MAX_DEPTH] = {};    // tile kernel: reversed-path staging per query
   size_t pend_stride = 0;
   int rev_cap = 16800;             // g < 2^24 at >= 1000 per step bounds a path to 16 777 cells
-  int mode = 0;                    // 0 = frontier kernel (astar.hip), 1 = tile kernel, 2 = persistent cross-CU tile scheduler
+  int mode = 1;                    // 0 = frontier kernel (astar.hip), 1 = tile kernel (default), 2 = persistent cross-CU tile scheduler
   void* pstate[MAX_DEPTH] = {};    // mode 2: scheduler state (control block, per-query state, job rings, tile states)
   hipStream_t side[MAX_DEPTH] = {};
   hipEvent_t done[MAX_DEPTH] = {}; // search of the batch that last used this set has finished
