@@ -329,7 +329,8 @@ int ensure_config(rna_engine* e) {
   RNA_HIP(e, hipMemGetInfo(&free_b, &total_b));
   const size_t field_words = a.mode != 0 ? tsa_field_words(e) : e->ncell;
   const size_t per_query = (field_words + 128) * sizeof(int32_t) +
-                           (a.mode != 0 ? tsa_pend_words(e) * 4 + (size_t)a.rev_cap * 4 : (size_t)3 * a.queue_cap * sizeof(int2));
+                           (a.mode != 0 ? tsa_pend_words(e) * 4 + (size_t)a.rev_cap * 4 + tsa_field_words(e) / 8 / 32
+                                        : (size_t)3 * a.queue_cap * sizeof(int2));
   while (a.depth > 1 && (double)per_query * a.max_queries * a.depth > 0.75 * (double)free_b) a.depth -= 1;
   while (a.max_queries > 1 && (double)per_query * a.max_queries * a.depth > 0.75 * (double)free_b) a.max_queries /= 2;
   int rc;
@@ -341,6 +342,13 @@ int ensure_config(rna_engine* e) {
     if (a.mode != 0) {
       if ((rc = dev_alloc(e, &a.pend[d], a.pend_stride * (size_t)a.max_queries)) != RNA_OK) return rc;
       if ((rc = dev_alloc(e, &a.rev[d], (size_t)a.rev_cap * a.max_queries)) != RNA_OK) return rc;
+      {
+        char* aux = nullptr;
+        const size_t aux_bytes = tsa_aux_bytes(e, a.max_queries);
+        if ((rc = dev_alloc(e, &aux, aux_bytes)) != RNA_OK) return rc;
+        a.tsa_aux[d] = aux;
+        RNA_HIP(e, hipMemsetAsync(aux, 0, aux_bytes, e->stream));   // clean = 0: the first launch writes every field
+      }
       if (a.mode == 2) {
         size_t s1 = 0, s2 = 0;
         char* st = nullptr;
@@ -374,12 +382,12 @@ int launch_chunk(rna_engine* e, const rna_astar_query* q_dev, int n, int32_t* pa
   if (a.depth > 1 && a.busy[slot]) RNA_HIP(e, hipStreamWaitEvent(e->stream, a.done[slot], 0));  // stage is free again
   if (a.mode == 2) {
     int rc = tsa_persist_launch(e, e->stream, search_stream, a.depth > 1 ? a.ev_init : nullptr, field, a.field_stride,
-                                a.pend[slot], a.pend_stride, a.pstate[slot], a.max_queries, a.rev[slot], a.rev_cap, q_dev, n,
+                                a.pend[slot], a.pend_stride, a.tsa_aux[slot], a.pstate[slot], a.max_queries, a.rev[slot], a.rev_cap, q_dev, n,
                                 paths_dev, max_len, res_dev);
     if (rc != RNA_OK) return rc;
   } else if (a.mode == 1) {
     int rc = tsa_launch(e, e->stream, search_stream, a.depth > 1 ? a.ev_init : nullptr, field, a.field_stride, a.pend[slot],
-                        a.pend_stride, a.rev[slot], a.rev_cap, q_dev, n, paths_dev, max_len, res_dev);
+                        a.pend_stride, a.tsa_aux[slot], a.max_queries, a.rev[slot], a.rev_cap, q_dev, n, paths_dev, max_len, res_dev);
     if (rc != RNA_OK) return rc;
   } else {
   {
@@ -426,6 +434,7 @@ int astar_release(rna_engine* e) {
   for (int d = 0; d < AstarDevice::MAX_DEPTH; ++d) {
     dev_free(&a.g[d]); dev_free(&a.queues[d]); dev_free(&a.pend[d]); dev_free(&a.rev[d]);
     if (a.pstate[d]) { (void)hipFree(a.pstate[d]); a.pstate[d] = nullptr; }
+    if (a.tsa_aux[d]) { (void)hipFree(a.tsa_aux[d]); a.tsa_aux[d] = nullptr; }
     if (a.side[d]) { (void)hipStreamDestroy(a.side[d]); a.side[d] = nullptr; }
     if (a.done[d]) { (void)hipEventDestroy(a.done[d]); a.done[d] = nullptr; }
     a.busy[d] = false;

@@ -58,22 +58,72 @@ __device__ __forceinline__ size_t tm_index(int i, int j, int tiles_i) {
   return ((size_t)((j >> 5) * tiles_i + (i >> 5)) << 10) + ((j & 31) << 5) + (i & 31);
 }
 
-// field[q][tile][jl][il] = (G_INF << 8) | nbr(i, j) (0 outside the map); pending bitmaps zeroed
+// Per pipeline stage, next to the fields: a tile-major snapshot of the neighbour masks (taken at
+// launch, so a later map update cannot disturb a search in flight), one touched-tile bitset per query,
+// and the `clean` flag.
+//
+// Invariant between launches: every field word is (G_INF << 8) and every pending word is 0, EXCEPT in
+// the tiles flagged in touched[q].  A search flags every tile it wrote (its jobs and the tiles it
+// handed cells to); the next launch on the same stage resets exactly those tiles -- typically a few
+// per cent of the map -- instead of rewriting 64 MiB per query.  clean == 0 (fresh allocation, or a
+// scheduler abort) makes the next launch rewrite everything.
+struct TsaAux {
+  int* clean;
+  uint8_t* nbr_tm;      // [ntile][32][32] neighbour masks, 0 outside the map
+  unsigned* touched;    // [max_queries][nt_words]
+};
+__host__ __device__ inline size_t tsa_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 __global__ void tsa_init_kernel(const uint8_t* __restrict__ nbr, int rows, int cols, int tiles_i, int tiles_j,
                                 unsigned* __restrict__ field, size_t field_stride, unsigned* __restrict__ pend,
-                                size_t pend_stride, int n) {
-  const size_t nw = (size_t)tiles_i * tiles_j * TILE_WORDS;
+                                size_t pend_stride, int max_queries, TsaAux aux) {
+  const int ntile = tiles_i * tiles_j;
+  const int nt_words = (ntile + 31) >> 5;
+  const size_t nw = (size_t)ntile * TILE_WORDS;
   const size_t step = (size_t)gridDim.x * blockDim.x;
-  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += step) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // (a) snapshot of the neighbour masks in tile-major order (4 cells per thread)
+  for (size_t w4 = gid; w4 < nw / 4; w4 += step) {
+    const size_t w = w4 * 4;
     const int t = (int)(w >> 10), l = (int)(w & 1023);
     const int i = (t % tiles_i) * TS + (l & 31), j = (t / tiles_i) * TS + (l >> 5);
-    const unsigned m = (i < rows && j < cols) ? nbr[(size_t)j * rows + i] : 0u;
-    const unsigned v = 0xFFFFFF00u | m;
-    for (int q = 0; q < n; ++q) field[(size_t)q * field_stride + w] = v;
+    unsigned v = 0u;
+    if (j < cols) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (i + k < rows) v |= (unsigned)nbr[(size_t)j * rows + i + k] << (8 * k);
+    }
+    reinterpret_cast<unsigned*>(aux.nbr_tm)[w4] = v;
   }
-  const size_t pw = (size_t)n * pend_stride;
-  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < pw; w += step) pend[w] = 0u;
+  if (*aux.clean == 0) {
+    // (b1) everything: fields to "unreached", pending bitmaps and touched bitsets to zero
+    for (int q = 0; q < max_queries; ++q) {
+      uint4* f4 = reinterpret_cast<uint4*>(field + (size_t)q * field_stride);
+      for (size_t w4 = gid; w4 < nw / 4; w4 += step) f4[w4] = make_uint4(0xFFFFFF00u, 0xFFFFFF00u, 0xFFFFFF00u, 0xFFFFFF00u);
+    }
+    for (size_t w = gid; w < (size_t)max_queries * pend_stride; w += step) pend[w] = 0u;
+    for (size_t w = gid; w < (size_t)max_queries * nt_words; w += step) aux.touched[w] = 0u;
+    return;
+  }
+  // (b2) only the tiles the previous launch on this stage wrote: one block per (query, bitset word) pair
+  const size_t pend_words = (size_t)ntile * TS;
+  for (size_t item = blockIdx.x; item < (size_t)max_queries * nt_words; item += gridDim.x) {
+    unsigned bits = aux.touched[item];
+    if (!bits) continue;
+    const int q = (int)(item / nt_words), w = (int)(item % nt_words);
+    unsigned* fq = field + (size_t)q * field_stride;
+    unsigned* pq = pend + (size_t)q * pend_stride;
+    while (bits) {
+      const int t = (w << 5) + (__ffs(bits) - 1);
+      bits &= bits - 1;
+      reinterpret_cast<uint4*>(fq + ((size_t)t << 10))[threadIdx.x] = make_uint4(0xFFFFFF00u, 0xFFFFFF00u, 0xFFFFFF00u, 0xFFFFFF00u);
+      if (threadIdx.x < 2 * TS) pq[(size_t)(threadIdx.x >> 5) * pend_words + (size_t)t * TS + (threadIdx.x & 31)] = 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) aux.touched[item] = 0u;
+  }
 }
+__global__ void tsa_mark_clean_kernel(int* clean) { *clean = 1; }
 
 #ifdef RNA_TSA_STATS
 // developer build: phase timers (100 MHz wall clock ticks summed over all jobs), printed by the host
@@ -91,12 +141,12 @@ __device__ unsigned long long g_tsa_stat[16];
 #define TSA_CNT(slot, v)
 #endif
 
-struct TsaWave {
+struct alignas(16) TsaWave {
   unsigned tile[TW * TW];        // (g << 8) | job flags, halo included; index (jl+1)*TW + (il+1).  Flags: bit0 in
                                  // the local queue, bit1 halo cell improved by this job, bit2 interior cell
                                  // improved beyond the current bucket
   unsigned short lq[LQ];         // local queue of LDS positions
-  unsigned char mask[TW * TW + 4];   // neighbour mask of every position (the low byte of the field word)
+  unsigned char mask[TILE_WORDS];    // neighbour masks of the 32 x 32 interior cells, index jl*32 + il
 };
 
 // One tile job, executed by one wavefront (lane = this wave's lane id).  `sch` supplies the
@@ -106,7 +156,7 @@ struct TsaWave {
 template <class Sched>
 __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, const int t, const int rows, const int cols,
                                        const int tiles_i, const int tiles_j, unsigned* __restrict__ field,
-                                       unsigned* __restrict__ pend_cur, unsigned* __restrict__ pend_far,
+                                       const uint8_t* __restrict__ nbr_tm, unsigned* __restrict__ pend_cur, unsigned* __restrict__ pend_far,
                                        const long long bucket_end, const int gi, const int gj TSA_ACC_PARAM) {
   const unsigned long long lane_lt = (1ull << lane) - 1ull;
   int expanded = 0;
@@ -124,14 +174,12 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
     unsigned tv[TILE_WORDS / 64];   // issue all 16 coalesced loads, then one wait, then the LDS stores
 #pragma unroll
     for (int r = 0; r < TILE_WORDS / 64; ++r) tv[r] = ld_l2(&ftile[r * 64 + lane]);
+    const uint4 mv = *reinterpret_cast<const uint4*>(nbr_tm + ((size_t)t << 10) + lane * 16);
     // cell r*64 + lane sits 2r rows below cell `lane`: one base address + compile-time offsets
     unsigned* tp = &W.tile[((lane >> 5) + 1) * TW + (lane & 31) + 1];
-    unsigned char* mp = &W.mask[((lane >> 5) + 1) * TW + (lane & 31) + 1];
 #pragma unroll
-    for (int r = 0; r < TILE_WORDS / 64; ++r) {
-      tp[r * 2 * TW] = tv[r] & 0xFFFFFF00u;
-      mp[r * 2 * TW] = (unsigned char)tv[r];
-    }
+    for (int r = 0; r < TILE_WORDS / 64; ++r) tp[r * 2 * TW] = tv[r];
+    *reinterpret_cast<uint4*>(&W.mask[lane * 16]) = mv;
   }
   {
     // halo: left/right neighbour columns (contiguous), top/bottom rows (strided), 4 corners
@@ -142,18 +190,14 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
       const int ntj = second ? tj + 1 : tj - 1;
       unsigned v = 0xFFFFFF00u;
       if (ntj >= 0 && ntj < tiles_j) v = ld_l2(&field[((size_t)(ntj * tiles_i + ti) << 10) + ((second ? 0 : 31) << 5) + h]);
-      const int pos = (second ? TS + 1 : 0) * TW + h + 1;
-      W.tile[pos] = v & 0xFFFFFF00u;
-      W.mask[pos] = (unsigned char)v;
+      W.tile[(second ? TS + 1 : 0) * TW + h + 1] = v;
     }
     // rows: tile (ti-1, tj) row 31 -> LDS il=-1 ; tile (ti+1, tj) row 0 -> LDS il=32
     {
       const int nti = second ? ti + 1 : ti - 1;
       unsigned v = 0xFFFFFF00u;
       if (nti >= 0 && nti < tiles_i) v = ld_l2(&field[((size_t)(tj * tiles_i + nti) << 10) + (h << 5) + (second ? 0 : 31)]);
-      const int pos = (h + 1) * TW + (second ? TS + 1 : 0);
-      W.tile[pos] = v & 0xFFFFFF00u;
-      W.mask[pos] = (unsigned char)v;
+      W.tile[(h + 1) * TW + (second ? TS + 1 : 0)] = v;
     }
     if (lane < 4) {
       const int di = (lane & 1) ? 1 : -1, dj = (lane & 2) ? 1 : -1;
@@ -161,9 +205,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
       unsigned v = 0xFFFFFF00u;
       if (nti >= 0 && nti < tiles_i && ntj >= 0 && ntj < tiles_j)
         v = ld_l2(&field[((size_t)(ntj * tiles_i + nti) << 10) + ((dj > 0 ? 0 : 31) << 5) + (di > 0 ? 0 : 31)]);
-      const int pos = (dj > 0 ? TS + 1 : 0) * TW + (di > 0 ? TS + 1 : 0);
-      W.tile[pos] = v & 0xFFFFFF00u;
-      W.mask[pos] = (unsigned char)v;
+      W.tile[(dj > 0 ? TS + 1 : 0) * TW + (di > 0 ? TS + 1 : 0)] = v;
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -212,9 +254,9 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
     TSA_CNT(8, 1);
     TSA_CNT(9, take);
     const unsigned cw = W.tile[p];
-    const unsigned mk = W.mask[p];
     const int g = (int)(cw >> 8);
     const int pil = p % TW - 1, pjl = p / TW - 1;
+    const unsigned mk = W.mask[pjl * TS + pil];
     const unsigned ax = (unsigned)abs(i0 + pil - gi), ay = (unsigned)abs(j0 + pjl - gj);
     const int fc = g + (int)(__umul24(ax > ay ? ax : ay, COST_S) + __umul24(ax > ay ? ay : ax, COST_D - COST_S));
     const int sb = sch.best();
@@ -256,12 +298,11 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
   //    atomicMin (a neighbouring tile's job may have improved them in HBM meanwhile).
   {
     const unsigned* tp = &W.tile[((lane >> 5) + 1) * TW + (lane & 31) + 1];
-    const unsigned char* mp = &W.mask[((lane >> 5) + 1) * TW + (lane & 31) + 1];
     const int il = lane & 31;
     const bool edge_col = il == 0 || il == TS - 1;
 #pragma unroll
     for (int r = 0; r < TILE_WORDS / 64; ++r) {
-      const unsigned v = (tp[r * 2 * TW] & 0xFFFFFF00u) | mp[r * 2 * TW];
+      const unsigned v = tp[r * 2 * TW] & 0xFFFFFF00u;
       const bool edge = edge_col || (r == 0 && lane < 32) || (r == TILE_WORDS / 64 - 1 && lane >= 32);
       if (edge) {
         if ((v >> 8) != G_INF) (void)atomicMin(&ftile[r * 64 + lane], v);
@@ -301,7 +342,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
     if (!(tw_ & 2u)) continue;
     const int ni = i0 + pil, nj = j0 + pjl;
     if (ni < 0 || nj < 0 || ni >= rows || nj >= cols) continue;
-    const unsigned v = (tw_ & 0xFFFFFF00u) | W.mask[p];
+    const unsigned v = tw_ & 0xFFFFFF00u;
     const size_t nidx = tm_index(ni, nj, tiles_i);
     const int fn = (int)(v >> 8) + tsa_octile(ni, nj, gi, gj);
     if (fn > sch.best()) continue;                         // pruned: f > upper bound on f*
@@ -339,10 +380,11 @@ struct TsaLocalSched {
 __global__ void __launch_bounds__(TSA_THREADS)
 tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_query* __restrict__ queries,
                   unsigned* __restrict__ field_all, size_t field_stride, unsigned* __restrict__ pend_all,
-                  size_t pend_stride, int bucket_width, int32_t* __restrict__ paths, int max_path_len,
+                  size_t pend_stride, const uint8_t* __restrict__ nbr_tm, unsigned* __restrict__ touched_all,
+                  int bucket_width, int32_t* __restrict__ paths, int max_path_len,
                   int32_t* __restrict__ rev_all, int rev_cap, rna_astar_result* __restrict__ results) {
   __shared__ TsaWave s_w[TSA_WAVES];
-  extern __shared__ unsigned s_dyn[];   // active-tile bitsets, sized by the launch: 2 x ((ntile + 31) / 32) words
+  extern __shared__ unsigned s_dyn[];   // tile bitsets, sized by the launch: 3 x ((ntile + 31) / 32) words
   __shared__ unsigned short s_jobs[TSA_JOBS];
   __shared__ int s_njobs, s_first_fail, s_job_next, s_best, s_state, s_bucket, s_bucket0, s_rounds, s_role, s_expanded, s_len;
 
@@ -353,6 +395,7 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
   const int ntile = tiles_i * tiles_j;
   const int nt_words = (ntile + 31) >> 5;
   unsigned* const s_act[2] = {s_dyn, s_dyn + nt_words};   // [0] current bucket (next round), [1] next bucket
+  unsigned* const s_touched = s_dyn + 2 * nt_words;        // every tile that ever became a job
   unsigned* field = field_all + (size_t)q * field_stride;
   unsigned* pend0 = pend_all + (size_t)q * pend_stride;   // two bitmaps of ntile*32 words each
   const size_t pend_words = (size_t)ntile * TS;
@@ -365,29 +408,28 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
   const int si = qu.start % rows, sj = qu.start / rows;
   const int gi = qu.goal % rows, gj = qu.goal / rows;
 
-  for (int w = tid; w < nt_words; w += TSA_THREADS) { s_act[0][w] = 0u; s_act[1][w] = 0u; }
+  for (int w = tid; w < nt_words; w += TSA_THREADS) { s_act[0][w] = 0u; s_act[1][w] = 0u; s_touched[w] = 0u; }
+  // a goal without a single traversable neighbour cannot be reached (blocked or walled in); nothing
+  // has been written yet, so the field stays clean
+  if (qu.goal != qu.start && nbr_tm[tm_index(gi, gj, tiles_i)] == 0) {
+    if (tid == 0) results[q] = rna_astar_result{1, 0, INF, 0, 0, 0};
+    return;
+  }
   if (tid == 0) {
     s_best = INF; s_state = 0; s_rounds = 0; s_role = 0; s_expanded = 0;
     s_bucket = tsa_octile(si, sj, gi, gj) / bucket_width;
     s_bucket0 = s_bucket;
     const size_t ws = tm_index(si, sj, tiles_i);
-    const unsigned w0 = ld_l2(&field[ws]);
-    __hip_atomic_store(&field[ws], w0 & 0xffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // g(start) = 0
+    __hip_atomic_store(&field[ws], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // g(start) = 0
     const int ts = (sj >> 5) * tiles_i + (si >> 5);
     atomicOr(&pend0[(size_t)ts * TS + (sj & 31)], 1u << (si & 31));
-    // a goal without a single traversable neighbour cannot be reached (blocked or walled in)
-    if (qu.goal != qu.start && (ld_l2(&field[tm_index(gi, gj, tiles_i)]) & 0xffu) == 0u) s_state = 2;
   }
   __syncthreads();
-  if (tid == 0 && s_state == 0) {
+  if (tid == 0) {
     const int ts = (sj >> 5) * tiles_i + (si >> 5);
     s_act[0][ts >> 5] = 1u << (ts & 31);
   }
   __syncthreads();
-  if (s_state == 2) {
-    if (tid == 0) results[q] = rna_astar_result{1, 0, INF, 0, 0, 0};
-    return;
-  }
 
   TsaWave& W = s_w[wv];
   int my_expanded = 0;
@@ -407,6 +449,7 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
       const int base = atomicAdd(&s_njobs, cnt);
       if (base + cnt <= TSA_JOBS) {
         s_act[0][w] = 0u;
+        s_touched[w] |= bits;
         int k = base;
         while (bits) { const int b = __ffs(bits) - 1; bits &= bits - 1; s_jobs[k++] = (unsigned short)((w << 5) + b); }
       } else {
@@ -455,7 +498,7 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
       job = __shfl(job, 0);
       if (job >= njobs) break;
       const int t = s_jobs[job];
-      my_expanded += tsa_job(sch, W, lane, t, rows, cols, tiles_i, tiles_j, field, pend_cur, pend_far, bucket_end, gi, gj TSA_ACC_ARG);
+      my_expanded += tsa_job(sch, W, lane, t, rows, cols, tiles_i, tiles_j, field, nbr_tm, pend_cur, pend_far, bucket_end, gi, gj TSA_ACC_ARG);
     }
     // all stores / atomics of this round are performed before any wave loads tiles in the next one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -465,6 +508,11 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
   }
   atomicAdd(&s_expanded, my_expanded);
   __syncthreads();
+  // every tile this search wrote: its jobs plus the tiles that were handed cells but never ran
+  {
+    unsigned* touched = touched_all + (size_t)q * nt_words;
+    for (int w = tid; w < nt_words; w += TSA_THREADS) touched[w] = s_touched[w] | s_act[0][w] | s_act[1][w];
+  }
 
   const int state = s_state;
   const int n_buckets = s_bucket - s_bucket0 + 1;
@@ -491,8 +539,9 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
       const int ni = ci + di, nj = cj + dj;
       const bool inb = ni >= 0 && nj >= 0 && ni < rows && nj < cols;
       const unsigned wc = ld_l2(&field[tm_index(ci, cj, tiles_i)]);
+      const unsigned mc = nbr_tm[tm_index(ci, cj, tiles_i)];
       const unsigned wn = ld_l2(&field[inb ? tm_index(ni, nj, tiles_i) : tm_index(ci, cj, tiles_i)]);
-      const bool hit = tid < 8 && inb && ((wc >> k) & 1u) && ((wn >> 8) != G_INF) && ((wn >> 8) + (unsigned)w == (wc >> 8));
+      const bool hit = tid < 8 && inb && ((mc >> k) & 1u) && ((wn >> 8) != G_INF) && ((wn >> 8) + (unsigned)w == (wc >> 8));
       const unsigned long long mask = __ballot(hit);
       if (!mask) { ok = false; break; }
       const int src = __ffsll((long long)mask) - 1;
@@ -663,6 +712,9 @@ struct TsaPersistArgs {
   TsaQ* qstate; TsaCtl* ctl; unsigned long long* ring;
   unsigned* tstate; size_t tstate_stride;
   unsigned* far_act; size_t far_stride;
+  const uint8_t* nbr_tm;       // tile-major neighbour masks (snapshot of this launch)
+  unsigned* touched;           // [n][nt_words] tiles written by each query
+  int* clean;                  // cleared on abort: the next launch rewrites every field
 };
 
 __global__ void tsa_persist_init_kernel(TsaPersistArgs A) {
@@ -715,11 +767,9 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_persist_kernel(TsaPersistArgs
 #ifdef RNA_TSA_STATS
           qs->pad[0] = (int)(wall_clock64() & 0x7fffffff);
 #endif
-          if (qu.goal != qu.start && (ld_l2(&field[tm_index(gi, gj, A.tiles_i)]) & 0xffu) == 0u) status = 1;  // walled-in goal
+          if (qu.goal != qu.start && A.nbr_tm[tm_index(gi, gj, A.tiles_i)] == 0) status = 1;  // walled-in goal: nothing written
           else {
-            const size_t ws = tm_index(si, sj, A.tiles_i);
-            const unsigned w0 = ld_l2(&field[ws]);
-            __hip_atomic_store(&field[ws], w0 & 0xffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // g(start) = 0
+            __hip_atomic_store(&field[tm_index(si, sj, A.tiles_i)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // g(start) = 0
             const int ts = (sj >> 5) * A.tiles_i + (si >> 5);
             unsigned* pend0 = A.pend + (size_t)qn * A.pend_stride;
             atomicOr(&pend0[(size_t)ts * TS + (sj & 31)], 1u << (si & 31));
@@ -755,6 +805,7 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_persist_kernel(TsaPersistArgs
     unsigned* tw = &tstate[t >> 4];
     const int sh = (t & 15) * 2;
     if (lane == 0) {   // QUEUED -> RUNNING
+      atomicOr(&A.touched[(size_t)q * nt_words + (t >> 5)], 1u << (t & 31));   // this search writes tile t
       for (int spin = 0;; ++spin) {
         const unsigned old = __hip_atomic_load(tw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (((old >> sh) & 3u) == 1u && atomicCAS(tw, old, (old & ~(3u << sh)) | (2u << sh)) == old) break;
@@ -768,7 +819,7 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_persist_kernel(TsaPersistArgs
     unsigned* pend0 = A.pend + (size_t)q * A.pend_stride;
     TsaGlobalSched sch{qs, A.ctl, A.ring, tstate, far_act, q, xcc, ld_i32(&qs->best)};
     const long long bucket_end = ((long long)bucket + 1) * A.bucket_width;
-    int exp = tsa_job(sch, W, lane, t, A.rows, A.cols, A.tiles_i, A.tiles_j, field, pend0 + (size_t)role * pend_words,
+    int exp = tsa_job(sch, W, lane, t, A.rows, A.cols, A.tiles_i, A.tiles_j, field, A.nbr_tm, pend0 + (size_t)role * pend_words,
                       pend0 + (size_t)(role ^ 1) * pend_words, bucket_end, gi, gj TSA_ACC_ARG);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // everything this job wrote is at L2 before the tile is released
 #pragma unroll
@@ -838,6 +889,12 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_persist_kernel(TsaPersistArgs
         }
       }
     }
+    if (status >= 0) {   // tiles that were handed next-bucket cells but never ran were written as well
+      for (int w = lane; w < nt_words; w += 64) {
+        const unsigned bits = ld_l2(&far_act[w]);
+        if (bits) atomicOr(&A.touched[(size_t)q * nt_words + w], bits);
+      }
+    }
     if (status >= 0 && lane == 0) {
 #ifdef RNA_TSA_STATS
       qs->pad[1] = (int)(wall_clock64() & 0x7fffffff);
@@ -856,6 +913,7 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_persist_kernel(TsaPersistArgs
 
 // canonical backtrace + result records for the persistent scheduler: one wavefront per query
 __global__ void tsa_backtrace_kernel(int rows, int cols, int tiles_i, const unsigned* __restrict__ field_all, size_t field_stride,
+                                     const uint8_t* __restrict__ nbr_tm, int* __restrict__ clean,
                                      const TsaQ* __restrict__ qstate, const TsaCtl* __restrict__ ctl, int32_t* __restrict__ paths,
                                      int max_path_len, int32_t* __restrict__ rev_all, int rev_cap,
                                      rna_astar_result* __restrict__ results) {
@@ -864,6 +922,7 @@ __global__ void tsa_backtrace_kernel(int rows, int cols, int tiles_i, const unsi
   const unsigned* field = field_all + (size_t)q * field_stride;
   const int n_buckets = qs.bucket - qs.bucket0 + 1;
   if (ctl->abort || qs.status < 0) {   // scheduler timeout: report it as a capacity/scheduling failure
+    if (tid == 0) *clean = 0;          // queued tiles were never recorded: rewrite every field next time
     if (tid == 0) results[q] = rna_astar_result{(int)RNA_ECAPACITY, ctl->abort, qs.status, qs.expanded, qs.jobs, qs.outstanding};
     return;
   }
@@ -888,8 +947,9 @@ __global__ void tsa_backtrace_kernel(int rows, int cols, int tiles_i, const unsi
     const int ni = ci + di, nj = cj + dj;
     const bool inb = ni >= 0 && nj >= 0 && ni < rows && nj < cols;
     const unsigned wc = field[tm_index(ci, cj, tiles_i)];
+    const unsigned mc = nbr_tm[tm_index(ci, cj, tiles_i)];
     const unsigned wn = field[inb ? tm_index(ni, nj, tiles_i) : tm_index(ci, cj, tiles_i)];
-    const bool hit = tid < 8 && inb && ((wc >> k) & 1u) && ((wn >> 8) != G_INF) && ((wn >> 8) + (unsigned)w == (wc >> 8));
+    const bool hit = tid < 8 && inb && ((mc >> k) & 1u) && ((wn >> 8) != G_INF) && ((wn >> 8) + (unsigned)w == (wc >> 8));
     const unsigned long long mask = __ballot(hit);
     if (!mask) { ok = false; break; }
     const int src = __ffsll((long long)mask) - 1;
@@ -921,15 +981,41 @@ bool tsa_supported(const rna_engine* e) {
   return ti * tj <= (size_t)TSA_MAX_TILE_WORDS * 32;
 }
 
-int tsa_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init, unsigned* field,
-               size_t field_stride, unsigned* pend, size_t pend_stride, int32_t* rev, int rev_cap,
-               const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len, rna_astar_result* res_dev) {
+// one allocation per pipeline stage: clean flag | tile-major neighbour masks | touched bitsets.
+// It must start zeroed (clean == 0: the first launch writes every field).
+size_t tsa_aux_bytes(const rna_engine* e, int max_queries) {
+  const size_t ti = (e->geom.size[0] + TS - 1) / TS, tj = (e->geom.size[1] + TS - 1) / TS;
+  const size_t ntile = ti * tj;
+  return 256 + tsa_align256(ntile * TILE_WORDS) + tsa_align256((size_t)max_queries * ((ntile + 31) / 32) * 4);
+}
+static TsaAux tsa_aux_view(const rna_engine* e, void* aux) {
+  const size_t ti = (e->geom.size[0] + TS - 1) / TS, tj = (e->geom.size[1] + TS - 1) / TS;
+  char* base = static_cast<char*>(aux);
+  TsaAux v;
+  v.clean = reinterpret_cast<int*>(base);
+  v.nbr_tm = reinterpret_cast<uint8_t*>(base + 256);
+  v.touched = reinterpret_cast<unsigned*>(base + 256 + tsa_align256(ti * tj * TILE_WORDS));
+  return v;
+}
+// snapshot the neighbour masks and bring every field of this stage back to "unreached"
+static void tsa_launch_init(rna_engine* e, hipStream_t stream, unsigned* field, size_t field_stride, unsigned* pend,
+                            size_t pend_stride, int max_queries, const TsaAux& aux) {
   const int rows = e->geom.size[0], cols = e->geom.size[1];
   const int ti = (rows + TS - 1) / TS, tj = (cols + TS - 1) / TS;
+  hipLaunchKernelGGL(tsa_init_kernel, dim3(4096), dim3(256), 0, stream, e->nbr, rows, cols, ti, tj, field, field_stride, pend,
+                     pend_stride, max_queries, aux);
+  hipLaunchKernelGGL(tsa_mark_clean_kernel, dim3(1), dim3(1), 0, stream, aux.clean);
+}
+
+int tsa_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init, unsigned* field,
+               size_t field_stride, unsigned* pend, size_t pend_stride, void* aux_mem, int max_queries, int32_t* rev,
+               int rev_cap, const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len, rna_astar_result* res_dev) {
+  const int rows = e->geom.size[0], cols = e->geom.size[1];
+  const int ti = (rows + TS - 1) / TS, tj = (cols + TS - 1) / TS;
+  const TsaAux aux = tsa_aux_view(e, aux_mem);
   {
     KernelTimer kt(e, RNA_K_ASTAR_INIT, init_stream);
-    hipLaunchKernelGGL(tsa_init_kernel, dim3(4096), dim3(256), 0, init_stream, e->nbr, rows, cols, ti, tj, field,
-                       field_stride, pend, pend_stride, n);
+    tsa_launch_init(e, init_stream, field, field_stride, pend, pend_stride, max_queries, aux);
     RNA_HIP(e, hipGetLastError());
   }
   if (ev_init) {
@@ -938,8 +1024,9 @@ int tsa_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream
   }
   {
     KernelTimer kt(e, RNA_K_ASTAR_SEARCH, search_stream);
-    hipLaunchKernelGGL(tsa_search_kernel, dim3(n), dim3(TSA_THREADS), (size_t)2 * ((ti * tj + 31) / 32) * sizeof(unsigned), search_stream, rows, cols, ti, tj, q_dev, field,
-                       field_stride, pend, pend_stride, e->astar.bucket_width, paths_dev, max_len, rev, rev_cap, res_dev);
+    hipLaunchKernelGGL(tsa_search_kernel, dim3(n), dim3(TSA_THREADS), (size_t)3 * ((ti * tj + 31) / 32) * sizeof(unsigned),
+                       search_stream, rows, cols, ti, tj, q_dev, field, field_stride, pend, pend_stride, aux.nbr_tm, aux.touched,
+                       e->astar.bucket_width, paths_dev, max_len, rev, rev_cap, res_dev);
     RNA_HIP(e, hipGetLastError());
   }
   return RNA_OK;
@@ -968,8 +1055,8 @@ size_t tsa_persist_state_bytes(const rna_engine* e, int max_queries, size_t* tst
 // persistent launch: init (field + scheduler state) on init_stream, then the worker grid and the
 // backtrace on search_stream.  `state` is one allocation laid out as ctl | qstate | ring | tstate | far_act.
 int tsa_persist_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init, unsigned* field,
-                       size_t field_stride, unsigned* pend, size_t pend_stride, void* state, int max_queries, int32_t* rev,
-                       int rev_cap, const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len,
+                       size_t field_stride, unsigned* pend, size_t pend_stride, void* aux_mem, void* state, int max_queries,
+                       int32_t* rev, int rev_cap, const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len,
                        rna_astar_result* res_dev) {
   const int rows = e->geom.size[0], cols = e->geom.size[1];
   const int ti = (rows + TS - 1) / TS, tj = (cols + TS - 1) / TS;
@@ -985,10 +1072,11 @@ int tsa_persist_launch(rna_engine* e, hipStream_t init_stream, hipStream_t searc
   A.ring = reinterpret_cast<unsigned long long*>(base); base += (size_t)8 * TSA_QN * 8;
   A.tstate = reinterpret_cast<unsigned*>(base); A.tstate_stride = ts_stride; base += (size_t)max_queries * ts_stride * 4;
   A.far_act = reinterpret_cast<unsigned*>(base); A.far_stride = far_stride;
+  const TsaAux aux = tsa_aux_view(e, aux_mem);
+  A.nbr_tm = aux.nbr_tm; A.touched = aux.touched; A.clean = aux.clean;
   {
     KernelTimer kt(e, RNA_K_ASTAR_INIT, init_stream);
-    hipLaunchKernelGGL(tsa_init_kernel, dim3(4096), dim3(256), 0, init_stream, e->nbr, rows, cols, ti, tj, field,
-                       field_stride, pend, pend_stride, n);
+    tsa_launch_init(e, init_stream, field, field_stride, pend, pend_stride, max_queries, aux);
     hipLaunchKernelGGL(tsa_persist_init_kernel, dim3(512), dim3(256), 0, init_stream, A);
     RNA_HIP(e, hipGetLastError());
   }
@@ -1004,7 +1092,7 @@ int tsa_persist_launch(rna_engine* e, hipStream_t init_stream, hipStream_t searc
     if (const char* m = getenv("RNA_TSA_BLOCKS_PER_CU")) cus *= std::max(1, atoi(m));
     hipLaunchKernelGGL(tsa_persist_kernel, dim3(cus), dim3(TSA_THREADS), 0, search_stream, A);
     hipLaunchKernelGGL(tsa_backtrace_kernel, dim3(n), dim3(64), 0, search_stream, rows, cols, ti, field, field_stride,
-                       A.qstate, A.ctl, paths_dev, max_len, rev, rev_cap, res_dev);
+                       aux.nbr_tm, aux.clean, A.qstate, A.ctl, paths_dev, max_len, rev, rev_cap, res_dev);
     RNA_HIP(e, hipGetLastError());
   }
 #ifdef RNA_TSA_STATS

@@ -62,7 +62,7 @@ struct AstarDevice {
   // stream, so the tail of batch k (few long queries) overlaps the head of batch k+1.
   static constexpr int MAX_DEPTH = 8;
   int depth = 2;
-  int32_t* g[MAX_DEPTH] = {};      // [max_queries][field_stride] packed (g << 8) | mask search fields
+  int32_t* g[MAX_DEPTH] = {};      // [max_queries][field_stride] search fields: (g << 8) | mask (frontier kernel), g << 8 (tile kernels)
   int2* queues[MAX_DEPTH] = {};    // [max_queries][3][queue_cap] (cell, g)
   unsigned* pend[MAX_DEPTH] = {};  // tile kernel: two pending bitmaps per query
   int32_t* rev[MAX_DEPTH] = {};    // tile kernel: reversed-path staging per query
@@ -70,6 +70,7 @@ struct AstarDevice {
   int rev_cap = 16800;             // g < 2^24 at >= 1000 per step bounds a path to 16 777 cells
   int mode = 1;                    // 0 = frontier kernel (astar.hip), 1 = tile kernel (default), 2 = persistent cross-CU tile scheduler
   void* pstate[MAX_DEPTH] = {};    // mode 2: scheduler state (control block, per-query state, job rings, tile states)
+  void* tsa_aux[MAX_DEPTH] = {};   // modes 1/2: clean flag, tile-major neighbour-mask snapshot, touched-tile bitsets
   hipStream_t side[MAX_DEPTH] = {};
   hipEvent_t done[MAX_DEPTH] = {}; // search of the batch that last used this set has finished
   bool busy[MAX_DEPTH] = {};
@@ -184,13 +185,14 @@ int sync_all(rna_engine* e);          // main stream + every A* side stream
 size_t tsa_field_words(const rna_engine* e);
 size_t tsa_pend_words(const rna_engine* e);
 bool tsa_supported(const rna_engine* e);
+size_t tsa_aux_bytes(const rna_engine* e, int max_queries);   // per pipeline stage, must start zeroed
 int tsa_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init, unsigned* field,
-               size_t field_stride, unsigned* pend, size_t pend_stride, int32_t* rev, int rev_cap,
+               size_t field_stride, unsigned* pend, size_t pend_stride, void* aux, int max_queries, int32_t* rev, int rev_cap,
                const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len, rna_astar_result* res_dev);
 size_t tsa_persist_state_bytes(const rna_engine* e, int max_queries, size_t* tstate_stride, size_t* far_stride);
 int tsa_persist_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init, unsigned* field,
-                       size_t field_stride, unsigned* pend, size_t pend_stride, void* state, int max_queries, int32_t* rev,
-                       int rev_cap, const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len,
+                       size_t field_stride, unsigned* pend, size_t pend_stride, void* aux, void* state, int max_queries,
+                       int32_t* rev, int rev_cap, const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len,
                        rna_astar_result* res_dev);
 int tsa_settled(rna_engine* e, const unsigned* field, size_t field_stride, const rna_astar_query* q,
                 const rna_astar_result* r, int n, int32_t* d_counts);
