@@ -53,6 +53,10 @@ __device__ __forceinline__ int tsa_octile(int i, int j, int gi, int gj) {
 __device__ __forceinline__ unsigned ld_l2(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// number of set bits of a wave mask below this lane (v_mbcnt_lo/hi)
+__device__ __forceinline__ unsigned tsa_rank(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 // word index of cell (i, j) in a tile-major field
 __device__ __forceinline__ size_t tm_index(int i, int j, int tiles_i) {
   return ((size_t)((j >> 5) * tiles_i + (i >> 5)) << 10) + ((j & 31) << 5) + (i & 31);
@@ -158,7 +162,6 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
                                        const int tiles_i, const int tiles_j, unsigned* __restrict__ field,
                                        const uint8_t* __restrict__ nbr_tm, unsigned* __restrict__ pend_cur, unsigned* __restrict__ pend_far,
                                        const long long bucket_end, const int gi, const int gj TSA_ACC_PARAM) {
-  const unsigned long long lane_lt = (1ull << lane) - 1ull;
   int expanded = 0;
   const int ti = t % tiles_i, tj = t / tiles_i;
   const int i0 = ti * TS, j0 = tj * TS;
@@ -225,7 +228,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
         const int il = __ffs(bits) - 1;
         bits &= bits - 1;
         const int p = (lane + 1) * TW + il + 1;
-        const int pos = tail + __popcll(m & lane_lt);
+        const int pos = tail + (int)tsa_rank(m);
         W.lq[pos & (LQ - 1)] = (unsigned short)p;
         W.tile[p] |= 1u;
       }
@@ -285,7 +288,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
       if (improve) W.tile[np_] = ng8 | (nwv & 7u) | (halo ? 2u : 1u);
       const bool doit = improve && !halo && !(nwv & 1u);
       const unsigned long long bm = __ballot(doit);
-      if (doit) W.lq[(tail + __popcll(bm & lane_lt)) & (LQ - 1)] = (unsigned short)np_;
+      if (doit) W.lq[(tail + (int)tsa_rank(bm)) & (LQ - 1)] = (unsigned short)np_;
       tail += __popcll(bm);
     }
     __builtin_amdgcn_wave_barrier();
