@@ -203,7 +203,7 @@ def main():
                        "cycles_per_step": nq, "rays_per_step": int(len(rays)), "astar_paths_found": found,
                        "astar_bucket_width": args.bucket_width or 16000, "astar_pipeline_depth": args.pipeline, "parallelism": "query-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "astar_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("astar_search_kernel<1024>"),
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("rna::tsa_search_kernel"),
                          "traffic_source": "profiles/r01_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                            "of this command (2*FETCH+WRITE)*1024 B per launch, see MI355X_MICROARCH.md",
                          "algorithmic_bytes_per_launch": alg_bytes, "settled_cells_per_launch": int(settled.sum()),
