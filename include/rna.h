@@ -198,10 +198,30 @@ int rna_rrt_batch(rna_engine* e, const rna_rrt_query* queries_host, int n, doubl
 int rna_rrt_batch_device(rna_engine* e, const rna_rrt_query* queries_device, int n, double* paths_xy_device,
                          int max_path_len, rna_rrt_result* results_device);
 
+/* ---- message formats either side of the path ------------------------------------------------- */
+/* GridMapRosConverter::toOccupancyGrid (grid_map-master/grid_map_ros/src/GridMapRosConverter.cpp:251-287)
+ * as MapProvider::publishMap calls it with (0, 255) (mc/src/map_provider.cpp:113-118,206-213):
+ * out[nCells-1-(ui + uj*rows)] = NaN or negative -> -1, else (int8)(clamp((v-min)/(max-min), 0, 1)*100),
+ * (ui, uj) the unwrapped index -- info.width = rows, info.height = cols, origin = position - length/2
+ * (rna_get_geometry).  out holds rows*cols int8. */
+int rna_to_occupancy_grid(rna_engine* e, int layer, float data_min, float data_max, int8_t* out_host);
+int rna_to_occupancy_grid_device(rna_engine* e, int layer, float data_min, float data_max, int8_t* out_device);
+/* GridMapRosConverter::fromOccupancyGrid, data part (:238-246): layer(i) = data[n-1-i], -1 -> NaN.  The
+ * geometry part (:208-236) is rna_create(resolution*size, resolution, origin + length/2). */
+int rna_from_occupancy_grid(rna_engine* e, int layer, const int8_t* data_host);
+/* Steerer::pubHist -> move_control/Histogram.msg (mc/src/steerer.cpp:201-220) for the first n VFH
+ * instances: num_bin = hist_size/2 per robot; x_data[num_bin] (shared), y_data / y_bin_data
+ * [n][num_bin] = (uint16)(int)OriginHist / Hist; thresholds = {yLowThreshold, yHighThreshold}. */
+int rna_vfh_hist_msg_batch(rna_engine* e, int n, uint16_t* x_data_host, uint16_t* y_data_host,
+                           uint16_t* y_bin_data_host, uint16_t thresholds[2]);
+/* Nav::taileredPlan (mc/src/nav_node.cpp:192-204): walk the plan backwards keeping every stride-th
+ * index and the last one (host only; out_xy holds up to n positions). */
+int rna_tailor_plan(const double* plan_xy, int n, unsigned stride, double* out_xy, int* n_out);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 typedef enum {
   RNA_K_HIMM_PREP = 0, RNA_K_HIMM_RASTER, RNA_K_HIMM_APPLY, RNA_K_COMPOSE, RNA_K_NBRMASK,
-  RNA_K_VFH_STEP, RNA_K_ASTAR_SEARCH, RNA_K_ASTAR_INIT, RNA_K_RRT, RNA_K_COUNT
+  RNA_K_VFH_STEP, RNA_K_ASTAR_SEARCH, RNA_K_ASTAR_INIT, RNA_K_RRT, RNA_K_OCCUPANCY, RNA_K_COUNT
 } rna_kernel_id;
 /* when enabled, every launch of the kernels above is bracketed by hipEvents on the engine stream */
 int rna_profile_enable(rna_engine* e, int on);

@@ -204,6 +204,16 @@ void og_rrt_plan(const og_geom* g, const float* master, const double start[2], c
                  double close_tol, unsigned seed, int max_samples, double* path_xy, int path_cap,
                  og_rrt_result* res);
 
+/* ---- message formats either side of the path (msgs.c) ---- */
+/* GridMapRosConverter::toOccupancyGrid / fromOccupancyGrid (grid_map_ros/src/GridMapRosConverter.cpp:205-287) */
+void og_to_occupancy_grid(const og_geom* g, const float* layer, float data_min, float data_max, int8_t* out);
+void og_from_occupancy_grid(int rows, int cols, const int8_t* data, float* layer);
+/* Steerer::pubHist (steerer.cpp:201-220); returns num_bin */
+int og_hist_msg(const float* hist, const float* origin_hist, int hist_size, int sector_angle, uint16_t* x_data,
+                uint16_t* y_data, uint16_t* y_bin_data, uint16_t thresholds[2]);
+/* Nav::taileredPlan (nav_node.cpp:192-204); returns the number of kept positions */
+int og_tailor_plan(const double* plan_xy, int n, unsigned stride, double* out_xy);
+
 #ifdef __cplusplus
 }
 #endif

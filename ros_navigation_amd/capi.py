@@ -18,7 +18,7 @@ STATUS = {0: "RNA_OK", -1: "RNA_EINVAL", -2: "RNA_ENOMEM", -3: "RNA_EHIP", -4: "
           -5: "RNA_ESTATE", -6: "RNA_ENODEVICE"}
 LAYER_MASTER, LAYER_LASER, LAYER_RANGE = 0, 1, 2
 KERNELS = ["himm_prep", "himm_raster", "himm_apply", "compose_master", "nbr_mask", "vfh_step",
-           "astar_search", "astar_init", "rrt"]
+           "astar_search", "astar_init", "rrt", "to_occupancy_grid"]
 
 # every symbol include/rna.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [
@@ -32,6 +32,8 @@ SYMBOLS = [
     "rna_astar_configure", "rna_astar_set_pipeline_depth", "rna_astar_batch", "rna_astar_batch_device", "rna_astar_settled_counts",
     "rna_astar_download_nbr_mask",
     "rna_graph_astar_batch", "rna_rrt_batch", "rna_rrt_batch_device",
+    "rna_to_occupancy_grid", "rna_to_occupancy_grid_device", "rna_from_occupancy_grid", "rna_vfh_hist_msg_batch",
+    "rna_tailor_plan",
     "rna_profile_enable", "rna_profile_reset", "rna_profile_get", "rna_kernel_name",
 ]
 
@@ -126,6 +128,11 @@ def lib():
     L.rna_graph_astar_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, vp]
     L.rna_rrt_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
     L.rna_rrt_batch_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
+    L.rna_to_occupancy_grid.argtypes = [vp, C.c_int, C.c_float, C.c_float, vp]
+    L.rna_to_occupancy_grid_device.argtypes = [vp, C.c_int, C.c_float, C.c_float, vp]
+    L.rna_from_occupancy_grid.argtypes = [vp, C.c_int, vp]
+    L.rna_vfh_hist_msg_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.rna_tailor_plan.argtypes = [vp, C.c_int, C.c_uint, vp, C.POINTER(C.c_int)]
     L.rna_profile_enable.argtypes = [vp, C.c_int]
     L.rna_profile_reset.argtypes = [vp]
     L.rna_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -133,6 +140,17 @@ def lib():
     L.rna_kernel_name.restype = C.c_char_p
     _lib = L
     return L
+
+
+def tailor_plan(plan_xy, stride=5):
+    """Nav::taileredPlan: every stride-th position of the plan walked backwards, plus the last one."""
+    plan = np.ascontiguousarray(plan_xy, np.float64).reshape(-1, 2)
+    out = np.empty_like(plan)
+    m = C.c_int(0)
+    rc = lib().rna_tailor_plan(_ptr(plan), len(plan), stride, _ptr(out), C.byref(m))
+    if rc != 0:
+        raise RnaError("rna_tailor_plan failed (%d)" % rc)
+    return out[:m.value].copy()
 
 
 def default_vfh_params():
@@ -331,6 +349,30 @@ class Engine:
         self._check(self._L.rna_rrt_batch_device(self.h, queries_ptr, n, paths_ptr, max_path_len, results_ptr))
 
     # ---- measurement ----
+    def to_occupancy_grid(self, layer, data_min=0.0, data_max=255.0):
+        """GridMapRosConverter::toOccupancyGrid: int8[rows*cols] in nav_msgs/OccupancyGrid order."""
+        g = self.geometry()
+        out = np.empty(g.size[0] * g.size[1], np.int8)
+        self._check(self._L.rna_to_occupancy_grid(self.h, layer, data_min, data_max, _ptr(out)))
+        return out
+
+    def to_occupancy_grid_device(self, layer, data_min, data_max, out_ptr):
+        self._check(self._L.rna_to_occupancy_grid_device(self.h, layer, data_min, data_max, out_ptr))
+
+    def from_occupancy_grid(self, layer, data):
+        data = np.ascontiguousarray(data, np.int8)
+        self._check(self._L.rna_from_occupancy_grid(self.h, layer, _ptr(data)))
+
+    def vfh_hist_msg(self, n):
+        """Steerer::pubHist for the first n robots: (xData[bins], yData[n, bins], yBinData[n, bins], (low, high))."""
+        bins = self._L.rna_vfh_hist_size(self.h) // 2
+        x = np.empty(bins, np.uint16)
+        y = np.empty((n, bins), np.uint16)
+        yb = np.empty((n, bins), np.uint16)
+        th = np.empty(2, np.uint16)
+        self._check(self._L.rna_vfh_hist_msg_batch(self.h, n, _ptr(x), _ptr(y), _ptr(yb), _ptr(th)))
+        return x, y, yb, (int(th[0]), int(th[1]))
+
     def profile(self, on=True):
         self._check(self._L.rna_profile_enable(self.h, 1 if on else 0))
 

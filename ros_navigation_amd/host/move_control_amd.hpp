@@ -129,6 +129,22 @@ struct RangeSample {
   bool ifClearEnd;
 };
 
+// The fields of nav_msgs/OccupancyGrid that GridMapRosConverter::toOccupancyGrid fills
+// (grid_map_ros/src/GridMapRosConverter.cpp:251-287); header/stamp stay with the ROS shim.
+struct OccupancyGrid {
+  float resolution;
+  unsigned width, height;          // info.width = size(0), info.height = size(1)
+  double origin_x, origin_y;       // position - length/2
+  std::vector<int8_t> data;        // -1 unknown, 0..100
+};
+
+// move_control/Histogram.msg as Steerer::pubHist fills it (mc/src/steerer.cpp:201-220)
+struct Histogram {
+  uint8_t num_bin;
+  std::vector<uint16_t> xData, yData, yBinData;
+  uint16_t yLowThreshold, yHighThreshold;
+};
+
 // The compute core of MapProvider (mc/src/map_provider.cpp:190-223): buffered samples are applied
 // in arrival order (laser_map_updater.cpp:7-21) and master is composed from the laser layer.
 class MapProvider {
@@ -149,6 +165,17 @@ class MapProvider {
     buffer_.clear();
   }
   GridMap& getMap() { return map_; }
+  // MapProvider::publishMap (:113-118,206-213): toOccupancyGrid(map, "master", 0.0, 255.0, msg) on the device
+  void publishMap(OccupancyGrid& msg) {
+    rna_geometry g;
+    grid_map::rna_check(rna_get_geometry(map_.engine(), &g), map_.engine(), "MapProvider::publishMap");
+    msg.resolution = (float)g.resolution;
+    msg.width = (unsigned)g.size[0]; msg.height = (unsigned)g.size[1];
+    msg.origin_x = g.position[0] - 0.5 * g.length[0]; msg.origin_y = g.position[1] - 0.5 * g.length[1];
+    msg.data.resize((size_t)g.size[0] * g.size[1]);
+    grid_map::rna_check(rna_to_occupancy_grid(map_.engine(), RNA_LAYER_MASTER, 0.0f, 255.0f, msg.data.data()), map_.engine(),
+                        "MapProvider::publishMap");
+  }
   bool ifCloseToPostion(const Position& robot, const Position& pos, double tolerance) const {  // :102-111
     return std::hypot(pos[0] - robot[0], pos[1] - robot[1]) < tolerance;
   }
@@ -209,6 +236,16 @@ class VFH {
     return 1;
   }
   float GetPickedAngle() const { return picked_; }
+  // Steerer::pubHist (steerer.cpp:201-220) for robot 0, packed on the device from the resident histograms
+  void pubHist(Histogram& msg) {
+    const int bins = getHistSize() / 2;
+    msg.num_bin = (uint8_t)bins;
+    msg.xData.resize(bins); msg.yData.resize(bins); msg.yBinData.resize(bins);
+    uint16_t th[2];
+    grid_map::rna_check(rna_vfh_hist_msg_batch(map_->engine(), 1, msg.xData.data(), msg.yData.data(), msg.yBinData.data(), th),
+                        map_->engine(), "Steerer::pubHist");
+    msg.yLowThreshold = th[0]; msg.yHighThreshold = th[1];
+  }
   int getHistSize() const { return rna_vfh_hist_size(map_->engine()); }
   int getSectorAngle() const { return p_.sector_angle; }
   float* Hist;        // public as in the reference (vfh.h:239-244); refreshed by every Update_VFH
@@ -278,6 +315,17 @@ class GridAStarPlanner {
 
 // RrtPlanner(GridMap&, start, target, closeTolerance).makePlan(path) (rrt_planner.h:17-28): clears
 // then fills `path` goal -> start; returns false (with the best-effort path) after 2000 iterations.
+// Nav::taileredPlan (mc/src/nav_node.cpp:192-204): the plan handed to the Steerer keeps every
+// tailerPlanStride_-th position (5, nav_node.cpp:84) of the detailed plan walked backwards, and its last one
+inline void taileredPlan(const std::vector<Position>& detailedPlan, std::vector<Position>& pathPlan, unsigned stride = 5) {
+  std::vector<double> in(2 * detailedPlan.size()), out(2 * detailedPlan.size());
+  for (size_t k = 0; k < detailedPlan.size(); ++k) { in[2 * k] = detailedPlan[k][0]; in[2 * k + 1] = detailedPlan[k][1]; }
+  int m = 0;
+  if (rna_tailor_plan(in.data(), (int)detailedPlan.size(), stride, out.data(), &m) != RNA_OK) throw std::invalid_argument("taileredPlan");
+  pathPlan.clear();
+  for (int k = 0; k < m; ++k) pathPlan.push_back(Position(out[2 * k], out[2 * k + 1]));
+}
+
 class RrtPlanner {
  public:
   RrtPlanner(GridMap& map, Position& start, Position& target, double closeTolerance = 0.2, unsigned seed = 1)

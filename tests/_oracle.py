@@ -145,6 +145,12 @@ def lib():
         L.og_rrt_plan.argtypes = [C.POINTER(Geom), fp, d2, d2, C.c_double, C.c_uint, C.c_int, d2, C.c_int,
                                   C.POINTER(RrtResult)]
         L.og_rrt_plan.restype = None
+        L.og_to_occupancy_grid.argtypes = [C.POINTER(Geom), fp, C.c_float, C.c_float, C.c_void_p]
+        L.og_to_occupancy_grid.restype = None
+        L.og_from_occupancy_grid.argtypes = [C.c_int, C.c_int, C.c_void_p, fp]
+        L.og_from_occupancy_grid.restype = None
+        L.og_hist_msg.argtypes = [fp, fp, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.og_tailor_plan.argtypes = [d2, C.c_int, C.c_uint, d2]
         _lib = L
     return _lib
 
@@ -330,3 +336,35 @@ def rrt_plan(g, master, start, target, tol=0.2, seed=1, max_samples=200000, cap=
     lib().og_rrt_plan(C.byref(g), fptr(master), d2(*start), d2(*target), tol, seed, max_samples,
                       path.ctypes.data_as(C.POINTER(C.c_double)), cap, C.byref(res))
     return res, path[:2 * min(res.path_len, cap)].reshape(-1, 2).copy()
+
+
+def to_occupancy_grid(g, layer, data_min=0.0, data_max=255.0):
+    out = np.empty(g.size[0] * g.size[1], np.int8)
+    lib().og_to_occupancy_grid(C.byref(g), fptr(layer), data_min, data_max, out.ctypes.data)
+    return out
+
+
+def from_occupancy_grid(rows, cols, data):
+    data = np.ascontiguousarray(data, np.int8)
+    layer = np.empty(rows * cols, np.float32)
+    lib().og_from_occupancy_grid(rows, cols, data.ctypes.data, fptr(layer))
+    return layer
+
+
+def hist_msg(hist, origin_hist, sector_angle):
+    hist = np.ascontiguousarray(hist, np.float32)
+    origin_hist = np.ascontiguousarray(origin_hist, np.float32)
+    bins = len(hist) // 2
+    x = np.empty(bins, np.uint16); y = np.empty(bins, np.uint16); yb = np.empty(bins, np.uint16); th = np.empty(2, np.uint16)
+    n = lib().og_hist_msg(fptr(hist), fptr(origin_hist), len(hist), sector_angle, x.ctypes.data, y.ctypes.data,
+                          yb.ctypes.data, th.ctypes.data)
+    assert n == bins
+    return x, y, yb, (int(th[0]), int(th[1]))
+
+
+def tailor_plan(plan_xy, stride=5):
+    plan = np.ascontiguousarray(plan_xy, np.float64).reshape(-1, 2)
+    out = np.empty_like(plan)
+    m = lib().og_tailor_plan(plan.ctypes.data_as(C.POINTER(C.c_double)), len(plan), stride,
+                             out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out[:m].copy()

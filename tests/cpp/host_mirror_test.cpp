@@ -66,7 +66,24 @@ int main() {
       CHECK(same_bits(vfh.OriginHist[s], og_vfh_origin_hist(ov)[s]));
     }
   }
+  {  // Steerer::pubHist (steerer.cpp:201-220) from the resident histograms of the last step
+    Histogram msg;
+    vfh.pubHist(msg);
+    uint16_t ox[36], oy[36], oyb[36], oth[2];
+    CHECK(og_hist_msg(og_vfh_hist(ov), og_vfh_origin_hist(ov), 72, 5, ox, oy, oyb, oth) == 36 && msg.num_bin == 36);
+    CHECK(msg.yLowThreshold == oth[0] && msg.yHighThreshold == oth[1]);
+    for (int i = 0; i < 36; ++i) CHECK(msg.xData[i] == ox[i] && msg.yData[i] == oy[i] && msg.yBinData[i] == oyb[i]);
+  }
   og_vfh_destroy(ov);
+
+  {  // MapProvider::publishMap (map_provider.cpp:113-118,206-213)
+    OccupancyGrid occ;
+    provider.publishMap(occ);
+    std::vector<int8_t> want(ref.size());
+    og_to_occupancy_grid(&g, ref.data(), 0.0f, 255.0f, want.data());
+    CHECK(occ.width == (unsigned)g.size[0] && occ.height == (unsigned)g.size[1] && occ.origin_x == -6.4 && occ.origin_y == -6.4);
+    CHECK(occ.data == want);
+  }
 
   // ---- planners ----
   Position start(-5.0, -5.0), target(5.5, 4.0);
@@ -92,6 +109,15 @@ int main() {
       og_position_from_index(&g, idx, p);
       CHECK(p[0] == path[k][0] && p[1] == path[k][1]);
     }
+  }
+  {  // Nav::taileredPlan (nav_node.cpp:192-204) on the detailed grid plan
+    std::vector<Position> tailored;
+    taileredPlan(path, tailored);
+    std::vector<double> in(2 * path.size()), out(2 * path.size());
+    for (size_t k = 0; k < path.size(); ++k) { in[2 * k] = path[k][0]; in[2 * k + 1] = path[k][1]; }
+    const int m = og_tailor_plan(in.data(), (int)path.size(), 5, out.data());
+    CHECK((size_t)m == tailored.size() && m >= 2);
+    for (int k = 0; k < m; ++k) CHECK(out[2 * k] == tailored[k][0] && out[2 * k + 1] == tailored[k][1]);
   }
   AStarPlanner graph_planner(map);
   Position gs(3.0, 0.5), gt(19.0, 10.5);

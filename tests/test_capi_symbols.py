@@ -66,6 +66,17 @@ def test_no_device_means_error_not_fallback(capi):
         capi.Engine(1.0, 1.0, 0.05)
 
 
+def test_tailor_plan_host_entry_point(capi):
+    """rna_tailor_plan (Nav::taileredPlan, mc/src/nav_node.cpp:192-204) is host-only: checked here against the oracle"""
+    import numpy as np
+    import _oracle as O
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 2, 5, 6, 11, 57):
+        plan = rng.normal(size=(n, 2))
+        for stride in (1, 2, 5):
+            assert np.array_equal(capi.tailor_plan(plan, stride), O.tailor_plan(plan, stride))
+
+
 def test_product_never_imports_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "ros_navigation_amd")):
         for f in files:

@@ -369,6 +369,64 @@ def test_himm_and_vfh_on_a_moved_map(R):
     e.close()
 
 
+# ------------------------------------------------------------------------------------------------
+# message formats either side of the path
+# ------------------------------------------------------------------------------------------------
+def test_occupancy_grid_matches_oracle_also_on_a_moved_map(R):
+    e = R.Engine(12.8, 9.6, 0.05)
+    g = O.make_geom(12.8, 9.6, 0.05)
+    rng = np.random.default_rng(21)
+    layer = (rng.integers(0, 19, e.ncell) * 10).astype(np.float32)      # HIMM values 0..180
+    layer[rng.random(e.ncell) < 0.2] = np.nan
+    layer[rng.random(e.ncell) < 0.01] = -3.0
+    layer[rng.random(e.ncell) < 0.01] = 300.0
+    for l in range(3):
+        e.upload(l, layer)
+    assert np.array_equal(e.to_occupancy_grid(R.capi.LAYER_MASTER), O.to_occupancy_grid(g, layer, 0.0, 255.0))
+    assert np.array_equal(e.to_occupancy_grid(R.capi.LAYER_LASER, -1.0, 100.0), O.to_occupancy_grid(g, layer, -1.0, 100.0))
+    ref = layer.copy()
+    ptrs = (C.POINTER(C.c_float) * 1)(O.fptr(ref))
+    regs = (O.Region * 4)()
+    mv = C.c_int(0)
+    O.lib().og_move(C.byref(g), ptrs, 1, O.d2(-2.13, 0.77), regs, C.byref(mv))
+    assert e.move(-2.13, 0.77) and tuple(g.start) != (0, 0)
+    want = O.to_occupancy_grid(g, ref, 0.0, 255.0)
+    assert np.array_equal(e.to_occupancy_grid(R.capi.LAYER_MASTER), want)
+    assert (want == -1).sum() > (np.isnan(layer) | (layer < 0)).sum()     # the dropped rows/columns are unobserved
+    with pytest.raises(R.RnaError):
+        e.from_occupancy_grid(R.capi.LAYER_RANGE, np.zeros(e.ncell, np.int8))   # reference resets the geometry here
+    e.close()
+
+
+def test_occupancy_grid_round_trip(R):
+    """grid_map_ros/test/GridMapRosTest.cpp:140-184 through the device path"""
+    rng = np.random.default_rng(5)
+    width, height = 50, 100
+    data = rng.integers(-1, 101, width * height).astype(np.int8)
+    e = R.Engine(0.1 * width, 0.1 * height, 0.1, 3.0 + 0.05 * width, 6.0 + 0.05 * height)
+    assert (e.rows, e.cols) == (width, height)
+    e.from_occupancy_grid(R.capi.LAYER_LASER, data)
+    assert same_f32(e.download(R.capi.LAYER_LASER), O.from_occupancy_grid(width, height, data))
+    assert np.array_equal(e.to_occupancy_grid(R.capi.LAYER_LASER, -1.0, 100.0), data)
+    e.close()
+
+
+def test_hist_msg_matches_oracle(R):
+    e = R.Engine(20.0, 20.0, 0.05)
+    master = R.synth.occupancy_sparse(e.rows, e.cols, seed=3, occupied=0.05)
+    e.upload(R.capi.LAYER_MASTER, master)
+    poses = R.synth.poses(40, 20.0, 20.0, seed=4)
+    e.vfh_init(len(poses))
+    for _ in range(2):
+        out, origin, hist = e.vfh_step(poses)
+    x, y, yb, th = e.vfh_hist_msg(len(poses))
+    assert origin.max() > 65535.0                                           # the uint16 narrowing is exercised
+    for k in range(len(poses)):
+        ox, oy, oyb, oth = O.hist_msg(hist[k], origin[k], 5)
+        assert np.array_equal(x, ox) and np.array_equal(y[k], oy) and np.array_equal(yb[k], oyb) and th == oth
+    e.close()
+
+
 def test_empty_batches_are_noops(R):
     e = R.Engine(3.2, 3.2, 0.05)
     e.himm_update(R.capi.LAYER_LASER, np.zeros(0, R.capi.RAY_DTYPE))
