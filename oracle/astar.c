@@ -166,6 +166,45 @@ void og_astar_query(const uint8_t* nbr, int rows, int cols, int start_lin, int g
   res->status = 0;
 }
 
+/* Grid A* on a map whose circular buffer has been moved (GridMap::move, gmc/src/GridMap.cpp:346-412):
+ * the contract is the one above applied in MAP space -- adjacency, heuristic and the canonical
+ * backtrace ("lowest linear index") use unwrapped indices (gmc/src/GridMapMath.cpp:467-476), the
+ * map does not wrap around at its edges; start, goal and the returned path are buffer linear indices
+ * (what GridMap::getIndex hands out).  With start index (0,0) this is og_astar_query. */
+void og_astar_query_on_map(const og_geom* g, const float* master, int start_lin, int goal_lin, int32_t* g_work,
+                           int32_t* path, int path_cap, og_astar_result* res) {
+  const int rows = g->size[0], cols = g->size[1];
+  const size_t n = (size_t)rows * cols;
+  res->status = 2; res->path_len = 0; res->cost = OG_ASTAR_INF; res->settled = 0;
+  if (start_lin < 0 || goal_lin < 0 || (size_t)start_lin >= n || (size_t)goal_lin >= n) return;
+  float* um = (float*)malloc(n * sizeof(float));
+  uint8_t* blocked = (uint8_t*)malloc(n);
+  uint8_t* nbr = (uint8_t*)malloc(n);
+  for (int uj = 0; uj < cols; ++uj)
+    for (int ui = 0; ui < rows; ++ui) {
+      const int u[2] = {ui, uj};
+      int b[2];
+      og_buffer_index(u, g->size, g->start, b);
+      um[(size_t)uj * rows + ui] = master[(size_t)b[1] * rows + b[0]];
+    }
+  og_astar_blocked_mask(um, n, blocked);
+  og_astar_nbr_mask(blocked, rows, cols, nbr);
+  const int sb[2] = {start_lin % rows, start_lin / rows}, gb[2] = {goal_lin % rows, goal_lin / rows};
+  int su[2], gu[2];
+  og_unwrap_index(sb, g->size, g->start, su);
+  og_unwrap_index(gb, g->size, g->start, gu);
+  og_astar_query(nbr, rows, cols, su[0] + su[1] * rows, gu[0] + gu[1] * rows, g_work, path, path_cap, res);
+  if (res->status == 0) {
+    for (int k = 0; k < res->path_len && k < path_cap; ++k) {
+      const int u[2] = {path[k] % rows, path[k] / rows};
+      int b[2];
+      og_buffer_index(u, g->size, g->start, b);
+      path[k] = b[0] + b[1] * rows;
+    }
+  }
+  free(um); free(blocked); free(nbr);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* Waypoint-graph A* with Boost.Graph semantics                                               */
 /* ------------------------------------------------------------------------------------------ */

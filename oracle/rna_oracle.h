@@ -177,6 +177,11 @@ typedef struct {
 void og_astar_query(const uint8_t* nbr, int rows, int cols, int start_lin, int goal_lin,
                     int32_t* g_work, int32_t* path, int path_cap, og_astar_result* res);
 
+/* the same contract in map space for a moved (circular-buffer) map: start/goal/path are buffer linear
+ * indices, adjacency and tie-breaking use unwrapped indices; g_work is left in unwrapped order */
+void og_astar_query_on_map(const og_geom* g, const float* master, int start_lin, int goal_lin, int32_t* g_work,
+                           int32_t* path, int path_cap, og_astar_result* res);
+
 /* ---- 9-vertex waypoint-graph A* (mc/src/astar_planner.cpp:63-145) ---- */
 /* Generic small-graph version with BGL astar_search semantics (boost/graph/astar_search.hpp,
  * Boost 1.54 as shipped with ROS Indigo): undirected CSR graph, float edge weights.

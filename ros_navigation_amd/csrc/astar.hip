@@ -478,11 +478,12 @@ extern "C" int rna_astar_batch_device(rna_engine* e, const rna_astar_query* quer
                                       int max_path_len, rna_astar_result* results) {
   if (!e || n < 0 || max_path_len <= 0 || (n > 0 && (!queries || !paths || !results))) return RNA_EINVAL;
   if (n == 0) return RNA_OK;
-  if (e->geom.start[0] != 0 || e->geom.start[1] != 0)
-    return fail(e, RNA_ESTATE, "grid A* needs startIndex (0,0): buffer adjacency must be map adjacency");
   RNA_HIP(e, hipSetDevice(e->device));
   int rc = ensure_config(e);
   if (rc != RNA_OK) return rc;
+  // the tile kernels search in map space (unwrapped indices); the frontier kernel walks buffer indices
+  if (e->astar.mode == 0 && (e->geom.start[0] != 0 || e->geom.start[1] != 0))
+    return fail(e, RNA_ESTATE, "grid A* (frontier kernel) needs startIndex (0,0): buffer adjacency must be map adjacency");
   if ((rc = map_prepare_nbr(e)) != RNA_OK) return rc;
   const int chunk = e->astar.max_queries;
   for (int o = 0; o < n; o += chunk) {
@@ -497,11 +498,12 @@ extern "C" int rna_astar_batch(rna_engine* e, const rna_astar_query* queries_hos
                                int max_path_len, rna_astar_result* results_host) {
   if (!e || n < 0 || max_path_len <= 0 || (n > 0 && (!queries_host || !paths_host || !results_host))) return RNA_EINVAL;
   if (n == 0) return RNA_OK;
-  if (e->geom.start[0] != 0 || e->geom.start[1] != 0)
-    return fail(e, RNA_ESTATE, "grid A* needs startIndex (0,0): buffer adjacency must be map adjacency");
   RNA_HIP(e, hipSetDevice(e->device));
   int rc = ensure_config(e);
   if (rc != RNA_OK) return rc;
+  // the tile kernels search in map space (unwrapped indices); the frontier kernel walks buffer indices
+  if (e->astar.mode == 0 && (e->geom.start[0] != 0 || e->geom.start[1] != 0))
+    return fail(e, RNA_ESTATE, "grid A* (frontier kernel) needs startIndex (0,0): buffer adjacency must be map adjacency");
   if ((rc = map_prepare_nbr(e)) != RNA_OK) return rc;
   AstarDevice& a = e->astar;
   const int chunk = a.max_queries;

@@ -57,6 +57,19 @@ __device__ __forceinline__ unsigned ld_l2(const unsigned* p) {
 __device__ __forceinline__ unsigned tsa_rank(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
+// buffer linear index <-> map-space (unwrapped) linear index (gmc/src/GridMapMath.cpp:467-476, 70-81)
+__device__ __forceinline__ int tsa_unwrap_lin(int lin, int rows, int cols, int s0, int s1) {
+  int i = lin % rows - s0, j = lin / rows - s1;
+  if (i < 0) i += rows;
+  if (j < 0) j += cols;
+  return j * rows + i;
+}
+__device__ __forceinline__ int tsa_buffer_lin(int lin, int rows, int cols, int s0, int s1) {
+  int i = lin % rows + s0, j = lin / rows + s1;
+  if (i >= rows) i -= rows;
+  if (j >= cols) j -= cols;
+  return j * rows + i;
+}
 // word index of cell (i, j) in a tile-major field
 __device__ __forceinline__ size_t tm_index(int i, int j, int tiles_i) {
   return ((size_t)((j >> 5) * tiles_i + (i >> 5)) << 10) + ((j & 31) << 5) + (i & 31);
@@ -80,22 +93,26 @@ __host__ __device__ inline size_t tsa_align256(size_t x) { return (x + 255) & ~(
 
 __global__ void tsa_init_kernel(const uint8_t* __restrict__ nbr, int rows, int cols, int tiles_i, int tiles_j,
                                 unsigned* __restrict__ field, size_t field_stride, unsigned* __restrict__ pend,
-                                size_t pend_stride, int max_queries, TsaAux aux) {
+                                size_t pend_stride, int max_queries, TsaAux aux, int s0, int s1) {
   const int ntile = tiles_i * tiles_j;
   const int nt_words = (ntile + 31) >> 5;
   const size_t nw = (size_t)ntile * TILE_WORDS;
   const size_t step = (size_t)gridDim.x * blockDim.x;
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // (a) snapshot of the neighbour masks in tile-major order (4 cells per thread)
+  // (a) snapshot of the neighbour masks in tile-major MAP-space order (4 cells per thread)
   for (size_t w4 = gid; w4 < nw / 4; w4 += step) {
     const size_t w = w4 * 4;
     const int t = (int)(w >> 10), l = (int)(w & 1023);
     const int i = (t % tiles_i) * TS + (l & 31), j = (t / tiles_i) * TS + (l >> 5);
-    unsigned v = 0u;
+    unsigned v = 0u;   // (i, j) is a MAP-space (unwrapped) index; nbr is stored at buffer indices
     if (j < cols) {
+      const int bj = j + s1 >= cols ? j + s1 - cols : j + s1;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (i + k < rows) v |= (unsigned)nbr[(size_t)j * rows + i + k] << (8 * k);
+        if (i + k < rows) {
+          const int bi = i + k + s0 >= rows ? i + k + s0 - rows : i + k + s0;
+          v |= (unsigned)nbr[(size_t)bj * rows + bi] << (8 * k);
+        }
     }
     reinterpret_cast<unsigned*>(aux.nbr_tm)[w4] = v;
   }
@@ -385,7 +402,7 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
                   unsigned* __restrict__ field_all, size_t field_stride, unsigned* __restrict__ pend_all,
                   size_t pend_stride, const uint8_t* __restrict__ nbr_tm, unsigned* __restrict__ touched_all,
                   int bucket_width, int32_t* __restrict__ paths, int max_path_len,
-                  int32_t* __restrict__ rev_all, int rev_cap, rna_astar_result* __restrict__ results) {
+                  int32_t* __restrict__ rev_all, int rev_cap, rna_astar_result* __restrict__ results, int s0, int s1) {
   __shared__ TsaWave s_w[TSA_WAVES];
   extern __shared__ unsigned s_dyn[];   // tile bitsets, sized by the launch: 3 x ((ntile + 31) / 32) words
   __shared__ unsigned short s_jobs[TSA_JOBS];
@@ -393,7 +410,7 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
 
   const int q = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const rna_astar_query qu = queries[q];
+  rna_astar_query qu = queries[q];   // buffer linear indices; the search itself runs in map space
   const int ncell = rows * cols;
   const int ntile = tiles_i * tiles_j;
   const int nt_words = (ntile + 31) >> 5;
@@ -408,6 +425,8 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
     if (tid == 0) results[q] = rna_astar_result{2, 0, INF, 0, 0, 0};
     return;
   }
+  qu.start = tsa_unwrap_lin(qu.start, rows, cols, s0, s1);
+  qu.goal = tsa_unwrap_lin(qu.goal, rows, cols, s0, s1);
   const int si = qu.start % rows, sj = qu.start / rows;
   const int gi = qu.goal % rows, gj = qu.goal / rows;
 
@@ -564,14 +583,14 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
     return;
   }
   int32_t* path = paths + (size_t)q * max_path_len;
-  for (int i = tid; i < len; i += TSA_THREADS) path[i] = rev[len - 1 - i];
+  for (int i = tid; i < len; i += TSA_THREADS) path[i] = tsa_buffer_lin(rev[len - 1 - i], rows, cols, s0, s1);
   if (tid == 0) results[q] = rna_astar_result{0, len, s_best, s_expanded, s_rounds, n_buckets};
 }
 
 // |{n : g(n) + h(n) <= f*}| per query from the resident tile-major fields (measurement utility)
 __global__ void tsa_settled_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_query* __restrict__ queries,
                                    const rna_astar_result* __restrict__ results, const unsigned* __restrict__ field_all,
-                                   size_t field_stride, int32_t* __restrict__ counts) {
+                                   size_t field_stride, int32_t* __restrict__ counts, int s0, int s1) {
   __shared__ int s_cnt;
   const int q = blockIdx.x;
   if (threadIdx.x == 0) s_cnt = 0;
@@ -579,7 +598,7 @@ __global__ void tsa_settled_kernel(int rows, int cols, int tiles_i, int tiles_j,
   const rna_astar_result r = results[q];
   int cnt = 0;
   if (r.status == 0 || r.status == 3) {
-    const int goal = queries[q].goal;
+    const int goal = tsa_unwrap_lin(queries[q].goal, rows, cols, s0, s1);
     const int gi = goal % rows, gj = goal / rows;
     const unsigned* field = field_all + (size_t)q * field_stride;
     const size_t nw = (size_t)tiles_i * tiles_j * TILE_WORDS;
@@ -709,6 +728,7 @@ struct TsaGlobalSched {
 
 struct TsaPersistArgs {
   int rows, cols, tiles_i, tiles_j, n, bucket_width;
+  int s0, s1;                  // circular-buffer start index: queries/paths are buffer indices, the search is in map space
   const rna_astar_query* queries;
   unsigned* field; size_t field_stride;
   unsigned* pend; size_t pend_stride;
@@ -757,12 +777,14 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_persist_kernel(TsaPersistArgs
     if (qn >= 0) {
       if (lane == 0) {
         TsaQ* qs = &A.qstate[qn];
-        const rna_astar_query qu = A.queries[qn];
+        rna_astar_query qu = A.queries[qn];
         const int ncell = A.rows * A.cols;
         unsigned* field = A.field + (size_t)qn * A.field_stride;
         int status = -1;
         if (!(qu.start >= 0 && qu.goal >= 0 && qu.start < ncell && qu.goal < ncell)) status = 2;
         else {
+          qu.start = tsa_unwrap_lin(qu.start, A.rows, A.cols, A.s0, A.s1);
+          qu.goal = tsa_unwrap_lin(qu.goal, A.rows, A.cols, A.s0, A.s1);
           const int si = qu.start % A.rows, sj = qu.start / A.rows, gi = qu.goal % A.rows, gj = qu.goal / A.rows;
           const int b0 = tsa_octile(si, sj, gi, gj) / A.bucket_width;
           qs->best = INF; qs->bucket = b0; qs->bucket0 = b0; qs->role = 0; qs->outstanding = 1; qs->xcc = xcc;
@@ -915,7 +937,7 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_persist_kernel(TsaPersistArgs
 }
 
 // canonical backtrace + result records for the persistent scheduler: one wavefront per query
-__global__ void tsa_backtrace_kernel(int rows, int cols, int tiles_i, const unsigned* __restrict__ field_all, size_t field_stride,
+__global__ void tsa_backtrace_kernel(int rows, int cols, int s0, int s1, int tiles_i, const unsigned* __restrict__ field_all, size_t field_stride,
                                      const uint8_t* __restrict__ nbr_tm, int* __restrict__ clean,
                                      const TsaQ* __restrict__ qstate, const TsaCtl* __restrict__ ctl, int32_t* __restrict__ paths,
                                      int max_path_len, int32_t* __restrict__ rev_all, int rev_cap,
@@ -966,7 +988,7 @@ __global__ void tsa_backtrace_kernel(int rows, int cols, int tiles_i, const unsi
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int32_t* path = paths + (size_t)q * max_path_len;
-  for (int i = tid; i < len; i += 64) path[i] = rev[len - 1 - i];
+  for (int i = tid; i < len; i += 64) path[i] = tsa_buffer_lin(rev[len - 1 - i], rows, cols, s0, s1);
   if (tid == 0) results[q] = rna_astar_result{0, len, qs.best, qs.expanded, qs.jobs, n_buckets};
 }
 
@@ -1006,7 +1028,7 @@ static void tsa_launch_init(rna_engine* e, hipStream_t stream, unsigned* field, 
   const int rows = e->geom.size[0], cols = e->geom.size[1];
   const int ti = (rows + TS - 1) / TS, tj = (cols + TS - 1) / TS;
   hipLaunchKernelGGL(tsa_init_kernel, dim3(4096), dim3(256), 0, stream, e->nbr, rows, cols, ti, tj, field, field_stride, pend,
-                     pend_stride, max_queries, aux);
+                     pend_stride, max_queries, aux, e->geom.start[0], e->geom.start[1]);
   hipLaunchKernelGGL(tsa_mark_clean_kernel, dim3(1), dim3(1), 0, stream, aux.clean);
 }
 
@@ -1029,7 +1051,7 @@ int tsa_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream
     KernelTimer kt(e, RNA_K_ASTAR_SEARCH, search_stream);
     hipLaunchKernelGGL(tsa_search_kernel, dim3(n), dim3(TSA_THREADS), (size_t)3 * ((ti * tj + 31) / 32) * sizeof(unsigned),
                        search_stream, rows, cols, ti, tj, q_dev, field, field_stride, pend, pend_stride, aux.nbr_tm, aux.touched,
-                       e->astar.bucket_width, paths_dev, max_len, rev, rev_cap, res_dev);
+                       e->astar.bucket_width, paths_dev, max_len, rev, rev_cap, res_dev, e->geom.start[0], e->geom.start[1]);
     RNA_HIP(e, hipGetLastError());
   }
   return RNA_OK;
@@ -1040,7 +1062,7 @@ int tsa_settled(rna_engine* e, const unsigned* field, size_t field_stride, const
   const int rows = e->geom.size[0], cols = e->geom.size[1];
   const int ti = (rows + TS - 1) / TS, tj = (cols + TS - 1) / TS;
   hipLaunchKernelGGL(tsa_settled_kernel, dim3(n), dim3(1024), 0, e->stream, rows, cols, ti, tj, q, r, field, field_stride,
-                     d_counts);
+                     d_counts, e->geom.start[0], e->geom.start[1]);
   RNA_HIP(e, hipGetLastError());
   return RNA_OK;
 }
@@ -1066,6 +1088,7 @@ int tsa_persist_launch(rna_engine* e, hipStream_t init_stream, hipStream_t searc
   if (n > 32767 || (size_t)ti * tj > 65536) return fail(e, RNA_EINVAL, "persistent A*: too many queries or tiles");
   TsaPersistArgs A{};
   A.rows = rows; A.cols = cols; A.tiles_i = ti; A.tiles_j = tj; A.n = n; A.bucket_width = e->astar.bucket_width;
+  A.s0 = e->geom.start[0]; A.s1 = e->geom.start[1];
   A.queries = q_dev; A.field = field; A.field_stride = field_stride; A.pend = pend; A.pend_stride = pend_stride;
   size_t ts_stride = 0, far_stride = 0;
   (void)tsa_persist_state_bytes(e, max_queries, &ts_stride, &far_stride);
@@ -1094,7 +1117,7 @@ int tsa_persist_launch(rna_engine* e, hipStream_t init_stream, hipStream_t searc
     if (cus <= 0) cus = 256;
     if (const char* m = getenv("RNA_TSA_BLOCKS_PER_CU")) cus *= std::max(1, atoi(m));
     hipLaunchKernelGGL(tsa_persist_kernel, dim3(cus), dim3(TSA_THREADS), 0, search_stream, A);
-    hipLaunchKernelGGL(tsa_backtrace_kernel, dim3(n), dim3(64), 0, search_stream, rows, cols, ti, field, field_stride,
+    hipLaunchKernelGGL(tsa_backtrace_kernel, dim3(n), dim3(64), 0, search_stream, rows, cols, A.s0, A.s1, ti, field, field_stride,
                        aux.nbr_tm, aux.clean, A.qstate, A.ctl, paths_dev, max_len, rev, rev_cap, res_dev);
     RNA_HIP(e, hipGetLastError());
   }

@@ -46,9 +46,13 @@ __device__ __forceinline__ bool cell_blocked(float v) { return !(v != v) && v > 
 // (di,dj) in the order (-1,-1),(0,-1),(1,-1),(-1,0),(1,0),(-1,1),(0,1),(1,1); a diagonal needs the
 // target and both orthogonal cells free.  One block per 64x64 tile with a 1-cell halo in LDS.
 // `all` != 0 recomputes every tile, otherwise only tiles that are dirty or touch a dirty tile.
+// Tiles and adjacency are taken in MAP space (unwrapped indices): on a moved map the neighbours of a
+// cell wrap around the circular buffer but not around the map edge; (s0, s1) is the buffer start
+// index and the mask is stored at the cell's buffer index.  The dirty-tile shortcut is in buffer
+// space, so the host passes all != 0 whenever the start index is non-zero.
 __global__ void nbr_mask_tiles_kernel(uint8_t* __restrict__ nbr, const float* __restrict__ master,
                                       const unsigned* __restrict__ dirty, int all, int rows, int cols,
-                                      int tiles_i, int tiles_j) {
+                                      int tiles_i, int tiles_j, int s0, int s1) {
   const int ti = blockIdx.x, tj = blockIdx.y;
   if (!all) {
     bool need = false;
@@ -67,7 +71,12 @@ __global__ void nbr_mask_tiles_kernel(uint8_t* __restrict__ nbr, const float* __
     const int ii = k % (TILE + 2), jj = k / (TILE + 2);
     const int i = i0 + ii, j = j0 + jj;
     uint8_t b = 1;
-    if (i >= 0 && j >= 0 && i < rows && j < cols) b = cell_blocked(master[(size_t)j * rows + i]) ? 1 : 0;
+    if (i >= 0 && j >= 0 && i < rows && j < cols) {
+      int bi = i + s0, bj = j + s1;
+      if (bi >= rows) bi -= rows;
+      if (bj >= cols) bj -= cols;
+      b = cell_blocked(master[(size_t)bj * rows + bi]) ? 1 : 0;
+    }
     blk[k] = b;
   }
   __syncthreads();
@@ -89,7 +98,10 @@ __global__ void nbr_mask_tiles_kernel(uint8_t* __restrict__ nbr, const float* __
       if (rt) m |= 64u;                           // ( 0, 1)
       if (rt && dn && !c[S + 1]) m |= 128u;       // ( 1, 1)
     }
-    nbr[(size_t)j * rows + i] = (uint8_t)m;
+    int bi = i + s0, bj = j + s1;
+    if (bi >= rows) bi -= rows;
+    if (bj >= cols) bj -= cols;
+    nbr[(size_t)bj * rows + bi] = (uint8_t)m;
   }
 }
 
@@ -291,7 +303,7 @@ int map_prepare_nbr(rna_engine* e) {
   KernelTimer kt(e, RNA_K_NBRMASK);
   hipLaunchKernelGGL(nbr_mask_tiles_kernel, dim3(e->tiles_i, e->tiles_j), dim3(256), 0, e->stream, e->nbr,
                      e->layer[RNA_LAYER_MASTER], e->dirty_tiles, 1, e->geom.size[0], e->geom.size[1], e->tiles_i,
-                     e->tiles_j);
+                     e->tiles_j, e->geom.start[0], e->geom.start[1]);
   RNA_HIP(e, hipGetLastError());
   e->nbr_all_dirty = false;
   return RNA_OK;
@@ -319,12 +331,14 @@ extern "C" int rna_compose_master(rna_engine* e, int mode) {
   if (e->laser_all_dirty) {
     // the laser layer was replaced wholesale: nothing is known about which masks are still valid
     e->nbr_all_dirty = true;
+  } else if (e->geom.start[0] != 0 || e->geom.start[1] != 0) {
+    e->nbr_all_dirty = true;   // moved map: dirty tiles (buffer space) do not line up with mask tiles (map space)
   } else if (!e->nbr_all_dirty) {
     // masks were valid before this update: refresh only tiles that are dirty or touch a dirty tile
     KernelTimer kt(e, RNA_K_NBRMASK);
     hipLaunchKernelGGL(nbr_mask_tiles_kernel, dim3(e->tiles_i, e->tiles_j), dim3(256), 0, e->stream, e->nbr,
                        e->layer[RNA_LAYER_MASTER], e->dirty_tiles, 0, e->geom.size[0], e->geom.size[1], e->tiles_i,
-                       e->tiles_j);
+                       e->tiles_j, 0, 0);
     RNA_HIP(e, hipGetLastError());
   }
   RNA_HIP(e, hipMemsetAsync(e->dirty_tiles, 0, words * sizeof(unsigned), e->stream));

@@ -135,6 +135,9 @@ def lib():
         L.og_astar_query.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.POINTER(AstarResult)]
         L.og_astar_query.restype = None
+        L.og_astar_query_on_map.argtypes = [C.POINTER(Geom), fp, C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_int32), C.c_int, C.POINTER(AstarResult)]
+        L.og_astar_query_on_map.restype = None
         L.og_graph_astar.argtypes = [C.c_int, d2, C.c_int, i2, fp, C.c_int, C.c_int, i2, C.c_int]
         L.og_graph_closest_vertex.argtypes = [C.c_int, d2, d2]
         L.og_reference_graph.argtypes = [d2, i2]
@@ -328,6 +331,19 @@ def astar_query(nbr, rows, cols, start, goal, path_cap=None, g_work=None):
                          path_cap, C.byref(res))
     n = res.path_len if res.status == 0 else 0
     return res, path[:n].copy(), g_work
+
+
+def astar_query_on_map(g, master, start, goal, path_cap=None):
+    """grid A* in map space on a (possibly moved) map; start/goal/path are buffer linear indices"""
+    n = g.size[0] * g.size[1]
+    path_cap = path_cap or n
+    g_work = np.empty(n, np.int32)
+    path = np.empty(path_cap, np.int32)
+    res = AstarResult()
+    lib().og_astar_query_on_map(C.byref(g), fptr(master), int(start), int(goal), g_work.ctypes.data_as(C.POINTER(C.c_int32)),
+                                path.ctypes.data_as(C.POINTER(C.c_int32)), path_cap, C.byref(res))
+    k = res.path_len if res.status == 0 else 0
+    return res, path[:k].copy()
 
 
 def rrt_plan(g, master, start, target, tol=0.2, seed=1, max_samples=200000, cap=2048):

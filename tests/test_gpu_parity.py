@@ -363,9 +363,51 @@ def test_himm_and_vfh_on_a_moved_map(R):
     poses["y"] -= 0.82
     e.vfh_init(len(poses))
     check_vfh_vs_oracle(R, e, g, ref, poses, steps=3)
-    q = np.zeros(1, R.capi.ASTAR_QUERY_DTYPE)
-    with pytest.raises(R.RnaError):       # grid A* refuses a moved map instead of planning across the seam
-        e.astar(q, 64)
+    e.close()
+
+
+def test_astar_on_a_moved_map_searches_in_map_space(R):
+    """SURVEY.md 8f row 1: after GridMap::move buffer neighbours are not map neighbours.  The tile
+    kernels search over unwrapped indices (paths cross the circular-buffer seam, never the map edge)
+    and speak buffer indices at the boundary; oracle = og_astar_query_on_map."""
+    e = R.Engine(12.8, 9.6, 0.05)
+    g = O.make_geom(12.8, 9.6, 0.05)
+    rows, cols = e.rows, e.cols
+    master = R.synth.obstacles_rect(rows, cols, density=0.25, seed=8)
+    for l in range(3):
+        e.upload(l, master)
+    ref = master.copy()
+    ptrs = (C.POINTER(C.c_float) * 1)(O.fptr(ref))
+    regs = (O.Region * 4)()
+    mv = C.c_int(0)
+    for step, target in enumerate(((3.21, -1.47), (2.0, 2.6))):
+        O.lib().og_move(C.byref(g), ptrs, 1, O.d2(*target), regs, C.byref(mv))
+        assert e.move(*target) and tuple(e.geometry().start_index) == tuple(g.start) != (0, 0)
+        # the dropped rows/columns came back as NaN (unknown = free): fill part of them with an obstacle
+        rays = random_rays(np.random.default_rng(step), 400, 3.0, outside=0.0)
+        rays["sx"] += target[0]; rays["ex"] += target[0]; rays["sy"] += target[1]; rays["ey"] += target[1]
+        O.himm_update(g, ref, rays)
+        e.update_map(rays.view(R.capi.RAY_DTYPE), compose_mode=1)
+        assert same_f32(e.download(R.capi.LAYER_MASTER), ref)
+        rng = np.random.default_rng(100 + step)
+        free = np.flatnonzero(~(np.isfinite(ref) & (ref > 0)))
+        q = np.zeros(48, R.capi.ASTAR_QUERY_DTYPE)
+        q["start"] = rng.choice(free, len(q))
+        q["goal"] = rng.choice(free, len(q))
+        q["goal"][0] = q["start"][0]
+        res, paths = e.astar(q, 4096)
+        settled = e.astar_settled(len(q))
+        crossed = 0
+        for k in range(len(q)):
+            ores, opath = O.astar_query_on_map(g, ref, q["start"][k], q["goal"][k])
+            assert res["status"][k] == (0 if ores.status == 0 else 1), k
+            if ores.status == 0:
+                assert res["path_len"][k] == ores.path_len and res["cost"][k] == ores.cost, k
+                assert np.array_equal(paths[k][:ores.path_len], opath), k
+                assert settled[k] == ores.settled, k
+                bi, bj = opath % rows, opath // rows
+                crossed += int((np.abs(np.diff(bi)) > 1).any() or (np.abs(np.diff(bj)) > 1).any())
+        assert crossed > 0      # some paths do run across the circular-buffer seam
     e.close()
 
 
