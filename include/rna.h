@@ -146,7 +146,9 @@ int rna_vfh_update_batch(rna_engine* e, const double* ranges_host /* n*361*2 */,
 /* ---- global planning: grid A* ------------------------------------------------------------------ */
 /* The reference's AStarPlanner::makePlan (mc/src/astar_planner.cpp:63-96) searches a 9-vertex
  * waypoint graph; BASELINE.json asks for a grid A* over the GridMap, whose contract is defined in
- * DESIGN.md ("Grid A* contract") and restated by oracle/astar.c. Cells are linear indices. */
+ * DESIGN.md ("Grid A* contract") and restated by oracle/astar.c.  Cells are buffer linear indices
+ * (i + j*rows, what GridMap::getIndex hands out); on a map that GridMap::move has recentred the
+ * search runs in map space (unwrapped indices) and paths cross the circular-buffer seam. */
 typedef struct { int32_t start, goal; } rna_astar_query;
 typedef struct {
   int32_t status;      /* 0 found, 1 no path, 2 invalid query, 3 path longer than max_path_len,
@@ -154,12 +156,13 @@ typedef struct {
   int32_t path_len;    /* cells, start..goal inclusive */
   int32_t cost;        /* 1000/1414 integer cost of the path */
   int32_t expanded;    /* cell expansions the device performed (>= the oracle's settled count) */
-  int32_t rounds;      /* frontier rounds (workgroup barriers pairs) the search took */
+  int32_t rounds;      /* rounds of tile jobs (tile kernel), tile jobs (persistent scheduler) or frontier rounds */
   int32_t buckets;     /* f-buckets visited */
 } rna_astar_result;
-/* max_queries: queries searched concurrently (one workgroup + one g-field each; larger batches are
- * processed in chunks); queue_capacity: entries of each per-query frontier queue; bucket_width: the
- * f-range (cost units, >= 2828) relaxed together before the search advances; 0 = keep/default. */
+/* max_queries: queries searched concurrently (one g-field each; larger batches are processed in
+ * chunks); queue_capacity: entries of each per-query queue of the fallback frontier kernel;
+ * bucket_width: the f-range (cost units, >= 2828) relaxed together before the search advances
+ * (default 16000); 0 = keep/default. */
 int rna_astar_configure(rna_engine* e, int max_queries, int queue_capacity, int bucket_width);
 /* Pipelined batches: with depth d > 1 consecutive rna_astar_batch_device calls run their searches on d
  * rotating internal streams (each with its own search fields), so the tail of one batch overlaps
