@@ -232,7 +232,7 @@ def main():
                          "achieved_per_step_wall": alg_bytes / (t_max / args.steps) / 1e9},
             "kernel_ms_per_step": {k: (v[0] / args.steps) for k, v in prof.items() if v[1]},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:   # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, R, master, rays, poses, queries, n, n, length)
         else:
             out["cpu_baseline"] = None

@@ -88,8 +88,7 @@ alg = float(settled.astype(np.int64).sum()) * 44
 out["config3_astar"] = dict(workload="4096x4096, 256 queries, one launch (pipeline depth 1)", queries_per_s=256 / wall,
                             search_ms=prof["astar_search"], init_ms=prof["astar_init"], settled_cells=int(settled.sum()),
                             algorithmic_bytes=alg, achieved_gbs=alg / (prof["astar_search"] * 1e-3) / 1e9,
-                            frac=alg / (prof["astar_search"] * 1e-3) / 1e9 / PEAK,
-                            init_gbs=256 * 4.0 * n * n / (prof["astar_init"] * 1e-3) / 1e9)
+                            frac=alg / (prof["astar_search"] * 1e-3) / 1e9 / PEAK)
 e.close()
 
 # ---- config 4: RRT, 512 queries (one GPU's share of 4096) on 2048^2 ---------------------------------
