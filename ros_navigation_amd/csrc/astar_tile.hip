@@ -291,26 +291,50 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
       else if (g >= (int)G_INF - 3 * COST_D) { ovf = true; ok = false; }   // 24-bit g exhausted
     }
     const unsigned m = ok ? mk : 0u;
+    // candidate words of a straight / diagonal step: new g in the high bits; "| 0xff" for the test
+    // g + w < g(neighbour) on whole words; flag byte of the stored word = in-queue (interior) or
+    // halo-dirty.  Old flags need not be kept: a re-queued cell is re-tested when it is popped.
+    // All predicates are kept as 64-bit wave masks in SGPRs (ballot / inverse ballot), so the
+    // boolean algebra runs on the scalar unit and the vector unit only compares, selects and stores.
     const unsigned gs = ((unsigned)(g + COST_S) << 8), gd = ((unsigned)(g + COST_D) << 8);
-    const bool il_lo = pil == 0, il_hi = pil == TS - 1, jl_lo = pjl == 0, jl_hi = pjl == TS - 1;
+    unsigned c_st = gs | 0xffu, c_dt = gd | 0xffu, c_si = gs | 1u, c_sh = gs | 2u, c_di = gd | 1u, c_dh = gd | 2u;
+    int pb = p - TW - 1;   // lowest neighbour: all eight offsets are non-negative immediates
+    // keep these in registers: recomputing them from g in every direction costs more than it saves
+    asm volatile("" : "+v"(pb), "+v"(c_st), "+v"(c_dt), "+v"(c_si), "+v"(c_sh), "+v"(c_di), "+v"(c_dh));
+    unsigned* const nb = &W.tile[pb];
+    const unsigned long long il_lo = __builtin_amdgcn_ballot_w64(pil == 0), il_hi = __builtin_amdgcn_ballot_w64(pil == TS - 1);
+    const unsigned long long jl_lo = __builtin_amdgcn_ballot_w64(pjl == 0), jl_hi = __builtin_amdgcn_ballot_w64(pjl == TS - 1);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int di = (k == 0 || k == 3 || k == 5) ? -1 : ((k == 2 || k == 4 || k == 7) ? 1 : 0);
       const int dj = k < 3 ? -1 : (k > 4 ? 1 : 0);
-      const int np_ = p + di + dj * TW;
-      const unsigned ng8 = (k == 1 || k == 3 || k == 4 || k == 6) ? gs : gd;
-      const unsigned nwv = W.tile[np_];
-      const bool improve = ((m >> k) & 1u) && (ng8 | 0xffu) < nwv;     // <=> g + w < g(neighbour)
-      const bool halo = (di < 0 && il_lo) || (di > 0 && il_hi) || (dj < 0 && jl_lo) || (dj > 0 && jl_hi);
-      if (improve) W.tile[np_] = ng8 | (nwv & 7u) | (halo ? 2u : 1u);
-      const bool doit = improve && !halo && !(nwv & 1u);
-      const unsigned long long bm = __ballot(doit);
-      if (doit) W.lq[(tail + (int)tsa_rank(bm)) & (LQ - 1)] = (unsigned short)np_;
-      tail += __popcll(bm);
+      const int off = (di + 1) + (dj + 1) * TW;
+      const bool straight = (k == 1 || k == 3 || k == 4 || k == 6);
+      const unsigned nwv = nb[off];
+      const unsigned long long valid = __builtin_amdgcn_ballot_w64((m & (1u << k)) != 0u);
+      const unsigned long long lt = __builtin_amdgcn_ballot_w64((straight ? c_st : c_dt) < nwv);   // g + w < g(neighbour)
+      const unsigned long long inq = __builtin_amdgcn_ballot_w64((nwv & 1u) != 0u);
+      const unsigned long long halo = (di < 0 ? il_lo : (di > 0 ? il_hi : 0ull)) | (dj < 0 ? jl_lo : (dj > 0 ? jl_hi : 0ull));
+      const unsigned long long improve = valid & lt;
+      const unsigned word = __builtin_amdgcn_inverse_ballot_w64(halo) ? (straight ? c_sh : c_dh) : (straight ? c_si : c_di);
+      if (__builtin_amdgcn_inverse_ballot_w64(improve)) nb[off] = word;
+      const unsigned long long push = improve & ~halo & ~inq;
+      if (__builtin_amdgcn_inverse_ballot_w64(push))
+        W.lq[(tail + (int)tsa_rank(push)) & (LQ - 1)] = (unsigned short)(pb + off);
+      tail += __popcll(push);
     }
     __builtin_amdgcn_wave_barrier();
   }
   if (ovf) sch.overflow();
+#ifdef RNA_TSA_STATS
+  {  // histogram of job sizes (expansions per job): slots 10..15 = 0, 1-15, 16-63, 64-255, 256-1023, 1024+
+    int ex = expanded;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ex += __shfl_xor(ex, o);
+    const int b = ex == 0 ? 0 : (ex < 16 ? 1 : (ex < 64 ? 2 : (ex < 256 ? 3 : (ex < 1024 ? 4 : 5))));
+    tsa_acc[10 + b] += 1;
+  }
+#endif
 
   TSA_T(t_c);
   TSA_ACC(1, t_b, t_c);
@@ -390,7 +414,7 @@ struct TsaLocalSched {
   int* state_;
   unsigned* act_cur_;
   unsigned* act_far_;
-  __device__ __forceinline__ int best() const { return *reinterpret_cast<volatile int*>(best_); }
+  __device__ __forceinline__ int best() const { return __hip_atomic_load(best_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   __device__ __forceinline__ void improve_best(int g) { atomicMin(best_, g); }
   __device__ __forceinline__ void overflow() { *state_ = 4; }
   __device__ __forceinline__ void act_cur(int t) { atomicOr(&act_cur_[t >> 5], 1u << (t & 31)); }
@@ -932,7 +956,7 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_persist_kernel(TsaPersistArgs
     TSA_ACC(6, t_w2, t_w3);
   }
 #ifdef RNA_TSA_STATS
-  if (lane == 0) for (int k = 0; k < 10; ++k) atomicAdd(&g_tsa_stat[k], tsa_acc[k]);
+  if (lane == 0) for (int k = 0; k < 16; ++k) atomicAdd(&g_tsa_stat[k], tsa_acc[k]);
 #endif
 }
 
@@ -1139,6 +1163,8 @@ int tsa_persist_launch(rna_engine* e, hipStream_t init_stream, hipStream_t searc
     fprintf(stderr, "[tsa stats] jobs %.0f | per job us: load %.2f relax %.2f wb %.2f handover %.2f finish %.2f advance %.2f | wait total %.1f ms-waves | relax iters/job %.1f cells/iter %.1f\n",
             jobs, st[0] * 0.01 / jobs, st[1] * 0.01 / jobs, st[2] * 0.01 / jobs, st[3] * 0.01 / jobs, (st[5] - st[0] - st[1] - st[2] - st[3]) * 0.01 / jobs,
             st[6] * 0.01 / jobs, st[4] * 1e-5, st[8] / jobs, st[9] / (double)std::max<unsigned long long>(1, st[8]));
+    fprintf(stderr, "[tsa stats] jobs by expansions: 0: %.1f%%  1-15: %.1f%%  16-63: %.1f%%  64-255: %.1f%%  256-1023: %.1f%%  1024+: %.1f%%\n",
+            100.0 * st[10] / jobs, 100.0 * st[11] / jobs, 100.0 * st[12] / jobs, 100.0 * st[13] / jobs, 100.0 * st[14] / jobs, 100.0 * st[15] / jobs);
     if (!fin.empty())
       fprintf(stderr, "[tsa stats] query finish ms: p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f | busy wave-ms %.1f\n", fin[fin.size() / 10],
               fin[fin.size() / 2], fin[fin.size() * 9 / 10], fin[fin.size() * 99 / 100], fin.back(), (st[5] + st[6]) * 1e-5);
