@@ -311,7 +311,7 @@ int ensure_config(rna_engine* e) {
   if (a.g[0]) return RNA_OK;
   if (a.max_queries <= 0) a.max_queries = 256;
   if (const char* t = getenv("RNA_ASTAR_THREADS")) a.threads = atoi(t);  // tuning knob: 256 / 512 / 1024
-  if (const char* k = getenv("RNA_ASTAR_KERNEL")) a.mode = (k[0] == 'p') ? 2 : ((k[0] == 'f') ? 0 : 1);  // persist | frontier | tile (default)
+  if (const char* k = getenv("RNA_ASTAR_KERNEL")) a.mode = (k[0] == 'p') ? 2 : ((k[0] == 'f') ? 0 : ((k[0] == 'a') ? 3 : 1));  // persist | frontier | async | tile (default)
   if (a.mode != 0 && !tsa_supported(e)) a.mode = 0;
   if (a.depth < 1) a.depth = 1;
   if (a.depth > AstarDevice::MAX_DEPTH) a.depth = AstarDevice::MAX_DEPTH;
@@ -385,7 +385,7 @@ int launch_chunk(rna_engine* e, const rna_astar_query* q_dev, int n, int32_t* pa
                                 a.pend[slot], a.pend_stride, a.tsa_aux[slot], a.pstate[slot], a.max_queries, a.rev[slot], a.rev_cap, q_dev, n,
                                 paths_dev, max_len, res_dev);
     if (rc != RNA_OK) return rc;
-  } else if (a.mode == 1) {
+  } else if (a.mode == 1 || a.mode == 3) {
     int rc = tsa_launch(e, e->stream, search_stream, a.depth > 1 ? a.ev_init : nullptr, field, a.field_stride, a.pend[slot],
                         a.pend_stride, a.tsa_aux[slot], a.max_queries, a.rev[slot], a.rev_cap, q_dev, n, paths_dev, max_len, res_dev);
     if (rc != RNA_OK) return rc;
@@ -428,9 +428,15 @@ int launch_chunk(rna_engine* e, const rna_astar_query* q_dev, int n, int32_t* pa
 }  // namespace
 
 namespace rna {
+#ifdef RNA_TSA_STATS
+void tsa_stats_dump();
+#endif
 int astar_release(rna_engine* e) {
   AstarDevice& a = e->astar;
   (void)sync_all(e);
+#ifdef RNA_TSA_STATS
+  if (a.mode == 1) tsa_stats_dump();
+#endif
   for (int d = 0; d < AstarDevice::MAX_DEPTH; ++d) {
     dev_free(&a.g[d]); dev_free(&a.queues[d]); dev_free(&a.pend[d]); dev_free(&a.rev[d]);
     if (a.pstate[d]) { (void)hipFree(a.pstate[d]); a.pstate[d] = nullptr; }

@@ -421,6 +421,31 @@ struct TsaLocalSched {
   __device__ __forceinline__ void act_far(int t) { atomicOr(&act_far_[t >> 5], 1u << (t & 31)); }
 };
 
+// Barrier-free variant of the same kernel: the active-tile set is a bitset in LDS that every
+// wavefront scans and claims from on its own; `outstanding` = active bits + running jobs, and the
+// wave that brings it to zero owns the query alone and opens the next bucket (or ends the search).
+struct TsaAsyncSched {
+  int* best_;
+  int* state_;
+  unsigned* act_;
+  unsigned* far_;
+  int* outstanding_;
+  __device__ __forceinline__ int best() const { return __hip_atomic_load(best_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  __device__ __forceinline__ void improve_best(int g) { atomicMin(best_, g); }
+  __device__ __forceinline__ void overflow() { *state_ = 4; }
+  __device__ __forceinline__ void act_cur(int t) {
+    const unsigned bit = 1u << (t & 31);
+    if (__hip_atomic_load(&act_[t >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & bit) return;   // already active
+    // count the tile BEFORE it can be claimed: a claimer that finishes first must not see the sum at 0
+    atomicAdd(outstanding_, 1);
+    if (atomicOr(&act_[t >> 5], bit) & bit) atomicSub(outstanding_, 1);   // lost the race to another activator
+  }
+  __device__ __forceinline__ void act_far(int t) { atomicOr(&far_[t >> 5], 1u << (t & 31)); }
+};
+__device__ __forceinline__ unsigned lds_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int lds_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+template <bool ASYNC>
 __global__ void __launch_bounds__(TSA_THREADS)
 tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_query* __restrict__ queries,
                   unsigned* __restrict__ field_all, size_t field_stride, unsigned* __restrict__ pend_all,
@@ -428,9 +453,10 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
                   int bucket_width, int32_t* __restrict__ paths, int max_path_len,
                   int32_t* __restrict__ rev_all, int rev_cap, rna_astar_result* __restrict__ results, int s0, int s1) {
   __shared__ TsaWave s_w[TSA_WAVES];
-  extern __shared__ unsigned s_dyn[];   // tile bitsets, sized by the launch: 3 x ((ntile + 31) / 32) words
-  __shared__ unsigned short s_jobs[TSA_JOBS];
+  extern __shared__ unsigned s_dyn[];   // tile bitsets, sized by the launch: (ASYNC ? 4 : 3) x ((ntile + 31) / 32) words
+  __shared__ unsigned short s_jobs[ASYNC ? 2 : TSA_JOBS];
   __shared__ int s_njobs, s_first_fail, s_job_next, s_best, s_state, s_bucket, s_bucket0, s_rounds, s_role, s_expanded, s_len;
+  __shared__ int s_outstanding;
 
   const int q = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -440,6 +466,7 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
   const int nt_words = (ntile + 31) >> 5;
   unsigned* const s_act[2] = {s_dyn, s_dyn + nt_words};   // [0] current bucket (next round), [1] next bucket
   unsigned* const s_touched = s_dyn + 2 * nt_words;        // every tile that ever became a job
+  unsigned* const s_running = s_dyn + 3 * nt_words;        // ASYNC only: a wavefront is inside a job of this tile
   unsigned* field = field_all + (size_t)q * field_stride;
   unsigned* pend0 = pend_all + (size_t)q * pend_stride;   // two bitmaps of ntile*32 words each
   const size_t pend_words = (size_t)ntile * TS;
@@ -454,7 +481,10 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
   const int si = qu.start % rows, sj = qu.start / rows;
   const int gi = qu.goal % rows, gj = qu.goal / rows;
 
-  for (int w = tid; w < nt_words; w += TSA_THREADS) { s_act[0][w] = 0u; s_act[1][w] = 0u; s_touched[w] = 0u; }
+  for (int w = tid; w < nt_words; w += TSA_THREADS) {
+    s_act[0][w] = 0u; s_act[1][w] = 0u; s_touched[w] = 0u;
+    if (ASYNC) s_running[w] = 0u;
+  }
   // a goal without a single traversable neighbour cannot be reached (blocked or walled in); nothing
   // has been written yet, so the field stays clean
   if (qu.goal != qu.start && nbr_tm[tm_index(gi, gj, tiles_i)] == 0) {
@@ -462,7 +492,7 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
     return;
   }
   if (tid == 0) {
-    s_best = INF; s_state = 0; s_rounds = 0; s_role = 0; s_expanded = 0;
+    s_best = INF; s_state = 0; s_rounds = 0; s_role = 0; s_expanded = 0; s_outstanding = 1;
     s_bucket = tsa_octile(si, sj, gi, gj) / bucket_width;
     s_bucket0 = s_bucket;
     const size_t ws = tm_index(si, sj, tiles_i);
@@ -481,7 +511,79 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
   int my_expanded = 0;
 #ifdef RNA_TSA_STATS
   unsigned long long tsa_acc[16] = {};
+  const unsigned long long t_life0 = wall_clock64();
 #endif
+  if constexpr (ASYNC) {
+    TsaAsyncSched sch{&s_best, &s_state, s_act[0], s_act[1], &s_outstanding};
+    int cursor = (int)(((long long)wv * nt_words) / TSA_WAVES);   // the waves start their sweeps at different words
+    for (;;) {
+      if (lds_ld(&s_state) != 0) break;
+      // ---- find and claim an active tile: sweep the bitset from `cursor`, 64 words per step ----
+      int t = -1;
+      for (int base = 0; base < nt_words && t < 0; base += 64) {
+        int w = cursor + base + lane;
+        if (w >= nt_words) w -= nt_words;
+        const unsigned bits = (base + lane < nt_words) ? lds_ld(&s_act[0][w]) : 0u;
+        unsigned long long m = __ballot(bits != 0u);
+        while (m && t < 0) {
+          const int src = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          const unsigned cb = __shfl(bits, src);
+          const int cw = __shfl(w, src);
+          int got = -1;
+          if (lane == 0) {
+            unsigned rem = cb;
+            while (rem) {
+              const int b = __ffs(rem) - 1;
+              rem &= rem - 1;
+              const unsigned bit = 1u << b;
+              if (atomicOr(&s_running[cw], bit) & bit) continue;        // a job of this tile is in flight: it stays active
+              if (atomicAnd(&s_act[0][cw], ~bit) & bit) { got = (cw << 5) + b; break; }   // claimed: active -> running
+              atomicAnd(&s_running[cw], ~bit);                           // somebody else took it meanwhile
+            }
+          }
+          got = __shfl(got, 0);
+          if (got >= 0) t = got;
+        }
+      }
+      if (t < 0) { __builtin_amdgcn_s_sleep(8); continue; }
+      cursor = (t >> 5) + 1;
+      if (cursor >= nt_words) cursor = 0;
+      const int role = lds_ld(&s_role), bucket = lds_ld(&s_bucket);
+      unsigned* pend_cur = pend0 + (size_t)role * pend_words;
+      unsigned* pend_far = pend0 + (size_t)(role ^ 1) * pend_words;
+      const long long bucket_end = ((long long)bucket + 1) * bucket_width;
+      if (lane == 0) atomicOr(&s_touched[t >> 5], 1u << (t & 31));
+      TSA_CNT(7, 1);
+      my_expanded += tsa_job(sch, W, lane, t, rows, cols, tiles_i, tiles_j, field, nbr_tm, pend_cur, pend_far, bucket_end, gi, gj TSA_ACC_ARG);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // everything this job wrote is at L2 before the tile is released
+      int left = 1;
+      if (lane == 0) {
+        atomicAnd(&s_running[t >> 5], ~(1u << (t & 31)));
+        atomicAdd(&s_rounds, 1);
+        left = atomicSub(&s_outstanding, 1) - 1;
+      }
+      left = __shfl(left, 0);
+      if (left != 0) continue;
+      // ---- this wave emptied the bucket: no tile is active or running, it owns the query alone ----
+      if (lds_ld(&s_state) != 0) break;   // overflow was flagged
+      const int best = lds_ld(&s_best);
+      const long long done_below = ((long long)bucket + 1) * bucket_width;
+      if (best != INF && (long long)best < done_below) { if (lane == 0) s_state = 1; break; }   // goal settled, ties included
+      int cnt = 0;
+      for (int w = lane; w < nt_words; w += 64) cnt += __popc(lds_ld(&s_act[1][w]));
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+      if (cnt == 0) { if (lane == 0) s_state = (best != INF) ? 1 : 2; break; }   // nothing left anywhere
+      if (lane == 0) { s_bucket = bucket + 1; s_role = role ^ 1; s_outstanding = cnt; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      for (int w = lane; w < nt_words; w += 64) {   // publish the next bucket's tiles (count and role are in place)
+        const unsigned b = s_act[1][w];
+        if (b) { s_act[1][w] = 0u; atomicOr(&s_act[0][w], b); }
+      }
+    }
+  } else {
   TsaLocalSched sch{&s_best, &s_state, s_act[0], s_act[1]};
 
   for (;;) {
@@ -544,6 +646,7 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
       job = __shfl(job, 0);
       if (job >= njobs) break;
       const int t = s_jobs[job];
+      TSA_CNT(7, 1);
       my_expanded += tsa_job(sch, W, lane, t, rows, cols, tiles_i, tiles_j, field, nbr_tm, pend_cur, pend_far, bucket_end, gi, gj TSA_ACC_ARG);
     }
     // all stores / atomics of this round are performed before any wave loads tiles in the next one
@@ -552,8 +655,13 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
     if (tid == 0) s_rounds += 1;
     if (stop) break;
   }
+  }   // !ASYNC
   atomicAdd(&s_expanded, my_expanded);
   __syncthreads();
+#ifdef RNA_TSA_STATS
+  tsa_acc[5] = wall_clock64() - t_life0;   // wave lifetime inside the search loop
+  if (lane == 0) for (int k = 0; k < 16; ++k) atomicAdd(&g_tsa_stat[k], tsa_acc[k]);
+#endif
   // every tile this search wrote: its jobs plus the tiles that were handed cells but never ran
   {
     unsigned* touched = touched_all + (size_t)q * nt_words;
@@ -1073,13 +1181,32 @@ int tsa_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream
   }
   {
     KernelTimer kt(e, RNA_K_ASTAR_SEARCH, search_stream);
-    hipLaunchKernelGGL(tsa_search_kernel, dim3(n), dim3(TSA_THREADS), (size_t)3 * ((ti * tj + 31) / 32) * sizeof(unsigned),
-                       search_stream, rows, cols, ti, tj, q_dev, field, field_stride, pend, pend_stride, aux.nbr_tm, aux.touched,
-                       e->astar.bucket_width, paths_dev, max_len, rev, rev_cap, res_dev, e->geom.start[0], e->geom.start[1]);
+    const size_t nt_bytes = (size_t)((ti * tj + 31) / 32) * sizeof(unsigned);
+    if (e->astar.mode == 3)
+      hipLaunchKernelGGL(tsa_search_kernel<true>, dim3(n), dim3(TSA_THREADS), 4 * nt_bytes, search_stream, rows, cols, ti, tj, q_dev,
+                         field, field_stride, pend, pend_stride, aux.nbr_tm, aux.touched, e->astar.bucket_width, paths_dev, max_len,
+                         rev, rev_cap, res_dev, e->geom.start[0], e->geom.start[1]);
+    else
+      hipLaunchKernelGGL(tsa_search_kernel<false>, dim3(n), dim3(TSA_THREADS), 3 * nt_bytes, search_stream, rows, cols, ti, tj, q_dev,
+                         field, field_stride, pend, pend_stride, aux.nbr_tm, aux.touched, e->astar.bucket_width, paths_dev, max_len,
+                         rev, rev_cap, res_dev, e->geom.start[0], e->geom.start[1]);
     RNA_HIP(e, hipGetLastError());
   }
   return RNA_OK;
 }
+
+#ifdef RNA_TSA_STATS
+void tsa_stats_dump() {
+  unsigned long long st[16];
+  if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_tsa_stat), sizeof(st)) != hipSuccess) return;
+  const double jobs = (double)st[7];
+  if (jobs <= 0) return;
+  const double busy = (double)(st[0] + st[1] + st[2] + st[3]);
+  fprintf(stderr, "[tsa stats, tile kernel, all launches] jobs %.0f | per job us: load %.2f relax %.2f wb %.2f handover %.2f | wave lifetime %.1f wave-ms, in jobs %.1f wave-ms (%.1f%%) | relax iters/job %.1f cells/iter %.1f\n",
+          jobs, st[0] * 0.01 / jobs, st[1] * 0.01 / jobs, st[2] * 0.01 / jobs, st[3] * 0.01 / jobs, st[5] * 1e-5, busy * 1e-5,
+          100.0 * busy / (double)st[5], st[8] / jobs, st[9] / (double)std::max<unsigned long long>(1, st[8]));
+}
+#endif
 
 int tsa_settled(rna_engine* e, const unsigned* field, size_t field_stride, const rna_astar_query* q, const rna_astar_result* r,
                 int n, int32_t* d_counts) {
