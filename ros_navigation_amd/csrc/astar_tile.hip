@@ -261,6 +261,9 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
   //    same word -- no LDS atomics (ds_min_rtn on 16 waves was the bottleneck of an earlier version)
   //    and no divergent branches.  All f-tests (prune against the upper bound, defer to the next
   //    bucket) happen once per POPPED cell, so the direction body is only compare / select / store.
+  //    (Tried and dropped: reading all eight neighbours at once and resolving write conflicts with
+  //    non-returning ds_min_u32 plus a returning ds_and at the pop -- four dependent LDS round trips
+  //    instead of ten, yet 27 % slower: LDS atomics cost more than the round trips they save.)
   const int best_in = sch.best();
   const int bend = bucket_end > (long long)INF ? INF : (int)bucket_end;
   const int goal_p = (gi >= i0 && gi < i0 + TS && gj >= j0 && gj < j0 + TS) ? (gj - j0 + 1) * TW + (gi - i0 + 1) : -1;
