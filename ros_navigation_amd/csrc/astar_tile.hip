@@ -39,7 +39,10 @@ constexpr int TILE_WORDS = TS * TS;    // 1024
 constexpr int TSA_WAVES = RNA_TSA_WAVES;
 constexpr int TSA_THREADS = TSA_WAVES * 64;
 constexpr int TSA_MAX_TILE_WORDS = 2048;   // active-tile bitset words -> up to 65536 tiles
-constexpr int TSA_JOBS = 4096;             // tile jobs per round (more stay flagged for the next round)
+#ifndef RNA_TSA_JOBS
+#define RNA_TSA_JOBS 4096
+#endif
+constexpr int TSA_JOBS = RNA_TSA_JOBS;             // tile jobs per round (more stay flagged for the next round)
 constexpr int LQ = 1024;                   // per-wave local queue (u16 LDS positions): <= 1024 live entries (in-queue filter)
 constexpr int COST_S = 1000, COST_D = 1414;
 constexpr int INF = 0x7fffffff;
