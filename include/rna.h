@@ -201,6 +201,24 @@ int rna_rrt_batch(rna_engine* e, const rna_rrt_query* queries_host, int n, doubl
 int rna_rrt_batch_device(rna_engine* e, const rna_rrt_query* queries_device, int n, double* paths_xy_device,
                          int max_path_len, rna_rrt_result* results_device);
 
+/* ---- laser ingestion ------------------------------------------------------------------------- */
+/* One sensor_msgs/LaserScan plus the sensor pose tf reports for it (planar, constant over the scan). */
+typedef struct {
+  float angle_min, angle_max, angle_increment, range_min, range_max;
+  int32_t n_ranges;
+  int64_t ranges_offset;   /* first range of this scan in the concatenated ranges array */
+  double x, y, yaw;        /* sensor pose in the map frame */
+} rna_laser_scan;
+/* LaserMapUpdater::bufferIncomingMsg (mc/src/laser_map_updater.cpp:37-75): simplifyLaserScan
+ * (:118-143), laser_geometry's projection + tf transform of every valid beam (:78-99), ray origin
+ * (:101-116) -> RangeSamples in scan order, beam order.  n_rays receives the number of rays produced;
+ * RNA_ECAPACITY if it exceeds max_rays (the first max_rays rays are still written).  The device
+ * variant leaves the count in device memory; max_beams_per_scan >= every scan's n_ranges (<= 8192). */
+int rna_scan_to_rays(rna_engine* e, const rna_laser_scan* scans_host, int n_scans, const float* ranges_host,
+                     size_t n_ranges_total, rna_ray* rays_host, int max_rays, int* n_rays);
+int rna_scan_to_rays_device(rna_engine* e, const rna_laser_scan* scans_device, int n_scans, const float* ranges_device,
+                            int max_beams_per_scan, rna_ray* rays_device, int max_rays, int* n_rays_device);
+
 /* ---- message formats either side of the path ------------------------------------------------- */
 /* GridMapRosConverter::toOccupancyGrid (grid_map-master/grid_map_ros/src/GridMapRosConverter.cpp:251-287)
  * as MapProvider::publishMap calls it with (0, 255) (mc/src/map_provider.cpp:113-118,206-213):

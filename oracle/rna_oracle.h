@@ -209,6 +209,16 @@ void og_rrt_plan(const og_geom* g, const float* master, const double start[2], c
                  double close_tol, unsigned seed, int max_samples, double* path_xy, int path_cap,
                  og_rrt_result* res);
 
+/* ---- laser ingestion: LaserScan -> RangeSamples (scan.c; laser_map_updater.cpp:37-143) ---- */
+typedef struct {
+  float angle_min, angle_max, angle_increment, range_min, range_max;   /* sensor_msgs/LaserScan fields */
+  int32_t n_ranges;
+  int64_t ranges_offset;   /* first range of this scan in the concatenated ranges array */
+  double x, y, yaw;        /* sensor pose in the map frame (tf), constant over the scan */
+} og_scan;
+int og_simplify_scan(int n, float angle_increment, int* sel, int cap, float* out_increment);
+int og_scan_to_rays(const og_scan* s, const float* ranges, og_ray* out, int cap);   /* returns the number of rays */
+
 /* ---- message formats either side of the path (msgs.c) ---- */
 /* GridMapRosConverter::toOccupancyGrid / fromOccupancyGrid (grid_map_ros/src/GridMapRosConverter.cpp:205-287) */
 void og_to_occupancy_grid(const og_geom* g, const float* layer, float data_min, float data_max, int8_t* out);

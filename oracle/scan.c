@@ -1,0 +1,79 @@
+/*
+ * oracle/scan.c -- TEST INFRASTRUCTURE ONLY (CPU restatement; never linked into the product).
+ *
+ * Laser ingestion: LaserMapUpdater::bufferIncomingMsg turns one
+ * sensor_msgs/LaserScan into RangeSamples (move_control/src/laser_map_updater.cpp:37-75) via
+ *   simplifyLaserScan            (laser_map_updater.cpp:118-143)   decimation to >= 0.017 rad,
+ *   laser_geometry::LaserProjection::transformLaserScanToPointCloud (laser_map_updater.cpp:78-99),
+ *   tf::TransformListener::transformPoint for the ray origin       (laser_map_updater.cpp:101-116).
+ * laser_geometry and tf are ROS packages that are NOT under /root/reference and are not
+ * version-pinned by it (move_control/package.xml:16-29 lists them without versions; ROS Indigo
+ * ships laser_geometry 1.6.x, tf 1.11.x).  Their published algorithm is restated here for the case
+ * the engine supports: a planar sensor pose (x, y, yaw) in the map frame that is constant over the
+ * scan (so tf's start/end interpolation of the high-fidelity projection is the identity):
+ *   projectLaser_:  x = r*cos(angle_min + i*angle_increment), y = r*sin(...) in double, a point is
+ *                   emitted iff r < range_max && r >= range_min, stored as float32 with its index;
+ *   transform:      p' = R(yaw) p + t in double on the float32 point, stored as float32 again.
+ * PARITY UNPINNED: no reference test covers this path and the dependencies cannot be built here.
+ * Reference quirks kept: the point's index refers to the SIMPLIFIED scan but ifClearEnd looks it
+ * up in the ORIGINAL ranges (laser_map_updater.cpp:62-69); the simplified scan starts with
+ * ranges[0] twice over (index 0 is pushed, then the loop starts at i = 0).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "rna_oracle.h"
+
+/* laser_map_updater.cpp:118-143; sel[k] = index into the original ranges of simplified beam k */
+int og_simplify_scan(int n, float angle_increment, int* sel, int cap, float* out_increment) {
+  int m = 0;
+  float increment = 0.0f;
+  *out_increment = 0.0f;               /* a fresh LaserScan message is zero-initialised */
+  if (n <= 0) return 0;
+  if (m < cap) sel[m] = 0;
+  ++m;
+  for (int i = 0; i < n; ++i) {
+    increment += angle_increment;
+    if (increment >= 0.017) {
+      *out_increment = increment;
+      increment = 0.0f;
+      if (m < cap) sel[m] = i;
+      ++m;
+    }
+  }
+  return m;
+}
+
+int og_scan_to_rays(const og_scan* s, const float* ranges, og_ray* out, int cap) {
+  const float* r = ranges + s->ranges_offset;
+  int n = s->n_ranges;
+  float inc = s->angle_increment;
+  static int sel_buf[1 << 16];
+  int* sel = NULL;
+  if (s->angle_increment < 0.017) {   /* laser_map_updater.cpp:82 */
+    n = og_simplify_scan(s->n_ranges, s->angle_increment, sel_buf, 1 << 16, &inc);
+    if (n > (1 << 16)) n = 1 << 16;
+    sel = sel_buf;
+  }
+  const double cy = cos(s->yaw), sy = sin(s->yaw);
+  const double range_cutoff = s->range_max;
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    const float range = r[sel ? sel[i] : i];
+    if (!(range < range_cutoff && range >= s->range_min)) continue;
+    const double a = s->angle_min + (double)i * inc;
+    const float px = (float)(range * cos(a)), py = (float)(range * sin(a));
+    const float gx = (float)(cy * (double)px - sy * (double)py + s->x);
+    const float gy = (float)(sy * (double)px + cy * (double)py + s->y);
+    const float orig = i < s->n_ranges ? r[i] : r[s->n_ranges - 1];   /* msg->ranges[index] of the ORIGINAL scan */
+    if (m < cap) {
+      out[m].sx = s->x; out[m].sy = s->y;
+      out[m].ex = gx; out[m].ey = gy;
+      out[m].clear_end = (isinf(orig) || orig == s->range_max) ? 1 : 0;
+      out[m]._pad = 0;
+    }
+    ++m;
+  }
+  return m;
+}

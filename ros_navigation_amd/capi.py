@@ -33,7 +33,7 @@ SYMBOLS = [
     "rna_astar_download_nbr_mask",
     "rna_graph_astar_batch", "rna_rrt_batch", "rna_rrt_batch_device",
     "rna_to_occupancy_grid", "rna_to_occupancy_grid_device", "rna_from_occupancy_grid", "rna_vfh_hist_msg_batch",
-    "rna_tailor_plan",
+    "rna_tailor_plan", "rna_scan_to_rays", "rna_scan_to_rays_device",
     "rna_profile_enable", "rna_profile_reset", "rna_profile_get", "rna_kernel_name",
 ]
 
@@ -63,6 +63,9 @@ POSE_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("yaw", "<f8"), ("dt", "<f8")
                        ("goal_tolerance", "<f4")])
 VFH_OUT_DTYPE = np.dtype([("chosen_speed", "<i4"), ("chosen_turnrate", "<i4"), ("picked_angle", "<f4"),
                           ("emergency", "<i4")])
+SCAN_DTYPE = np.dtype([("angle_min", "<f4"), ("angle_max", "<f4"), ("angle_increment", "<f4"), ("range_min", "<f4"),
+                       ("range_max", "<f4"), ("n_ranges", "<i4"), ("ranges_offset", "<i8"), ("x", "<f8"), ("y", "<f8"),
+                       ("yaw", "<f8")])
 ASTAR_QUERY_DTYPE = np.dtype([("start", "<i4"), ("goal", "<i4")])
 ASTAR_RESULT_DTYPE = np.dtype([("status", "<i4"), ("path_len", "<i4"), ("cost", "<i4"), ("expanded", "<i4"),
                                ("rounds", "<i4"), ("buckets", "<i4")])
@@ -133,6 +136,8 @@ def lib():
     L.rna_from_occupancy_grid.argtypes = [vp, C.c_int, vp]
     L.rna_vfh_hist_msg_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.rna_tailor_plan.argtypes = [vp, C.c_int, C.c_uint, vp, C.POINTER(C.c_int)]
+    L.rna_scan_to_rays.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp, C.c_int, C.POINTER(C.c_int)]
+    L.rna_scan_to_rays_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
     L.rna_profile_enable.argtypes = [vp, C.c_int]
     L.rna_profile_reset.argtypes = [vp]
     L.rna_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -349,6 +354,18 @@ class Engine:
         self._check(self._L.rna_rrt_batch_device(self.h, queries_ptr, n, paths_ptr, max_path_len, results_ptr))
 
     # ---- measurement ----
+    def scan_to_rays(self, scans, ranges, max_rays=None):
+        """LaserMapUpdater::bufferIncomingMsg for a batch of scans: RAY_DTYPE array in scan order, beam order."""
+        scans = np.ascontiguousarray(scans, SCAN_DTYPE)
+        ranges = np.ascontiguousarray(ranges, np.float32)
+        if max_rays is None:
+            max_rays = int(scans["n_ranges"].sum()) + 1
+        rays = np.zeros(max_rays, RAY_DTYPE)
+        n = C.c_int(0)
+        self._check(self._L.rna_scan_to_rays(self.h, _ptr(scans), len(scans), _ptr(ranges), ranges.size, _ptr(rays), max_rays,
+                                             C.byref(n)))
+        return rays[:n.value]
+
     def to_occupancy_grid(self, layer, data_min=0.0, data_max=255.0):
         """GridMapRosConverter::toOccupancyGrid: int8[rows*cols] in nav_msgs/OccupancyGrid order."""
         g = self.geometry()

@@ -158,6 +158,17 @@ class MapProvider {
     r.clear_end = s.ifClearEnd ? 1 : 0; r._pad = 0;
     buffer_.push_back(r);
   }
+  // LaserMapUpdater::bufferIncomingMsg (laser_map_updater.cpp:37-75) for whole scans: decimation,
+  // projection and the tf transform run on the device (sensor pose planar and constant over the scan)
+  void bufferScans(const std::vector<rna_laser_scan>& scans, const std::vector<float>& ranges) {
+    size_t cap = 1;
+    for (size_t k = 0; k < scans.size(); ++k) cap += (size_t)scans[k].n_ranges;
+    std::vector<rna_ray> rays(cap);
+    int n = 0;
+    grid_map::rna_check(rna_scan_to_rays(map_.engine(), scans.data(), (int)scans.size(), ranges.data(), ranges.size(), rays.data(),
+                                         (int)cap, &n), map_.engine(), "LaserMapUpdater::bufferIncomingMsg");
+    buffer_.insert(buffer_.end(), rays.begin(), rays.begin() + n);
+  }
   // MapProvider::updateMap: drain the buffer through HIMM, then compose master (fused, dirty tiles)
   void updateMap(bool wholeLayerCopy = false) {
     grid_map::rna_check(rna_update_map(map_.engine(), buffer_.data(), (int)buffer_.size(), wholeLayerCopy ? 1 : 0),

@@ -108,3 +108,27 @@ def rrt_queries(n, master, rows, cols, engine_get_position, seed=3, max_samples=
     q["seed"] = np.arange(1, n + 1, dtype=np.uint32)
     q["max_samples"] = max_samples
     return q
+
+
+def laser_scans(n_scans, n_beams, length_x, length_y, seed=6, angle_increment=None, range_max=6.0, hit=0.8):
+    """Synthetic sensor_msgs/LaserScan batch (capi.SCAN_DTYPE descriptors + concatenated float32 ranges): sensor
+    poses inside the map, 270-degree fans, ranges uniform in [range_min, range_max) for hits, range_max or +inf for
+    misses, a few NaN / below-range_min returns (all dropped by the projection as in laser_geometry)."""
+    from .capi import SCAN_DTYPE
+    rng = np.random.default_rng(seed)
+    scans = np.zeros(n_scans, SCAN_DTYPE)
+    ranges = np.empty(n_scans * n_beams, np.float32)
+    fan = np.float32(1.5 * np.pi)
+    inc = np.float32(fan / n_beams) if angle_increment is None else np.float32(angle_increment)
+    for k in range(n_scans):
+        r = rng.uniform(0.12, range_max, n_beams).astype(np.float32)
+        u = rng.random(n_beams)
+        r[u > hit] = np.float32(range_max)
+        r[u > hit + 0.1] = np.inf
+        r[rng.random(n_beams) < 0.01] = np.nan
+        r[rng.random(n_beams) < 0.01] = np.float32(0.01)
+        ranges[k * n_beams:(k + 1) * n_beams] = r
+        scans[k] = (np.float32(-0.5 * fan), np.float32(-0.5 * fan + inc * n_beams), inc, np.float32(0.1), np.float32(range_max),
+                    n_beams, k * n_beams, rng.uniform(-0.4, 0.4) * length_x, rng.uniform(-0.4, 0.4) * length_y,
+                    rng.uniform(-np.pi, np.pi))
+    return scans, ranges

@@ -148,6 +148,8 @@ def lib():
         L.og_rrt_plan.argtypes = [C.POINTER(Geom), fp, d2, d2, C.c_double, C.c_uint, C.c_int, d2, C.c_int,
                                   C.POINTER(RrtResult)]
         L.og_rrt_plan.restype = None
+        L.og_scan_to_rays.argtypes = [C.c_void_p, fp, C.c_void_p, C.c_int]
+        L.og_simplify_scan.argtypes = [C.c_int, C.c_float, i2, C.c_int, fp]
         L.og_to_occupancy_grid.argtypes = [C.POINTER(Geom), fp, C.c_float, C.c_float, C.c_void_p]
         L.og_to_occupancy_grid.restype = None
         L.og_from_occupancy_grid.argtypes = [C.c_int, C.c_int, C.c_void_p, fp]
@@ -352,6 +354,32 @@ def rrt_plan(g, master, start, target, tol=0.2, seed=1, max_samples=200000, cap=
     lib().og_rrt_plan(C.byref(g), fptr(master), d2(*start), d2(*target), tol, seed, max_samples,
                       path.ctypes.data_as(C.POINTER(C.c_double)), cap, C.byref(res))
     return res, path[:2 * min(res.path_len, cap)].reshape(-1, 2).copy()
+
+
+SCAN_DTYPE = np.dtype([("angle_min", "<f4"), ("angle_max", "<f4"), ("angle_increment", "<f4"), ("range_min", "<f4"),
+                       ("range_max", "<f4"), ("n_ranges", "<i4"), ("ranges_offset", "<i8"), ("x", "<f8"), ("y", "<f8"),
+                       ("yaw", "<f8")])
+
+
+def scan_to_rays(scans, ranges):
+    """LaserMapUpdater::bufferIncomingMsg for every scan, concatenated in order"""
+    scans = np.ascontiguousarray(scans, SCAN_DTYPE)
+    ranges = np.ascontiguousarray(ranges, np.float32)
+    out = []
+    for k in range(len(scans)):
+        cap = int(scans["n_ranges"][k]) + 1
+        rays = np.zeros(cap, RAY_DTYPE)
+        n = lib().og_scan_to_rays(scans[k:k + 1].ctypes.data, fptr(ranges), rays.ctypes.data, cap)
+        assert n <= cap
+        out.append(rays[:n])
+    return np.concatenate(out) if out else np.zeros(0, RAY_DTYPE)
+
+
+def simplify_scan(n, angle_increment):
+    sel = (C.c_int * (n + 1))()
+    inc = C.c_float(0)
+    m = lib().og_simplify_scan(n, angle_increment, sel, n + 1, C.byref(inc))
+    return list(sel[:m]), inc.value
 
 
 def to_occupancy_grid(g, layer, data_min=0.0, data_max=255.0):

@@ -40,9 +40,9 @@ def test_struct_layouts_match_header(capi):
     #include <stdio.h>
     #include "rna.h"
     int main(void) {
-      printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(rna_geometry), sizeof(rna_ray), sizeof(rna_vfh_params),
+      printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(rna_geometry), sizeof(rna_ray), sizeof(rna_vfh_params),
              sizeof(rna_pose), sizeof(rna_vfh_out), sizeof(rna_astar_query), sizeof(rna_astar_result),
-             sizeof(rna_rrt_query), sizeof(rna_rrt_result), (size_t)RNA_K_COUNT);
+             sizeof(rna_rrt_query), sizeof(rna_rrt_result), (size_t)RNA_K_COUNT, sizeof(rna_laser_scan));
       return 0;
     }"""
     exe = "/tmp/rna_layout_check"
@@ -51,7 +51,7 @@ def test_struct_layouts_match_header(capi):
     assert sizes == [C.sizeof(capi.Geometry), capi.RAY_DTYPE.itemsize, C.sizeof(capi.VfhParams),
                      capi.POSE_DTYPE.itemsize, capi.VFH_OUT_DTYPE.itemsize, capi.ASTAR_QUERY_DTYPE.itemsize,
                      capi.ASTAR_RESULT_DTYPE.itemsize, capi.RRT_QUERY_DTYPE.itemsize, capi.RRT_RESULT_DTYPE.itemsize,
-                     len(capi.KERNELS)]
+                     len(capi.KERNELS), capi.SCAN_DTYPE.itemsize]
     assert src.count("extern \"C\"") == 1
 
 

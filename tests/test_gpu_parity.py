@@ -469,6 +469,35 @@ def test_hist_msg_matches_oracle(R):
     e.close()
 
 
+def test_scan_to_rays_matches_oracle_and_feeds_himm(R):
+    """LaserScan batches -> RangeSamples on the device.  Ray counts, order, origins and
+    ifClearEnd flags are exact; end points are float32 values built from device cos/sin (f64), so they may
+    differ from the oracle's libm by one float32 ulp -- compared at 1e-6 m, and bit-exactly for the
+    overwhelming majority."""
+    e = R.Engine(25.6, 25.6, 0.05)
+    g = O.make_geom(25.6, 25.6, 0.05)
+    for inc, beams in ((None, 1081), (np.float32(0.02), 200), (np.float32(0.0005), 4000)):
+        scans, ranges = R.synth.laser_scans(24, beams, 25.6, 25.6, seed=beams, angle_increment=inc)
+        want = O.scan_to_rays(scans, ranges)
+        got = e.scan_to_rays(scans, ranges)
+        assert len(got) == len(want) > 0
+        assert np.array_equal(got["sx"], want["sx"]) and np.array_equal(got["sy"], want["sy"])
+        assert np.array_equal(got["clear_end"], want["clear_end"])
+        assert np.allclose(got["ex"], want["ex"], rtol=0, atol=1e-6) and np.allclose(got["ey"], want["ey"], rtol=0, atol=1e-6)
+        exact = (got["ex"] == want["ex"]) & (got["ey"] == want["ey"])
+        assert exact.mean() > 0.99
+        if inc is None:
+            assert want["clear_end"].sum() > 0                       # the index quirk is exercised
+    # the rays feed the HIMM update unchanged: same map as the oracle fed with the same (device-made) rays
+    ref = np.full(e.ncell, np.nan, np.float32)
+    O.himm_update(g, ref, got.view(O.RAY_DTYPE))
+    e.update_map(got, compose_mode=1)
+    assert same_f32(e.download(R.capi.LAYER_MASTER), ref)
+    with pytest.raises(R.RnaError):
+        e.scan_to_rays(scans, ranges, max_rays=10)                   # RNA_ECAPACITY, not a silent truncation
+    e.close()
+
+
 def test_empty_batches_are_noops(R):
     e = R.Engine(3.2, 3.2, 0.05)
     e.himm_update(R.capi.LAYER_LASER, np.zeros(0, R.capi.RAY_DTYPE))

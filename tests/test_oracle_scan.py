@@ -1,0 +1,46 @@
+"""Oracle checks for the laser-ingestion restatement (oracle/scan.c; laser_map_updater.cpp:37-143).
+Parity is UNPINNED (no reference test, laser_geometry/tf not buildable here): these tests pin the
+restatement's own invariants, line by line against the cited reference code."""
+import numpy as np
+
+import _oracle as O
+
+
+# laser_map_updater.cpp:118-143: ranges[0] first, then every beam at which the float accumulator reaches 0.017
+def test_simplify_scan_follows_the_reference_loop():
+    for n, inc in ((1081, np.float32(0.004363323)), (720, np.float32(0.0087266)), (10, np.float32(0.001)), (5, np.float32(0.02))):
+        sel, out_inc = O.simplify_scan(n, inc)
+        want, acc, last = [0], np.float32(0.0), np.float32(0.0)
+        for i in range(n):
+            acc = np.float32(acc + inc)
+            if float(acc) >= 0.017:
+                last, acc = acc, np.float32(0.0)
+                want.append(i)
+        assert sel == want and np.float32(out_inc) == last
+    assert O.simplify_scan(0, np.float32(0.004))[0] == []
+
+
+def test_scan_to_rays_projection_filter_and_quirks():
+    scans = np.zeros(2, O.SCAN_DTYPE)
+    # scan 0: coarse increment (no decimation), sensor at (1, 2) looking along +y
+    r0 = np.array([0.05, 1.0, 2.0, np.inf, 6.0, np.nan, 3.0], np.float32)
+    scans[0] = (np.float32(-0.3), 0, np.float32(0.1), np.float32(0.1), np.float32(6.0), len(r0), 0, 1.0, 2.0, np.pi / 2)
+    # scan 1: fine increment -> decimated; index quirk: clear_end looks up the ORIGINAL ranges at the simplified index
+    n1 = 40
+    r1 = np.full(n1, 2.5, np.float32)
+    r1[3] = 6.0         # original beam 3 == range_max: simplified beam 3 (a different beam) is flagged ifClearEnd
+    scans[1] = (np.float32(0.0), 0, np.float32(0.004), np.float32(0.1), np.float32(6.0), n1, len(r0), -1.0, 0.5, 0.0)
+    rays = O.scan_to_rays(scans, np.concatenate([r0, r1]))
+    sel, inc = O.simplify_scan(n1, np.float32(0.004))
+    n0 = 3                                             # beams 1, 2 and 6 of scan 0 survive (0.05 < range_min, inf/max/NaN dropped)
+    assert len(rays) == n0 + len(sel)
+    a = np.float64(np.float32(-0.3)) + 1 * np.float64(np.float32(0.1))
+    px, py = np.float32(1.0 * np.cos(a)), np.float32(1.0 * np.sin(a))
+    ex = np.float32(np.cos(np.pi / 2) * np.float64(px) - np.sin(np.pi / 2) * np.float64(py) + 1.0)
+    ey = np.float32(np.sin(np.pi / 2) * np.float64(px) + np.cos(np.pi / 2) * np.float64(py) + 2.0)
+    assert (rays["sx"][0], rays["sy"][0]) == (1.0, 2.0) and (rays["ex"][0], rays["ey"][0]) == (float(ex), float(ey))
+    assert rays["clear_end"][:n0].tolist() == [0, 0, 0]
+    second = rays[n0:]
+    assert second["clear_end"].tolist() == [1 if k == 3 else 0 for k in range(len(sel))]
+    ang = np.float64(0.0) + np.arange(len(sel)) * np.float64(np.float32(inc))
+    assert np.allclose(second["ex"], -1.0 + 2.5 * np.cos(ang), atol=1e-6) and np.allclose(second["ey"], 0.5 + 2.5 * np.sin(ang), atol=1e-6)
