@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "librna_oracle.so")
+ORACLE_SO = os.environ.get("RNA_ORACLE_SO") or os.path.join(ORACLE_DIR, "librna_oracle.so")   # override: sanitizer build
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_vfh.so")
 
 
