@@ -236,15 +236,16 @@ __device__ bool wave_if_blocked(const Geom& g, const float* __restrict__ master,
 
 __global__ void __launch_bounds__(64 * RRT_WAVES)
 rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __restrict__ queries, int n,
-           double* __restrict__ tree_x, double* __restrict__ tree_y, int* __restrict__ tree_parent,
+           int* __restrict__ tree_parent,
            double* __restrict__ paths, int max_path_len, rna_rrt_result* __restrict__ results) {
   __shared__ RandState s_rng[RRT_WAVES];
+  __shared__ double s_tx[RRT_WAVES][RRT_ITER], s_ty[RRT_WAVES][RRT_ITER];   // the tree of each wave's query: 32 KB per wave
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int q = blockIdx.x * RRT_WAVES + wave;
   if (q >= n) return;
   const rna_rrt_query qu = queries[q];
-  double* tx = tree_x + (size_t)q * RRT_ITER;
-  double* ty = tree_y + (size_t)q * RRT_ITER;
+  double* const tx = s_tx[wave];
+  double* const ty = s_ty[wave];
   int* tp = tree_parent + (size_t)q * RRT_ITER;
   RandState& rs = s_rng[wave];
   if (lane == 0) rng_seed(rs, qu.seed);
@@ -263,7 +264,7 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
   for (int it = 0; it < RRT_ITER && !aborted; ++it) {
     if (lane == 0) { tx[n_tree] = nx; ty[n_tree] = ny; tp[n_tree] = nparent; }
     n_tree++;
-    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
     bool fin;  // ifFinishPlan, map_global_planner.h:32-37,56-86
     if (target_inside) fin = hypot(nx - qu.target[0], ny - qu.target[1]) < qu.close_tolerance;
     else fin = ((pbx - nx) < qu.close_tolerance) || ((pby - ny) < qu.close_tolerance) ||
@@ -288,12 +289,26 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
       } else {
         rx = qu.target[0]; ry = qu.target[1];
       }
-      // findNearNode, rrt_planner.cpp:70-89 : strict < keeps the lowest index among equals
+      // findNearNode, rrt_planner.cpp:70-89 : strict < on hypot() keeps the lowest index among equals.
+      // hypot costs ~10x a squared distance, so the scan runs on squared distances first; hypot (error
+      // < 1 ulp, i.e. 2^-52 relative) can only reorder nodes whose squared distances agree to within
+      // 2^-48, and exactly those are re-examined with hypot in the reference's order.
+      double m2 = 1.0e300;
+      for (int i = lane; i < n_tree; i += 64) {
+        const double dx = rx - tx[i], dy = ry - ty[i];
+        const double d2 = dx * dx + dy * dy;
+        m2 = d2 < m2 ? d2 : m2;
+      }
+      for (int o = 32; o >= 1; o >>= 1) { const double om = __shfl_xor(m2, o); m2 = om < m2 ? om : m2; }
+      const double band = m2 + m2 * 0x1p-46 + 1.0e-300;
       double best = 9999.0;
       int best_i = 0x7fffffff;
       for (int i = lane; i < n_tree; i += 64) {
-        const double d = hypot(rx - tx[i], ry - ty[i]);
-        if (d < best) { best = d; best_i = i; }
+        const double dx = rx - tx[i], dy = ry - ty[i];
+        if (dx * dx + dy * dy <= band) {
+          const double d = hypot(dx, dy);
+          if (d < best) { best = d; best_i = i; }
+        }
       }
       for (int o = 32; o >= 1; o >>= 1) {
         const double ob = __shfl_xor(best, o);
@@ -392,12 +407,11 @@ extern "C" int rna_graph_astar_batch(rna_engine* e, int nv, const double* vertex
 static int rrt_launch(rna_engine* e, const rna_rrt_query* q_dev, int n, double* paths_dev, int max_len,
                       rna_rrt_result* res_dev, double** tx, double** ty, int** tp) {
   int rc;
-  if ((rc = dev_alloc(e, tx, (size_t)n * RRT_ITER)) != RNA_OK) return rc;
-  if ((rc = dev_alloc(e, ty, (size_t)n * RRT_ITER)) != RNA_OK) return rc;
+  (void)tx; (void)ty;   // node positions live in LDS; only the parent links go through HBM
   if ((rc = dev_alloc(e, tp, (size_t)n * RRT_ITER)) != RNA_OK) return rc;
   KernelTimer kt(e, RNA_K_RRT);
   hipLaunchKernelGGL(rrt_kernel, dim3((n + RRT_WAVES - 1) / RRT_WAVES), dim3(64 * RRT_WAVES), 0, e->stream, e->geom,
-                     e->layer[RNA_LAYER_MASTER], q_dev, n, *tx, *ty, *tp, paths_dev, max_len, res_dev);
+                     e->layer[RNA_LAYER_MASTER], q_dev, n, *tp, paths_dev, max_len, res_dev);
   RNA_HIP(e, hipGetLastError());
   return RNA_OK;
 }
