@@ -91,6 +91,7 @@ struct TsaAux {
   int* clean;
   uint8_t* nbr_tm;      // [ntile][32][32] neighbour masks, 0 outside the map
   unsigned* touched;    // [max_queries][nt_words]
+  int* perm;            // [max_queries] launch order of this batch: workgroup b serves query perm[b]
 };
 __host__ __device__ inline size_t tsa_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -149,9 +150,43 @@ __global__ void tsa_init_kernel(const uint8_t* __restrict__ nbr, int rows, int c
 }
 __global__ void tsa_mark_clean_kernel(int* clean) { *clean = 1; }
 
+// Launch order of a batch: longest expected search first (key = Chebyshev distance start -> goal,
+// ties by index).  Workgroups are dispatched in index order and land on the XCDs round-robin, so this
+// both starts the long queries early and deals them evenly over the eight XCDs; with the caller's
+// (arbitrary) order one XCD regularly ended up with most of the long searches (+11 % throughput).
+__global__ void __launch_bounds__(1024) tsa_order_kernel(const rna_astar_query* __restrict__ queries, int n, int rows, int cols,
+                                                          int* __restrict__ perm) {
+  extern __shared__ int s_key[];
+  const int ncell = rows * cols;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const rna_astar_query q = queries[i];
+    int key = -1;   // invalid queries go last
+    if (q.start >= 0 && q.goal >= 0 && q.start < ncell && q.goal < ncell) {
+      // the circular-buffer offset cancels in the differences except across the seam; the key is only a heuristic
+      const int di = abs(q.start % rows - q.goal % rows), dj = abs(q.start / rows - q.goal / rows);
+      key = di > dj ? di : dj;
+    }
+    s_key[i] = key;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int ki = s_key[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const int kj = s_key[j];
+      rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0;
+    }
+    perm[rank] = i;
+  }
+}
+__global__ void tsa_identity_order_kernel(int n, int* __restrict__ perm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) perm[i] = i;
+}
+
 #ifdef RNA_TSA_STATS
 // developer build: phase timers (100 MHz wall clock ticks summed over all jobs), printed by the host
-__device__ unsigned long long g_tsa_stat[16];
+__device__ unsigned long long g_tsa_stat[32];
 #define TSA_T(var) const unsigned long long var = wall_clock64()
 #define TSA_ACC(slot, t0, t1) tsa_acc[slot] += (unsigned long long)((t1) - (t0))
 #define TSA_CNT(slot, v) tsa_acc[slot] += (unsigned long long)(v)
@@ -457,14 +492,15 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
                   unsigned* __restrict__ field_all, size_t field_stride, unsigned* __restrict__ pend_all,
                   size_t pend_stride, const uint8_t* __restrict__ nbr_tm, unsigned* __restrict__ touched_all,
                   int bucket_width, int32_t* __restrict__ paths, int max_path_len,
-                  int32_t* __restrict__ rev_all, int rev_cap, rna_astar_result* __restrict__ results, int s0, int s1) {
+                  int32_t* __restrict__ rev_all, int rev_cap, rna_astar_result* __restrict__ results, int s0, int s1,
+                  const int* __restrict__ perm) {
   __shared__ TsaWave s_w[TSA_WAVES];
   extern __shared__ unsigned s_dyn[];   // tile bitsets, sized by the launch: (ASYNC ? 4 : 3) x ((ntile + 31) / 32) words
   __shared__ unsigned short s_jobs[ASYNC ? 2 : TSA_JOBS];
   __shared__ int s_njobs, s_first_fail, s_job_next, s_best, s_state, s_bucket, s_bucket0, s_rounds, s_role, s_expanded, s_len;
   __shared__ int s_outstanding;
 
-  const int q = blockIdx.x;
+  const int q = perm[blockIdx.x];    // launch order: longest expected search first
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   rna_astar_query qu = queries[q];   // buffer linear indices; the search itself runs in map space
   const int ncell = rows * cols;
@@ -612,6 +648,13 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
     }
     __syncthreads();
     const int njobs = s_njobs < s_first_fail ? s_njobs : s_first_fail;
+#ifdef RNA_TSA_STATS
+    if (tid == 0 && njobs > 0) {   // rounds by size: slots 16..21 = 1-4, 5-8, 9-16, 17-32, 33-64, 65+ jobs; 22 = rounds
+      const int b = njobs <= 4 ? 0 : (njobs <= 8 ? 1 : (njobs <= 16 ? 2 : (njobs <= 32 ? 3 : (njobs <= 64 ? 4 : 5))));
+      atomicAdd(&g_tsa_stat[16 + b], 1ull);
+      atomicAdd(&g_tsa_stat[24 + b], (unsigned long long)njobs);
+    }
+#endif
     if (njobs == 0) {
       // bucket k is at its fixed point: every cell with f < (k+1)*B has its exact g
       __syncthreads();
@@ -723,6 +766,245 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
   int32_t* path = paths + (size_t)q * max_path_len;
   for (int i = tid; i < len; i += TSA_THREADS) path[i] = tsa_buffer_lin(rev[len - 1 - i], rows, cols, s0, s1);
   if (tid == 0) results[q] = rna_astar_result{0, len, s_best, s_expanded, s_rounds, n_buckets};
+}
+
+// -------------------------------------------------------------------------------------------------
+// Several queries per workgroup.  Profiling the kernel above shows 61 % of its rounds holding <= 16 tile
+// jobs for 16 wavefronts (they carry 16 % of the jobs but 30 % of the time): a single query rarely has
+// enough active tiles to keep a CU's wavefronts busy.  Here QB queries share the 16 wavefronts of one
+// workgroup: every round's job list is the union of their active tiles, so thin rounds of one query are
+// filled by the others.  Each query keeps its own bucket, role, bound and bitsets; a query whose current
+// bucket ran dry opens its next bucket at the start of the round, independently of its neighbours.
+// -------------------------------------------------------------------------------------------------
+constexpr int TSA_MQ_JOBS = 2048;   // job list entries per round: (local query << 16) | tile
+
+template <int QB>
+__global__ void __launch_bounds__(TSA_THREADS)
+tsa_multi_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_query* __restrict__ queries, int n_queries,
+                 unsigned* __restrict__ field_all, size_t field_stride, unsigned* __restrict__ pend_all, size_t pend_stride,
+                 const uint8_t* __restrict__ nbr_tm, unsigned* __restrict__ touched_all, int bucket_width,
+                 int32_t* __restrict__ paths, int max_path_len, int32_t* __restrict__ rev_all, int rev_cap,
+                 rna_astar_result* __restrict__ results, int s0, int s1, const int* __restrict__ perm) {
+  __shared__ TsaWave s_w[TSA_WAVES];
+  extern __shared__ unsigned s_dyn[];   // [QB][3][nt_words]: active (current bucket), active (next bucket), touched
+  __shared__ unsigned s_jobs[TSA_MQ_JOBS];
+  __shared__ int s_njobs, s_first_fail, s_job_next, s_running;
+  // per-query state: 0 searching, 1 goal settled, 2 no path, 4 cost overflow, 5 never started (invalid / walled-in goal)
+  __shared__ int s_state[QB], s_best[QB], s_bucket[QB], s_bucket0[QB], s_role[QB], s_rounds[QB], s_expanded[QB], s_len[QB];
+  __shared__ int s_any[QB], s_adv[QB], s_si[QB], s_sj[QB], s_gi[QB], s_gj[QB], s_q[QB];   // s_q: global query index, -1 = none
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ncell = rows * cols;
+  const int ntile = tiles_i * tiles_j;
+  const int nt_words = (ntile + 31) >> 5;
+  const size_t pend_words = (size_t)ntile * TS;
+  auto act = [&](int ql, int which) -> unsigned* { return s_dyn + (size_t)(ql * 3 + which) * nt_words; };
+
+  for (int w = tid; w < QB * 3 * nt_words; w += TSA_THREADS) s_dyn[w] = 0u;
+  if (tid < QB) {
+    const int ql = tid;
+    // queries are dealt round-robin in launch order, so each workgroup gets a mix of long and short searches
+    const int slot = ql * (int)gridDim.x + (int)blockIdx.x;
+    const int q = slot < n_queries ? perm[slot] : -1;
+    s_q[ql] = q;
+    s_best[ql] = INF; s_rounds[ql] = 0; s_role[ql] = 0; s_expanded[ql] = 0; s_bucket[ql] = 0; s_bucket0[ql] = 0; s_len[ql] = 0;
+    s_state[ql] = 5;
+    if (q >= 0) {
+      rna_astar_query qu = queries[q];
+      if (!(qu.start >= 0 && qu.goal >= 0 && qu.start < ncell && qu.goal < ncell)) {
+        results[q] = rna_astar_result{2, 0, INF, 0, 0, 0};
+      } else {
+        qu.start = tsa_unwrap_lin(qu.start, rows, cols, s0, s1);
+        qu.goal = tsa_unwrap_lin(qu.goal, rows, cols, s0, s1);
+        const int si = qu.start % rows, sj = qu.start / rows, gi = qu.goal % rows, gj = qu.goal / rows;
+        s_si[ql] = si; s_sj[ql] = sj; s_gi[ql] = gi; s_gj[ql] = gj;
+        if (qu.goal != qu.start && nbr_tm[tm_index(gi, gj, tiles_i)] == 0) {
+          results[q] = rna_astar_result{1, 0, INF, 0, 0, 0};   // walled-in goal: nothing written
+        } else {
+          s_state[ql] = 0;
+          s_bucket[ql] = s_bucket0[ql] = tsa_octile(si, sj, gi, gj) / bucket_width;
+          unsigned* field = field_all + (size_t)q * field_stride;
+          unsigned* pend0 = pend_all + (size_t)q * pend_stride;
+          __hip_atomic_store(&field[tm_index(si, sj, tiles_i)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // g(start) = 0
+          const int ts = (sj >> 5) * tiles_i + (si >> 5);
+          atomicOr(&pend0[(size_t)ts * TS + (sj & 31)], 1u << (si & 31));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < QB && s_state[tid] == 0) {
+    const int ts = (s_sj[tid] >> 5) * tiles_i + (s_si[tid] >> 5);
+    act(tid, 0)[ts >> 5] = 1u << (ts & 31);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  TsaWave& W = s_w[wv];
+  int my_expanded[QB];
+#pragma unroll
+  for (int k = 0; k < QB; ++k) my_expanded[k] = 0;
+#ifdef RNA_TSA_STATS
+  unsigned long long tsa_acc[16] = {};
+  const unsigned long long t_life0 = wall_clock64();
+#endif
+
+  for (;;) {
+    // ---- 1. which searching queries still have tiles in their current bucket? ----
+    if (tid < QB) { s_any[tid] = 0; s_adv[tid] = 0; }
+    if (tid == 0) { s_njobs = 0; s_job_next = 0; s_first_fail = TSA_MQ_JOBS; s_running = 0; }
+    __syncthreads();
+#pragma unroll
+    for (int ql = 0; ql < QB; ++ql) {
+      if (s_state[ql] != 0) continue;
+      const unsigned* a = act(ql, 0);
+      unsigned any = 0u;
+      for (int w = tid; w < nt_words; w += TSA_THREADS) any |= a[w];
+      if (__ballot(any != 0u) && lane == 0) s_any[ql] = 1;
+    }
+    __syncthreads();
+    // ---- 2. a query whose bucket ran dry is at that bucket's fixed point: finish it or open the next bucket ----
+    if (tid < QB && s_state[tid] == 0 && !s_any[tid]) {
+      const int ql = tid;
+      const long long done_below = ((long long)s_bucket[ql] + 1) * bucket_width;
+      if (s_best[ql] != INF && (long long)s_best[ql] < done_below) s_state[ql] = 1;   // goal settled, ties included
+      else s_adv[ql] = 1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ql = 0; ql < QB; ++ql) {
+      if (!s_adv[ql]) continue;
+      unsigned* a0 = act(ql, 0);
+      unsigned* a1 = act(ql, 1);
+      unsigned any = 0u;
+      for (int w = tid; w < nt_words; w += TSA_THREADS) {
+        const unsigned b = a1[w];
+        a0[w] = b;
+        a1[w] = 0u;
+        any |= b;
+      }
+      if (__ballot(any != 0u) && lane == 0) s_any[ql] = 1;
+    }
+    __syncthreads();
+    if (tid < QB && s_adv[tid]) {
+      const int ql = tid;
+      if (!s_any[ql]) s_state[ql] = (s_best[ql] != INF) ? 1 : 2;   // nothing left anywhere
+      else { s_bucket[ql] += 1; s_role[ql] ^= 1; }
+    }
+    __syncthreads();
+    // ---- 3. this round's job list: the active tiles of every searching query ----
+#pragma unroll
+    for (int ql = 0; ql < QB; ++ql) {
+      if (s_state[ql] != 0) continue;
+      if (tid == 0) s_running = 1;
+      unsigned* a0 = act(ql, 0);
+      unsigned* tch = act(ql, 2);
+      for (int w = tid; w < nt_words; w += TSA_THREADS) {
+        unsigned bits = a0[w];
+        if (!bits) continue;
+        const int cnt = __popc(bits);
+        const int base = atomicAdd(&s_njobs, cnt);
+        if (base + cnt <= TSA_MQ_JOBS) {
+          a0[w] = 0u;
+          tch[w] |= bits;
+          int k = base;
+          while (bits) { const int b = __ffs(bits) - 1; bits &= bits - 1; s_jobs[k++] = ((unsigned)ql << 16) | (unsigned)((w << 5) + b); }
+        } else {
+          atomicMin(&s_first_fail, base);   // job list full: these tiles stay flagged for the next round
+        }
+      }
+    }
+    __syncthreads();
+    if (!s_running) break;
+    const int njobs = s_njobs < s_first_fail ? s_njobs : s_first_fail;
+    if (tid < QB && s_state[tid] == 0) s_rounds[tid] += 1;
+
+    // ---- 4. tile jobs: one wavefront per job ----
+    for (;;) {
+      int job = 0;
+      if (lane == 0) job = atomicAdd(&s_job_next, 1);
+      job = __shfl(job, 0);
+      if (job >= njobs) break;
+      const unsigned je = s_jobs[job];
+      const int ql = (int)(je >> 16), t = (int)(je & 0xffffu);
+      const int q = s_q[ql];
+      unsigned* field = field_all + (size_t)q * field_stride;
+      unsigned* pend0 = pend_all + (size_t)q * pend_stride;
+      const int role = s_role[ql];
+      const long long bucket_end = ((long long)s_bucket[ql] + 1) * bucket_width;
+      TsaLocalSched sch{&s_best[ql], &s_state[ql], act(ql, 0), act(ql, 1)};
+      TSA_CNT(7, 1);
+      const int ex = tsa_job(sch, W, lane, t, rows, cols, tiles_i, tiles_j, field, nbr_tm, pend0 + (size_t)role * pend_words,
+                             pend0 + (size_t)(role ^ 1) * pend_words, bucket_end, s_gi[ql], s_gj[ql] TSA_ACC_ARG);
+#pragma unroll
+      for (int k = 0; k < QB; ++k) my_expanded[k] += (k == ql) ? ex : 0;
+    }
+    // all stores / atomics of this round are performed before any wave loads tiles in the next one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < QB; ++k) atomicAdd(&s_expanded[k], my_expanded[k]);
+  __syncthreads();
+#ifdef RNA_TSA_STATS
+  tsa_acc[5] = wall_clock64() - t_life0;
+  if (lane == 0) for (int k = 0; k < 16; ++k) atomicAdd(&g_tsa_stat[k], tsa_acc[k]);
+#endif
+  // every tile a search wrote: its jobs plus the tiles that were handed cells but never ran
+  for (int ql = 0; ql < QB; ++ql) {
+    if (s_q[ql] < 0) continue;
+    unsigned* touched = touched_all + (size_t)s_q[ql] * nt_words;
+    const unsigned *a0 = act(ql, 0), *a1 = act(ql, 1), *tch = act(ql, 2);
+    for (int w = tid; w < nt_words; w += TSA_THREADS) touched[w] = tch[w] | a0[w] | a1[w];
+  }
+
+  // ---- canonical backtrace: wavefront ql serves query ql (lane k probes neighbour k) ----
+  if (wv < QB && s_q[wv] >= 0 && s_state[wv] != 5) {
+    const int ql = wv, q = s_q[ql];
+    const int state = s_state[ql];
+    const int n_buckets = s_bucket[ql] - s_bucket0[ql] + 1;
+    const unsigned* field = field_all + (size_t)q * field_stride;
+    if (state != 1) {
+      if (lane == 0) results[q] = rna_astar_result{state == 4 ? 4 : 1, 0, INF, s_expanded[ql], s_rounds[ql], n_buckets};
+    } else {
+      const int si = s_si[ql], sj = s_sj[ql];
+      int* rev = rev_all + (size_t)q * rev_cap;
+      int ci = s_gi[ql], cj = s_gj[ql];
+      int len = 0;
+      bool ok = true;
+      const int k = lane & 7;
+      const int w = (k == 1 || k == 3 || k == 4 || k == 6) ? COST_S : COST_D;
+      const int di = (k == 0 || k == 3 || k == 5) ? -1 : ((k == 2 || k == 4 || k == 7) ? 1 : 0);
+      const int dj = k < 3 ? -1 : (k > 4 ? 1 : 0);
+      for (;;) {
+        if (lane == 0 && len < rev_cap) rev[len] = cj * rows + ci;
+        ++len;
+        if (ci == si && cj == sj) break;
+        if (len > ncell) { ok = false; break; }
+        const int ni = ci + di, nj = cj + dj;
+        const bool inb = ni >= 0 && nj >= 0 && ni < rows && nj < cols;
+        const unsigned wc = ld_l2(&field[tm_index(ci, cj, tiles_i)]);
+        const unsigned mc = nbr_tm[tm_index(ci, cj, tiles_i)];
+        const unsigned wn = ld_l2(&field[inb ? tm_index(ni, nj, tiles_i) : tm_index(ci, cj, tiles_i)]);
+        const bool hit = lane < 8 && inb && ((mc >> k) & 1u) && ((wn >> 8) != G_INF) && ((wn >> 8) + (unsigned)w == (wc >> 8));
+        const unsigned long long mask = __ballot(hit);
+        if (!mask) { ok = false; break; }
+        const int src = __ffsll((long long)mask) - 1;
+        ci = __shfl(ni, src);
+        cj = __shfl(nj, src);
+      }
+      if (!ok) {
+        if (lane == 0) results[q] = rna_astar_result{1, 0, INF, s_expanded[ql], s_rounds[ql], n_buckets};
+      } else if (len > max_path_len || len > rev_cap) {
+        if (lane == 0) results[q] = rna_astar_result{3, len, s_best[ql], s_expanded[ql], s_rounds[ql], n_buckets};
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int32_t* path = paths + (size_t)q * max_path_len;
+        for (int i = lane; i < len; i += 64) path[i] = tsa_buffer_lin(rev[len - 1 - i], rows, cols, s0, s1);
+        if (lane == 0) results[q] = rna_astar_result{0, len, s_best[ql], s_expanded[ql], s_rounds[ql], n_buckets};
+      }
+    }
+  }
 }
 
 // |{n : g(n) + h(n) <= f*}| per query from the resident tile-major fields (measurement utility)
@@ -876,6 +1158,7 @@ struct TsaPersistArgs {
   const uint8_t* nbr_tm;       // tile-major neighbour masks (snapshot of this launch)
   unsigned* touched;           // [n][nt_words] tiles written by each query
   int* clean;                  // cleared on abort: the next launch rewrites every field
+  const int* perm;             // launch order (longest expected search first)
 };
 
 __global__ void tsa_persist_init_kernel(TsaPersistArgs A) {
@@ -908,7 +1191,7 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_persist_kernel(TsaPersistArgs
     // ---- unstarted queries first: the worker that starts a query binds it to its own XCD ----
     int qn = -1;
     if (lane == 0 && ld_i32(&A.ctl->next_query) < A.n) {
-      qn = atomicAdd(&A.ctl->next_query, 1);
+      qn = atomicAdd(&A.ctl->next_query, 1);   // caller's order: longest-first (A.perm) measured slower here
       if (qn >= A.n) qn = -1;
     }
     qn = __shfl(qn, 0);
@@ -1149,7 +1432,8 @@ bool tsa_supported(const rna_engine* e) {
 size_t tsa_aux_bytes(const rna_engine* e, int max_queries) {
   const size_t ti = (e->geom.size[0] + TS - 1) / TS, tj = (e->geom.size[1] + TS - 1) / TS;
   const size_t ntile = ti * tj;
-  return 256 + tsa_align256(ntile * TILE_WORDS) + tsa_align256((size_t)max_queries * ((ntile + 31) / 32) * 4);
+  return 256 + tsa_align256(ntile * TILE_WORDS) + tsa_align256((size_t)max_queries * ((ntile + 31) / 32) * 4) +
+         tsa_align256((size_t)max_queries * sizeof(int));
 }
 static TsaAux tsa_aux_view(const rna_engine* e, void* aux) {
   const size_t ti = (e->geom.size[0] + TS - 1) / TS, tj = (e->geom.size[1] + TS - 1) / TS;
@@ -1158,16 +1442,22 @@ static TsaAux tsa_aux_view(const rna_engine* e, void* aux) {
   v.clean = reinterpret_cast<int*>(base);
   v.nbr_tm = reinterpret_cast<uint8_t*>(base + 256);
   v.touched = reinterpret_cast<unsigned*>(base + 256 + tsa_align256(ti * tj * TILE_WORDS));
+  v.perm = reinterpret_cast<int*>(base + 256 + tsa_align256(ti * tj * TILE_WORDS) +
+                                  tsa_align256((size_t)e->astar.max_queries * ((ti * tj + 31) / 32) * 4));
   return v;
 }
 // snapshot the neighbour masks and bring every field of this stage back to "unreached"
 static void tsa_launch_init(rna_engine* e, hipStream_t stream, unsigned* field, size_t field_stride, unsigned* pend,
-                            size_t pend_stride, int max_queries, const TsaAux& aux) {
+                            size_t pend_stride, int max_queries, const TsaAux& aux, const rna_astar_query* q_dev, int n) {
   const int rows = e->geom.size[0], cols = e->geom.size[1];
   const int ti = (rows + TS - 1) / TS, tj = (cols + TS - 1) / TS;
   hipLaunchKernelGGL(tsa_init_kernel, dim3(4096), dim3(256), 0, stream, e->nbr, rows, cols, ti, tj, field, field_stride, pend,
                      pend_stride, max_queries, aux, e->geom.start[0], e->geom.start[1]);
   hipLaunchKernelGGL(tsa_mark_clean_kernel, dim3(1), dim3(1), 0, stream, aux.clean);
+  if (n <= 8192)
+    hipLaunchKernelGGL(tsa_order_kernel, dim3(1), dim3(1024), (size_t)n * sizeof(int), stream, q_dev, n, rows, cols, aux.perm);
+  else
+    hipLaunchKernelGGL(tsa_identity_order_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, aux.perm);
 }
 
 int tsa_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init, unsigned* field,
@@ -1178,7 +1468,7 @@ int tsa_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream
   const TsaAux aux = tsa_aux_view(e, aux_mem);
   {
     KernelTimer kt(e, RNA_K_ASTAR_INIT, init_stream);
-    tsa_launch_init(e, init_stream, field, field_stride, pend, pend_stride, max_queries, aux);
+    tsa_launch_init(e, init_stream, field, field_stride, pend, pend_stride, max_queries, aux, q_dev, n);
     RNA_HIP(e, hipGetLastError());
   }
   if (ev_init) {
@@ -1188,14 +1478,29 @@ int tsa_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream
   {
     KernelTimer kt(e, RNA_K_ASTAR_SEARCH, search_stream);
     const size_t nt_bytes = (size_t)((ti * tj + 31) / 32) * sizeof(unsigned);
-    if (e->astar.mode == 3)
+    // queries per workgroup: as many (<= 4) as the three bitsets per query leave room for in the 160 KB of LDS
+    int qb = 1;
+    if (const char* m = getenv("RNA_TSA_QUERIES_PER_BLOCK")) qb = atoi(m);
+    if (qb > 1) {   // opt-in: several queries per workgroup (fills thin rounds, but measured no faster when pipelined)
+      const size_t fixed = sizeof(TsaWave) * TSA_WAVES + sizeof(unsigned) * TSA_MQ_JOBS + 1024;
+      if (qb > 4) qb = 4;
+      if (qb == 3) qb = 2;
+      while (qb > 1 && fixed + 3 * nt_bytes * qb > 160 * 1024) qb >>= 1;
+    }
+#define RNA_LAUNCH_MQ(QB)                                                                                               \
+  hipLaunchKernelGGL(tsa_multi_kernel<QB>, dim3((n + QB - 1) / QB), dim3(TSA_THREADS), 3 * nt_bytes * QB, search_stream, rows,   \
+                     cols, ti, tj, q_dev, n, field, field_stride, pend, pend_stride, aux.nbr_tm, aux.touched,          \
+                     e->astar.bucket_width, paths_dev, max_len, rev, rev_cap, res_dev, e->geom.start[0], e->geom.start[1], aux.perm)
+    if (e->astar.mode == 1 && qb == 4) RNA_LAUNCH_MQ(4);
+    else if (e->astar.mode == 1 && qb == 2) RNA_LAUNCH_MQ(2);
+    else if (e->astar.mode == 3)
       hipLaunchKernelGGL(tsa_search_kernel<true>, dim3(n), dim3(TSA_THREADS), 4 * nt_bytes, search_stream, rows, cols, ti, tj, q_dev,
                          field, field_stride, pend, pend_stride, aux.nbr_tm, aux.touched, e->astar.bucket_width, paths_dev, max_len,
-                         rev, rev_cap, res_dev, e->geom.start[0], e->geom.start[1]);
+                         rev, rev_cap, res_dev, e->geom.start[0], e->geom.start[1], aux.perm);
     else
       hipLaunchKernelGGL(tsa_search_kernel<false>, dim3(n), dim3(TSA_THREADS), 3 * nt_bytes, search_stream, rows, cols, ti, tj, q_dev,
                          field, field_stride, pend, pend_stride, aux.nbr_tm, aux.touched, e->astar.bucket_width, paths_dev, max_len,
-                         rev, rev_cap, res_dev, e->geom.start[0], e->geom.start[1]);
+                         rev, rev_cap, res_dev, e->geom.start[0], e->geom.start[1], aux.perm);
     RNA_HIP(e, hipGetLastError());
   }
   return RNA_OK;
@@ -1203,8 +1508,16 @@ int tsa_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream
 
 #ifdef RNA_TSA_STATS
 void tsa_stats_dump() {
-  unsigned long long st[16];
+  unsigned long long st[32];
   if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_tsa_stat), sizeof(st)) != hipSuccess) return;
+  {
+    double rounds = 0, jj = 0;
+    for (int b = 0; b < 6; ++b) { rounds += (double)st[16 + b]; jj += (double)st[24 + b]; }
+    if (rounds > 0)
+      fprintf(stderr, "[tsa stats] rounds by jobs 1-4: %.1f%% (%.1f%% of jobs)  5-8: %.1f%% (%.1f%%)  9-16: %.1f%% (%.1f%%)  17-32: %.1f%% (%.1f%%)  33-64: %.1f%% (%.1f%%)  65+: %.1f%% (%.1f%%)\n",
+              100 * st[16] / rounds, 100 * st[24] / jj, 100 * st[17] / rounds, 100 * st[25] / jj, 100 * st[18] / rounds, 100 * st[26] / jj,
+              100 * st[19] / rounds, 100 * st[27] / jj, 100 * st[20] / rounds, 100 * st[28] / jj, 100 * st[21] / rounds, 100 * st[29] / jj);
+  }
   const double jobs = (double)st[7];
   if (jobs <= 0) return;
   const double busy = (double)(st[0] + st[1] + st[2] + st[3]);
@@ -1256,10 +1569,10 @@ int tsa_persist_launch(rna_engine* e, hipStream_t init_stream, hipStream_t searc
   A.tstate = reinterpret_cast<unsigned*>(base); A.tstate_stride = ts_stride; base += (size_t)max_queries * ts_stride * 4;
   A.far_act = reinterpret_cast<unsigned*>(base); A.far_stride = far_stride;
   const TsaAux aux = tsa_aux_view(e, aux_mem);
-  A.nbr_tm = aux.nbr_tm; A.touched = aux.touched; A.clean = aux.clean;
+  A.nbr_tm = aux.nbr_tm; A.touched = aux.touched; A.clean = aux.clean; A.perm = aux.perm;
   {
     KernelTimer kt(e, RNA_K_ASTAR_INIT, init_stream);
-    tsa_launch_init(e, init_stream, field, field_stride, pend, pend_stride, max_queries, aux);
+    tsa_launch_init(e, init_stream, field, field_stride, pend, pend_stride, max_queries, aux, q_dev, n);
     hipLaunchKernelGGL(tsa_persist_init_kernel, dim3(512), dim3(256), 0, init_stream, A);
     RNA_HIP(e, hipGetLastError());
   }
@@ -1281,9 +1594,9 @@ int tsa_persist_launch(rna_engine* e, hipStream_t init_stream, hipStream_t searc
 #ifdef RNA_TSA_STATS
   {
     RNA_HIP(e, hipStreamSynchronize(search_stream));
-    unsigned long long st[16];
+    unsigned long long st[32];
     RNA_HIP(e, hipMemcpyFromSymbol(st, HIP_SYMBOL(g_tsa_stat), sizeof(st)));
-    static const unsigned long long zero[16] = {};
+    static const unsigned long long zero[32] = {};
     RNA_HIP(e, hipMemcpyToSymbol(HIP_SYMBOL(g_tsa_stat), zero, sizeof(zero)));
     std::vector<TsaQ> qh(n);
     RNA_HIP(e, hipMemcpy(qh.data(), A.qstate, (size_t)n * sizeof(TsaQ), hipMemcpyDeviceToHost));
