@@ -91,7 +91,8 @@ struct TsaAux {
   int* clean;
   uint8_t* nbr_tm;      // [ntile][32][32] neighbour masks, 0 outside the map
   unsigned* touched;    // [max_queries][nt_words]
-  int* perm;            // [max_queries] launch order of this batch: workgroup b serves query perm[b]
+  int* perm;            // [max_queries] launch order of this batch: the k-th workgroup to START serves query perm[k]
+  int* ticket;          // next position of perm to hand out (reset by every launch's init)
 };
 __host__ __device__ inline size_t tsa_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -148,7 +149,7 @@ __global__ void tsa_init_kernel(const uint8_t* __restrict__ nbr, int rows, int c
     if (threadIdx.x == 0) aux.touched[item] = 0u;
   }
 }
-__global__ void tsa_mark_clean_kernel(int* clean) { *clean = 1; }
+__global__ void tsa_mark_clean_kernel(int* clean, int* ticket) { *clean = 1; *ticket = 0; }
 
 // Launch order of a batch: longest expected search first (key = Chebyshev distance start -> goal,
 // ties by index).  Workgroups are dispatched in index order and land on the XCDs round-robin, so this
@@ -493,14 +494,21 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
                   size_t pend_stride, const uint8_t* __restrict__ nbr_tm, unsigned* __restrict__ touched_all,
                   int bucket_width, int32_t* __restrict__ paths, int max_path_len,
                   int32_t* __restrict__ rev_all, int rev_cap, rna_astar_result* __restrict__ results, int s0, int s1,
-                  const int* __restrict__ perm) {
+                  const int* __restrict__ perm, int* __restrict__ ticket) {
   __shared__ TsaWave s_w[TSA_WAVES];
   extern __shared__ unsigned s_dyn[];   // tile bitsets, sized by the launch: (ASYNC ? 4 : 3) x ((ntile + 31) / 32) words
   __shared__ unsigned short s_jobs[ASYNC ? 2 : TSA_JOBS];
   __shared__ int s_njobs, s_first_fail, s_job_next, s_best, s_state, s_bucket, s_bucket0, s_rounds, s_role, s_expanded, s_len;
   __shared__ int s_outstanding;
 
-  const int q = perm[blockIdx.x];    // launch order: longest expected search first
+  // Workgroups take their query when they START (a ticket), not by blockIdx: the hardware deals workgroup
+  // indices round-robin to the XCDs, so a fixed mapping lets one XCD with several long searches hold back
+  // its share of the batch while the other XCDs idle.  With tickets a free CU anywhere takes the next
+  // (longest remaining) query.
+  __shared__ int s_q;
+  if (threadIdx.x == 0) s_q = perm[atomicAdd(ticket, 1)];
+  __syncthreads();
+  const int q = s_q;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   rna_astar_query qu = queries[q];   // buffer linear indices; the search itself runs in map space
   const int ncell = rows * cols;
@@ -1440,6 +1448,7 @@ static TsaAux tsa_aux_view(const rna_engine* e, void* aux) {
   char* base = static_cast<char*>(aux);
   TsaAux v;
   v.clean = reinterpret_cast<int*>(base);
+  v.ticket = reinterpret_cast<int*>(base + 64);
   v.nbr_tm = reinterpret_cast<uint8_t*>(base + 256);
   v.touched = reinterpret_cast<unsigned*>(base + 256 + tsa_align256(ti * tj * TILE_WORDS));
   v.perm = reinterpret_cast<int*>(base + 256 + tsa_align256(ti * tj * TILE_WORDS) +
@@ -1453,7 +1462,7 @@ static void tsa_launch_init(rna_engine* e, hipStream_t stream, unsigned* field, 
   const int ti = (rows + TS - 1) / TS, tj = (cols + TS - 1) / TS;
   hipLaunchKernelGGL(tsa_init_kernel, dim3(4096), dim3(256), 0, stream, e->nbr, rows, cols, ti, tj, field, field_stride, pend,
                      pend_stride, max_queries, aux, e->geom.start[0], e->geom.start[1]);
-  hipLaunchKernelGGL(tsa_mark_clean_kernel, dim3(1), dim3(1), 0, stream, aux.clean);
+  hipLaunchKernelGGL(tsa_mark_clean_kernel, dim3(1), dim3(1), 0, stream, aux.clean, aux.ticket);
   if (n <= 8192)
     hipLaunchKernelGGL(tsa_order_kernel, dim3(1), dim3(1024), (size_t)n * sizeof(int), stream, q_dev, n, rows, cols, aux.perm);
   else
@@ -1496,11 +1505,11 @@ int tsa_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream
     else if (e->astar.mode == 3)
       hipLaunchKernelGGL(tsa_search_kernel<true>, dim3(n), dim3(TSA_THREADS), 4 * nt_bytes, search_stream, rows, cols, ti, tj, q_dev,
                          field, field_stride, pend, pend_stride, aux.nbr_tm, aux.touched, e->astar.bucket_width, paths_dev, max_len,
-                         rev, rev_cap, res_dev, e->geom.start[0], e->geom.start[1], aux.perm);
+                         rev, rev_cap, res_dev, e->geom.start[0], e->geom.start[1], aux.perm, aux.ticket);
     else
       hipLaunchKernelGGL(tsa_search_kernel<false>, dim3(n), dim3(TSA_THREADS), 3 * nt_bytes, search_stream, rows, cols, ti, tj, q_dev,
                          field, field_stride, pend, pend_stride, aux.nbr_tm, aux.touched, e->astar.bucket_width, paths_dev, max_len,
-                         rev, rev_cap, res_dev, e->geom.start[0], e->geom.start[1], aux.perm);
+                         rev, rev_cap, res_dev, e->geom.start[0], e->geom.start[1], aux.perm, aux.ticket);
     RNA_HIP(e, hipGetLastError());
   }
   return RNA_OK;
