@@ -34,8 +34,8 @@ ASTAR_BYTES_PER_SETTLED = 44   # 8 neighbour occupancy reads x 4 B
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--grid", type=int, default=4096)
     ap.add_argument("--queries", type=int, default=256, help="A* queries == VFH poses per step (cycles per step)")
     ap.add_argument("--ray-poses", type=int, default=64)
@@ -221,7 +221,7 @@ def main():
                        "cycles_per_step": nq, "rays_per_step": int(len(rays)), "astar_paths_found": found,
                        "astar_bucket_width": args.bucket_width or 16000, "astar_pipeline_depth": args.pipeline, "parallelism": "query-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "tsa_search_kernel (astar_search)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("rna::tsa_search_kernel"),
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("rna::tsa_search_kernel<false>"),
                          "traffic_source": "profiles/r01_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                            "of this command (2*FETCH+WRITE)*1024 B per launch, see MI355X_MICROARCH.md",
                          "algorithmic_bytes_per_launch": alg_bytes, "settled_cells_per_launch": int(settled.sum()),

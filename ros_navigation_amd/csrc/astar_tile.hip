@@ -155,7 +155,7 @@ __global__ void tsa_mark_clean_kernel(int* clean, int* ticket) { *clean = 1; *ti
 // ties by index).  Workgroups are dispatched in index order and land on the XCDs round-robin, so this
 // both starts the long queries early and deals them evenly over the eight XCDs; with the caller's
 // (arbitrary) order one XCD regularly ended up with most of the long searches (+11 % throughput).
-__global__ void __launch_bounds__(1024) tsa_order_kernel(const rna_astar_query* __restrict__ queries, int n, int rows, int cols,
+__global__ void __launch_bounds__(256) tsa_order_kernel(const rna_astar_query* __restrict__ queries, int n, int rows, int cols,
                                                           int* __restrict__ perm) {
   extern __shared__ int s_key[];
   const int ncell = rows * cols;
@@ -1464,7 +1464,8 @@ static void tsa_launch_init(rna_engine* e, hipStream_t stream, unsigned* field, 
                      pend_stride, max_queries, aux, e->geom.start[0], e->geom.start[1]);
   hipLaunchKernelGGL(tsa_mark_clean_kernel, dim3(1), dim3(1), 0, stream, aux.clean, aux.ticket);
   if (n <= 8192)
-    hipLaunchKernelGGL(tsa_order_kernel, dim3(1), dim3(1024), (size_t)n * sizeof(int), stream, q_dev, n, rows, cols, aux.perm);
+    // one small workgroup: it has to fit next to the search workgroups that fill every CU when batches are pipelined
+    hipLaunchKernelGGL(tsa_order_kernel, dim3(1), dim3(256), (size_t)n * sizeof(int), stream, q_dev, n, rows, cols, aux.perm);
   else
     hipLaunchKernelGGL(tsa_identity_order_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, aux.perm);
 }
