@@ -638,6 +638,7 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
 
   for (;;) {
     // ---- build this round's job list from the active-tile bitset ----
+    TSA_T(t_r0);
     if (tid == 0) { s_njobs = 0; s_job_next = 0; s_first_fail = TSA_JOBS; }
     __syncthreads();
     for (int w = tid; w < nt_words; w += TSA_THREADS) {
@@ -697,6 +698,9 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
     const long long bucket_end = ((long long)s_bucket + 1) * bucket_width;
 
     // ---- tile jobs: one wavefront per job ----
+    TSA_T(t_r1);
+    TSA_ACC(4, t_r0, t_r1);   // list build + barriers of this round
+    TSA_CNT(6, 1);            // rounds (per wave)
     for (;;) {
       int job = 0;
       if (lane == 0) job = atomicAdd(&s_job_next, 1);
@@ -1531,9 +1535,10 @@ void tsa_stats_dump() {
   const double jobs = (double)st[7];
   if (jobs <= 0) return;
   const double busy = (double)(st[0] + st[1] + st[2] + st[3]);
-  fprintf(stderr, "[tsa stats, tile kernel, all launches] jobs %.0f | per job us: load %.2f relax %.2f wb %.2f handover %.2f | wave lifetime %.1f wave-ms, in jobs %.1f wave-ms (%.1f%%) | relax iters/job %.1f cells/iter %.1f\n",
+  fprintf(stderr, "[tsa stats, tile kernel, all launches] jobs %.0f | per job us: load %.2f relax %.2f wb %.2f handover %.2f | wave lifetime %.1f wave-ms, in jobs %.1f wave-ms (%.1f%%), in round set-up %.1f wave-ms (%.1f%%, %.2f us per round) | relax iters/job %.1f cells/iter %.1f\n",
           jobs, st[0] * 0.01 / jobs, st[1] * 0.01 / jobs, st[2] * 0.01 / jobs, st[3] * 0.01 / jobs, st[5] * 1e-5, busy * 1e-5,
-          100.0 * busy / (double)st[5], st[8] / jobs, st[9] / (double)std::max<unsigned long long>(1, st[8]));
+          100.0 * busy / (double)st[5], st[4] * 1e-5, 100.0 * (double)st[4] / (double)st[5], st[4] * 0.01 / (double)std::max<unsigned long long>(1, st[6]),
+          st[8] / jobs, st[9] / (double)std::max<unsigned long long>(1, st[8]));
 }
 #endif
 
