@@ -43,7 +43,11 @@ constexpr int TSA_MAX_TILE_WORDS = 2048;   // active-tile bitset words -> up to 
 #define RNA_TSA_JOBS 4096
 #endif
 constexpr int TSA_JOBS = RNA_TSA_JOBS;             // tile jobs per round (more stay flagged for the next round)
-constexpr int LQ = 1024;                   // per-wave local queue (u16 LDS positions): <= 1024 live entries (in-queue filter)
+#ifndef RNA_TSA_LQ
+#define RNA_TSA_LQ 1024
+#endif
+constexpr int LQ = RNA_TSA_LQ;   // per-wave local queue (u16 LDS positions, power of two).  Live entries are distinct interior cells
+                                 // (in-queue flag), so 1024 can never overflow; a smaller queue falls back to a rescan of the flags
 constexpr int COST_S = 1000, COST_D = 1414;
 constexpr int INF = 0x7fffffff;
 constexpr unsigned G_INF = 0xFFFFFFu;
@@ -274,21 +278,23 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
   TSA_ACC(0, t_a, t_b);
   // 3. seed the local queue from the pending bits
   int head = 0, tail = 0;   // wave-uniform
+  bool lq_full = false;     // a push did not fit: those cells keep their in-queue flag and are found by a rescan
   {
     unsigned bits = seed;   // lane jl holds the bits (il) of its column
     for (;;) {
       const bool has = bits != 0u;
       const unsigned long long m = __ballot(has);
       if (!m) break;
+      const int cnt = __popcll(m);
+      const bool fits = LQ >= TILE_WORDS || tail + cnt <= LQ;
       if (has) {
         const int il = __ffs(bits) - 1;
         bits &= bits - 1;
         const int p = (lane + 1) * TW + il + 1;
-        const int pos = tail + (int)tsa_rank(m);
-        W.lq[pos & (LQ - 1)] = (unsigned short)p;
+        if (fits) W.lq[(tail + (int)tsa_rank(m)) & (LQ - 1)] = (unsigned short)p;
         W.tile[p] |= 1u;
       }
-      tail += __popcll(m);
+      if (fits) tail += cnt; else lq_full = true;
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -307,7 +313,26 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
   const int bend = bucket_end > (long long)INF ? INF : (int)bucket_end;
   const int goal_p = (gi >= i0 && gi < i0 + TS && gj >= j0 && gj < j0 + TS) ? (gj - j0 + 1) * TW + (gi - i0 + 1) : -1;
   bool ovf = false;
-  while (tail != head) {
+  for (;;) {
+    if (tail == head) {
+      if (LQ >= TILE_WORDS || !lq_full) break;
+      // rare: the queue overflowed earlier; it is empty now, so every flagged cell is un-queued: queue them again
+      lq_full = false;
+#pragma unroll 1
+      for (int r = 0; r < TILE_WORDS / 64; ++r) {
+        const int pos = ((lane >> 5) + 1 + 2 * r) * TW + (lane & 31) + 1;
+        const unsigned long long fq = __builtin_amdgcn_ballot_w64((W.tile[pos] & 1u) != 0u);
+        const int cnt = __popcll(fq);
+        if (tail - head + cnt <= LQ) {
+          if (__builtin_amdgcn_inverse_ballot_w64(fq)) W.lq[(tail + (int)tsa_rank(fq)) & (LQ - 1)] = (unsigned short)pos;
+          tail += cnt;
+        } else if (cnt) {
+          lq_full = true;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (tail == head) break;
+    }
     const int n = tail - head;
     const int take = n < 64 ? n : 64;
     const bool act = lane < take;
@@ -361,9 +386,14 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
       const unsigned word = __builtin_amdgcn_inverse_ballot_w64(halo) ? (straight ? c_sh : c_dh) : (straight ? c_si : c_di);
       if (__builtin_amdgcn_inverse_ballot_w64(improve)) nb[off] = word;
       const unsigned long long push = improve & ~halo & ~inq;
-      if (__builtin_amdgcn_inverse_ballot_w64(push))
-        W.lq[(tail + (int)tsa_rank(push)) & (LQ - 1)] = (unsigned short)(pb + off);
-      tail += __popcll(push);
+      const int cnt = __popcll(push);
+      if (LQ >= TILE_WORDS || tail - head + cnt <= LQ) {
+        if (__builtin_amdgcn_inverse_ballot_w64(push))
+          W.lq[(tail + (int)tsa_rank(push)) & (LQ - 1)] = (unsigned short)(pb + off);
+        tail += cnt;
+      } else {
+        lq_full = true;   // the stored words carry the in-queue flag: the rescan picks these cells up
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
