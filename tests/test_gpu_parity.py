@@ -546,3 +546,60 @@ def test_astar_large_grid_properties(R):
         assert np.all((nbr[p[:-1]] >> kk) & 1)                          # each move allowed by the mask
         assert int(cost[kk].sum()) == res["cost"][k]
     e.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json's full sizes for the rows whose oracle is fast enough to run them whole
+# ------------------------------------------------------------------------------------------------
+def test_himm_full_ray_batch_on_4096_matches_oracle(R):
+    """Config 5's ray batch (100 032 rays from 64 origins, 1-6 m, 80 % hits) on the 4096 x 4096 bench map, applied
+    three times in a row (steady state: marks saturate, clears and marks interleave on shared cells): bit-exact."""
+    n = 4096
+    L = n * 0.05
+    e = R.Engine(L, L, 0.05)
+    g = O.make_geom(L, L, 0.05)
+    laser = R.synth.obstacles_rect(n, n, density=0.30, seed=2)
+    e.upload(R.capi.LAYER_LASER, laser)
+    ref = laser.copy()
+    for rep in range(3):
+        rays = R.synth.rays(64, 1563, L, L, seed=4 + rep)
+        O.himm_update(g, ref, rays.view(O.RAY_DTYPE))
+        e.update_map(rays, compose_mode=0)
+    assert same_f32(e.download(R.capi.LAYER_LASER), ref)
+    assert same_f32(e.download(R.capi.LAYER_MASTER), ref)       # fused dirty-tile compose == whole-layer copy
+    e.close()
+
+
+def test_vfh_config2_full_batch_matches_oracle(R):
+    """Config 2 as BASELINE.json states it: 1024 x 1024 grid (2 % occupied, 10 % unknown), 1024 poses, Steerer
+    parameters, two consecutive steps (the second one exercises the stateful binary histogram)."""
+    n = 1024
+    L = n * 0.05
+    e = R.Engine(L, L, 0.05)
+    g = O.make_geom(L, L, 0.05)
+    master = R.synth.occupancy_sparse(n, n, seed=1)
+    e.upload(R.capi.LAYER_MASTER, master)
+    poses = R.synth.poses(1024, L, L, seed=1)
+    e.vfh_init(len(poses))
+    check_vfh_vs_oracle(R, e, g, master, poses, steps=2)
+    e.close()
+
+
+def test_rrt_config4_sample_matches_oracle(R):
+    """Config 4's map (2048 x 2048, 30 % rectangles, seed 3): a sample of its queries against the oracle --
+    status, tree size, sample count exact; way points at 1e-9 m."""
+    n = 2048
+    L = n * 0.05
+    e = R.Engine(L, L, 0.05)
+    g = O.make_geom(L, L, 0.05)
+    master = R.synth.obstacles_rect(n, n, density=0.30, seed=3)
+    e.upload(R.capi.LAYER_MASTER, master)
+    q = R.synth.rrt_queries(24, master, n, n, e.get_position, seed=3, max_samples=20000)
+    res, paths = e.rrt(q)
+    for k in range(len(q)):
+        ores, opath = O.rrt_plan(g, master, tuple(q["start"][k]), tuple(q["target"][k]), tol=0.2,
+                                 seed=int(q["seed"][k]), max_samples=int(q["max_samples"][k]))
+        assert (res["status"][k], res["tree_size"][k], res["samples"][k], res["path_len"][k]) == \
+               (ores.status, ores.tree_size, ores.samples, ores.path_len), k
+        assert np.allclose(paths[k, :ores.path_len], opath, rtol=0, atol=1e-9), k
+    e.close()
