@@ -545,6 +545,15 @@ def test_astar_large_grid_properties(R):
         assert np.all(off[np.clip(kk, 0, 7)] == d)                      # only the 8 neighbour offsets
         assert np.all((nbr[p[:-1]] >> kk) & 1)                          # each move allowed by the mask
         assert int(cost[kk].sum()) == res["cost"][k]
+    # and the first few queries against the CPU oracle at this size: path, cost, settled count
+    settled = e.astar_settled(len(q))
+    _, onbr = O.astar_masks(master, n, n)
+    assert np.array_equal(onbr, nbr)
+    gw = np.empty(n * n, np.int32)
+    for k in range(6):
+        ores, opath, _ = O.astar_query(onbr, n, n, q["start"][k], q["goal"][k], g_work=gw)
+        assert ores.status == 0 and ores.cost == res2["cost"][k] and ores.settled == settled[k]
+        assert np.array_equal(opath, paths2[k, :res2["path_len"][k]])
     e.close()
 
 
