@@ -51,6 +51,14 @@ bytes_pose = 4 * 31 * 31 + 2 * 72 * 4 + 32
 gbs = len(poses) * bytes_pose / (prof["vfh_step"] * 1e-3) / 1e9
 out["config2_vfh"] = dict(workload="1024x1024 grid, 1024 poses, Steerer VFH params", poses_per_s=len(poses) / wall,
                           kernel_ms=prof["vfh_step"], algorithmic_bytes_per_pose=bytes_pose, achieved_gbs=gbs, frac=gbs / PEAK)
+# the same kernel with a batch that fills the GPU (16 384 poses): the 1024-pose row is launch-latency bound
+poses16 = R.synth.poses(16384, n * 0.05, n * 0.05, seed=2)
+e.vfh_init(len(poses16))
+d_p16, d_o16 = dev(poses16), torch.zeros(len(poses16) * 16, dtype=torch.uint8, device="cuda")
+wall16, prof16 = timed(e, lambda: e.vfh_step_device(d_p16.data_ptr(), len(poses16), d_o16.data_ptr()), 50)
+gbs16 = len(poses16) * bytes_pose / (prof16["vfh_step"] * 1e-3) / 1e9
+out["vfh_16384_poses"] = dict(workload="1024x1024 grid, 16384 poses", poses_per_s=len(poses16) / wall16, kernel_ms=prof16["vfh_step"],
+                              achieved_gbs=gbs16, frac=gbs16 / PEAK)
 e.close()
 
 # ---- HIMM: 100k-ray batch (config 5's ray batch) on 4096^2 ------------------------------------------
