@@ -219,33 +219,80 @@ __device__ bool wave_if_blocked(const Geom& g, const float* __restrict__ master,
   const int ni = tu[0] - su[0] + 1, nj = tu[1] - su[1] + 1;
   bool hit = false;
   const int total = (ni > 0 && nj > 0) ? ni * nj : 0;
-  for (int k = lane; k < total; k += 64) {
-    const int u[2] = {su[0] + k % ni, su[1] + k / ni};
-    int bi[2];
-    buffer_index(g, u, bi);
-    double p[2];
-    position_from_index(g, bi, p);
-    const double dx = p[0] - px, dy = p[1] - py;
-    if (dx * dx + dy * dy <= r2) {
-      const float v = master[(size_t)bi[1] * g.size[0] + bi[0]];
-      if (!(v != v) && v > 0.0f) hit = true;
+  // three cells per lane and trip (the 0.3 m disc at 0.05 m resolution spans <= 169 cells): the map reads of one
+  // trip are issued together, so the test costs one memory round trip instead of three
+  for (int k0 = lane; k0 < total; k0 += 192) {
+    float v[3];
+    bool in[3];
+#pragma unroll
+    for (int u3 = 0; u3 < 3; ++u3) {
+      const int k = k0 + 64 * u3;
+      in[u3] = false;
+      v[u3] = 0.0f;
+      if (k < total) {
+        const int u[2] = {su[0] + k % ni, su[1] + k / ni};
+        int bi[2];
+        buffer_index(g, u, bi);
+        double p[2];
+        position_from_index(g, bi, p);
+        const double dx = p[0] - px, dy = p[1] - py;
+        in[u3] = dx * dx + dy * dy <= r2;
+        if (in[u3]) v[u3] = master[(size_t)bi[1] * g.size[0] + bi[0]];
+      }
     }
+#pragma unroll
+    for (int u3 = 0; u3 < 3; ++u3)
+      if (in[u3] && !(v[u3] != v[u3]) && v[u3] > 0.0f) hit = true;
   }
   return __ballot(hit) != 0ULL;
 }
+
+// Wave-wide minimum of (non-negative double, index) pairs -- smallest value, lowest index among equals --
+// with DPP row shifts / row broadcasts instead of six rounds of ds_bpermute shuffles (which were two
+// thirds of the nearest-node time).  All 64 lanes must be active; every lane receives the result.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_min_step(unsigned& lo, unsigned& hi, int& idx) {
+  const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xF, false);
+  const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xF, false);
+  const int oidx = __builtin_amdgcn_update_dpp(idx, idx, CTRL, ROW_MASK, 0xF, false);
+  const unsigned long long a = ((unsigned long long)ohi << 32) | olo, b = ((unsigned long long)hi << 32) | lo;
+  if (a < b || (a == b && oidx < idx)) { lo = olo; hi = ohi; idx = oidx; }
+}
+__device__ __forceinline__ void wave_min_pair(double& v, int& idx) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(v);   // v >= 0: bit order == value order
+  unsigned lo = (unsigned)bits, hi = (unsigned)(bits >> 32);
+  dpp_min_step<0x111, 0xF>(lo, hi, idx);   // row_shr:1
+  dpp_min_step<0x112, 0xF>(lo, hi, idx);   // row_shr:2
+  dpp_min_step<0x114, 0xF>(lo, hi, idx);   // row_shr:4
+  dpp_min_step<0x118, 0xF>(lo, hi, idx);   // row_shr:8  -> lane 15 of every row holds the row minimum
+  dpp_min_step<0x142, 0xA>(lo, hi, idx);   // row_bcast:15 into rows 1 and 3
+  dpp_min_step<0x143, 0xC>(lo, hi, idx);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave minimum
+  lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+  hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
+  idx = __builtin_amdgcn_readlane(idx, 63);
+  v = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+#ifdef RNA_RRT_STATS
+__device__ unsigned long long g_rrt_stat[8];
+#define RRT_T(v) const unsigned long long v = wall_clock64()
+#define RRT_ACC(slot, a, b) rrt_acc[slot] += (b) - (a)
+#else
+#define RRT_T(v)
+#define RRT_ACC(slot, a, b)
+#endif
 
 __global__ void __launch_bounds__(64 * RRT_WAVES)
 rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __restrict__ queries, int n,
            int* __restrict__ tree_parent,
            double* __restrict__ paths, int max_path_len, rna_rrt_result* __restrict__ results) {
   __shared__ RandState s_rng[RRT_WAVES];
-  __shared__ double s_tx[RRT_WAVES][RRT_ITER], s_ty[RRT_WAVES][RRT_ITER];   // the tree of each wave's query: 32 KB per wave
+  __shared__ double2 s_t[RRT_WAVES][RRT_ITER];   // node positions of each wave's query: 32 KB per wave, one 16-byte LDS read per node
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int q = blockIdx.x * RRT_WAVES + wave;
   if (q >= n) return;
   const rna_rrt_query qu = queries[q];
-  double* const tx = s_tx[wave];
-  double* const ty = s_ty[wave];
+  double2* const tn = s_t[wave];
   int* tp = tree_parent + (size_t)q * RRT_ITER;
   RandState& rs = s_rng[wave];
   if (lane == 0) rng_seed(rs, qu.seed);
@@ -256,13 +303,16 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
   const double pbx = g.pos[0] + g.len[0] / 2, pby = g.pos[1] + g.len[1] / 2;
   const double mbx = g.pos[0] - g.len[0] / 2, mby = g.pos[1] - g.len[1] / 2;
 
+#ifdef RNA_RRT_STATS
+  unsigned long long rrt_acc[8] = {};
+#endif
   double nx = qu.start[0], ny = qu.start[1];
   int nparent = -1;
   int n_tree = 0, samples = 0;
   bool finished = false, aborted = false;
 
   for (int it = 0; it < RRT_ITER && !aborted; ++it) {
-    if (lane == 0) { tx[n_tree] = nx; ty[n_tree] = ny; tp[n_tree] = nparent; }
+    if (lane == 0) { tn[n_tree] = make_double2(nx, ny); tp[n_tree] = nparent; }
     n_tree++;
     __builtin_amdgcn_wave_barrier();
     bool fin;  // ifFinishPlan, map_global_planner.h:32-37,56-86
@@ -274,6 +324,7 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
     for (;;) {  // extendTree, rrt_planner.cpp:26-59
       if (samples >= qu.max_samples) { aborted = true; break; }
       samples++;
+      RRT_T(t0);
       int r0 = 0, r1 = 0, r2 = 0;
       if (lane == 0) {
         r0 = rng_next(rs);
@@ -289,34 +340,52 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
       } else {
         rx = qu.target[0]; ry = qu.target[1];
       }
+      RRT_T(t1);
+      RRT_ACC(0, t0, t1);
       // findNearNode, rrt_planner.cpp:70-89 : strict < on hypot() keeps the lowest index among equals.
       // hypot costs ~10x a squared distance, so the scan runs on squared distances first; hypot (error
       // < 1 ulp, i.e. 2^-52 relative) can only reorder nodes whose squared distances agree to within
       // 2^-48, and exactly those are re-examined with hypot in the reference's order.
-      double m2 = 1.0e300;
+      // One pass: every lane keeps its nearest node by squared distance (lowest index among equals) and
+      // its second-smallest squared distance.  After the wave reduction, hypot is evaluated for at most one
+      // node per lane; only if some lane holds TWO nodes inside the 2^-46 band (practically never) the
+      // band is rescanned in full.
+      double l1 = 1.0e300, l2 = 1.0e300;
+      int i1 = 0x7fffffff;
       for (int i = lane; i < n_tree; i += 64) {
-        const double dx = rx - tx[i], dy = ry - ty[i];
+        const double2 t = tn[i];
+        const double dx = rx - t.x, dy = ry - t.y;
         const double d2 = dx * dx + dy * dy;
-        m2 = d2 < m2 ? d2 : m2;
+        if (d2 < l1) { l2 = l1; l1 = d2; i1 = i; }
+        else if (d2 < l2) l2 = d2;
       }
-      for (int o = 32; o >= 1; o >>= 1) { const double om = __shfl_xor(m2, o); m2 = om < m2 ? om : m2; }
+      double m2 = l1;
+      int imin = i1;
+      wave_min_pair(m2, imin);                       // nearest by squared distance, lowest index among equals
       const double band = m2 + m2 * 0x1p-46 + 1.0e-300;
       double best = 9999.0;
       int best_i = 0x7fffffff;
-      for (int i = lane; i < n_tree; i += 64) {
-        const double dx = rx - tx[i], dy = ry - ty[i];
-        if (dx * dx + dy * dy <= band) {
-          const double d = hypot(dx, dy);
-          if (d < best) { best = d; best_i = i; }
+      if (__ballot(l2 <= band || (l1 <= band && i1 != imin)) == 0ull) {
+        // the usual case: no other node within the band, the answer is imin (if it beats the reference's 9999 start)
+        if (imin != 0x7fffffff) {
+          const double2 t = tn[imin];
+          if (hypot(rx - t.x, ry - t.y) < best) best_i = imin;
         }
-      }
-      for (int o = 32; o >= 1; o >>= 1) {
-        const double ob = __shfl_xor(best, o);
-        const int oi = __shfl_xor(best_i, o);
-        if (ob < best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+      } else {
+        for (int i = lane; i < n_tree; i += 64) {
+          const double2 t = tn[i];
+          const double dx = rx - t.x, dy = ry - t.y;
+          if (dx * dx + dy * dy <= band) {
+            const double d = hypot(dx, dy);
+            if (d < best) { best = d; best_i = i; }
+          }
+        }
+        wave_min_pair(best, best_i);
       }
       const int near = (best_i == 0x7fffffff) ? 0 : best_i;
-      const double npx = tx[near], npy = ty[near];
+      RRT_T(t2);
+      RRT_ACC(1, t1, t2);
+      const double npx = tn[near].x, npy = tn[near].y;
       double wx, wy;
       if (hypot(npx - rx, npy - ry) < strideStep) { wx = rx; wy = ry; }
       else {
@@ -324,7 +393,12 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
         wx = npx + strideStep * cos(a);
         wy = npy + strideStep * sin(a);
       }
-      if (!wave_if_blocked(g, master, wx, wy, lane)) { nx = wx; ny = wy; nparent = near; break; }
+      RRT_T(t3);
+      RRT_ACC(2, t2, t3);
+      const bool blocked = wave_if_blocked(g, master, wx, wy, lane);
+      RRT_T(t4);
+      RRT_ACC(3, t3, t4);
+      if (!blocked) { nx = wx; ny = wy; nparent = near; break; }
     }
   }
 
@@ -334,7 +408,7 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
     double* out = paths + (size_t)q * max_path_len * 2;
     int i = n_tree - 1;
     for (;;) {
-      if (lane == 0 && len < max_path_len) { out[2 * len] = tx[i]; out[2 * len + 1] = ty[i]; }
+      if (lane == 0 && len < max_path_len) { out[2 * len] = tn[i].x; out[2 * len + 1] = tn[i].y; }
       len++;
       const int par = tp[i];
       if (par == -1) break;
@@ -342,6 +416,9 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
     }
   }
   if (lane == 0) results[q] = rna_rrt_result{aborted ? -1 : (finished ? 1 : 0), len, n_tree, samples};
+#ifdef RNA_RRT_STATS
+  if (lane == 0) { for (int k = 0; k < 4; ++k) atomicAdd(&g_rrt_stat[k], rrt_acc[k]); atomicAdd(&g_rrt_stat[4], (unsigned long long)samples); }
+#endif
 }
 
 }  // namespace
@@ -413,6 +490,18 @@ static int rrt_launch(rna_engine* e, const rna_rrt_query* q_dev, int n, double* 
   hipLaunchKernelGGL(rrt_kernel, dim3((n + RRT_WAVES - 1) / RRT_WAVES), dim3(64 * RRT_WAVES), 0, e->stream, e->geom,
                      e->layer[RNA_LAYER_MASTER], q_dev, n, *tp, paths_dev, max_len, res_dev);
   RNA_HIP(e, hipGetLastError());
+#ifdef RNA_RRT_STATS
+  {
+    RNA_HIP(e, hipStreamSynchronize(e->stream));
+    unsigned long long st[8];
+    RNA_HIP(e, hipMemcpyFromSymbol(st, HIP_SYMBOL(g_rrt_stat), sizeof(st)));
+    static const unsigned long long zero[8] = {};
+    RNA_HIP(e, hipMemcpyToSymbol(HIP_SYMBOL(g_rrt_stat), zero, sizeof(zero)));
+    const double ns = (double)st[4];
+    fprintf(stderr, "[rrt stats] samples %.0f | per sample us: rng+sample %.2f  nearest %.2f  steer %.2f  ifBlocked %.2f\n", ns,
+            st[0] * 0.01 / ns, st[1] * 0.01 / ns, st[2] * 0.01 / ns, st[3] * 0.01 / ns);
+  }
+#endif
   return RNA_OK;
 }
 
