@@ -275,6 +275,32 @@ def test_astar_paths_bit_identical(R, rows, cols, density, seed):
     e.close()
 
 
+@pytest.mark.parametrize("env", [{"RNA_ASTAR_KERNEL": "frontier"}, {"RNA_ASTAR_KERNEL": "persist"}, {"RNA_ASTAR_KERNEL": "async"},
+                                 {"RNA_TSA_QUERIES_PER_BLOCK": "2"}, {"RNA_TSA_QUERIES_PER_BLOCK": "4"}])
+def test_astar_opt_in_kernels_keep_the_contract(R, env):
+    """The default is the tile-synchronous kernel; the fallback frontier kernel, the persistent cross-CU scheduler,
+    the barrier-free variant and the several-queries-per-workgroup kernel are selected by environment variables
+    read when an engine first plans.  All of them must reproduce the oracle's paths, costs and settled counts, also
+    when the same engine is reused for a second, different batch (the lazy field reset)."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        e = R.Engine(200 * 0.05, 120 * 0.05, 0.05)
+        master = R.synth.obstacles_rect(e.rows, e.cols, density=0.3, seed=12)
+        e.upload(R.capi.LAYER_MASTER, master)
+        for seed in (1, 2):
+            q = R.synth.astar_queries(40, master, e.rows, e.cols, seed=seed)
+            q["goal"][0] = q["start"][0]
+            check_astar(R, e, master, q, e.ncell, max_queries=64, bucket_width=4000)
+        e.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_astar_invalid_and_short_buffer(R):
     e = R.Engine(3.2, 3.2, 0.05)
     master = np.zeros(e.ncell, np.float32)
