@@ -122,8 +122,15 @@ def main():
     rank, local_rank, world = D.env_rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
+    # developer switch: RNA_BENCH_SHARE_GPU=1 runs every rank on cuda:0 with a gloo barrier, to exercise the
+    # multi-rank code path on a one-GPU box (RCCL refuses two ranks on one device)
+    share = os.environ.get("RNA_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = D.init("nccl", torch.device("cuda", local_rank)) if world > 1 else None
+    dist = None
+    if world > 1:
+        dist = D.init("gloo") if share else D.init("nccl", torch.device("cuda", local_rank))
 
     n = args.grid
     length = n * 0.05
@@ -203,7 +210,7 @@ def main():
         raise SystemExit("A* batch did not complete (status %s)" % sorted(set(res[:, 0].tolist())))
     settled = e.astar_settled(nq)          # E per query of the last launch, from the resident g fields
 
-    t_max = D.max_over_ranks(elapsed, dev) if world > 1 else elapsed
+    t_max = D.max_over_ranks(elapsed, "cpu" if share else dev) if world > 1 else elapsed
 
     if rank == 0:
         cycles = args.queries * world * args.steps
