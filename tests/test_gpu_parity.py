@@ -301,6 +301,81 @@ def test_astar_opt_in_kernels_keep_the_contract(R, env):
                 os.environ[k] = v
 
 
+class _Hip:
+    """device buffers for the *_device entry points, through the HIP runtime librna.so itself links"""
+
+    def __init__(self):
+        self.h = C.CDLL("libamdhip64.so")
+        self.h.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.h.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.h.hipFree.argtypes = [C.c_void_p]
+
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        assert self.h.hipMalloc(C.byref(p), nbytes) == 0
+        return p.value
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        p = self.alloc(a.nbytes)
+        assert self.h.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0
+        return p
+
+    def download(self, p, dtype, count):
+        out = np.empty(count, dtype)
+        assert self.h.hipMemcpy(out.ctypes.data, p, out.nbytes, 2) == 0
+        return out
+
+    def free(self, p):
+        self.h.hipFree(p)
+
+
+def test_astar_pipelined_batches_with_map_updates_in_between(R):
+    """The bench's usage pattern: rna_update_map_device -> rna_astar_batch_device, repeated without waiting, with
+    four batches in flight on rotating streams and search fields.  Every batch must see exactly the map of its own
+    launch time (the neighbour-mask snapshot) and clean fields (the lazy reset of the stage it reuses)."""
+    hip = _Hip()
+    e = R.Engine(25.6, 25.6, 0.05)   # 512 x 512
+    g = O.make_geom(25.6, 25.6, 0.05)
+    ref = R.synth.obstacles_rect(e.rows, e.cols, density=0.25, seed=4)
+    e.upload(R.capi.LAYER_LASER, ref)
+    e.compose_master(1)
+    e.astar_pipeline_depth(4)
+    e.astar_configure(max_queries=48, bucket_width=6000)
+    nb, nq, max_len = 7, 48, 4096
+    rng = np.random.default_rng(3)
+    maps, queries, outs, bufs = [], [], [], []
+    for b in range(nb):
+        rays = random_rays(rng, 600, 10.0, outside=0.0)
+        O.himm_update(g, ref, rays)
+        d_rays = hip.upload(rays)
+        e.update_map_device(d_rays, len(rays), compose_mode=0)
+        free = np.flatnonzero(~(np.isfinite(ref) & (ref > 0)))
+        q = np.zeros(nq, R.capi.ASTAR_QUERY_DTYPE)
+        q["start"], q["goal"] = rng.choice(free, nq), rng.choice(free, nq)
+        d_q, d_paths, d_res = hip.upload(q), hip.alloc(nq * max_len * 4), hip.alloc(nq * 24)
+        e.astar_device(d_q, nq, d_paths, max_len, d_res)          # asynchronous: no wait before the next map update
+        maps.append(ref.copy()); queries.append(q); outs.append((d_paths, d_res)); bufs += [d_rays, d_q, d_paths, d_res]
+    e.synchronize()
+    found = 0
+    for b in range(nb):
+        res = hip.download(outs[b][1], np.int32, nq * 6).reshape(nq, 6)
+        paths = hip.download(outs[b][0], np.int32, nq * max_len).reshape(nq, max_len)
+        _, nbr = O.astar_masks(maps[b], e.rows, e.cols)
+        for k in range(nq):
+            ores, opath, _ = O.astar_query(nbr, e.rows, e.cols, queries[b]["start"][k], queries[b]["goal"][k])
+            assert res[k, 0] == (0 if ores.status == 0 else 1), (b, k)
+            if ores.status == 0:
+                assert res[k, 1] == ores.path_len and res[k, 2] == ores.cost, (b, k)
+                assert np.array_equal(paths[k, :ores.path_len], opath), (b, k)
+                found += 1
+    assert found > nb * nq // 2
+    assert same_f32(e.download(R.capi.LAYER_MASTER), ref)
+    for p in bufs:
+        hip.free(p)
+    e.close()
+
+
 def test_astar_invalid_and_short_buffer(R):
     e = R.Engine(3.2, 3.2, 0.05)
     master = np.zeros(e.ncell, np.float32)
