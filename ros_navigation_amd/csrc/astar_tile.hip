@@ -205,8 +205,9 @@ __device__ unsigned long long g_tsa_stat[32];
 #define TSA_CNT(slot, v)
 #endif
 
+constexpr int TSA_SCRATCH = 2 * TW + 4;   // words behind the tile that idle lanes of a relaxation step read and rewrite
 struct alignas(16) TsaWave {
-  unsigned tile[TW * TW];        // (g << 8) | job flags, halo included; index (jl+1)*TW + (il+1).  Flags: bit0 in
+  unsigned tile[TW * TW + TSA_SCRATCH];   // (g << 8) | job flags, halo included; index (jl+1)*TW + (il+1).  Flags: bit0 in
                                  // the local queue, bit1 halo cell improved by this job, bit2 interior cell
                                  // improved beyond the current bucket
   unsigned short lq[LQ];         // local queue of LDS positions
@@ -276,6 +277,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
 
   TSA_T(t_b);
   TSA_ACC(0, t_a, t_b);
+  if (lane < TSA_SCRATCH) W.tile[TW * TW + lane] = 0xFFFFFF00u;   // scratch words behind the tile (see the relaxation loop)
   // 3. seed the local queue from the pending bits
   int head = 0, tail = 0;   // wave-uniform
   bool lq_full = false;     // a push did not fit: those cells keep their in-queue flag and are found by a rescan
@@ -336,14 +338,16 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
     const int n = tail - head;
     const int take = n < 64 ? n : 64;
     const bool act = lane < take;
-    const int p = act ? (int)W.lq[(head + lane) & (LQ - 1)] : (TW + 1);
+    // lanes without a cell point at the scratch words behind the tile: every lane can then run the same
+    // unpredicated read-select-write per direction without ever touching a cell another lane updates
+    const int p = act ? (int)W.lq[(head + lane) & (LQ - 1)] : (TW * TW + TW + 1);
     head += take;
     TSA_CNT(8, 1);
     TSA_CNT(9, take);
     const unsigned cw = W.tile[p];
     const int g = (int)(cw >> 8);
     const int pil = p % TW - 1, pjl = p / TW - 1;
-    const unsigned mk = W.mask[pjl * TS + pil];
+    const unsigned mk = W.mask[act ? pjl * TS + pil : 0];
     const unsigned ax = (unsigned)abs(i0 + pil - gi), ay = (unsigned)abs(j0 + pjl - gj);
     const int fc = g + (int)(__umul24(ax > ay ? ax : ay, COST_S) + __umul24(ax > ay ? ay : ax, COST_D - COST_S));
     const int sb = sch.best();
@@ -351,13 +355,17 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
     const bool live = act && fc <= best_now;      // else pruned: f > upper bound on f*
     const bool later = live && fc >= bend;        // belongs to a later bucket: flag it, do not expand
     if (act) W.tile[p] = (cw & ~1u) | (later ? 4u : 0u);   // popped: may be queued again
-    bool ok = live && !later;
-    if (ok) {
-      ++expanded;
-      if (p == goal_p) { sch.improve_best(g); ok = false; }
-      else if (g >= (int)G_INF - 3 * COST_D) { ovf = true; ok = false; }   // 24-bit g exhausted
+    const bool ex = live && !later;               // this lane expands its cell
+    expanded += ex ? 1 : 0;
+    // rare events, kept out of the straight-line path: the popped cell is the goal (tighten the bound, do not
+    // expand it), or its g is about to leave the 24-bit range
+    const bool at_goal = ex && p == goal_p;
+    const bool too_far = ex && g >= (int)G_INF - 3 * COST_D;
+    if (__builtin_amdgcn_ballot_w64(at_goal || too_far)) {
+      if (at_goal) sch.improve_best(g);
+      ovf |= too_far;
     }
-    const unsigned m = ok ? mk : 0u;
+    const unsigned m = (ex && !at_goal && !too_far) ? mk : 0u;
     // candidate words of a straight / diagonal step: new g in the high bits; "| 0xff" for the test
     // g + w < g(neighbour) on whole words; flag byte of the stored word = in-queue (interior) or
     // halo-dirty.  Old flags need not be kept: a re-queued cell is re-tested when it is popped.
@@ -369,6 +377,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
     // keep these in registers: recomputing them from g in every direction costs more than it saves
     asm volatile("" : "+v"(pb), "+v"(c_st), "+v"(c_dt), "+v"(c_si), "+v"(c_sh), "+v"(c_di), "+v"(c_dh));
     unsigned* const nb = &W.tile[pb];
+    const unsigned nm = ~m;
     const unsigned long long il_lo = __builtin_amdgcn_ballot_w64(pil == 0), il_hi = __builtin_amdgcn_ballot_w64(pil == TS - 1);
     const unsigned long long jl_lo = __builtin_amdgcn_ballot_w64(pjl == 0), jl_hi = __builtin_amdgcn_ballot_w64(pjl == TS - 1);
 #pragma unroll
@@ -378,13 +387,14 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
       const int off = (di + 1) + (dj + 1) * TW;
       const bool straight = (k == 1 || k == 3 || k == 4 || k == 6);
       const unsigned nwv = nb[off];
-      const unsigned long long valid = __builtin_amdgcn_ballot_w64((m & (1u << k)) != 0u);
-      const unsigned long long lt = __builtin_amdgcn_ballot_w64((straight ? c_st : c_dt) < nwv);   // g + w < g(neighbour)
+      // candidate word, all ones where direction k is not allowed (bit k of ~m set): "candidate < neighbour" is
+      // then the whole improvement test g + w < g(neighbour)
+      const unsigned cand = (straight ? c_st : c_dt) | (unsigned)__builtin_amdgcn_sbfe((int)nm, k, 1);
+      const unsigned long long improve = __builtin_amdgcn_ballot_w64(cand < nwv);
       const unsigned long long inq = __builtin_amdgcn_ballot_w64((nwv & 1u) != 0u);
       const unsigned long long halo = (di < 0 ? il_lo : (di > 0 ? il_hi : 0ull)) | (dj < 0 ? jl_lo : (dj > 0 ? jl_hi : 0ull));
-      const unsigned long long improve = valid & lt;
       const unsigned word = __builtin_amdgcn_inverse_ballot_w64(halo) ? (straight ? c_sh : c_dh) : (straight ? c_si : c_di);
-      if (__builtin_amdgcn_inverse_ballot_w64(improve)) nb[off] = word;
+      nb[off] = __builtin_amdgcn_inverse_ballot_w64(improve) ? word : nwv;   // unpredicated: rewrites the old word otherwise
       const unsigned long long push = improve & ~halo & ~inq;
       const int cnt = __popcll(push);
       if (LQ >= TILE_WORDS || tail - head + cnt <= LQ) {
