@@ -61,8 +61,8 @@ __device__ __forceinline__ unsigned ld_l2(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // number of set bits of a wave mask below this lane (v_mbcnt_lo/hi)
-__device__ __forceinline__ unsigned tsa_rank(unsigned long long m) {
-  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+__device__ __forceinline__ unsigned tsa_rank(unsigned long long m, unsigned base = 0u) {   // base + rank: v_mbcnt adds for free
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, base));
 }
 // buffer linear index <-> map-space (unwrapped) linear index (gmc/src/GridMapMath.cpp:467-476, 70-81)
 __device__ __forceinline__ int tsa_unwrap_lin(int lin, int rows, int cols, int s0, int s1) {
@@ -378,6 +378,8 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
     asm volatile("" : "+v"(pb), "+v"(c_st), "+v"(c_dt), "+v"(c_si), "+v"(c_sh), "+v"(c_di), "+v"(c_dh));
     unsigned* const nb = &W.tile[pb];
     const unsigned nm = ~m;
+    unsigned tail_v = (unsigned)tail;   // the queue tail as a (uniform) vector register: v_mbcnt adds it to the rank for free
+    asm volatile("" : "+v"(tail_v));
     const unsigned long long il_lo = __builtin_amdgcn_ballot_w64(pil == 0), il_hi = __builtin_amdgcn_ballot_w64(pil == TS - 1);
     const unsigned long long jl_lo = __builtin_amdgcn_ballot_w64(pjl == 0), jl_hi = __builtin_amdgcn_ballot_w64(pjl == TS - 1);
 #pragma unroll
@@ -391,20 +393,23 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
       // then the whole improvement test g + w < g(neighbour)
       const unsigned cand = (straight ? c_st : c_dt) | (unsigned)__builtin_amdgcn_sbfe((int)nm, k, 1);
       const unsigned long long improve = __builtin_amdgcn_ballot_w64(cand < nwv);
-      const unsigned long long inq = __builtin_amdgcn_ballot_w64((nwv & 1u) != 0u);
+      // flag byte: 0 idle, 1 in the queue, 2 halo-dirty, 4 deferred to the next bucket (never combined: a popped
+      // cell drops to 0 / 4, an improved one is rewritten to exactly 1 / 2)
+      const unsigned long long inq = __builtin_amdgcn_ballot_w64((nwv & 0xffu) == 1u);
       const unsigned long long halo = (di < 0 ? il_lo : (di > 0 ? il_hi : 0ull)) | (dj < 0 ? jl_lo : (dj > 0 ? jl_hi : 0ull));
       const unsigned word = __builtin_amdgcn_inverse_ballot_w64(halo) ? (straight ? c_sh : c_dh) : (straight ? c_si : c_di);
       nb[off] = __builtin_amdgcn_inverse_ballot_w64(improve) ? word : nwv;   // unpredicated: rewrites the old word otherwise
       const unsigned long long push = improve & ~halo & ~inq;
       const int cnt = __popcll(push);
-      if (LQ >= TILE_WORDS || tail - head + cnt <= LQ) {
+      if (LQ >= TILE_WORDS || (int)__builtin_amdgcn_readfirstlane(tail_v) - head + cnt <= LQ) {
         if (__builtin_amdgcn_inverse_ballot_w64(push))
-          W.lq[(tail + (int)tsa_rank(push)) & (LQ - 1)] = (unsigned short)(pb + off);
-        tail += cnt;
+          W.lq[tsa_rank(push, tail_v) & (LQ - 1)] = (unsigned short)(pb + off);
+        tail_v += (unsigned)cnt;
       } else {
         lq_full = true;   // the stored words carry the in-queue flag: the rescan picks these cells up
       }
     }
+    tail = (int)__builtin_amdgcn_readfirstlane(tail_v);
     __builtin_amdgcn_wave_barrier();
   }
   if (ovf) sch.overflow();
