@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # per-kernel time of the default bench command (pipeline depth 4) and of the unpipelined one
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python3 $ROOT/bench.py --steps 30 --warmup 6 --no-cpu > $OUT/bench_under_rocprof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python3 $ROOT/bench.py > $OUT/bench_under_rocprof.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_p1 -o bench_p1 -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu --pipeline 1 > $OUT/bench_p1_under_rocprof.log 2>&1
 # HBM traffic counters: one counter per pass, kernel-trace only
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --pipeline 1 > $OUT/pmc_fetch.log 2>&1
