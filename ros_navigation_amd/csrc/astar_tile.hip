@@ -1,21 +1,30 @@
 // astar_tile.hip -- tile-synchronous grid A* for gfx950 ("TSA"): the same contract and the same
-// label-correcting argument as astar.hip, but the relaxation runs inside LDS.
+// label-correcting argument as astar.hip, but the relaxation runs inside LDS.  This file holds the
+// default search kernel of the engine and its variants:
+//   tsa_search_kernel<false>  one workgroup (16 wavefronts) per query, rounds of tile jobs   (default)
+//   tsa_search_kernel<true>   the same without round barriers (RNA_ASTAR_KERNEL=async, experiment)
+//   tsa_multi_kernel<QB>      QB queries share a workgroup (RNA_TSA_QUERIES_PER_BLOCK, experiment)
+//   tsa_persist_kernel        every wavefront of the GPU pulls (query, tile) jobs from per-XCD rings
+//                             (RNA_ASTAR_KERNEL=persist: lowest latency of a single batch)
+// All of them run the same tile job (tsa_job) and pass the same parity tests.
 //
-// Why: the frontier kernel of astar.hip pays two HBM/L2 round trips plus two workgroup barriers per
-// search GENERATION (~5 us), and a long query has >10^4 generations.  Here the search field is
-// stored TILE-MAJOR (32 x 32 cells = 4 KiB per tile) and a wavefront owns one tile at a time:
+// Why tiles: the frontier kernel of astar.hip pays two HBM/L2 round trips plus two workgroup barriers
+// per search GENERATION (~5 us), and a long query has >10^4 generations.  Here the search field is
+// stored TILE-MAJOR (32 x 32 cells = 4 KiB per tile, word = g << 8) and a wavefront owns one tile at a
+// time:
 //   1. grab-and-clear the tile's pending bits (cells improved since its last visit),
-//   2. load the tile + a one-cell halo into LDS with coalesced loads,
-//   3. relax to the tile-local fixed point of the current f-bucket entirely in LDS (ds_min_rtn,
-//      wave-synchronous queue, ~0.3 us per generation instead of ~5 us),
+//   2. load the tile + a one-cell halo (and the tile's neighbour masks) into LDS with coalesced loads,
+//   3. relax to the tile-local fixed point of the current f-bucket entirely in LDS: a wave-synchronous
+//      queue, one lane per popped cell, plain LDS reads and writes (no LDS atomics), ~1 us per generation,
 //   4. write the tile back (inner cells: coalesced stores; edge ring and improved halo cells:
 //      atomicMin, because neighbouring tiles may be in flight on other wavefronts), hand improved
 //      halo cells to their tiles as pending bits and activate those tiles.
-// A workgroup (8 wavefronts) serves one query; rounds of tile jobs are separated by one workgroup
-// barrier.  Two pending bitmaps per query (current bucket / next bucket) replace the frontier
-// queues, so nothing can overflow.  Exactness: every update is a min over lengths of real paths and
-// the schedule runs every bucket to its fixed point, so at termination g is exact for f <= f*, which
-// is all the canonical backtrace reads (DESIGN.md "Grid A* contract").
+// Two pending bitmaps per query (current bucket / next bucket) replace the frontier queues, so nothing
+// can overflow.  Fields are never initialised wholesale: each search records the tiles it wrote and
+// the next launch on that pipeline stage resets exactly those (tsa_init_kernel).  Exactness: every
+// update is a min over lengths of real paths and the schedule runs every bucket to its fixed point, so
+// at termination g is exact for f <= f*, which is all the canonical backtrace reads (DESIGN.md "Grid A*
+// contract").  Measurements, the ceiling of the design and the experiments that were dropped: DESIGN.md 5.
 #include "engine.hpp"
 #include <algorithm>
 #include <vector>
