@@ -167,7 +167,7 @@ int rna_astar_configure(rna_engine* e, int max_queries, int queue_capacity, int 
 /* Pipelined batches: with depth d > 1 consecutive rna_astar_batch_device calls run their searches on d
  * rotating internal streams (each with its own search fields), so the tail of one batch overlaps
  * the next batch and the next map update.  Outputs of a call are valid after rna_synchronize(); the
- * caller must give calls that may be in flight together distinct output buffers.  Default 2. */
+ * caller must give calls that may be in flight together distinct output buffers.  Default 4. */
 int rna_astar_set_pipeline_depth(rna_engine* e, int depth);
 int rna_astar_batch(rna_engine* e, const rna_astar_query* queries_host, int n, int32_t* paths_host,
                     int max_path_len, rna_astar_result* results_host);

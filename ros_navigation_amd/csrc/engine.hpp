@@ -61,7 +61,7 @@ struct AstarDevice {
   // Pipelined batches: `depth` independent sets of search fields + queues, each with its own HIP
   // stream, so the tail of batch k (few long queries) overlaps the head of batch k+1.
   static constexpr int MAX_DEPTH = 8;
-  int depth = 2;
+  int depth = 4;
   int32_t* g[MAX_DEPTH] = {};      // [max_queries][field_stride] search fields: (g << 8) | mask (frontier kernel), g << 8 (tile kernels)
   int2* queues[MAX_DEPTH] = {};    // [max_queries][3][queue_cap] (cell, g)
   unsigned* pend[MAX_DEPTH] = {};  // tile kernel: two pending bitmaps per query
