@@ -301,7 +301,12 @@ class AStarPlanner {
 // Grid A* over the GridMap's master layer (BASELINE.json's planner): same makePlan shape.
 class GridAStarPlanner {
  public:
-  explicit GridAStarPlanner(GridMap& map) : map_(map) {}
+  // One synchronous query at a time is the reference's usage (nav_graph_node.cpp): one search field, no
+  // pipelining -- 4 B per cell of HBM instead of the batch default (256 fields x 4 stages).
+  explicit GridAStarPlanner(GridMap& map, int concurrent_queries = 1) : map_(map) {
+    grid_map::rna_check(rna_astar_set_pipeline_depth(map.engine(), 1), map.engine(), "GridAStarPlanner");
+    grid_map::rna_check(rna_astar_configure(map.engine(), concurrent_queries, 0, 0), map.engine(), "GridAStarPlanner");
+  }
   bool makePlan(Position& start, Position& target, std::vector<Position>& path) {
     grid_map::Index s, t;
     if (!map_.getIndex(start, s) || !map_.getIndex(target, t)) return false;
