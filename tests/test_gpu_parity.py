@@ -394,6 +394,37 @@ def test_astar_batches_larger_than_max_queries_are_chunked(R):
     e.close()
 
 
+def test_engines_release_their_hbm(R):
+    """create -> plan (pipelined stages, per-stage fields, scheduler state) -> destroy, repeatedly: free HBM returns"""
+    hip = _Hip()
+    hip.h.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+    def free_bytes():
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        assert hip.h.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    master = R.synth.obstacles_rect(256, 256, density=0.2, seed=1)
+    q = R.synth.astar_queries(16, master, 256, 256, seed=1)
+    rq = R.synth.rrt_queries(4, master, 256, 256, lambda i, j: (6.4 - 0.025 - 0.05 * i, 6.4 - 0.025 - 0.05 * j), seed=1, max_samples=2000)
+    before = None
+    for rep in range(12):
+        for kernel in ("tile", "persist"):
+            os.environ["RNA_ASTAR_KERNEL"] = kernel
+            e = R.Engine(12.8, 12.8, 0.05)
+            e.upload(R.capi.LAYER_MASTER, master)
+            e.astar_configure(max_queries=16)
+            e.astar(q, 4096)
+            e.vfh_init(8)
+            e.vfh_step(R.synth.poses(8, 12.8, 12.8, seed=2))
+            e.rrt(rq)
+            e.close()
+        if rep == 1:
+            before = free_bytes()     # after the runtime's own pools have warmed up
+    os.environ.pop("RNA_ASTAR_KERNEL", None)
+    assert before is not None and free_bytes() >= before - (64 << 20)
+
+
 def test_astar_invalid_and_short_buffer(R):
     e = R.Engine(3.2, 3.2, 0.05)
     master = np.zeros(e.ncell, np.float32)
