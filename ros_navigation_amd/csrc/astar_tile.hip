@@ -221,6 +221,9 @@ struct alignas(16) TsaWave {
                                  // improved beyond the current bucket
   unsigned short lq[LQ];         // local queue of LDS positions
   unsigned char mask[TILE_WORDS];    // neighbour masks of the 32 x 32 interior cells, index jl*32 + il
+#ifdef RNA_TSA_STATS_REEXP
+  unsigned char seen[TW * TW + TSA_SCRATCH];   // developer build: cell already expanded in this job
+#endif
 };
 
 // One tile job, executed by one wavefront (lane = this wave's lane id).  `sch` supplies the
@@ -287,6 +290,9 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
   TSA_T(t_b);
   TSA_ACC(0, t_a, t_b);
   if (lane < TSA_SCRATCH) W.tile[TW * TW + lane] = 0xFFFFFF00u;   // scratch words behind the tile (see the relaxation loop)
+#ifdef RNA_TSA_STATS_REEXP
+  for (int w = lane; w < TW * TW + TSA_SCRATCH; w += 64) W.seen[w] = 0;
+#endif
   // 3. seed the local queue from the pending bits
   int head = 0, tail = 0;   // wave-uniform
   bool lq_full = false;     // a push did not fit: those cells keep their in-queue flag and are found by a rescan
@@ -365,6 +371,14 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
     const bool later = live && fc >= bend;        // belongs to a later bucket: flag it, do not expand
     if (act) W.tile[p] = (cw & ~1u) | (later ? 4u : 0u);   // popped: may be queued again
     const bool ex = live && !later;               // this lane expands its cell
+#ifdef RNA_TSA_STATS_REEXP
+    {
+      const bool again = ex && W.seen[p] != 0;
+      TSA_CNT(14, __popcll(__builtin_amdgcn_ballot_w64(again)));
+      TSA_CNT(15, __popcll(__builtin_amdgcn_ballot_w64(ex)));
+      if (ex) W.seen[p] = 1;
+    }
+#endif
     expanded += ex ? 1 : 0;
     // rare events, kept out of the straight-line path: the popped cell is the goal (tighten the bound, do not
     // expand it), or its g is about to leave the 24-bit range
@@ -1589,6 +1603,7 @@ void tsa_stats_dump() {
   const double jobs = (double)st[7];
   if (jobs <= 0) return;
   const double busy = (double)(st[0] + st[1] + st[2] + st[3]);
+  fprintf(stderr, "[tsa stats] expansions %.0f, of which repeated inside the same job %.0f (%.1f%%)\n", (double)st[15], (double)st[14], 100.0 * (double)st[14] / (double)std::max<unsigned long long>(1, st[15]));
   fprintf(stderr, "[tsa stats, tile kernel, all launches] jobs %.0f | per job us: load %.2f relax %.2f wb %.2f handover %.2f | wave lifetime %.1f wave-ms, in jobs %.1f wave-ms (%.1f%%), in round set-up %.1f wave-ms (%.1f%%, %.2f us per round) | relax iters/job %.1f cells/iter %.1f\n",
           jobs, st[0] * 0.01 / jobs, st[1] * 0.01 / jobs, st[2] * 0.01 / jobs, st[3] * 0.01 / jobs, st[5] * 1e-5, busy * 1e-5,
           100.0 * busy / (double)st[5], st[4] * 1e-5, 100.0 * (double)st[4] / (double)st[5], st[4] * 0.01 / (double)std::max<unsigned long long>(1, st[6]),
