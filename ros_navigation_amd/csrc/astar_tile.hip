@@ -1535,7 +1535,7 @@ static void tsa_launch_init(rna_engine* e, hipStream_t stream, unsigned* field, 
   hipLaunchKernelGGL(tsa_init_kernel, dim3(4096), dim3(256), 0, stream, e->nbr, rows, cols, ti, tj, field, field_stride, pend,
                      pend_stride, max_queries, aux, e->geom.start[0], e->geom.start[1]);
   hipLaunchKernelGGL(tsa_mark_clean_kernel, dim3(1), dim3(1), 0, stream, aux.clean, aux.ticket);
-  if (n <= 8192)
+  if (n <= 2048)   // the ranking is O(n^2 / 256) per thread: beyond this the caller order is kept
     // one small workgroup: it has to fit next to the search workgroups that fill every CU when batches are pipelined
     hipLaunchKernelGGL(tsa_order_kernel, dim3(1), dim3(256), (size_t)n * sizeof(int), stream, q_dev, n, rows, cols, aux.perm);
   else
