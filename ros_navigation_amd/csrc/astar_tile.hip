@@ -86,6 +86,20 @@ __device__ __forceinline__ int tsa_buffer_lin(int lin, int rows, int cols, int s
   if (j >= cols) j -= cols;
   return j * rows + i;
 }
+// wave-wide OR with DPP row shifts / row broadcasts; every lane receives the result (all 64 lanes active)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned tsa_dpp_or_step(unsigned v) {
+  return v | (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ unsigned tsa_wave_or(unsigned v) {
+  v = tsa_dpp_or_step<0x111, 0xF>(v);   // row_shr:1
+  v = tsa_dpp_or_step<0x112, 0xF>(v);   // row_shr:2
+  v = tsa_dpp_or_step<0x114, 0xF>(v);   // row_shr:4
+  v = tsa_dpp_or_step<0x118, 0xF>(v);   // row_shr:8
+  v = tsa_dpp_or_step<0x142, 0xA>(v);   // row_bcast:15
+  v = tsa_dpp_or_step<0x143, 0xC>(v);   // row_bcast:31 -> lane 63 holds the OR of the wave
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 // word index of cell (i, j) in a tile-major field
 __device__ __forceinline__ size_t tm_index(int i, int j, int tiles_i) {
   return ((size_t)((j >> 5) * tiles_i + (i >> 5)) << 10) + ((j & 31) << 5) + (i & 31);
@@ -247,14 +261,20 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
   // 2. tile + halo -> LDS (after the pending bits: every grabbed bit's value is already in L2)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   {
-    unsigned tv[TILE_WORDS / 64];   // issue all 16 coalesced loads, then one wait, then the LDS stores
-#pragma unroll
-    for (int r = 0; r < TILE_WORDS / 64; ++r) tv[r] = ld_l2(&ftile[r * 64 + lane]);
-    const uint4 mv = *reinterpret_cast<const uint4*>(nbr_tm + ((size_t)t << 10) + lane * 16);
     // cell r*64 + lane sits 2r rows below cell `lane`: one base address + compile-time offsets
     unsigned* tp = &W.tile[((lane >> 5) + 1) * TW + (lane & 31) + 1];
+    const uint4 mv = *reinterpret_cast<const uint4*>(nbr_tm + ((size_t)t << 10) + lane * 16);
+    // two batches of eight coalesced loads (each: issue all, one wait, LDS stores): sixteen at once cost 12 more
+    // VGPRs for the whole kernel, and the registers this kernel leaves free per SIMD decide how many wavefronts
+    // of the short map-update kernels can run next to the searches (they gate the next pipelined launch)
+#pragma unroll 1
+    for (int h8 = 0; h8 < 2; ++h8) {
+      unsigned tv[TILE_WORDS / 128];
 #pragma unroll
-    for (int r = 0; r < TILE_WORDS / 64; ++r) tp[r * 2 * TW] = tv[r];
+      for (int r = 0; r < TILE_WORDS / 128; ++r) tv[r] = ld_l2(&ftile[(h8 * 8 + r) * 64 + lane]);
+#pragma unroll
+      for (int r = 0; r < TILE_WORDS / 128; ++r) tp[(h8 * 8 + r) * 2 * TW] = tv[r];
+    }
     *reinterpret_cast<uint4*>(&W.mask[lane * 16]) = mv;
   }
   {
@@ -330,6 +350,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
   const int bend = bucket_end > (long long)INF ? INF : (int)bucket_end;
   const int goal_p = (gi >= i0 && gi < i0 + TS && gj >= j0 && gj < j0 + TS) ? (gj - j0 + 1) * TW + (gi - i0 + 1) : -1;
   bool ovf = false;
+  unsigned dirty_lane = 0u;   // rows (jl) of the cells this lane popped: only those rows can have changed
   for (;;) {
     if (tail == head) {
       if (LQ >= TILE_WORDS || !lq_full) break;
@@ -363,6 +384,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
     const int g = (int)(cw >> 8);
     const int pil = p % TW - 1, pjl = p / TW - 1;
     const unsigned mk = W.mask[act ? pjl * TS + pil : 0];
+    dirty_lane |= act ? 1u << pjl : 0u;
     const unsigned ax = (unsigned)abs(i0 + pil - gi), ay = (unsigned)abs(j0 + pjl - gj);
     const int fc = g + (int)(__umul24(ax > ay ? ax : ay, COST_S) + __umul24(ax > ay ? ay : ax, COST_D - COST_S));
     const int sb = sch.best();
@@ -449,13 +471,17 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
   TSA_T(t_c);
   TSA_ACC(1, t_b, t_c);
   // 5. write back.  Inner 30 x 30 cells are private to this tile: coalesced stores.  Edge ring:
-  //    atomicMin (a neighbouring tile's job may have improved them in HBM meanwhile).
+  //    atomicMin (a neighbouring tile's job may have improved them in HBM meanwhile).  Only rows that hold a
+  //    popped cell can differ from what was loaded (every improved interior cell is queued, hence popped).
+  const unsigned dirty = tsa_wave_or(dirty_lane);
   {
     const unsigned* tp = &W.tile[((lane >> 5) + 1) * TW + (lane & 31) + 1];
     const int il = lane & 31;
     const bool edge_col = il == 0 || il == TS - 1;
-#pragma unroll
+#pragma unroll 2
     for (int r = 0; r < TILE_WORDS / 64; ++r) {
+      if (((dirty >> (2 * r)) & 3u) == 0u) continue;            // neither row of this pair changed
+      if (!((dirty >> (2 * r + (lane >> 5))) & 1u)) continue;   // this lane's row did not
       const unsigned v = tp[r * 2 * TW] & 0xFFFFFF00u;
       const bool edge = edge_col || (r == 0 && lane < 32) || (r == TILE_WORDS / 64 - 1 && lane >= 32);
       if (edge) {
@@ -465,11 +491,12 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
       }
     }
   }
-  //    far-bucket cells of this tile: column jl -> one pending word (bit il)
+  //    far-bucket cells of this tile: column jl -> one pending word (bit il); deferred cells were popped too
   {
     bool anyfar = false;
 #pragma unroll 4
     for (int r = 0; r < TS / 2; ++r) {
+      if (((dirty >> (2 * r)) & 3u) == 0u) continue;
       const int jl = 2 * r + (lane >> 5), il = lane & 31;
       const bool f = (W.tile[(jl + 1) * TW + il + 1] & 4u) != 0u;
       const unsigned long long bm = __ballot(f);
