@@ -508,35 +508,59 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
   }
   TSA_T(t_d);
   TSA_ACC(2, t_c, t_d);
-  //    improved halo cells -> their tiles (value first, then the pending bit, then the activation)
-  for (int hh = lane; hh < 4 * TW; hh += 64) {
-    // ring positions: hh in [0,TW): jl=-1 row; [TW,2TW): jl=32 row; [2TW,3TW): il=-1 col; [3TW,4TW): il=32 col
-    const int side = hh / TW, u = hh % TW;
-    int pil, pjl;
-    if (side == 0) { pjl = -1; pil = u - 1; }
-    else if (side == 1) { pjl = TS; pil = u - 1; }
-    else if (side == 2) { pil = -1; pjl = u - 1; }
-    else { pil = TS; pjl = u - 1; }
-    if (side >= 2 && (pjl < 0 || pjl >= TS)) continue;   // corners are covered by the row sides
-    const int p = (pjl + 1) * TW + pil + 1;
-    const unsigned tw_ = W.tile[p];
-    if (!(tw_ & 2u)) continue;
-    const int ni = i0 + pil, nj = j0 + pjl;
-    if (ni < 0 || nj < 0 || ni >= rows || nj >= cols) continue;
-    const unsigned v = tw_ & 0xFFFFFF00u;
-    const size_t nidx = tm_index(ni, nj, tiles_i);
-    const int fn = (int)(v >> 8) + tsa_octile(ni, nj, gi, gj);
-    if (fn > sch.best()) continue;                         // pruned: f > upper bound on f*
-    if (ni == gi && nj == gj) sch.improve_best((int)(v >> 8));
-    const unsigned old = atomicMin(&field[nidx], v);
-    if (v < old) {
-      const int nt = (int)(nidx >> 10);
-      const bool far = fn >= bucket_end;
-      atomicOr(&(far ? pend_far : pend_cur)[(size_t)nt * TS + (nj & 31)], 1u << (ni & 31));
-      // the value and its pending bit must be performed at L2 before the tile can be scheduled
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (far) sch.act_far(nt); else sch.act_cur(nt);
+  //    improved halo cells -> their tiles: value first, then the pending bit, then the activation.  The 136 ring
+  //    positions are three cells per lane; each stage is issued for all three before its single wait, so the
+  //    hand-over costs two memory round trips, not two per cell.
+  {
+    constexpr int HK = (4 * TW + 63) / 64;
+    unsigned hv[HK];
+    unsigned hix[HK];
+    int hfn[HK];
+    bool hdo[HK];
+#pragma unroll
+    for (int k = 0; k < HK; ++k) {
+      const int hh = lane + 64 * k;
+      hdo[k] = false; hv[k] = 0u; hix[k] = 0u; hfn[k] = 0;
+      if (hh < 4 * TW) {
+        // ring positions: hh in [0,TW): jl=-1 row; [TW,2TW): jl=32 row; [2TW,3TW): il=-1 col; [3TW,4TW): il=32 col
+        const int side = hh / TW, u = hh % TW;
+        int pil, pjl;
+        if (side == 0) { pjl = -1; pil = u - 1; }
+        else if (side == 1) { pjl = TS; pil = u - 1; }
+        else if (side == 2) { pil = -1; pjl = u - 1; }
+        else { pil = TS; pjl = u - 1; }
+        const bool corner_dup = side >= 2 && (pjl < 0 || pjl >= TS);   // corners are covered by the row sides
+        const unsigned tw_ = W.tile[(pjl + 1) * TW + pil + 1];
+        const int ni = i0 + pil, nj = j0 + pjl;
+        if (!corner_dup && (tw_ & 2u) && ni >= 0 && nj >= 0 && ni < rows && nj < cols) {
+          const unsigned v = tw_ & 0xFFFFFF00u;
+          const int fn = (int)(v >> 8) + tsa_octile(ni, nj, gi, gj);
+          if (fn <= sch.best()) {                                // else pruned: f > upper bound on f*
+            if (ni == gi && nj == gj) sch.improve_best((int)(v >> 8));
+            hdo[k] = true; hv[k] = v; hix[k] = (unsigned)tm_index(ni, nj, tiles_i); hfn[k] = fn;
+          }
+        }
+      }
     }
+    unsigned hold[HK];
+#pragma unroll
+    for (int k = 0; k < HK; ++k) hold[k] = hdo[k] ? atomicMin(&field[hix[k]], hv[k]) : 0u;
+#pragma unroll
+    for (int k = 0; k < HK; ++k) {
+      hdo[k] = hdo[k] && hv[k] < hold[k];
+      if (hdo[k]) {
+        const unsigned nt = hix[k] >> 10, l = hix[k] & 1023u;
+        atomicOr(&(hfn[k] >= bucket_end ? pend_far : pend_cur)[(size_t)nt * TS + (l >> 5)], 1u << (l & 31));
+      }
+    }
+    // the values and their pending bits must be performed at L2 before the tiles can be scheduled
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < HK; ++k)
+      if (hdo[k]) {
+        const int nt = (int)(hix[k] >> 10);
+        if (hfn[k] >= bucket_end) sch.act_far(nt); else sch.act_cur(nt);
+      }
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_wave_barrier();
