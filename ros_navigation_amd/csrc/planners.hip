@@ -6,12 +6,12 @@
 //   GlobalPlanner::ifBlocked/ifFinishPlan + CircleIterator  mc/include/move_control/map_global_planner.h:32-86,
 //                                               gmc/src/iterators/CircleIterator.cpp:16-93
 //
-// RRT layout: one wavefront (64 lanes) per query, four queries per 256-thread workgroup.  The
-// tree (<= 2000 nodes) lives in HBM as SoA doubles; the nearest-node scan strides the tree across
-// the 64 lanes and finishes with a shuffle arg-min that keeps the lowest index on ties (the
-// reference's strict `<` scan); the 0.3 m footprint test spreads the <= 13 x 13 CircleIterator
-// window over the lanes and reduces with a ballot.  Each query owns a glibc-compatible rand()
-// (TYPE_3 additive feedback) in LDS so sample sequences equal srand(seed); rand() on the CPU.
+// RRT layout: one query per workgroup, RRT_SPEC wavefronts that each evaluate one of the next RRT_SPEC samples
+// against the current tree (see rrt_kernel).  The tree positions (<= 2000 nodes) live in LDS, the parent
+// links in HBM; the nearest-node scan strides the tree across the 64 lanes and finishes with a DPP arg-min
+// that keeps the lowest index on ties (the reference's strict `<` scan); the 0.3 m footprint test spreads the
+// <= 13 x 13 CircleIterator window over the lanes and reduces with a ballot.  Each wavefront carries a
+// glibc-compatible rand() (TYPE_3 additive feedback) in registers so sample sequences equal srand(seed); rand().
 #include "engine.hpp"
 
 #include <vector>
@@ -174,32 +174,59 @@ __global__ void graph_astar_kernel(GraphK G, const double* __restrict__ start_ta
 // RRT
 // ------------------------------------------------------------------------------------------------
 constexpr int RRT_ITER = 2000;          // rrt_planner.cpp:6
-constexpr int RRT_WAVES = 4;
+#ifndef RNA_RRT_SPEC
+#define RNA_RRT_SPEC 8
+#endif
+constexpr int RRT_SPEC = RNA_RRT_SPEC;  // wavefronts per query = samples evaluated speculatively per round
+static_assert(RRT_SPEC >= 1 && RRT_SPEC <= 10, "3 draws per sample must fit the 31-draw look-ahead");
 
-struct RandState { int r[31]; int f, b; };
+// glibc rand() (random_r, TYPE_3) is the additive lagged recurrence o[n] = o[n-31] + o[n-3] mod 2^32 with
+// result o[n] >> 1.  A wavefront keeps the stream in registers: `d` holds 62 consecutive raw outputs, one per
+// lane (two blocks of 31), `last` the newest block (lanes 0..30), `pos` the next unread lane of `d`.  A block
+// of 31 new outputs is an inclusive scan along the three stride-3 chains -- four shuffles, no LDS state, no
+// sequential draws -- so every wavefront of a query carries its own identical copy of the stream.
+struct WaveRng { unsigned d, last; int pos; };
 
-__device__ int rng_next(RandState& s) {  // glibc random_r, TYPE_3
-  const unsigned val = (unsigned)s.r[s.f] + (unsigned)s.r[s.b];
-  s.r[s.f] = (int)val;
-  const int result = (int)(val >> 1);
-  s.f++;
-  if (s.f >= 31) { s.f = 0; s.b++; }
-  else { s.b++; if (s.b >= 31) s.b = 0; }
-  return result;
+__device__ __forceinline__ unsigned rng_block(unsigned x, int lane) {
+  const unsigned wrap = (unsigned)__shfl((int)x, lane < 3 ? 28 + lane : lane);
+  unsigned y = x + (lane < 3 ? wrap : 0u);
+#pragma unroll
+  for (int s = 3; s < 31; s <<= 1) {
+    const unsigned u = (unsigned)__shfl_up((int)y, s);
+    if (lane >= s) y += u;
+  }
+  return y;
 }
 
-__device__ void rng_seed(RandState& s, unsigned seed) {  // glibc srandom_r, TYPE_3
+__device__ void rng_seed(WaveRng& r, unsigned seed, int lane) {  // glibc srandom_r, TYPE_3
   if (seed == 0) seed = 1;
   int word = (int)seed;
-  s.r[0] = word;
-  for (int i = 1; i < 31; ++i) {
-    const long long hi = word / 127773, lo = word % 127773;
-    word = (int)(16807 * lo - 2836 * hi);
-    if (word < 0) word += 2147483647;
-    s.r[i] = word;
+  for (int i = 1; i < 31; ++i) {        // lane l keeps r[l] of the seeding LCG
+    if (i <= lane) {
+      const long long hi = word / 127773, lo = word % 127773;
+      word = (int)(16807 * lo - 2836 * hi);
+      if (word < 0) word += 2147483647;
+    }
   }
-  s.f = 3; s.b = 0;
-  for (int i = 0; i < 310; ++i) (void)rng_next(s);
+  // front pointer starts at r[3], rear at r[0]: the "previous 31 outputs" are r[3..30], r[0..2]
+  unsigned x = (unsigned)__shfl(word, lane < 31 ? (lane + 3) % 31 : lane);
+  for (int i = 0; i < 10; ++i) x = rng_block(x, lane);   // srandom_r discards 310 draws
+  const unsigned y0 = rng_block(x, lane), y1 = rng_block(y0, lane);
+  const unsigned up = (unsigned)__shfl((int)y1, lane >= 31 ? lane - 31 : lane);
+  r.d = lane < 31 ? y0 : up;
+  r.last = y1;
+  r.pos = 0;
+}
+
+__device__ __forceinline__ void rng_refill(WaveRng& r, int lane) {  // keep >= 31 unread draws behind pos
+  while (r.pos >= 31) {
+    const unsigned y = rng_block(r.last, lane);
+    const unsigned lo = (unsigned)__shfl((int)r.d, lane < 31 ? lane + 31 : lane);
+    const unsigned hi = (unsigned)__shfl((int)y, lane >= 31 ? lane - 31 : lane);
+    r.d = lane < 31 ? lo : hi;
+    r.last = y;
+    r.pos -= 31;
+  }
 }
 
 // GlobalPlanner::ifBlocked (map_global_planner.h:39-54) through CircleIterator (CircleIterator.cpp:16-93):
@@ -282,21 +309,26 @@ __device__ unsigned long long g_rrt_stat[8];
 #define RRT_ACC(slot, a, b)
 #endif
 
-__global__ void __launch_bounds__(64 * RRT_WAVES)
+// One query per workgroup, RRT_SPEC wavefronts.  extendTree (rrt_planner.cpp:26-59) draws samples until one is
+// not blocked; the draws do not depend on the outcomes and the tree only changes when a sample is accepted, so
+// the next RRT_SPEC samples are evaluated against the current tree at once, one per wavefront, and the first
+// unblocked one IN DRAW ORDER is accepted -- the later ones are discarded and their draws re-used.  Every
+// wavefront carries the rand() stream and takes the same decisions, so one barrier per round is all the
+// synchronisation there is.  (On the bench maps 94 % of the samples are blocked: a round of 8 consumes 6.4.)
+struct RrtSlot { double wx, wy; int near, blocked; };
+
+__global__ void __launch_bounds__(64 * RRT_SPEC)
 rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __restrict__ queries, int n,
            int* __restrict__ tree_parent,
            double* __restrict__ paths, int max_path_len, rna_rrt_result* __restrict__ results) {
-  __shared__ RandState s_rng[RRT_WAVES];
-  __shared__ double2 s_t[RRT_WAVES][RRT_ITER];   // node positions of each wave's query: 32 KB per wave, one 16-byte LDS read per node
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int q = blockIdx.x * RRT_WAVES + wave;
-  if (q >= n) return;
+  __shared__ double2 tn[RRT_ITER];          // node positions: 32 KB, one 16-byte LDS read per node
+  __shared__ RrtSlot slot[2][RRT_SPEC];     // per-round results, double-buffered by round parity
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int q = blockIdx.x;
   const rna_rrt_query qu = queries[q];
-  double2* const tn = s_t[wave];
   int* tp = tree_parent + (size_t)q * RRT_ITER;
-  RandState& rs = s_rng[wave];
-  if (lane == 0) rng_seed(rs, qu.seed);
-  __builtin_amdgcn_wave_barrier();
+  WaveRng rs;
+  rng_seed(rs, qu.seed, lane);
 
   const double strideStep = 0.4;   // rrt_planner.h:23 ; targetTendency_ is int(0.5) == 0 (rrt_planner.h:24,32)
   const bool target_inside = position_within_map(g, qu.target[0], qu.target[1]);
@@ -309,10 +341,12 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
   double nx = qu.start[0], ny = qu.start[1];
   int nparent = -1;
   int n_tree = 0, samples = 0;
+  unsigned round = 0;
   bool finished = false, aborted = false;
 
   for (int it = 0; it < RRT_ITER && !aborted; ++it) {
-    if (lane == 0) { tn[n_tree] = make_double2(nx, ny); tp[n_tree] = nparent; }
+    // every wavefront appends the node itself (same values): its own scan sees it without a barrier
+    if (lane == 0) { tn[n_tree] = make_double2(nx, ny); if (wave == 0) tp[n_tree] = nparent; }
     n_tree++;
     __builtin_amdgcn_wave_barrier();
     bool fin;  // ifFinishPlan, map_global_planner.h:32-37,56-86
@@ -321,104 +355,127 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
                ((nx - mbx) < qu.close_tolerance) || ((ny - mby) < qu.close_tolerance);
     if (fin) { finished = true; break; }
 
-    for (;;) {  // extendTree, rrt_planner.cpp:26-59
+    for (;;) {  // extendTree, rrt_planner.cpp:26-59, RRT_SPEC samples per round
       if (samples >= qu.max_samples) { aborted = true; break; }
-      samples++;
+      const int valid = min(RRT_SPEC, qu.max_samples - samples);
       RRT_T(t0);
-      int r0 = 0, r1 = 0, r2 = 0;
-      if (lane == 0) {
-        r0 = rng_next(rs);
-        if (r0 % 10 > 3) { r1 = rng_next(rs); r2 = rng_next(rs); }
+      rng_refill(rs, lane);
+      // sample(), rrt_planner.cpp:61-68: one draw decides goal or random, a random sample takes two more
+      const int res = (int)(rs.d >> 1);
+      const unsigned long long three = __ballot(res % 10 > 3);
+      int p = rs.pos, mine = rs.pos;
+#pragma unroll
+      for (int k = 0; k < RRT_SPEC; ++k) {
+        if (k == wave) mine = p;
+        p += ((three >> p) & 1ull) ? 3 : 1;
       }
-      r0 = __shfl(r0, 0); r1 = __shfl(r1, 0); r2 = __shfl(r2, 0);
-      double rx, ry;
-      if (r0 % 10 > 3) {  // sample(), rrt_planner.cpp:61-68
-        const int ridx[2] = {r1 % g.size[0], r2 % g.size[1]};
-        double p[2];
-        position_from_index(g, ridx, p);
-        rx = p[0]; ry = p[1];
-      } else {
-        rx = qu.target[0]; ry = qu.target[1];
-      }
-      RRT_T(t1);
-      RRT_ACC(0, t0, t1);
-      // findNearNode, rrt_planner.cpp:70-89 : strict < on hypot() keeps the lowest index among equals.
-      // hypot costs ~10x a squared distance, so the scan runs on squared distances first; hypot (error
-      // < 1 ulp, i.e. 2^-52 relative) can only reorder nodes whose squared distances agree to within
-      // 2^-48, and exactly those are re-examined with hypot in the reference's order.
-      // One pass: every lane keeps its nearest node by squared distance (lowest index among equals) and
-      // its second-smallest squared distance.  After the wave reduction, hypot is evaluated for at most one
-      // node per lane; only if some lane holds TWO nodes inside the 2^-46 band (practically never) the
-      // band is rescanned in full.
-      double l1 = 1.0e300, l2 = 1.0e300;
-      int i1 = 0x7fffffff;
-      for (int i = lane; i < n_tree; i += 64) {
-        const double2 t = tn[i];
-        const double dx = rx - t.x, dy = ry - t.y;
-        const double d2 = dx * dx + dy * dy;
-        if (d2 < l1) { l2 = l1; l1 = d2; i1 = i; }
-        else if (d2 < l2) l2 = d2;
-      }
-      double m2 = l1;
-      int imin = i1;
-      wave_min_pair(m2, imin);                       // nearest by squared distance, lowest index among equals
-      const double band = m2 + m2 * 0x1p-46 + 1.0e-300;
-      double best = 9999.0;
-      int best_i = 0x7fffffff;
-      if (__ballot(l2 <= band || (l1 <= band && i1 != imin)) == 0ull) {
-        // the usual case: no other node within the band, the answer is imin (if it beats the reference's 9999 start)
-        if (imin != 0x7fffffff) {
-          const double2 t = tn[imin];
-          if (hypot(rx - t.x, ry - t.y) < best) best_i = imin;
+      RrtSlot* const out = slot[round & 1u];
+      if (wave < valid) {
+        double rx, ry;
+        if ((three >> mine) & 1ull) {
+          const int r1 = __builtin_amdgcn_readlane(res, mine + 1), r2 = __builtin_amdgcn_readlane(res, mine + 2);
+          const int ridx[2] = {r1 % g.size[0], r2 % g.size[1]};
+          double pp[2];
+          position_from_index(g, ridx, pp);
+          rx = pp[0]; ry = pp[1];
+        } else {
+          rx = qu.target[0]; ry = qu.target[1];
         }
-      } else {
+        RRT_T(t1);
+        RRT_ACC(0, t0, t1);
+        // findNearNode, rrt_planner.cpp:70-89 : strict < on hypot() keeps the lowest index among equals.
+        // hypot costs ~10x a squared distance, so the scan runs on squared distances first; hypot (error
+        // < 1 ulp, i.e. 2^-52 relative) can only reorder nodes whose squared distances agree to within
+        // 2^-48, and exactly those are re-examined with hypot in the reference's order.
+        // One pass: every lane keeps its nearest node by squared distance (lowest index among equals) and
+        // its second-smallest squared distance.  After the wave reduction, hypot is evaluated for at most one
+        // node per lane; only if some lane holds TWO nodes inside the 2^-46 band (practically never) the
+        // band is rescanned in full.
+        double l1 = 1.0e300, l2 = 1.0e300;
+        int i1 = 0x7fffffff;
         for (int i = lane; i < n_tree; i += 64) {
           const double2 t = tn[i];
           const double dx = rx - t.x, dy = ry - t.y;
-          if (dx * dx + dy * dy <= band) {
-            const double d = hypot(dx, dy);
-            if (d < best) { best = d; best_i = i; }
-          }
+          const double d2 = dx * dx + dy * dy;
+          if (d2 < l1) { l2 = l1; l1 = d2; i1 = i; }
+          else if (d2 < l2) l2 = d2;
         }
-        wave_min_pair(best, best_i);
+        double m2 = l1;
+        int imin = i1;
+        wave_min_pair(m2, imin);                       // nearest by squared distance, lowest index among equals
+        const double band = m2 + m2 * 0x1p-46 + 1.0e-300;
+        double best = 9999.0;
+        int best_i = 0x7fffffff;
+        if (__ballot(l2 <= band || (l1 <= band && i1 != imin)) == 0ull) {
+          // the usual case: no other node within the band, the answer is imin (if it beats the reference's 9999 start)
+          if (imin != 0x7fffffff) {
+            const double2 t = tn[imin];
+            if (hypot(rx - t.x, ry - t.y) < best) best_i = imin;
+          }
+        } else {
+          for (int i = lane; i < n_tree; i += 64) {
+            const double2 t = tn[i];
+            const double dx = rx - t.x, dy = ry - t.y;
+            if (dx * dx + dy * dy <= band) {
+              const double d = hypot(dx, dy);
+              if (d < best) { best = d; best_i = i; }
+            }
+          }
+          wave_min_pair(best, best_i);
+        }
+        const int near = (best_i == 0x7fffffff) ? 0 : best_i;
+        RRT_T(t2);
+        RRT_ACC(1, t1, t2);
+        const double npx = tn[near].x, npy = tn[near].y;
+        double wx, wy;
+        if (hypot(npx - rx, npy - ry) < strideStep) { wx = rx; wy = ry; }
+        else {
+          const double a = atan2(ry - npy, rx - npx);
+          wx = npx + strideStep * cos(a);
+          wy = npy + strideStep * sin(a);
+        }
+        RRT_T(t3);
+        RRT_ACC(2, t2, t3);
+        const bool blocked = wave_if_blocked(g, master, wx, wy, lane);
+        RRT_T(t4);
+        RRT_ACC(3, t3, t4);
+        if (lane == 0) out[wave] = RrtSlot{wx, wy, near, blocked ? 1 : 0};
       }
-      const int near = (best_i == 0x7fffffff) ? 0 : best_i;
-      RRT_T(t2);
-      RRT_ACC(1, t1, t2);
-      const double npx = tn[near].x, npy = tn[near].y;
-      double wx, wy;
-      if (hypot(npx - rx, npy - ry) < strideStep) { wx = rx; wy = ry; }
-      else {
-        const double a = atan2(ry - npy, rx - npx);
-        wx = npx + strideStep * cos(a);
-        wy = npy + strideStep * sin(a);
-      }
-      RRT_T(t3);
-      RRT_ACC(2, t2, t3);
-      const bool blocked = wave_if_blocked(g, master, wx, wy, lane);
-      RRT_T(t4);
-      RRT_ACC(3, t3, t4);
-      if (!blocked) { nx = wx; ny = wy; nparent = near; break; }
+      RRT_T(t5);
+      __syncthreads();
+      RRT_T(t6);
+      RRT_ACC(5, t5, t6);
+      ++round;
+      const unsigned long long open = __ballot(lane < valid && out[lane < RRT_SPEC ? lane : 0].blocked == 0);
+      const int taken = open ? __ffsll((long long)open) : valid;   // samples consumed this round (1-based winner)
+      samples += taken;
+      p = rs.pos;
+      for (int k = 0; k < taken; ++k) p += ((three >> p) & 1ull) ? 3 : 1;
+      rs.pos = p;
+      if (open) { const RrtSlot w = out[taken - 1]; nx = w.wx; ny = w.wy; nparent = w.near; break; }
     }
   }
 
   // backtraceTree, rrt_planner.cpp:91-104 : goal -> start
   int len = 0;
-  if (!aborted && n_tree > 0) {
-    double* out = paths + (size_t)q * max_path_len * 2;
-    int i = n_tree - 1;
-    for (;;) {
-      if (lane == 0 && len < max_path_len) { out[2 * len] = tn[i].x; out[2 * len + 1] = tn[i].y; }
-      len++;
-      const int par = tp[i];
-      if (par == -1) break;
-      i = par;
+  if (wave == 0) {
+    __threadfence_block();
+    if (!aborted && n_tree > 0) {
+      double* out = paths + (size_t)q * max_path_len * 2;
+      int i = n_tree - 1;
+      for (;;) {
+        if (lane == 0 && len < max_path_len) { out[2 * len] = tn[i].x; out[2 * len + 1] = tn[i].y; }
+        len++;
+        const int par = tp[i];
+        if (par == -1) break;
+        i = par;
+      }
     }
-  }
-  if (lane == 0) results[q] = rna_rrt_result{aborted ? -1 : (finished ? 1 : 0), len, n_tree, samples};
+    if (lane == 0) results[q] = rna_rrt_result{aborted ? -1 : (finished ? 1 : 0), len, n_tree, samples};
 #ifdef RNA_RRT_STATS
-  if (lane == 0) { for (int k = 0; k < 4; ++k) atomicAdd(&g_rrt_stat[k], rrt_acc[k]); atomicAdd(&g_rrt_stat[4], (unsigned long long)samples); }
+    if (lane == 0) { for (int k = 0; k < 6; ++k) atomicAdd(&g_rrt_stat[k], rrt_acc[k]); atomicAdd(&g_rrt_stat[4], (unsigned long long)samples); atomicAdd(&g_rrt_stat[6], (unsigned long long)round); }
 #endif
+  }
 }
 
 }  // namespace
@@ -487,7 +544,7 @@ static int rrt_launch(rna_engine* e, const rna_rrt_query* q_dev, int n, double* 
   (void)tx; (void)ty;   // node positions live in LDS; only the parent links go through HBM
   if ((rc = dev_alloc(e, tp, (size_t)n * RRT_ITER)) != RNA_OK) return rc;
   KernelTimer kt(e, RNA_K_RRT);
-  hipLaunchKernelGGL(rrt_kernel, dim3((n + RRT_WAVES - 1) / RRT_WAVES), dim3(64 * RRT_WAVES), 0, e->stream, e->geom,
+  hipLaunchKernelGGL(rrt_kernel, dim3(n), dim3(64 * RRT_SPEC), 0, e->stream, e->geom,
                      e->layer[RNA_LAYER_MASTER], q_dev, n, *tp, paths_dev, max_len, res_dev);
   RNA_HIP(e, hipGetLastError());
 #ifdef RNA_RRT_STATS
@@ -498,8 +555,10 @@ static int rrt_launch(rna_engine* e, const rna_rrt_query* q_dev, int n, double* 
     static const unsigned long long zero[8] = {};
     RNA_HIP(e, hipMemcpyToSymbol(HIP_SYMBOL(g_rrt_stat), zero, sizeof(zero)));
     const double ns = (double)st[4];
-    fprintf(stderr, "[rrt stats] samples %.0f | per sample us: rng+sample %.2f  nearest %.2f  steer %.2f  ifBlocked %.2f\n", ns,
-            st[0] * 0.01 / ns, st[1] * 0.01 / ns, st[2] * 0.01 / ns, st[3] * 0.01 / ns);
+    const double nr = (double)st[6];
+    fprintf(stderr, "[rrt stats] samples %.0f rounds %.0f (%.2f samples per round) | wave 0, us per round: rng+sample %.2f  nearest %.2f  "
+            "steer %.2f  ifBlocked %.2f  barrier wait %.2f\n", ns, nr, ns / nr,
+            st[0] * 0.01 / nr, st[1] * 0.01 / nr, st[2] * 0.01 / nr, st[3] * 0.01 / nr, st[5] * 0.01 / nr);
   }
 #endif
   return RNA_OK;

@@ -1,0 +1,25 @@
+"""RRT row alone: kernel time and the distribution of samples / tree nodes per query (config 4's per-GPU share).
+With a library built with -DRNA_RRT_STATS (RNA_LIB=...) the kernel also prints its per-sample time split."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import ros_navigation_amd as R
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+nq = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+torch.zeros(1, device="cuda")
+e = R.Engine(n * 0.05, n * 0.05, 0.05)
+master = R.synth.obstacles_rect(n, n, density=0.30, seed=3)
+e.upload(R.capi.LAYER_MASTER, master)
+q = R.synth.rrt_queries(nq, master, n, n, e.get_position, seed=3, max_samples=100000)
+res, paths = e.rrt(q)
+e.profile(True)
+e.profile_reset()
+res, paths = e.rrt(q)
+ms = e.profile_get()["rrt"][0]
+s = np.sort(res["samples"])
+print("rrt %d queries on %d^2: %.1f ms | samples total %d, median %d, p90 %d, max %d (x%d at max) | nodes total %d | reached %d aborted %d" % (
+    nq, n, ms, s.sum(), s[len(s) // 2], s[int(len(s) * 0.9)], s[-1], int((s == s[-1]).sum()), res["tree_size"].sum(),
+    int((res["status"] == 1).sum()), int((res["status"] == -1).sum())))
+print("us per sample on the longest query: %.2f" % (ms * 1e3 / s[-1]))
