@@ -469,7 +469,9 @@ def test_rrt_matches_oracle(R):
     q = R.synth.rrt_queries(24, master, e.rows, e.cols, e.get_position, seed=3)
     q["target"][0] = (40.0, 0.0)          # target outside the map: plan to the boundary
     q["max_samples"][1] = 3               # sample budget exhausted
+    q["max_samples"][2:12] = (1, 2, 7, 8, 9, 15, 16, 17, 40, 100)   # ... at and around the speculation round sizes
     res, paths = e.rrt(q)
+    assert (res["status"] == -1).sum() >= 3 and (res["status"] == 1).sum() >= 3
     for k in range(len(q)):
         ores, opath = O.rrt_plan(g, master, tuple(q["start"][k]), tuple(q["target"][k]), tol=0.2,
                                  seed=int(q["seed"][k]), max_samples=int(q["max_samples"][k]))
