@@ -252,42 +252,66 @@ __device__ __forceinline__ void rng_refill(WaveRng& r, int lane) {  // keep >= 3
 __device__ bool wave_if_blocked(const Geom& g, const float* __restrict__ master, double px, double py, int lane) {
   const double radius = 0.3;
   const double r2 = radius * radius;  // pow(radius, 2)
-  double tl[2] = {px + radius, py + radius};
-  double br[2] = {px - radius, py - radius};
-  limit_position_to_range(g, tl);
-  limit_position_to_range(g, br);
-  int s[2] = {0, 0}, t[2] = {0, 0}, su[2], tu[2];
-  index_from_position(g, tl[0], tl[1], s);
-  index_from_position(g, br[0], br[1], t);
-  unwrap_index(g, s, su);
-  unwrap_index(g, t, tu);
-  const int ni = tu[0] - su[0] + 1, nj = tu[1] - su[1] + 1;
+  // The four corner coordinates (top-left x, y = p + radius; bottom-right x, y = p - radius) go through
+  // limitPositionToRange and getIndexFromPosition in lanes 0..3 at once: one pass of the double-precision
+  // divide instead of four.
+  const int a = lane & 1;
+  const double c = a ? py : px;
+  const double len = g.len[a], pos = g.pos[a];
+  double v = (lane & 2) ? c - radius : c + radius;
+  {  // limit_position_to_range, one coordinate
+    const double vto = 0.5 * len;
+    double shifted = (v - pos) + vto;
+    double eps = 10.0 * DBL_EPSILON;
+    if (fabs(v) > 1.0) eps *= fabs(v);
+    if (shifted <= 0) shifted = eps;
+    else if (shifted >= len) shifted = len - eps;
+    v = (shifted + pos) - vto;
+  }
+  const double t = -((v - pos) - 0.5 * len);
+  const unsigned long long inside = __ballot(t >= 0.0 && t < len);
+  const int uc = -(int)(((v - 0.5 * len) - pos) / g.res);
+  // index_from_position leaves {0,0} (a buffer index) when the position is outside: unwrapped, that is -start
+  const bool tl_ok = (inside & 3ull) == 3ull, br_ok = (inside & 12ull) == 12ull;
+  const int su0 = tl_ok ? __builtin_amdgcn_readlane(uc, 0) : wrap_index(-g.start[0], g.size[0]);
+  const int su1 = tl_ok ? __builtin_amdgcn_readlane(uc, 1) : wrap_index(-g.start[1], g.size[1]);
+  const int tu0 = br_ok ? __builtin_amdgcn_readlane(uc, 2) : wrap_index(-g.start[0], g.size[0]);
+  const int tu1 = br_ok ? __builtin_amdgcn_readlane(uc, 3) : wrap_index(-g.start[1], g.size[1]);
+  const int ni = tu0 - su0 + 1, nj = tu1 - su1 + 1;
   bool hit = false;
   const int total = (ni > 0 && nj > 0) ? ni * nj : 0;
+  const float rcp_ni = 1.0f / (float)(ni > 0 ? ni : 1);
+  const double ox = g.pos[0] + (0.5 * g.len[0] - 0.5 * g.res), oy = g.pos[1] + (0.5 * g.len[1] - 0.5 * g.res);
   // three cells per lane and trip (the 0.3 m disc at 0.05 m resolution spans <= 169 cells): the map reads of one
   // trip are issued together, so the test costs one memory round trip instead of three
   for (int k0 = lane; k0 < total; k0 += 192) {
-    float v[3];
+    float val[3];
     bool in[3];
 #pragma unroll
     for (int u3 = 0; u3 < 3; ++u3) {
       const int k = k0 + 64 * u3;
       in[u3] = false;
-      v[u3] = 0.0f;
+      val[u3] = 0.0f;
       if (k < total) {
-        const int u[2] = {su[0] + k % ni, su[1] + k / ni};
+        int row = (int)((float)k * rcp_ni);      // k / ni without the integer divide (k < 2^23), corrected below
+        int col = k - row * ni;
+        if (col < 0) { row--; col += ni; } else if (col >= ni) { row++; col -= ni; }
+        const int u[2] = {su0 + col, su1 + row};
         int bi[2];
         buffer_index(g, u, bi);
-        double p[2];
-        position_from_index(g, bi, p);
-        const double dx = p[0] - px, dy = p[1] - py;
+        // position_from_index(bi) unwraps bi again: that is u itself, wrapped into the map
+        const int w0 = (unsigned)u[0] < (unsigned)g.size[0] ? u[0] : wrap_index(u[0], g.size[0]);
+        const int w1 = (unsigned)u[1] < (unsigned)g.size[1] ? u[1] : wrap_index(u[1], g.size[1]);
+        const double x = ox + g.res * (double)(-w0);
+        const double y = oy + g.res * (double)(-w1);
+        const double dx = x - px, dy = y - py;
         in[u3] = dx * dx + dy * dy <= r2;
-        if (in[u3]) v[u3] = master[(size_t)bi[1] * g.size[0] + bi[0]];
+        if (in[u3]) val[u3] = master[(size_t)bi[1] * g.size[0] + bi[0]];
       }
     }
 #pragma unroll
     for (int u3 = 0; u3 < 3; ++u3)
-      if (in[u3] && !(v[u3] != v[u3]) && v[u3] > 0.0f) hit = true;
+      if (in[u3] && !(val[u3] != val[u3]) && val[u3] > 0.0f) hit = true;
   }
   return __ballot(hit) != 0ULL;
 }
@@ -336,7 +360,8 @@ __device__ unsigned long long g_rrt_stat[8];
 // from the last evaluation, see below, a round consumes 8.7 samples on average and 13 on a stuck tree.)
 struct RrtSlot { double wx, wy; int near, blocked; };
 
-__global__ void __launch_bounds__(64 * RRT_SPEC)
+// 4 wavefronts per SIMD (<= 128 VGPRs): two 8-wavefront workgroups per CU, 512 queries resident on the chip
+__global__ void __launch_bounds__(64 * RRT_SPEC) __attribute__((amdgpu_waves_per_eu(4, 4)))
 rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __restrict__ queries, int n,
            int* __restrict__ tree_parent,
            double* __restrict__ paths, int max_path_len, rna_rrt_result* __restrict__ results) {
@@ -432,12 +457,18 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
         // band is rescanned in full.
         double l1 = 1.0e300, l2 = 1.0e300;
         int i1 = 0x7fffffff;
-        for (int i = lane; i < n_tree; i += 64) {
-          const double2 t = tn[i];
-          const double dx = rx - t.x, dy = ry - t.y;
-          const double d2 = dx * dx + dy * dy;
-          if (d2 < l1) { l2 = l1; l1 = d2; i1 = i; }
-          else if (d2 < l2) l2 = d2;
+        for (int i0 = lane; i0 < n_tree; i0 += 256) {   // four nodes per lane and trip: the LDS reads go out together
+          double2 t[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) t[u] = tn[min(i0 + 64 * u, RRT_ITER - 1)];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u;
+            const double dx = rx - t[u].x, dy = ry - t[u].y;
+            const double d2 = i < n_tree ? dx * dx + dy * dy : 1.0e300;
+            if (d2 < l1) { l2 = l1; l1 = d2; i1 = i; }
+            else if (d2 < l2) l2 = d2;
+          }
         }
         double m2 = l1;
         int imin = i1;
