@@ -470,6 +470,7 @@ def test_rrt_matches_oracle(R):
     q["target"][0] = (40.0, 0.0)          # target outside the map: plan to the boundary
     q["max_samples"][1] = 3               # sample budget exhausted
     q["max_samples"][2:12] = (1, 2, 7, 8, 9, 15, 16, 17, 40, 100)   # ... at and around the speculation round sizes
+    q["seed"][12:16] = (0, 2**31, 2**32 - 1, 2**31 - 1)             # srand(0) == srand(1); seeds that are negative as int32_t
     res, paths = e.rrt(q)
     assert (res["status"] == -1).sum() >= 3 and (res["status"] == 1).sum() >= 3
     for k in range(len(q)):
