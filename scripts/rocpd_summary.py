@@ -31,13 +31,13 @@ def main():
     src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
     os.makedirs(dst, exist_ok=True)
     out = {}
-    for sub, fn in (("trace", "bench_results.db"), ("trace_p1", "bench_p1_results.db")):
+    for sub, fn in (("trace", "bench_results.db"), ("trace_p1", "bench_p1_results.db"), ("trace_rows", "rows_results.db")):
         p = os.path.join(src, sub, fn)
         if os.path.exists(p):
             st = kernel_stats(p)
             out[sub] = st
             with open(os.path.join(dst, "%s_kernel_stats_%s.txt" % (tag, sub)), "w") as f:
-                f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py ... (%s)\n" % sub)
+                f.write("# rocprofv3 --kernel-trace --stats -- python3 %s ... (%s)\n" % ("scripts/bench_rows.py" if sub == "trace_rows" else "bench.py", sub))
                 f.write("%-34s %6s %14s %14s %14s %14s %7s\n" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct"))
                 for r in st:
                     f.write("%-34s %6d %14d %14.0f %14d %14d %7.2f\n" % (short(r["name"]), r["calls"], r["total_ns"], r["avg_ns"],
