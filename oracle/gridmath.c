@@ -75,6 +75,12 @@ int og_index_from_position(const og_geom* g, const double pos[2], int idx[2]) {
     double iv = ((pos[a] - 0.5 * g->len[a]) - g->pos[a]) / g->res;
     u[a] = -(int)iv; /* cast<int>() truncates toward zero, then the -I transform */
   }
+  /* A position within rounding of the far edge passes the strict `<` of checkIfPositionWithinMap and still divides
+   * to index == size.  getBufferIndexFromIndex wraps that to 0 on a moved buffer (kept) and returns it unchanged on
+   * an unmoved one, where the reference goes on to index its matrices out of bounds (undefined).  Defined here and
+   * in the HIP gridmath.hpp: such a position is outside the map. */
+  if (g->start[0] == 0 && g->start[1] == 0 &&
+      (u[0] < 0 || u[0] >= g->size[0] || u[1] < 0 || u[1] >= g->size[1])) return 0;
   og_buffer_index(u, g->size, g->start, idx);
   return 1;
 }
@@ -413,7 +419,12 @@ int og_circle_cells(const og_geom* g, const double center[2], double radius, int
   double br[2] = { center[0] - radius, center[1] - radius };
   og_limit_position_to_range(tl, g->len, g->pos);
   og_limit_position_to_range(br, g->len, g->pos);
-  int s[2], e[2], su[2], eu[2], size[2];
+  /* CircleIterator.cpp:89-91 leaves startIndex / endIndex untouched when getIndexFromPosition fails, and endIndex is
+   * an uninitialised Index there (a bottom-right corner exactly on the map's far edge fails the strict `<` of
+   * checkIfPositionWithinMap even after limitPositionToRange when length = size * resolution rounds up).  The
+   * reference's result is undefined in that case; this restatement and the HIP kernel define the index as (0, 0).
+   * Whatever the size, the iterator visits its first cell (SubmapIterator starts not-past-end). */
+  int s[2] = { 0, 0 }, e[2] = { 0, 0 }, su[2], eu[2], size[2];
   og_index_from_position(g, tl, s);
   og_index_from_position(g, br, e);
   og_unwrap_index(s, g->size, g->start, su);

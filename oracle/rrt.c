@@ -48,6 +48,9 @@ int og_if_blocked(const og_geom* g, const float* master, const double p[2]) {
   int n = og_circle_cells(g, p, 0.3, cells, 1024);
   if (n > 1024) n = 1024;
   for (int k = 0; k < n; ++k) {
+    /* A corner within rounding of the map's far edge gives index == size (getIndexFromPosition does not wrap on an
+     * unmoved map); the reference then reads the layer out of bounds.  Defined here and in the HIP kernel: skipped. */
+    if (cells[2 * k] < 0 || cells[2 * k] >= g->size[0] || cells[2 * k + 1] < 0 || cells[2 * k + 1] >= g->size[1]) continue;
     float v = master[(size_t)cells[2 * k + 1] * g->size[0] + cells[2 * k]];
     if (isnan(v)) continue;
     if (v > 0.0f) return 1;

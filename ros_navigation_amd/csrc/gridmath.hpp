@@ -22,6 +22,31 @@ struct Geom {
 
 #define RNA_HD __host__ __device__ __forceinline__
 
+// hypot() as glibc 2.35 computes it (sysdeps/ieee754/dbl-64/e_hypot.c, the non-FMA kernel: Borges' corrected
+// square root).  The reference's findNearNode / findClosedVertex compare hypot() values with a strict `<`, and on
+// coarse grids lattice-symmetric nodes tie exactly in glibc's rounding: the device libm's hypot (also < 1 ulp, but a
+// different last bit) would break such ties the other way.  Only IEEE +,-,*,/ and sqrt, evaluated without
+// contraction (-ffp-contract=off), so the value is the host's bit for bit; the huge / tiny scaling branches of the
+// original are not needed for map coordinates (|x| < 2^511, exact zeros handled by the first return).
+RNA_HD double glibc_hypot(double x, double y) {
+  x = fabs(x); y = fabs(y);
+  const double ax = x < y ? y : x, ay = x < y ? x : y;
+  if (ax >= ay / 0x1p-54) return ax + ay;
+  double h = sqrt(ax * ax + ay * ay);
+  double t1, t2;
+  if (h <= 2.0 * ay) {
+    const double delta = h - ay;
+    t1 = ax * (2.0 * delta - ax);
+    t2 = (delta - 2.0 * (ax - ay)) * delta;
+  } else {
+    const double delta = h - ax;
+    t1 = 2.0 * delta * (ax - 2.0 * ay);
+    t2 = (4.0 * delta - ay) * ay + delta * delta;
+  }
+  h -= (t1 + t2) / (2.0 * h);
+  return h;
+}
+
 // gmc/src/GridMapMath.cpp:216-220
 RNA_HD int wrap_index(int idx, int size) {
   if (idx < 0) idx += ((-idx / size) + 1) * size;
@@ -55,6 +80,12 @@ RNA_HD bool index_from_position(const Geom& g, double x, double y, int idx[2]) {
   int u[2];
   u[0] = -(int)(((x - 0.5 * g.len[0]) - g.pos[0]) / g.res);
   u[1] = -(int)(((y - 0.5 * g.len[1]) - g.pos[1]) / g.res);
+  // A position within rounding of the far edge passes the strict `<` above and still divides to index == size.
+  // getBufferIndexFromIndex wraps it to 0 on a moved buffer (kept: defined reference behaviour) and leaves it out of
+  // range on an unmoved one, where the reference then indexes its matrices out of bounds.  Defined here and in
+  // oracle/gridmath.c: such a position is outside the map.
+  if (g.start[0] == 0 && g.start[1] == 0 &&
+      ((unsigned)u[0] >= (unsigned)g.size[0] || (unsigned)u[1] >= (unsigned)g.size[1])) return false;
   buffer_index(g, u, idx);
   return true;
 }

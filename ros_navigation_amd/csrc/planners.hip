@@ -43,7 +43,7 @@ __device__ int graph_closest_vertex(const GraphK& G, double x, double y) {  // a
   float closed = 999.0f;
   int best = 0;
   for (int v = 0; v < G.nv; ++v) {
-    const float d = (float)hypot(x - G.loc[2 * v], y - G.loc[2 * v + 1]);
+    const float d = (float)glibc_hypot(x - G.loc[2 * v], y - G.loc[2 * v + 1]);
     if (d < closed) { closed = d; best = v; }
   }
   return best;
@@ -269,18 +269,25 @@ __device__ bool wave_if_blocked(const Geom& g, const float* __restrict__ master,
     v = (shifted + pos) - vto;
   }
   const double t = -((v - pos) - 0.5 * len);
-  const unsigned long long inside = __ballot(t >= 0.0 && t < len);
-  const int uc = -(int)(((v - 0.5 * len) - pos) / g.res);
+  int uc = -(int)(((v - 0.5 * len) - pos) / g.res);
+  // index_from_position (gridmath.hpp), one coordinate per lane: a corner within rounding of the far edge yields
+  // index == size, which wraps to 0 on a moved buffer and counts as outside the map on an unmoved one
+  const bool moved = g.start[0] != 0 || g.start[1] != 0;
+  if (moved) uc = wrap_index(uc, g.size[a]);
+  const unsigned long long inside = __ballot(t >= 0.0 && t < len && (unsigned)uc < (unsigned)g.size[a]);
   // index_from_position leaves {0,0} (a buffer index) when the position is outside: unwrapped, that is -start
   const bool tl_ok = (inside & 3ull) == 3ull, br_ok = (inside & 12ull) == 12ull;
   const int su0 = tl_ok ? __builtin_amdgcn_readlane(uc, 0) : wrap_index(-g.start[0], g.size[0]);
   const int su1 = tl_ok ? __builtin_amdgcn_readlane(uc, 1) : wrap_index(-g.start[1], g.size[1]);
   const int tu0 = br_ok ? __builtin_amdgcn_readlane(uc, 2) : wrap_index(-g.start[0], g.size[0]);
   const int tu1 = br_ok ? __builtin_amdgcn_readlane(uc, 3) : wrap_index(-g.start[1], g.size[1]);
-  const int ni = tu0 - su0 + 1, nj = tu1 - su1 + 1;
+  // a non-positive size (a corner index that failed, see oracle/gridmath.c og_circle_cells) still visits the
+  // first cell: SubmapIterator starts not-past-end and CircleIterator tests that cell before incrementing
+  const bool whole = (tu0 - su0 + 1) > 0 && (tu1 - su1 + 1) > 0;
+  const int ni = whole ? tu0 - su0 + 1 : 1, nj = whole ? tu1 - su1 + 1 : 1;
   bool hit = false;
-  const int total = (ni > 0 && nj > 0) ? ni * nj : 0;
-  const float rcp_ni = 1.0f / (float)(ni > 0 ? ni : 1);
+  const int total = ni * nj;
+  const float rcp_ni = 1.0f / (float)ni;
   const double ox = g.pos[0] + (0.5 * g.len[0] - 0.5 * g.res), oy = g.pos[1] + (0.5 * g.len[1] - 0.5 * g.res);
   // three cells per lane and trip (the 0.3 m disc at 0.05 m resolution spans <= 169 cells): the map reads of one
   // trip are issued together, so the test costs one memory round trip instead of three
@@ -305,7 +312,8 @@ __device__ bool wave_if_blocked(const Geom& g, const float* __restrict__ master,
         const double x = ox + g.res * (double)(-w0);
         const double y = oy + g.res * (double)(-w1);
         const double dx = x - px, dy = y - py;
-        in[u3] = dx * dx + dy * dy <= r2;
+        // an index past the map (unmoved map, corner on the far edge) is read out of bounds by the reference: skipped here
+        in[u3] = dx * dx + dy * dy <= r2 && (unsigned)bi[0] < (unsigned)g.size[0] && (unsigned)bi[1] < (unsigned)g.size[1];
         if (in[u3]) val[u3] = master[(size_t)bi[1] * g.size[0] + bi[0]];
       }
     }
@@ -394,7 +402,7 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
     n_tree++;
     __builtin_amdgcn_wave_barrier();
     bool fin;  // ifFinishPlan, map_global_planner.h:32-37,56-86
-    if (target_inside) fin = hypot(nx - qu.target[0], ny - qu.target[1]) < qu.close_tolerance;
+    if (target_inside) fin = glibc_hypot(nx - qu.target[0], ny - qu.target[1]) < qu.close_tolerance;
     else fin = ((pbx - nx) < qu.close_tolerance) || ((pby - ny) < qu.close_tolerance) ||
                ((nx - mbx) < qu.close_tolerance) || ((ny - mby) < qu.close_tolerance);
     if (fin) { finished = true; break; }
@@ -448,9 +456,9 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
         RRT_T(t1);
         RRT_ACC(0, t0, t1);
         // findNearNode, rrt_planner.cpp:70-89 : strict < on hypot() keeps the lowest index among equals.
-        // hypot costs ~10x a squared distance, so the scan runs on squared distances first; hypot (error
+        // hypot costs ~10x a squared distance, so the scan runs on squared distances first; hypot (glibc's, error
         // < 1 ulp, i.e. 2^-52 relative) can only reorder nodes whose squared distances agree to within
-        // 2^-48, and exactly those are re-examined with hypot in the reference's order.
+        // 2^-48, and exactly those are re-examined with glibc_hypot in the reference's order.
         // One pass: every lane keeps its nearest node by squared distance (lowest index among equals) and
         // its second-smallest squared distance.  After the wave reduction, hypot is evaluated for at most one
         // node per lane; only if some lane holds TWO nodes inside the 2^-46 band (practically never) the
@@ -480,14 +488,14 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
           // the usual case: no other node within the band, the answer is imin (if it beats the reference's 9999 start)
           if (imin != 0x7fffffff) {
             const double2 t = tn[imin];
-            if (hypot(rx - t.x, ry - t.y) < best) best_i = imin;
+            if (glibc_hypot(rx - t.x, ry - t.y) < best) best_i = imin;
           }
         } else {
           for (int i = lane; i < n_tree; i += 64) {
             const double2 t = tn[i];
             const double dx = rx - t.x, dy = ry - t.y;
             if (dx * dx + dy * dy <= band) {
-              const double d = hypot(dx, dy);
+              const double d = glibc_hypot(dx, dy);
               if (d < best) { best = d; best_i = i; }
             }
           }
@@ -498,7 +506,7 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
         RRT_ACC(1, t1, t2);
         const double npx = tn[near].x, npy = tn[near].y;
         double wx, wy;
-        if (hypot(npx - rx, npy - ry) < strideStep) { wx = rx; wy = ry; }
+        if (glibc_hypot(npx - rx, npy - ry) < strideStep) { wx = rx; wy = ry; }
         else {
           const double a = atan2(ry - npy, rx - npx);
           wx = npx + strideStep * cos(a);

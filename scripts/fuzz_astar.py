@@ -1,0 +1,69 @@
+"""Developer tool: time-boxed random parity run of the grid A* kernels against the CPU oracle (status, cost, path,
+settled count) over random map shapes (not multiples of the 32-cell tile), obstacle densities, unknown cells,
+bucket widths, batch sizes and engine reuse (the lazy field reset).  usage: python scripts/fuzz_astar.py [seconds] [seed]
+Exits non-zero on the first mismatch and prints the configuration that reproduces it."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402  (initialises the HIP runtime before librna.so loads)
+import ros_navigation_amd as R  # noqa: E402
+import _oracle as O  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+torch.zeros(1, device="cuda")
+rng = np.random.default_rng(seed)
+t_end = time.time() + budget
+cases = queries = found = 0
+while time.time() < t_end:
+    rows, cols = int(rng.integers(3, 420)), int(rng.integers(3, 420))
+    if rng.random() < 0.15:
+        rows, cols = int(rng.integers(400, 900)), int(rng.integers(400, 900))
+    density = float(rng.choice([0.0, 0.05, 0.2, 0.3, 0.45, 0.6]))
+    side_hi = int(rng.integers(2, max(3, min(rows, cols) // 3 + 2)))
+    cfg = dict(rows=rows, cols=cols, density=density, side_hi=side_hi)
+    e = R.Engine(rows * 0.05, cols * 0.05, 0.05)
+    assert (e.rows, e.cols) == (rows, cols), cfg
+    for rep in range(int(rng.integers(1, 4))):         # the same engine plans on changing maps
+        mseed = int(rng.integers(0, 1 << 30))
+        master = R.synth.obstacles_rect(rows, cols, density=density, seed=mseed, side=(1, side_hi))
+        if rng.random() < 0.5:
+            master[rng.random(rows * cols) < 0.05] = np.nan
+        e.upload(R.capi.LAYER_MASTER, master)
+        nq = int(rng.integers(1, 70))
+        bw = int(rng.choice([2828, 3000, 5000, 8000, 16000, 60000, 400000]))
+        mq = int(rng.choice([nq, max(1, nq // 3), 256]))
+        q = np.zeros(nq, R.capi.ASTAR_QUERY_DTYPE)
+        free = np.flatnonzero(~(np.isfinite(master) & (master > 0)))
+        if len(free) and rng.random() < 0.8:
+            q["start"], q["goal"] = rng.choice(free, nq), rng.choice(free, nq)
+        else:
+            q["start"], q["goal"] = rng.integers(0, rows * cols, nq), rng.integers(0, rows * cols, nq)
+        here = dict(cfg, mseed=mseed, nq=nq, bucket_width=bw, max_queries=mq, rep=rep, fuzz_seed=seed, case=cases)
+        e.astar_configure(max_queries=mq, bucket_width=bw)
+        res, paths = e.astar(q, rows * cols)
+        settled = e.astar_settled(nq) if mq >= nq else None
+        _, nbr = O.astar_masks(master, rows, cols)
+        assert np.array_equal(e.nbr_mask(), nbr), here
+        gw = np.empty(rows * cols, np.int32)
+        for k in range(nq):
+            ores, opath, _ = O.astar_query(nbr, rows, cols, q["start"][k], q["goal"][k], g_work=gw)
+            ok = res["status"][k] == ores.status
+            if ok and ores.status == 0:
+                ok = (res["cost"][k] == ores.cost and res["path_len"][k] == ores.path_len and
+                      np.array_equal(paths[k, :ores.path_len], opath) and (settled is None or settled[k] == ores.settled))
+                found += 1
+            if not ok:
+                print("MISMATCH", here, "query", k, int(q["start"][k]), int(q["goal"][k]), "gpu", res[k], "oracle", ores.status,
+                      ores.cost, ores.path_len, ores.settled)
+                sys.exit(1)
+        queries += nq
+        cases += 1
+    e.close()
+print("fuzz ok: %d maps, %d queries (%d with a path) in %.0f s, seed %d" % (cases, queries, found, budget, seed))

@@ -1,0 +1,167 @@
+"""Developer tool: time-boxed random parity run of rrt_kernel against the CPU oracle (status, tree size, sample count,
+path length exact; way points at 1e-9 m) over random map sizes, resolutions, obstacle densities, moved maps
+(circular-buffer start != 0), targets inside / outside the map, seeds and sample budgets.
+usage: python scripts/fuzz_rrt.py [seconds] [seed]
+       python scripts/fuzz_rrt.py repro <seed> <case> <query>    # first diverging sample of a reported mismatch"""
+import ctypes as C
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+import ros_navigation_amd as R  # noqa: E402
+import _oracle as O  # noqa: E402
+
+
+def gen_case(rng):
+    """one random case, CPU side only: geometry (moved or not), map in buffer order, queries"""
+    res_m = float(rng.choice([0.05, 0.05, 0.1, 0.025, 0.2]))
+    lx, ly = float(rng.uniform(4, 30)), float(rng.uniform(4, 30))
+    g = O.make_geom(lx, ly, res_m)
+    rows, cols = int(g.size[0]), int(g.size[1])
+    density = float(rng.choice([0.0, 0.05, 0.15, 0.3]))
+    mseed = int(rng.integers(0, 1 << 30))
+    master = R.synth.obstacles_rect(rows, cols, density=density, seed=mseed, side=(2, max(3, min(rows, cols) // 6)))
+    if rng.random() < 0.3:
+        master[rng.random(rows * cols) < 0.05] = np.nan
+    moved = (float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3))) if rng.random() < 0.4 else None
+    ref = master.copy()
+    if moved:
+        ptrs = (C.POINTER(C.c_float) * 1)(O.fptr(ref))
+        regs = (O.Region * 4)()
+        mv = C.c_int(0)
+        O.lib().og_move(C.byref(g), ptrs, 1, O.d2(*moved), regs, C.byref(mv))
+    nq = int(rng.integers(1, 24))
+    q = np.zeros(nq, R.capi.RRT_QUERY_DTYPE)
+    cx, cy = float(g.pos[0]), float(g.pos[1])
+    q["start"][:, 0] = rng.uniform(cx - lx / 2 + 0.4, cx + lx / 2 - 0.4, nq)
+    q["start"][:, 1] = rng.uniform(cy - ly / 2 + 0.4, cy + ly / 2 - 0.4, nq)
+    q["target"][:, 0] = rng.uniform(cx - lx / 2 - 2.0, cx + lx / 2 + 2.0, nq)     # some targets outside the map
+    q["target"][:, 1] = rng.uniform(cy - ly / 2 - 2.0, cy + ly / 2 + 2.0, nq)
+    q["close_tolerance"] = rng.choice([0.2, 0.05, 0.5], nq)
+    q["seed"] = rng.integers(0, 1 << 32, nq, dtype=np.uint64).astype(np.uint32)
+    q["max_samples"] = rng.choice([0, 1, 5, 9, 33, 500, 5000, 30000], nq)
+    return dict(lx=lx, ly=ly, res=res_m, density=density, mseed=mseed, moved=moved), g, master, ref, q
+
+
+def engine_for(info, g, master, ref):
+    e = R.Engine(info["lx"], info["ly"], info["res"])
+    for l in range(3):
+        e.upload(l, master)
+    if info["moved"]:
+        e.move(*info["moved"])
+        assert tuple(e.geometry().start_index) == tuple(g.start)
+        dev = e.download(R.capi.LAYER_MASTER)
+        assert np.array_equal(np.isnan(dev), np.isnan(ref)) and np.array_equal(dev[~np.isnan(dev)], ref[~np.isnan(ref)])
+    return e
+
+
+def oracle_plan(g, ref, q, k, budget=None):
+    return O.rrt_plan(g, ref, tuple(q["start"][k]), tuple(q["target"][k]), tol=float(q["close_tolerance"][k]),
+                      seed=int(q["seed"][k]), max_samples=int(q["max_samples"][k]) if budget is None else budget)
+
+
+def repro(seed, case, k):
+    rng = np.random.default_rng(seed)
+    for _ in range(case + 1):
+        info, g, master, ref, q = gen_case(rng)
+    e = engine_for(info, g, master, ref)
+    print(info, "start index", tuple(g.start), "size", tuple(g.size), "pos", tuple(g.pos), q[k])
+    qq = q[k:k + 1].copy()
+
+    def run(m):
+        qq["max_samples"] = m
+        res, _ = e.rrt(qq)
+        ores, _ = oracle_plan(g, ref, q, k, m)
+        return (int(res["status"][0]), int(res["tree_size"][0]), int(res["samples"][0])), (ores.status, ores.tree_size, ores.samples)
+    lo, hi = 0, int(q["max_samples"][k])
+    assert run(hi)[0] != run(hi)[1], "no mismatch"
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        a, b = run(mid)
+        lo, hi = (mid, hi) if a == b else (lo, mid)
+    print("first diverging sample", hi, "gpu/oracle", run(hi))
+    # CPU replica of the oracle up to that sample, with the details of the decision
+    L = O.lib()
+    libm = C.CDLL("libm.so.6")                   # the oracle's hypot (CPython's math.hypot is a different algorithm)
+    libm.hypot.restype = C.c_double
+    libm.hypot.argtypes = [C.c_double, C.c_double]
+    rs = O.RandState()
+    L.og_srand(C.byref(rs), int(q["seed"][k]))
+    rows, cols = int(g.size[0]), int(g.size[1])
+    tree = [tuple(q["start"][k])]
+    target = tuple(q["target"][k])
+    for s in range(1, hi + 1):
+        if L.og_rand(C.byref(rs)) % 10 > 3:
+            ridx = (C.c_int * 2)(L.og_rand(C.byref(rs)) % rows, L.og_rand(C.byref(rs)) % cols)
+            p = (C.c_double * 2)()
+            L.og_position_from_index(C.byref(g), ridx, p)
+            rnd, kind = (p[0], p[1]), "random"
+        else:
+            rnd, kind = target, "goal"
+        d = [libm.hypot(rnd[0] - t[0], rnd[1] - t[1]) for t in tree]
+        near = int(np.argmin(d)) if min(d) < 9999.0 else 0
+        npx, npy = tree[near]
+        if libm.hypot(npx - rnd[0], npy - rnd[1]) < 0.4:
+            nw, snap = rnd, True
+        else:
+            a = math.atan2(rnd[1] - npy, rnd[0] - npx)
+            nw, snap = (npx + 0.4 * math.cos(a), npy + 0.4 * math.sin(a)), False
+        blk = L.og_if_blocked(C.byref(g), O.fptr(ref), O.d2(*nw))
+        if s == hi:
+            print("sample", s, kind, "rnd", rnd, "near", near, tree[near], "two nearest", sorted(d)[:2], "snap", snap, "new", nw, "oracle blocked", blk)
+            cells = (C.c_int * 4096)()
+            n = L.og_circle_cells(C.byref(g), O.d2(*nw), 0.3, cells, 2048)
+            for c in range(n):
+                i, j = cells[2 * c], cells[2 * c + 1]
+                p = (C.c_double * 2)()
+                L.og_position_from_index(C.byref(g), (C.c_int * 2)(i, j), p)
+                print("  disc cell (buffer)", (i, j), "value", float(ref[j * rows + i]), "d2 - r2", (p[0] - nw[0]) ** 2 + (p[1] - nw[1]) ** 2 - 0.09)
+            for nm, c in (("top-left", (nw[0] + 0.3, nw[1] + 0.3)), ("bottom-right", (nw[0] - 0.3, nw[1] - 0.3))):
+                pp = (C.c_double * 2)(*c)
+                L.og_limit_position_to_range(pp, g.len, g.pos)
+                ci = (C.c_int * 2)(-1, -1)
+                ok = L.og_index_from_position(C.byref(g), pp, ci)
+                print("  corner", nm, repr(pp[0]), repr(pp[1]), "inside", ok, "buffer index", ci[0], ci[1])
+        if not blk:
+            tree.append(nw)
+    e.close()
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    cases = queries = reached = aborted = 0
+    while time.time() < t_end:
+        info, g, master, ref, q = gen_case(rng)
+        e = engine_for(info, g, master, ref)
+        res, paths = e.rrt(q)
+        for k in range(len(q)):
+            ores, opath = oracle_plan(g, ref, q, k)
+            got = (int(res["status"][k]), int(res["tree_size"][k]), int(res["samples"][k]), int(res["path_len"][k]))
+            want = (ores.status, ores.tree_size, ores.samples, ores.path_len)
+            if got != want or not np.allclose(paths[k, :ores.path_len], opath, rtol=0, atol=1e-9):
+                print("MISMATCH", info, "repro: %d %d %d" % (seed, cases, k), "gpu", got, "oracle", want)
+                sys.exit(1)
+            reached += ores.status == 1
+            aborted += ores.status == -1
+        queries += len(q)
+        cases += 1
+        e.close()
+    print("rrt fuzz ok: %d maps, %d queries (%d reached, %d out of budget) in %.0f s, seed %d" % (cases, queries, reached, aborted, budget, seed))
+
+
+if __name__ == "__main__":
+    torch.zeros(1, device="cuda")
+    if len(sys.argv) > 1 and sys.argv[1] == "repro":
+        repro(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
+    else:
+        main()
