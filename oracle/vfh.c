@@ -308,12 +308,16 @@ static void build_binary_polar_histogram(og_vfh* v, int speed) {
 /* vfh.cpp:1131-1213 */
 static void build_masked_polar_histogram(og_vfh* v, int speed) {
   const int W = v->WINDOW_DIAMETER;
-  float center_x_right = v->CENTER_X + (v->Min_Turning_Radius[speed] / (float)v->CELL_WIDTH);
-  float center_x_left = v->CENTER_X - (v->Min_Turning_Radius[speed] / (float)v->CELL_WIDTH);
+  /* A current speed above Current_Max_Speed indexes Min_Turning_Radius out of bounds in the reference (Update_VFH
+   * does not clamp, vfh.cpp:495-515).  Defined here and in the HIP kernel: the per-speed quantities of this function
+   * are taken at Current_Max_Speed; valid inputs are unaffected. */
+  const int ts = speed > v->Current_Max_Speed ? v->Current_Max_Speed : speed;
+  float center_x_right = v->CENTER_X + (v->Min_Turning_Radius[ts] / (float)v->CELL_WIDTH);
+  float center_x_left = v->CENTER_X - (v->Min_Turning_Radius[ts] / (float)v->CELL_WIDTH);
   float center_y = v->CENTER_Y;
   float angle_ahead = 90, phi_left = 180, phi_right = 0;
 
-  v->Blocked_Circle_Radius = v->Min_Turning_Radius[speed] + v->ROBOT_RADIUS + get_safety_dist(v, speed);
+  v->Blocked_Circle_Radius = v->Min_Turning_Radius[ts] + v->ROBOT_RADIUS + get_safety_dist(v, ts);
 
   for (int y = 0; y < (int)ceil(W / 2.0); y++) {
     for (int x = 0; x < W; x++) {
