@@ -71,6 +71,13 @@ def repro(seed, case, k):
     rng = np.random.default_rng(seed)
     for _ in range(case + 1):
         info, g, master, ref, q = gen_case(rng)
+    return first_divergence(info, g, master, ref, q, k)
+
+
+def first_divergence(info, g, master, ref, q, k):
+    """binary search over the sample budget for the first sample GPU and oracle decide differently, then a CPU
+    replica of the oracle up to that sample.  Returns True when the two nearest tree nodes of that sample are within
+    2 ulp of each other: a tie the last bit of atan2 / cos / sin (device libm vs glibc) decides -- see DESIGN.md 4."""
     e = engine_for(info, g, master, ref)
     print(info, "start index", tuple(g.start), "size", tuple(g.size), "pos", tuple(g.pos), q[k])
     qq = q[k:k + 1].copy()
@@ -115,7 +122,9 @@ def repro(seed, case, k):
             nw, snap = (npx + 0.4 * math.cos(a), npy + 0.4 * math.sin(a)), False
         blk = L.og_if_blocked(C.byref(g), O.fptr(ref), O.d2(*nw))
         if s == hi:
-            print("sample", s, kind, "rnd", rnd, "near", near, tree[near], "two nearest", sorted(d)[:2], "snap", snap, "new", nw, "oracle blocked", blk)
+            ds = sorted(d)
+            near_tie = len(ds) > 1 and abs(ds[1] - ds[0]) <= 2 * np.spacing(ds[0])
+            print("sample", s, kind, "rnd", rnd, "near", near, tree[near], "two nearest", [(i, repr(d[i]), tree[i]) for i in np.argsort(d)[:2]], "snap", snap, "new", nw, "oracle blocked", blk)
             cells = (C.c_int * 4096)()
             n = L.og_circle_cells(C.byref(g), O.d2(*nw), 0.3, cells, 2048)
             for c in range(n):
@@ -132,6 +141,7 @@ def repro(seed, case, k):
         if not blk:
             tree.append(nw)
     e.close()
+    return near_tie
 
 
 def main():
@@ -139,7 +149,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
-    cases = queries = reached = aborted = 0
+    cases = queries = reached = aborted = libm_ties = 0
     while time.time() < t_end:
         info, g, master, ref, q = gen_case(rng)
         e = engine_for(info, g, master, ref)
@@ -150,13 +160,18 @@ def main():
             want = (ores.status, ores.tree_size, ores.samples, ores.path_len)
             if got != want or not np.allclose(paths[k, :ores.path_len], opath, rtol=0, atol=1e-9):
                 print("MISMATCH", info, "repro: %d %d %d" % (seed, cases, k), "gpu", got, "oracle", want)
+                if got[:3] != want[:3] and int(q["max_samples"][k]) > 0 and first_divergence(info, g, master, ref, q, k):
+                    print("-> a nearest-node tie within 2 ulp (libm last bit): counted, not a failure")
+                    libm_ties += 1
+                    continue
                 sys.exit(1)
             reached += ores.status == 1
             aborted += ores.status == -1
         queries += len(q)
         cases += 1
         e.close()
-    print("rrt fuzz ok: %d maps, %d queries (%d reached, %d out of budget) in %.0f s, seed %d" % (cases, queries, reached, aborted, budget, seed))
+    print("rrt fuzz ok: %d maps, %d queries (%d reached, %d out of budget; %d diverged at a 2-ulp nearest-node tie) in %.0f s, seed %d"
+          % (cases, queries, reached, aborted, libm_ties, budget, seed))
 
 
 if __name__ == "__main__":
