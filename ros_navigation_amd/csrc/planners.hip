@@ -292,31 +292,30 @@ __device__ bool wave_if_blocked(const Geom& g, const float* __restrict__ master,
   // three cells per lane and trip (the 0.3 m disc at 0.05 m resolution spans <= 169 cells): the map reads of one
   // trip are issued together, so the test costs one memory round trip instead of three
   for (int k0 = lane; k0 < total; k0 += 192) {
-    float val[3];
+    size_t at[3];
     bool in[3];
 #pragma unroll
-    for (int u3 = 0; u3 < 3; ++u3) {
+    for (int u3 = 0; u3 < 3; ++u3) {   // pure arithmetic first ...
       const int k = k0 + 64 * u3;
-      in[u3] = false;
-      val[u3] = 0.0f;
-      if (k < total) {
-        int row = (int)((float)k * rcp_ni);      // k / ni without the integer divide (k < 2^23), corrected below
-        int col = k - row * ni;
-        if (col < 0) { row--; col += ni; } else if (col >= ni) { row++; col -= ni; }
-        const int u[2] = {su0 + col, su1 + row};
-        int bi[2];
-        buffer_index(g, u, bi);
-        // position_from_index(bi) unwraps bi again: that is u itself, wrapped into the map
-        const int w0 = (unsigned)u[0] < (unsigned)g.size[0] ? u[0] : wrap_index(u[0], g.size[0]);
-        const int w1 = (unsigned)u[1] < (unsigned)g.size[1] ? u[1] : wrap_index(u[1], g.size[1]);
-        const double x = ox + g.res * (double)(-w0);
-        const double y = oy + g.res * (double)(-w1);
-        const double dx = x - px, dy = y - py;
-        // an index past the map (unmoved map, corner on the far edge) is read out of bounds by the reference: skipped here
-        in[u3] = dx * dx + dy * dy <= r2 && (unsigned)bi[0] < (unsigned)g.size[0] && (unsigned)bi[1] < (unsigned)g.size[1];
-        if (in[u3]) val[u3] = master[(size_t)bi[1] * g.size[0] + bi[0]];
-      }
+      int row = (int)((float)k * rcp_ni);      // k / ni without the integer divide (k < 2^23), corrected below
+      int col = k - row * ni;
+      if (col < 0) { row--; col += ni; } else if (col >= ni) { row++; col -= ni; }
+      const int u[2] = {su0 + col, su1 + row};
+      int bi[2];
+      buffer_index(g, u, bi);
+      // position_from_index(bi) unwraps bi again: that is u itself, wrapped into the map
+      const int w0 = (unsigned)u[0] < (unsigned)g.size[0] ? u[0] : wrap_index(u[0], g.size[0]);
+      const int w1 = (unsigned)u[1] < (unsigned)g.size[1] ? u[1] : wrap_index(u[1], g.size[1]);
+      const double x = ox + g.res * (double)(-w0);
+      const double y = oy + g.res * (double)(-w1);
+      const double dx = x - px, dy = y - py;
+      // an index past the map (unmoved map, corner on the far edge) is read out of bounds by the reference: skipped here
+      in[u3] = (k < total) & (dx * dx + dy * dy <= r2) & ((unsigned)bi[0] < (unsigned)g.size[0]) & ((unsigned)bi[1] < (unsigned)g.size[1]);
+      at[u3] = in[u3] ? (size_t)bi[1] * g.size[0] + bi[0] : 0;
     }
+    float val[3];
+#pragma unroll
+    for (int u3 = 0; u3 < 3; ++u3) val[u3] = master[at[u3]];   // ... then the three reads together (cell 0 for lanes without one)
 #pragma unroll
     for (int u3 = 0; u3 < 3; ++u3)
       if (in[u3] && !(val[u3] != val[u3]) && val[u3] > 0.0f) hit = true;
@@ -486,9 +485,10 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
         int best_i = 0x7fffffff;
         if (__ballot(l2 <= band || (l1 <= band && i1 != imin)) == 0ull) {
           // the usual case: no other node within the band, the answer is imin (if it beats the reference's 9999 start)
+          // hypot < 9999 needs no hypot when the squared distance is far below 9999^2
           if (imin != 0x7fffffff) {
             const double2 t = tn[imin];
-            if (glibc_hypot(rx - t.x, ry - t.y) < best) best_i = imin;
+            if (m2 < 9.0e7 || glibc_hypot(rx - t.x, ry - t.y) < best) best_i = imin;
           }
         } else {
           for (int i = lane; i < n_tree; i += 64) {
@@ -506,7 +506,10 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
         RRT_ACC(1, t1, t2);
         const double npx = tn[near].x, npy = tn[near].y;
         double wx, wy;
-        if (glibc_hypot(npx - rx, npy - ry) < strideStep) { wx = rx; wy = ry; }
+        // hypot < 0.4 is decided by the squared distance except within rounding of 0.16
+        const double ddx = npx - rx, ddy = npy - ry, dd2 = ddx * ddx + ddy * ddy;
+        const bool within = dd2 < 0.1599 ? true : (dd2 > 0.1601 ? false : glibc_hypot(ddx, ddy) < strideStep);
+        if (within) { wx = rx; wy = ry; }
         else {
           const double a = atan2(ry - npy, rx - npx);
           wx = npx + strideStep * cos(a);
