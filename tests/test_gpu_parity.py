@@ -651,6 +651,38 @@ def test_scan_to_rays_matches_oracle_and_feeds_himm(R):
     e.close()
 
 
+def test_positions_on_the_far_edge_are_outside_not_out_of_bounds(R):
+    """A position within rounding of the map's far edge can divide to index == size (see
+    test_oracle_gridmap.test_index_from_position_never_returns_an_index_past_the_map).  rna_get_index, HIMM ray end
+    points there and RRT discs touching it must agree with the oracle -- and stay inside the layer."""
+    from test_oracle_gridmap import far_edge_positions
+    probes = far_edge_positions(n_geoms=60, seed=10)
+    rejected = 0
+    k = 0
+    while k < len(probes):
+        g = probes[k][0]
+        same = [p for gg, p in probes[k:k + 12] if gg is g]
+        k += len(same)
+        e = R.Engine(g.len[0], g.len[1], g.res, g.pos[0], g.pos[1])
+        assert (e.rows, e.cols) == (g.size[0], g.size[1])
+        rays = np.zeros(len(same), O.RAY_DTYPE)
+        for i, p in enumerate(same):
+            idx = O.i2(0, 0)
+            ok = O.lib().og_index_from_position(C.byref(g), O.d2(*p), idx)
+            got = e.get_index(*p)
+            assert (got is not None) == bool(ok) and (not ok or got == (idx[0], idx[1])), p
+            rejected += (not ok) and bool(O.lib().og_position_within_map(O.d2(*p), g.len, g.pos))
+            rays[i] = (g.pos[0], g.pos[1], p[0], p[1], 0, 0)       # a hit exactly there
+        init = np.zeros(e.ncell, np.float32)
+        e.upload(R.capi.LAYER_LASER, init)
+        ref = init.copy()
+        O.himm_update(g, ref, rays)
+        e.himm_update(R.capi.LAYER_LASER, rays.view(R.capi.RAY_DTYPE))
+        assert same_f32(e.download(R.capi.LAYER_LASER), ref)
+        e.close()
+    assert rejected > 0
+
+
 def test_empty_batches_are_noops(R):
     e = R.Engine(3.2, 3.2, 0.05)
     e.himm_update(R.capi.LAYER_LASER, np.zeros(0, R.capi.RAY_DTYPE))

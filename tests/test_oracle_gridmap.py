@@ -358,3 +358,43 @@ def test_at_position_nearest():
     g = O.make_geom(3.0, 3.0, 1.0)
     assert idx_from_pos(g, 1.35, -0.4) == (True, (0, 1))
     assert idx_from_pos(g, -0.3, 0.0) == (True, (1, 1))
+
+
+def far_edge_positions(n_geoms=400, seed=9):
+    """(geometry, position) pairs within a few ulp of the map's far edge, where ((p - len/2) - pos) / res rounds to
+    -size although checkIfPositionWithinMap's strict `<` still holds"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_geoms):
+        res = float(rng.choice([0.05, 0.1, 0.2, 0.025]))
+        lx, ly = float(rng.uniform(3, 30)), float(rng.uniform(3, 30))
+        px, py = (float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5))) if rng.random() < 0.5 else (0.0, 0.0)
+        g = O.make_geom(lx, ly, res, px, py)
+        edge = (g.pos[0] - 0.5 * g.len[0], g.pos[1] - 0.5 * g.len[1])
+        for a in range(2):
+            v = edge[a]
+            for _ in range(6):
+                p = [float(rng.uniform(g.pos[0] - 0.4 * g.len[0], g.pos[0] + 0.4 * g.len[0])),
+                     float(rng.uniform(g.pos[1] - 0.4 * g.len[1], g.pos[1] + 0.4 * g.len[1]))]
+                p[a] = v
+                out.append((g, tuple(p)))
+                v = float(np.nextafter(v, np.inf))
+    return out
+
+
+def test_index_from_position_never_returns_an_index_past_the_map():
+    """The reference's getIndexFromPosition can return index == size for a position within rounding of the far edge
+    (unmoved buffer) and then indexes its matrices out of bounds; oracle and kernels define that position as outside
+    (gridmath.c og_index_from_position).  Here: whenever the lookup succeeds the index is in range, and the defined
+    case does occur among the probes."""
+    hit = inside_but_rejected = 0
+    for g, p in far_edge_positions():
+        idx = O.i2(-7, -7)
+        ok = O.lib().og_index_from_position(C.byref(g), O.d2(*p), idx)
+        within = O.lib().og_position_within_map(O.d2(*p), g.len, g.pos)
+        if ok:
+            assert 0 <= idx[0] < g.size[0] and 0 <= idx[1] < g.size[1], (p, idx[0], idx[1])
+            hit += 1
+        elif within:
+            inside_but_rejected += 1
+    assert hit > 100 and inside_but_rejected > 0
