@@ -521,6 +521,14 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
         RRT_T(t4);
         RRT_ACC(3, t3, t4);
         if (lane == 0) out[wave] = RrtSlot{wx, wy, near, blocked ? 1 : 0};
+#ifdef RNA_RRT_DEBUG_SAMPLE
+        {
+          const int sno = samples + __popcll(startmask & ((2ull << mine) - 1ull));
+          if (lane == 0 && sno == RNA_RRT_DEBUG_SAMPLE)
+            printf("[rrt dbg] q %d sample %d rnd (%.17g, %.17g) near %d (%.17g, %.17g) n_tree %d new (%.17g, %.17g) blocked %d m2 %.17g\n",
+                   q, sno, rx, ry, near, npx, npy, n_tree, wx, wy, (int)blocked, m2);
+        }
+#endif
       }
       RRT_T(t5);
       __syncthreads();
@@ -542,6 +550,9 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
         rs.pos = wl + (wr ? 3 : 1);
         const RrtSlot w = out[wr ? __popcll(slotmask & ((1ull << wl) - 1ull)) : goal_slot];
         nx = w.wx; ny = w.wy; nparent = w.near;
+#ifdef RNA_RRT_DEBUG_SAMPLE
+        if (wave == 0 && lane == 0) printf("[rrt acc] q %d sample %d node %d near %d new (%.17g, %.17g)\n", q, samples, n_tree, nparent, nx, ny);
+#endif
         break;
       }
       samples += __popcll(startmask);

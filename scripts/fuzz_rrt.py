@@ -76,8 +76,9 @@ def repro(seed, case, k):
 
 def first_divergence(info, g, master, ref, q, k):
     """binary search over the sample budget for the first sample GPU and oracle decide differently, then a CPU
-    replica of the oracle up to that sample.  Returns True when the two nearest tree nodes of that sample are within
-    2 ulp of each other: a tie the last bit of atan2 / cos / sin (device libm vs glibc) decides -- see DESIGN.md 4."""
+    replica of the oracle up to that sample.  Returns True when the two nearest tree nodes of that sample -- or of an
+    earlier one: sample and node counts can coincide again after the trees diverged -- are within 2 ulp of each other:
+    a tie the last bit of atan2 / cos / sin (device libm vs glibc) decides -- see DESIGN.md 4."""
     e = engine_for(info, g, master, ref)
     print(info, "start index", tuple(g.start), "size", tuple(g.size), "pos", tuple(g.pos), q[k])
     qq = q[k:k + 1].copy()
@@ -94,6 +95,8 @@ def first_divergence(info, g, master, ref, q, k):
         a, b = run(mid)
         lo, hi = (mid, hi) if a == b else (lo, mid)
     print("first diverging sample", hi, "gpu/oracle", run(hi))
+    if os.environ.get("FUZZ_RRT_AT"):      # counts can re-coincide after a divergence: look at an earlier sample
+        hi = int(os.environ["FUZZ_RRT_AT"])
     # CPU replica of the oracle up to that sample, with the details of the decision
     L = O.lib()
     libm = C.CDLL("libm.so.6")                   # the oracle's hypot (CPython's math.hypot is a different algorithm)
@@ -104,6 +107,7 @@ def first_divergence(info, g, master, ref, q, k):
     rows, cols = int(g.size[0]), int(g.size[1])
     tree = [tuple(q["start"][k])]
     target = tuple(q["target"][k])
+    tie_at = None
     for s in range(1, hi + 1):
         if L.og_rand(C.byref(rs)) % 10 > 3:
             ridx = (C.c_int * 2)(L.og_rand(C.byref(rs)) % rows, L.og_rand(C.byref(rs)) % cols)
@@ -113,6 +117,14 @@ def first_divergence(info, g, master, ref, q, k):
         else:
             rnd, kind = target, "goal"
         d = [libm.hypot(rnd[0] - t[0], rnd[1] - t[1]) for t in tree]
+        if len(d) > 1 and tie_at is None:
+            two = np.partition(np.array(d), 1)[:2]
+            # 1-2 ulp apart but not equal: the order depends on the last bit of the node coordinates.  (Equal
+            # distances are resolved by index on both sides and do not count.)  Sample and node counts can coincide
+            # again after the trees diverged, so the binary search above may land later than this sample.
+            if two[0] != two[1] and abs(two[1] - two[0]) <= 2 * np.spacing(two.min()):
+                tie_at = s
+                print("nearest-node distances 1-2 ulp apart at sample", s, repr(float(two.min())), repr(float(two.max())))
         near = int(np.argmin(d)) if min(d) < 9999.0 else 0
         npx, npy = tree[near]
         if libm.hypot(npx - rnd[0], npy - rnd[1]) < 0.4:
@@ -139,9 +151,11 @@ def first_divergence(info, g, master, ref, q, k):
                 ok = L.og_index_from_position(C.byref(g), pp, ci)
                 print("  corner", nm, repr(pp[0]), repr(pp[1]), "inside", ok, "buffer index", ci[0], ci[1])
         if not blk:
+            if os.environ.get("FUZZ_RRT_TRACE"):
+                print("[cpu acc] sample %d node %d near %d new (%.17g, %.17g)" % (s, len(tree), near, nw[0], nw[1]))
             tree.append(nw)
     e.close()
-    return near_tie
+    return near_tie or tie_at is not None
 
 
 def main():
