@@ -2,6 +2,7 @@
 settled count) over random map shapes (not multiples of the 32-cell tile), obstacle densities, unknown cells,
 bucket widths, batch sizes and engine reuse (the lazy field reset).  usage: python scripts/fuzz_astar.py [seconds] [seed]
 Exits non-zero on the first mismatch and prints the configuration that reproduces it."""
+import ctypes as C
 import os
 import sys
 import time
@@ -20,7 +21,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 torch.zeros(1, device="cuda")
 rng = np.random.default_rng(seed)
 t_end = time.time() + budget
-cases = queries = found = 0
+cases = queries = found = moved_found = 0
 while time.time() < t_end:
     rows, cols = int(rng.integers(3, 420)), int(rng.integers(3, 420))
     if rng.random() < 0.15:
@@ -65,5 +66,41 @@ while time.time() < t_end:
                 sys.exit(1)
         queries += nq
         cases += 1
+    if rng.random() < 0.5:
+        # the same engine after GridMap::move: the search runs in map space, indices at the boundary are buffer indices
+        g = O.make_geom(rows * 0.05, cols * 0.05, 0.05)
+        ref = master.copy()
+        for l in range(3):
+            e.upload(l, ref)
+        ptrs = (C.POINTER(C.c_float) * 1)(O.fptr(ref))
+        regs = (O.Region * 4)()
+        mv = C.c_int(0)
+        for step in range(int(rng.integers(1, 3))):
+            target = (float(g.pos[0] + rng.uniform(-0.4, 0.4) * rows * 0.05), float(g.pos[1] + rng.uniform(-0.4, 0.4) * cols * 0.05))
+            O.lib().og_move(C.byref(g), ptrs, 1, O.d2(*target), regs, C.byref(mv))
+            e.move(*target)
+        e.compose_master(1)
+        assert tuple(e.geometry().start_index) == tuple(g.start), cfg
+        nq = int(rng.integers(1, 50))
+        q = np.zeros(nq, R.capi.ASTAR_QUERY_DTYPE)
+        free = np.flatnonzero(~(np.isfinite(ref) & (ref > 0)))
+        q["start"], q["goal"] = rng.choice(free, nq), rng.choice(free, nq)
+        bw = int(rng.choice([2828, 8000, 16000, 60000]))
+        here = dict(cfg, mseed=mseed, moved_to=target, start_index=tuple(g.start), nq=nq, bucket_width=bw, fuzz_seed=seed, case=cases)
+        e.astar_configure(max_queries=nq, bucket_width=bw)
+        res, paths = e.astar(q, rows * cols)
+        settled = e.astar_settled(nq)
+        for k in range(nq):
+            ores, opath = O.astar_query_on_map(g, ref, q["start"][k], q["goal"][k])
+            ok = res["status"][k] == (0 if ores.status == 0 else 1)
+            if ok and ores.status == 0:
+                ok = (res["cost"][k] == ores.cost and res["path_len"][k] == ores.path_len and
+                      np.array_equal(paths[k, :ores.path_len], opath) and settled[k] == ores.settled)
+                moved_found += 1
+            if not ok:
+                print("MISMATCH (moved map)", here, "query", k, int(q["start"][k]), int(q["goal"][k]), "gpu", res[k], "oracle",
+                      ores.status, ores.cost, ores.path_len, ores.settled)
+                sys.exit(1)
+        queries += nq
     e.close()
-print("fuzz ok: %d maps, %d queries (%d with a path) in %.0f s, seed %d" % (cases, queries, found, budget, seed))
+print("fuzz ok (%d paths on moved maps): %d maps, %d queries (%d with a path) in %.0f s, seed %d" % (moved_found, cases, queries, found, budget, seed))
