@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=4, help="A* batches in flight (rna_astar_set_pipeline_depth)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--tiled", action="store_true",
+                    help="SURVEY 8e mode 2 / BASELINE config 5: ONE map tiled 2 x N/2 over the GPUs (windowed HIMM, halo "
+                         "exchange for VFH+, all-gather of the owner windows for A*) instead of replicated maps")
     return ap.parse_args()
 
 
@@ -149,6 +152,16 @@ def main():
     # weak scaling: the global batch holds `queries` cycles per GPU; each rank serves its own shard
     lo, hi = D.shard_bounds(args.queries * world, rank, world)
     poses = R.synth.poses(args.queries * world, length, length, seed=1)[lo:hi]
+    layout = halo = None
+    if args.tiled:
+        # one map, one window per GPU: a pose is served by the GPU that owns its cell
+        layout = D.TileLayout.for_world(n, n, world)
+        halo = D.vfh_halo(0.05)
+        e.himm_set_window(*[layout.window(rank)[k] for k in (0, 2, 1, 3)])
+        cand = R.synth.poses(args.queries * world * 4, length, length, seed=1)
+        idx = np.array([e.get_index(p["x"], p["y"]) for p in cand])
+        poses = cand[layout.owner(idx[:, 0], idx[:, 1]) == rank][:hi - lo].copy()
+        assert len(poses) == hi - lo, "not enough synthetic poses inside this rank's window"
     queries = R.synth.astar_queries(args.queries * world, master, n, n, seed=2)[lo:hi]
     nq = hi - lo
 
@@ -168,12 +181,17 @@ def main():
     torch.cuda.synchronize()
 
     step_no = [0]
+    xfer = [0, 0]          # bytes received: halo strips, gathered windows
 
     def step():
         b = step_no[0] % args.pipeline
         step_no[0] += 1
         e.update_map_device(d_rays.data_ptr(), len(rays), compose_mode=0)
+        if layout is not None and world > 1:
+            xfer[0] += D.exchange_halo(e, R.capi.LAYER_MASTER, layout, rank, halo, dist)
         e.vfh_step_device(d_poses.data_ptr(), nq, d_vfh_out.data_ptr())
+        if layout is not None and world > 1:
+            xfer[1] += D.gather_layer(e, R.capi.LAYER_MASTER, layout, rank, dist)
         e.astar_device(d_queries.data_ptr(), nq, d_paths[b].data_ptr(), args.max_path, d_results[b].data_ptr())
         return b
 
@@ -192,6 +210,7 @@ def main():
 
     e.profile(True)
     e.profile_reset()
+    xfer[0] = xfer[1] = 0
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -226,7 +245,10 @@ def main():
                                    "compose -> %d VFH+ poses -> %d grid-A* queries per step; 30%% rectangle "
                                    "obstacles (seed 2)" % (n, n, len(rays), nq, nq),
                        "cycles_per_step": nq, "rays_per_step": int(len(rays)), "astar_paths_found": found,
-                       "astar_bucket_width": args.bucket_width or 16000, "astar_pipeline_depth": args.pipeline, "parallelism": "query-sharded x%d" % world},
+                       "astar_bucket_width": args.bucket_width or 16000, "astar_pipeline_depth": args.pipeline,
+                       "parallelism": ("query-sharded x%d" % world) if layout is None else
+                                      ("one map tiled %d x %d (windowed HIMM, %d-cell halo exchange, all-gather of owner "
+                                       "windows), A* query-sharded x%d" % (layout.ti, layout.tj, halo, world))},
             "roofline": {"bound": "hbm", "kernel": "tsa_search_kernel (astar_search)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("rna::tsa_search_kernel<false>"),
                          "traffic_source": "profiles/r01_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
@@ -239,6 +261,10 @@ def main():
                          "achieved_per_step_wall": alg_bytes / (t_max / args.steps) / 1e9},
             "kernel_ms_per_step": {k: (v[0] / args.steps) for k, v in prof.items() if v[1]},
         }
+        if layout is not None:
+            out["tiled"] = {"layout": [layout.ti, layout.tj], "halo_cells": halo,
+                            "halo_bytes_per_step_rank0": xfer[0] / args.steps,
+                            "gather_bytes_per_step_rank0": xfer[1] / args.steps}
         if not args.no_cpu and world == 1:   # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, R, master, rays, poses, queries, n, n, length)
         else:

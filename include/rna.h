@@ -91,6 +91,16 @@ int rna_compose_master(rna_engine* e, int mode);
 /* MapProvider::updateMap (mc/src/map_provider.cpp:190-205): laser HIMM batch, then compose(mode) */
 int rna_update_map(rna_engine* e, const rna_ray* rays_host, int n, int compose_mode);
 int rna_update_map_device(rna_engine* e, const rna_ray* rays_device, int n, int compose_mode);
+/* Tiled single map (SURVEY.md 8e mode 2, BASELINE config 5): every GPU holds a full-size layer but
+ * owns one window of it.  rna_himm_set_window restricts every later HIMM batch to the cells
+ * [i0, i0+ni) x [j0, j0+nj) (buffer indices): lines are still clipped and walked on the whole map's
+ * geometry (LineIterator.cpp:60-150), so inside the window the result is bit-identical to the
+ * untiled update.  ni <= 0 or nj <= 0 restores the whole map. */
+int rna_himm_set_window(rna_engine* e, int i0, int j0, int ni, int nj);
+/* Rectangular block of a layer <-> dense column-major device buffer (ni*nj floats, i fastest):
+ * halo strips and owner tiles exchanged between GPUs.  Both return after the copy has finished. */
+int rna_layer_pack_region(rna_engine* e, int layer, int i0, int ni, int j0, int nj, float* dense_device);
+int rna_layer_unpack_region(rna_engine* e, int layer, int i0, int ni, int j0, int nj, const float* dense_device);
 /* GridMap::move (gmc/src/GridMap.cpp:346-412): recentre the circular buffer, dropped cells -> NaN */
 int rna_move(rna_engine* e, double position_x, double position_y, int* moved);
 

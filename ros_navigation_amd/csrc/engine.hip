@@ -246,6 +246,35 @@ extern "C" void* rna_layer_device_ptr(rna_engine* e, int layer) {
   return e->layer[layer];
 }
 
+// Rectangular block of a layer <-> a dense column-major device buffer (ni fastest): the halo
+// strips and owner tiles of the tiled single-map mode travel through these (ros_navigation_amd/dist.py).
+static int region_copy(rna_engine* e, int layer, int i0, int ni, int j0, int nj, float* dense, bool pack) {
+  if (!e || !dense || layer < 0 || layer >= RNA_NUM_LAYERS) return RNA_EINVAL;
+  if (ni <= 0 || nj <= 0) return RNA_OK;
+  if (i0 < 0 || j0 < 0 || i0 + ni > e->geom.size[0] || j0 + nj > e->geom.size[1])
+    return rna::fail(e, RNA_EINVAL, "region outside the map");
+  RNA_HIP(e, hipSetDevice(e->device));
+  float* blk = e->layer[layer] + (size_t)j0 * e->geom.size[0] + i0;
+  const size_t lpitch = (size_t)e->geom.size[0] * sizeof(float), dpitch = (size_t)ni * sizeof(float);
+  if (pack) {
+    RNA_HIP(e, hipMemcpy2DAsync(dense, dpitch, blk, lpitch, dpitch, (size_t)nj, hipMemcpyDeviceToDevice, e->stream));
+  } else {
+    RNA_HIP(e, hipMemcpy2DAsync(blk, lpitch, dense, dpitch, dpitch, (size_t)nj, hipMemcpyDeviceToDevice, e->stream));
+    layer_changed(e, layer);
+  }
+  RNA_HIP(e, hipStreamSynchronize(e->stream));
+  return RNA_OK;
+}
+
+extern "C" int rna_layer_pack_region(rna_engine* e, int layer, int i0, int ni, int j0, int nj, float* dense_device) {
+  return region_copy(e, layer, i0, ni, j0, nj, dense_device, true);
+}
+
+extern "C" int rna_layer_unpack_region(rna_engine* e, int layer, int i0, int ni, int j0, int nj,
+                                       const float* dense_device) {
+  return region_copy(e, layer, i0, ni, j0, nj, const_cast<float*>(dense_device), false);
+}
+
 extern "C" void* rna_stream(rna_engine* e) { return e ? (void*)e->stream : nullptr; }
 
 extern "C" int rna_synchronize(rna_engine* e) {

@@ -30,6 +30,7 @@ struct HimmScratch {
   unsigned* after = nullptr;     // clears after the last mark of the cell
   int* total = nullptr;          // allocation cursor into seqs
   unsigned* mark_bitmap = nullptr;  // 1 bit per cell: cell holds >= 1 mark in the current batch
+  int win[4] = {0, 0, 0, 0};     // owner window [i0, i1) x [j0, j1) in buffer indices; i1 == 0: whole map
 };
 
 struct VfhDevice {

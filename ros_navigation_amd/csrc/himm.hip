@@ -78,7 +78,7 @@ __global__ void himm_init_slots_kernel(HimmSlot* __restrict__ slots, int n_slots
 
 __global__ void himm_prep_kernel(Geom g, const rna_ray* __restrict__ rays, int n, int4* __restrict__ desc,
                                  int* __restrict__ ncells, int* __restrict__ next, HimmSlot* __restrict__ slots,
-                                 int slot_mask, unsigned* __restrict__ mark_bitmap) {
+                                 int slot_mask, unsigned* __restrict__ mark_bitmap, int4 win) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   const rna_ray ray = rays[r];
@@ -94,7 +94,8 @@ __global__ void himm_prep_kernel(Geom g, const rna_ray* __restrict__ rays, int n
   next[r] = -1;
   if (!ray.clear_end) {  // map_updater.h:44-49
     int ei[2];
-    if (index_from_position(g, ray.ex, ray.ey, ei)) {
+    if (index_from_position(g, ray.ex, ray.ey, ei) && ei[0] >= win.x && ei[0] < win.y && ei[1] >= win.z &&
+        ei[1] < win.w) {  // marks outside the owner window belong to another tile's GPU
       const int cell = ei[1] * g.size[0] + ei[0];
       unsigned h = hash_cell((unsigned)cell) & (unsigned)slot_mask;
       for (;;) {
@@ -154,7 +155,8 @@ __global__ void himm_raster_kernel(int rows, const int4* __restrict__ desc, cons
                                    float* __restrict__ layer, const unsigned* __restrict__ mark_bitmap,
                                    const HimmSlot* __restrict__ slots, int slot_mask,
                                    const int* __restrict__ seqs, unsigned* __restrict__ before,
-                                   unsigned* __restrict__ after, unsigned* __restrict__ dirty_tiles, int tiles_i) {
+                                   unsigned* __restrict__ after, unsigned* __restrict__ dirty_tiles, int tiles_i,
+                                   int4 win) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = gid / LANES_PER_RAY;
   const int lane = gid % LANES_PER_RAY;
@@ -175,6 +177,9 @@ __global__ void himm_raster_kernel(int rows, const int4* __restrict__ desc, cons
     const int m = den > 0 ? (int)(((long long)num0 + (long long)k * add) / den) : 0;
     const int i = d.x + (xmajor ? k : m) * sx;
     const int j = d.y + (xmajor ? m : k) * sy;
+    // tiled single map (SURVEY 8e mode 2): the line is rasterised on the GLOBAL geometry and only
+    // the cells of this GPU's window are written, so every cell sees exactly the full batch's ops
+    if (i < win.x || i >= win.y || j < win.z || j >= win.w) continue;
     const int cell = j * rows + i;
     const int tile = (j >> 6) * tiles_i + (i >> 6);
     if (tile != last_tile) {
@@ -265,12 +270,14 @@ int himm_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n) {
   int n_slots = 1024;
   while (n_slots < 2 * n) n_slots <<= 1;
   if (n_slots > s.n_slots) n_slots = s.n_slots;
+  const int4 win = s.win[1] > 0 ? make_int4(s.win[0], s.win[1], s.win[2], s.win[3])
+                                : make_int4(0, g.size[0], 0, g.size[1]);
   {
     KernelTimer kt(e, RNA_K_HIMM_PREP);
     hipLaunchKernelGGL(himm_init_slots_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, e->stream, s.slots,
                        n_slots, s.total);
     hipLaunchKernelGGL(himm_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, g, rays_dev, n, s.desc,
-                       s.ncells, s.next, s.slots, n_slots - 1, s.mark_bitmap);
+                       s.ncells, s.next, s.slots, n_slots - 1, s.mark_bitmap, win);
     hipLaunchKernelGGL(himm_collect_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, e->stream, s.slots, n_slots,
                        s.next, s.seqs, s.before, s.after, s.total);
     RNA_HIP(e, hipGetLastError());
@@ -280,7 +287,7 @@ int himm_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n) {
     const long long threads = (long long)n * LANES_PER_RAY;
     hipLaunchKernelGGL(himm_raster_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream,
                        g.size[0], s.desc, s.ncells, n, e->layer[layer], s.mark_bitmap, s.slots, n_slots - 1,
-                       s.seqs, s.before, s.after, e->dirty_tiles, e->tiles_i);
+                       s.seqs, s.before, s.after, e->dirty_tiles, e->tiles_i, win);
     RNA_HIP(e, hipGetLastError());
   }
   {
@@ -305,6 +312,18 @@ int himm_release(rna_engine* e) {
   return RNA_OK;
 }
 }  // namespace rna
+
+extern "C" int rna_himm_set_window(rna_engine* e, int i0, int j0, int ni, int nj) {
+  if (!e) return RNA_EINVAL;
+  if (ni <= 0 || nj <= 0) {  // back to the whole map
+    e->himm.win[0] = e->himm.win[1] = e->himm.win[2] = e->himm.win[3] = 0;
+    return RNA_OK;
+  }
+  if (i0 < 0 || j0 < 0 || i0 + ni > e->geom.size[0] || j0 + nj > e->geom.size[1])
+    return fail(e, RNA_EINVAL, "rna_himm_set_window: window outside the map");
+  e->himm.win[0] = i0; e->himm.win[1] = i0 + ni; e->himm.win[2] = j0; e->himm.win[3] = j0 + nj;
+  return RNA_OK;
+}
 
 extern "C" int rna_himm_update_device(rna_engine* e, int layer, const rna_ray* rays_device, int n) {
   if (!e || layer < 0 || layer >= RNA_NUM_LAYERS || n < 0 || (n > 0 && !rays_device)) return RNA_EINVAL;

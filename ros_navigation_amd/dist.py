@@ -1,6 +1,9 @@
-"""Multi-GPU plumbing: one process per GPU, queries/poses sharded across ranks with NO data-path
-collective (the grid is replicated; every rank applies the same ray batch).  torch.distributed is
-used only for the benchmark barrier and the max-over-ranks timing, as the bench contract requires."""
+"""Multi-GPU plumbing, one process per GPU.
+Mode 1 (default): queries/poses sharded across ranks with NO data-path collective (the grid is
+replicated; every rank applies the same ray batch); torch.distributed only carries the benchmark
+barrier and the max-over-ranks timing, as the bench contract requires.
+Mode 2 (opt-in, `bench.py --tiled`): one map tiled over the GPUs with a halo exchange and an
+all-gather of the owner windows -- see TileLayout below."""
 import os
 
 
@@ -41,3 +44,152 @@ def sum_over_ranks(value, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+# ---------------------------------------------------------------------------------------------------
+# Tiled single map (SURVEY.md 8e mode 2, BASELINE config 5): one map split into ti x tj windows, one
+# per GPU.  Every GPU holds a full-size layer but is authoritative only for its window:
+#   HIMM      every rank receives the whole ray batch; rna_himm_set_window makes it write only its own
+#             cells of the globally rasterised lines -- no exchange, bit-identical inside the window;
+#   VFH+      a pose is served by the rank that owns its cell; the 1.5 m submap reaches <= halo cells
+#             into the neighbours, so after each map update the window edges travel to the (up to 8)
+#             neighbours: exchange_halo, two rounds of send/recv (RCCL over xGMI under "nccl");
+#   grid A*   searches cross the whole map: gather_layer all-gathers the owner windows into every
+#             rank's master layer once per update, then the queries are sharded as in mode 1.
+# `grid` is anything with pack_region(layer, i0, ni, j0, nj) -> dense float32 tensor (i fastest) and
+# unpack_region(layer, i0, ni, j0, nj, tensor): capi.Engine on the GPU, a numpy stand-in in CPU tests.
+# ---------------------------------------------------------------------------------------------------
+class TileLayout:
+    """rows x cols buffer-index space cut into ti x tj windows; rank = a * tj + b owns window (a, b)."""
+
+    def __init__(self, rows, cols, ti, tj):
+        if ti < 1 or tj < 1 or ti > rows or tj > cols:
+            raise ValueError("TileLayout: %d x %d windows do not fit a %d x %d map" % (ti, tj, rows, cols))
+        self.rows, self.cols, self.ti, self.tj = rows, cols, ti, tj
+
+    @classmethod
+    def for_world(cls, rows, cols, world):
+        """BASELINE config 5's shape: 2 x world/2 (8 GPUs -> 2 x 4); odd world sizes -> 1 x world."""
+        ti = 2 if world % 2 == 0 else 1
+        return cls(rows, cols, ti, world // ti)
+
+    @property
+    def world(self):
+        return self.ti * self.tj
+
+    def coords(self, rank):
+        return divmod(rank, self.tj)
+
+    def rank_of(self, a, b):
+        return a * self.tj + b if 0 <= a < self.ti and 0 <= b < self.tj else None
+
+    def window(self, rank):
+        """(i0, ni, j0, nj) of the window `rank` owns."""
+        a, b = self.coords(rank)
+        i0, i1 = shard_bounds(self.rows, a, self.ti)
+        j0, j1 = shard_bounds(self.cols, b, self.tj)
+        return i0, i1 - i0, j0, j1 - j0
+
+    def owner(self, i, j):
+        """Rank that owns cell (i, j) (numpy arrays accepted)."""
+        import numpy as np
+        ib = np.array([shard_bounds(self.rows, a, self.ti)[1] for a in range(self.ti)])
+        jb = np.array([shard_bounds(self.cols, b, self.tj)[1] for b in range(self.tj)])
+        return np.searchsorted(ib, i, side="right") * self.tj + np.searchsorted(jb, j, side="right")
+
+
+def vfh_halo(resolution, submap_length=1.5):
+    """Cells a Steerer submap (1.5 m, mc/src/steerer.cpp:128-135) can reach past its centre cell."""
+    import math
+    return int(math.ceil(0.5 * submap_length / resolution)) + 1
+
+
+def _p2p(dist, sends, recvs):
+    """sends / recvs: lists of (tensor, peer).  One batch of non-blocking send/recv; device tensors go
+    straight to RCCL, and are staged through the host under gloo (CPU tests, one-GPU developer runs)."""
+    import torch
+    if not sends and not recvs:
+        return
+    stage = dist.get_backend() == "gloo"
+    ops, back = [], []
+    for t, peer in sends:
+        ops.append(dist.P2POp(dist.isend, t.cpu() if (stage and t.is_cuda) else t, peer))
+    for t, peer in recvs:
+        if stage and t.is_cuda:
+            h = torch.empty(t.shape, dtype=t.dtype)
+            back.append((t, h))
+            t = h
+        ops.append(dist.P2POp(dist.irecv, t, peer))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    for t, h in back:
+        t.copy_(h)
+
+
+def exchange_halo(grid, layer, layout, rank, halo, dist):
+    """Bring the `halo`-cell frame around this rank's window up to date from its owners.  Round 1 moves
+    row strips (i direction) of the own columns, round 2 column strips that include the rows just
+    received, which carries the corners: 4 messages per rank instead of 8.  Returns the bytes received."""
+    import torch
+    a, b = layout.coords(rank)
+    i0, ni, j0, nj = layout.window(rank)
+    got = 0
+
+    def one_round(strips):
+        nonlocal got
+        sends, recvs, into = [], [], []
+        for peer, send_box, recv_box in strips:
+            if peer is None:
+                continue
+            sends.append((grid.pack_region(layer, *send_box), peer))
+            buf = torch.empty(recv_box[1] * recv_box[3], dtype=torch.float32, device=sends[-1][0].device)
+            recvs.append((buf, peer))
+            into.append((recv_box, buf))
+        _p2p(dist, sends, recvs)
+        for box, buf in into:
+            grid.unpack_region(layer, box[0], box[1], box[2], box[3], buf)
+            got += buf.numel() * 4
+
+    up, down = layout.rank_of(a - 1, b), layout.rank_of(a + 1, b)
+    for peer in (up, down):
+        if peer is not None and layout.window(peer)[1] < halo:
+            raise ValueError("halo of %d cells is wider than a neighbouring window" % halo)
+    if ni < halo or nj < halo:
+        raise ValueError("halo of %d cells is wider than this rank's window" % halo)
+    one_round([(up, (i0, halo, j0, nj), (i0 - halo, halo, j0, nj)),
+               (down, (i0 + ni - halo, halo, j0, nj), (i0 + ni, halo, j0, nj))])
+    ie0 = i0 - (halo if up is not None else 0)
+    ie1 = i0 + ni + (halo if down is not None else 0)
+    left, right = layout.rank_of(a, b - 1), layout.rank_of(a, b + 1)
+    for peer in (left, right):
+        if peer is not None and layout.window(peer)[3] < halo:
+            raise ValueError("halo of %d cells is wider than a neighbouring window" % halo)
+    one_round([(left, (ie0, ie1 - ie0, j0, halo), (ie0, ie1 - ie0, j0 - halo, halo)),
+               (right, (ie0, ie1 - ie0, j0 + nj - halo, halo), (ie0, ie1 - ie0, j0 + nj, halo))])
+    return got
+
+
+def gather_layer(grid, layer, layout, rank, dist):
+    """All-gather of the owner windows: afterwards `layer` is complete and identical on every rank.
+    Windows are padded to the largest one (collectives want equal counts).  Returns the bytes received."""
+    import torch
+    if layout.world == 1:
+        return 0
+    wins = [layout.window(r) for r in range(layout.world)]
+    cap = max(w[1] * w[3] for w in wins)
+    i0, ni, j0, nj = wins[rank]
+    mine = grid.pack_region(layer, i0, ni, j0, nj)
+    if mine.numel() < cap:
+        mine = torch.cat([mine, mine.new_zeros(cap - mine.numel())])
+    stage = dist.get_backend() == "gloo" and mine.is_cuda
+    src = mine.cpu() if stage else mine
+    parts = [torch.empty_like(src) for _ in range(layout.world)]
+    dist.all_gather(parts, src)
+    got = 0
+    for r, (ri0, rni, rj0, rnj) in enumerate(wins):
+        if r == rank:
+            continue
+        part = parts[r][:rni * rnj]
+        grid.unpack_region(layer, ri0, rni, rj0, rnj, part.to(mine.device).contiguous() if stage else part.contiguous())
+        got += rni * rnj * 4
+    return got

@@ -1,0 +1,167 @@
+"""Tiled single-map mode on the GPU (SURVEY.md 8e mode 2, BASELINE config 5): the window-restricted
+HIMM update against the oracle's whole-map update, and the complete tiled loop (windowed HIMM + compose
+-> halo exchange -> VFH+ for the owned poses -> all-gather -> sharded grid A*) run by two ranks that
+share the one GPU of the test box (gloo carries the messages there; RCCL needs one device per rank)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def same_f32(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(bits(a)[~np.isnan(a)], bits(b)[~np.isnan(b)])
+
+
+def test_windowed_himm_is_the_whole_map_update_inside_the_window():
+    import ros_navigation_amd as R
+    from ros_navigation_amd import dist as D
+    rows, cols = 300, 260
+    e = R.Engine(rows * 0.05, cols * 0.05, 0.05)
+    g = O.make_geom(rows * 0.05, cols * 0.05, 0.05)
+    rng = np.random.default_rng(11)
+    before = rng.choice(np.array([np.nan, 0, 10, 50, 150, 160, 170, 180, 7.5, -3], np.float32), e.ncell)
+    rays = R.synth.rays(12, 900, rows * 0.05, cols * 0.05, seed=12, lmin=0.2, lmax=7.0, margin=0.5)
+    # many marks on a few cells that sit on both sides of a window border (row 150 = first row of tile a=1)
+    for k, i in enumerate((148, 149, 150, 151)):
+        x, y = e.get_position(i, 65 * 2)
+        rays["ex"][k * 40:(k + 1) * 40] = x
+        rays["ey"][k * 40:(k + 1) * 40] = y
+        rays["clear_end"][k * 40:(k + 1) * 40] = 0
+    after = before.copy()
+    O.himm_update(g, after, rays.view(O.RAY_DTYPE))
+    L = D.TileLayout.for_world(rows, cols, 8)
+    B, A = before.reshape(cols, rows), after.reshape(cols, rows)
+    for rank in range(8):
+        i0, ni, j0, nj = L.window(rank)
+        e.upload(R.capi.LAYER_LASER, before)
+        e.himm_set_window(i0, j0, ni, nj)
+        e.himm_update(R.capi.LAYER_LASER, rays)
+        got = e.download(R.capi.LAYER_LASER).reshape(cols, rows)
+        want = B.copy()
+        want[j0:j0 + nj, i0:i0 + ni] = A[j0:j0 + nj, i0:i0 + ni]
+        assert same_f32(got, want), rank
+        # region pack / unpack round trip of exactly that window
+        t = e.pack_region(R.capi.LAYER_LASER, i0, ni, j0, nj)
+        assert same_f32(t.cpu().numpy().reshape(nj, ni), A[j0:j0 + nj, i0:i0 + ni])
+        e.fill(R.capi.LAYER_RANGE, 0.0)
+        e.unpack_region(R.capi.LAYER_RANGE, i0, ni, j0, nj, t)
+        z = np.zeros((cols, rows), np.float32)
+        z[j0:j0 + nj, i0:i0 + ni] = A[j0:j0 + nj, i0:i0 + ni]
+        assert same_f32(e.download(R.capi.LAYER_RANGE).reshape(cols, rows), z)
+    e.himm_set_window()                      # whole map again
+    e.upload(R.capi.LAYER_LASER, before)
+    e.himm_update(R.capi.LAYER_LASER, rays)
+    assert same_f32(e.download(R.capi.LAYER_LASER), after)
+    with pytest.raises(R.capi.RnaError):
+        e.himm_set_window(0, 0, rows + 1, 4)
+    e.close()
+
+
+def _tiled_worker(rank, world, port, out):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port))
+        import torch
+        import _oracle as Or
+        import ros_navigation_amd as R
+        from ros_navigation_amd import dist as D
+        torch.cuda.set_device(0)
+        dist = D.init("gloo")
+        rows, cols, res = 256, 192, 0.05
+        lx, ly = rows * res, cols * res
+        e = R.Engine(lx, ly, res)
+        g = Or.make_geom(lx, ly, res)
+        L = D.TileLayout.for_world(rows, cols, world)
+        halo = D.vfh_halo(res)
+        i0, ni, j0, nj = L.window(rank)
+        full = R.synth.obstacles_rect(rows, cols, density=0.12, seed=21, side=(2, 10))
+        e.upload(R.capi.LAYER_LASER, full)
+        e.compose_master(1)
+        e.himm_set_window(i0, j0, ni, nj)
+        # poses: uniform ones plus a row of robots right on both sides of every window border
+        poses = R.synth.poses(64, lx, ly, seed=3, margin=0.9)
+        edge = R.synth.poses(32, lx, ly, seed=4, margin=0.9)
+        for k in range(len(edge)):                      # the same poses on every rank
+            wi0, wni = L.window(k % world)[:2]
+            bi = (wi0 if k % 2 else wi0 + wni - 1) + (k % 5) - 2
+            bi = min(max(bi, 18), rows - 19)
+            edge["x"][k] = e.get_position(bi, 0)[0]
+        poses = np.concatenate([poses, edge])
+        idx = np.array([e.get_index(p["x"], p["y"]) for p in poses])
+        mine = poses[L.owner(idx[:, 0], idx[:, 1]) == rank].copy()
+        e.vfh_init(len(mine))
+        oracles = [Or.OracleVfh() for _ in range(len(mine))]
+        checked = {"vfh": 0, "astar": 0, "halo_bytes": 0, "gather_bytes": 0}
+        for rnd in range(3):
+            rays = R.synth.rays(10, 700, lx, ly, seed=30 + rnd, lmin=0.3, lmax=6.0, margin=0.4)
+            Or.himm_update(g, full, rays.view(Or.RAY_DTYPE))          # whole-map truth (laser == master)
+            e.update_map(rays, compose_mode=0)                         # this rank's window only
+            checked["halo_bytes"] += D.exchange_halo(e, R.capi.LAYER_MASTER, L, rank, halo, dist)
+            vout, origin, hist = e.vfh_step(mine)
+            for k in range(len(mine)):
+                p = mine[k]
+                cs, ct = oracles[k].step_pose(g, full, p["x"], p["y"], p["yaw"], int(p["current_speed"]),
+                                              p["goal_direction"], p["goal_distance"], p["goal_tolerance"], float(p["dt"]))
+                assert (vout["chosen_speed"][k], vout["chosen_turnrate"][k]) == (cs, ct), (rnd, k)
+                assert origin[k].tobytes() == oracles[k].origin_hist().tobytes(), (rnd, k)
+                assert hist[k].tobytes() == oracles[k].hist().tobytes(), (rnd, k)
+                checked["vfh"] += 1
+            mine["current_speed"] = vout["chosen_speed"]
+            checked["gather_bytes"] += D.gather_layer(e, R.capi.LAYER_MASTER, L, rank, dist)
+            got = e.download(R.capi.LAYER_MASTER)
+            assert np.array_equal(np.isnan(got), np.isnan(full)) and np.array_equal(got[~np.isnan(got)], full[~np.isnan(full)]), rnd
+            queries = R.synth.astar_queries(24, full, rows, cols, seed=40 + rnd)
+            lo, hi = D.shard_bounds(len(queries), rank, world)
+            res_, paths = e.astar(queries[lo:hi], 4096)
+            _, nbr = Or.astar_masks(full, rows, cols)
+            assert np.array_equal(e.nbr_mask(), nbr), rnd
+            gw = np.empty(rows * cols, np.int32)
+            for k, q in enumerate(queries[lo:hi]):
+                ores, opath, _ = Or.astar_query(nbr, rows, cols, q["start"], q["goal"], g_work=gw)
+                assert res_["status"][k] == ores.status, (rnd, k)
+                if ores.status == 0:
+                    assert res_["cost"][k] == ores.cost and np.array_equal(paths[k, :ores.path_len], opath), (rnd, k)
+                checked["astar"] += 1
+        e.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        out.put((rank, "ok", checked, len(mine)))
+    except BaseException as ex:  # noqa: BLE001 -- reported to the parent, which fails the test
+        import traceback
+        out.put((rank, "fail", traceback.format_exc(), repr(ex)))
+
+
+def test_tiled_loop_two_ranks_on_one_gpu_matches_the_whole_map_oracle():
+    import torch.multiprocessing as mp
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_tiled_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", r[2]
+    assert sum(r[3] for r in res) == 96                       # every pose served by exactly one rank
+    assert all(r[2]["vfh"] == 3 * r[3] and r[2]["astar"] == 36 for r in res)
+    # 2 x 1 layout: one 16-row strip of 192 columns per rank per round, the other window per gather
+    assert all(r[2]["halo_bytes"] == 3 * 16 * 192 * 4 and r[2]["gather_bytes"] == 3 * 128 * 192 * 4 for r in res)
