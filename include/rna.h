@@ -104,6 +104,24 @@ int rna_layer_unpack_region(rna_engine* e, int layer, int i0, int ni, int j0, in
 /* GridMap::move (gmc/src/GridMap.cpp:346-412): recentre the circular buffer, dropped cells -> NaN */
 int rna_move(rna_engine* e, double position_x, double position_y, int* moved);
 
+/* MapProvider::getSubMap -> GridMap::getSubmap (mc/src/map_provider.cpp:93-100, gmc/src/GridMap.cpp:287-339,
+ * getSubmapInformation gmc/src/GridMapMath.cpp:246-296): the requested window is clamped to the map, and the
+ * submap's cells are gathered across the circular-buffer seam (the reference's <= 4 quadrant block copies) into
+ * out (column-major, info->size[0]*info->size[1] floats, startIndex (0,0)).  Callers: Steerer (1.5 m window,
+ * mc/src/steerer.cpp:158; fused into rna_vfh_step_batch here) and Nav::makePlan's planning window
+ * (mc/src/nav_node.cpp:141).  Returns 1 = success, 0 = the reference's isSuccess == false, < 0 = rna_status
+ * (RNA_ECAPACITY when the submap has more than cap_cells cells; info is filled in that case too). */
+typedef struct {
+  double length[2];      /* submap length_ (size * resolution) */
+  double position[2];    /* submap position_ (centre) */
+  int32_t size[2];
+  int32_t top_left[2];   /* buffer index of the submap's first cell in the parent map */
+} rna_submap_info;
+int rna_get_submap(rna_engine* e, int layer, double position_x, double position_y, double length_x, double length_y,
+                   float* out_host, size_t cap_cells, rna_submap_info* info);
+int rna_get_submap_device(rna_engine* e, int layer, double position_x, double position_y, double length_x,
+                          double length_y, float* out_device, size_t cap_cells, rna_submap_info* info);
+
 /* ---- VFH+ local avoidance -------------------------------------------------------------------- */
 /* VFH constructor arguments + SetRobotRadius (mc/include/move_control/vfh.h:185-203,235;
  * defaults of Steerer::initVfh, mc/src/steerer.cpp:69-121) */
@@ -248,6 +266,14 @@ int rna_vfh_hist_msg_batch(rna_engine* e, int n, uint16_t* x_data_host, uint16_t
 /* Nav::taileredPlan (mc/src/nav_node.cpp:192-204): walk the plan backwards keeping every stride-th
  * index and the last one (host only; out_xy holds up to n positions). */
 int rna_tailor_plan(const double* plan_xy, int n, unsigned stride, double* out_xy, int* n_out);
+/* Steerer::acceptPlan + the plan-following head of Steerer::update (mc/src/steerer.cpp:27-33,222-256), host only:
+ * *plan_index is Steerer::planIndex_ (acceptPlan sets it to 1); way points closer than 250 mm are skipped, then
+ * goal distance (mm, float hypot), goal direction (deg, RAD2DEG(normalize_angle_positive(atan2f(dy,dx) - yaw + M_PI/2)))
+ * and current_speed = (int)(linear_velocity * 1000.0) are written to *pose together with x, y, yaw, dt -- ready for
+ * rna_vfh_step_batch.  Returns 1 while the plan is being followed, 0 when it is finished (ifPlanReady_ = false;
+ * also for a plan of fewer than 2 points, where the reference reads plan_[1] out of bounds), < 0 on bad arguments. */
+int rna_follow_plan(const double* plan_xy, int n, int32_t* plan_index, double x, double y, double yaw,
+                    double linear_velocity, double dt, rna_pose* pose);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 typedef enum {

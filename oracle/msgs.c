@@ -75,3 +75,29 @@ int og_tailor_plan(const double* plan_xy, int n, unsigned stride, double* out_xy
   }
   return m;
 }
+
+/* Steerer::acceptPlan (steerer.cpp:27-33: planIndex_ = 1) and Steerer::update up to Update_VFH (steerer.cpp:222-256).
+ * float deltaX, deltaY, desiredDist, desiredAngle; hypot / atan2 on floats are the float overloads there
+ * (map_provider.h:8 `using namespace std`, -std=c++11 in mc/CMakeLists.txt:20).  out = {desiredAngle, desiredDist};
+ * returns 1 while following, 0 when planIndex_ runs past the plan (ifPlanReady_ = false).  A plan shorter than
+ * 2 points is finished at once (the reference reads plan_[1] out of bounds). */
+int og_follow_plan(const double* plan_xy, int n, int* plan_index, double x, double y, double yaw, float out[2]) {
+  float deltaX, deltaY, desiredDist;
+  const float currGoalDistanceTolerance = 250;
+  while (1) {
+    if (*plan_index >= n) return 0;
+    deltaX = (plan_xy[2 * *plan_index] - x) * 1000.0;
+    deltaY = (plan_xy[2 * *plan_index + 1] - y) * 1000.0;
+    desiredDist = hypotf(deltaX, deltaY);
+    if (desiredDist < currGoalDistanceTolerance) {
+      (*plan_index)++;
+      if (*plan_index >= n) return 0;
+    } else
+      break;
+  }
+  double a = atan2f(deltaY, deltaX) - yaw + M_PI / 2;
+  a = fmod(fmod(a, 2.0 * M_PI) + 2.0 * M_PI, 2.0 * M_PI); /* angles::normalize_angle_positive */
+  out[0] = (a) * 180.0 / M_PI;                               /* RAD2DEG */
+  out[1] = desiredDist;
+  return 1;
+}

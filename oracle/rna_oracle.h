@@ -228,6 +228,8 @@ int og_hist_msg(const float* hist, const float* origin_hist, int hist_size, int 
                 uint16_t* y_data, uint16_t* y_bin_data, uint16_t thresholds[2]);
 /* Nav::taileredPlan (nav_node.cpp:192-204); returns the number of kept positions */
 int og_tailor_plan(const double* plan_xy, int n, unsigned stride, double* out_xy);
+/* mc/src/steerer.cpp:27-33,222-256 */
+int og_follow_plan(const double* plan_xy, int n, int* plan_index, double x, double y, double yaw, float out[2]);
 
 #ifdef __cplusplus
 }

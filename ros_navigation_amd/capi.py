@@ -33,7 +33,7 @@ SYMBOLS = [
     "rna_astar_download_nbr_mask",
     "rna_graph_astar_batch", "rna_rrt_batch", "rna_rrt_batch_device",
     "rna_to_occupancy_grid", "rna_to_occupancy_grid_device", "rna_from_occupancy_grid", "rna_vfh_hist_msg_batch",
-    "rna_tailor_plan", "rna_scan_to_rays", "rna_scan_to_rays_device",
+    "rna_tailor_plan", "rna_follow_plan", "rna_get_submap", "rna_get_submap_device", "rna_scan_to_rays", "rna_scan_to_rays_device",
     "rna_profile_enable", "rna_profile_reset", "rna_profile_get", "rna_kernel_name",
 ]
 
@@ -41,6 +41,11 @@ SYMBOLS = [
 class Geometry(C.Structure):
     _fields_ = [("length", C.c_double * 2), ("position", C.c_double * 2), ("resolution", C.c_double),
                 ("size", C.c_int32 * 2), ("start_index", C.c_int32 * 2)]
+
+
+class SubmapInfo(C.Structure):
+    _fields_ = [("length", C.c_double * 2), ("position", C.c_double * 2), ("size", C.c_int32 * 2),
+                ("top_left", C.c_int32 * 2)]
 
 
 class VfhParams(C.Structure):
@@ -146,6 +151,11 @@ def lib():
     L.rna_from_occupancy_grid.argtypes = [vp, C.c_int, vp]
     L.rna_vfh_hist_msg_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.rna_tailor_plan.argtypes = [vp, C.c_int, C.c_uint, vp, C.POINTER(C.c_int)]
+    L.rna_follow_plan.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.c_double, C.c_double, C.c_double, C.c_double,
+                                  C.c_double, vp]
+    L.rna_get_submap.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, vp, C.c_size_t,
+                                 C.POINTER(SubmapInfo)]
+    L.rna_get_submap_device.argtypes = L.rna_get_submap.argtypes
     L.rna_scan_to_rays.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp, C.c_int, C.POINTER(C.c_int)]
     L.rna_scan_to_rays_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
     L.rna_profile_enable.argtypes = [vp, C.c_int]
@@ -166,6 +176,18 @@ def tailor_plan(plan_xy, stride=5):
     if rc != 0:
         raise RnaError("rna_tailor_plan failed (%d)" % rc)
     return out[:m.value].copy()
+
+
+def follow_plan(plan_xy, plan_index, x, y, yaw, linear_velocity=0.0, dt=0.2):
+    """Steerer::update's plan-following head: returns (following, plan_index, pose) -- pose is a POSE_DTYPE record
+    ready for Engine.vfh_step, valid while following is True."""
+    plan = np.ascontiguousarray(plan_xy, np.float64).reshape(-1, 2)
+    idx = C.c_int32(plan_index)
+    pose = np.zeros(1, POSE_DTYPE)
+    rc = lib().rna_follow_plan(_ptr(plan), len(plan), C.byref(idx), x, y, yaw, linear_velocity, dt, _ptr(pose))
+    if rc < 0:
+        raise RnaError("rna_follow_plan failed (%d)" % rc)
+    return rc == 1, idx.value, pose[0]
 
 
 def default_vfh_params():
@@ -192,6 +214,7 @@ class Engine:
         g = self.geometry()
         self.rows, self.cols = g.size[0], g.size[1]
         self.ncell = self.rows * self.cols
+        self.resolution = g.resolution
         self.hist_size = None
 
     def close(self):
@@ -243,6 +266,20 @@ class Engine:
         out = (C.c_double * 2)()
         ok = self._L.rna_get_position(self.h, i, j, out)
         return (out[0], out[1]) if ok == 1 else None
+
+    def get_submap(self, layer, x, y, length_x, length_y):
+        """GridMap::getSubmap: (info, data) with data column-major info.size[0] x info.size[1], or None when the
+        reference's isSuccess is false."""
+        info = SubmapInfo()
+        cap = (int(np.ceil(length_x / self.resolution)) + 2) * (int(np.ceil(length_y / self.resolution)) + 2)
+        cap = max(1, min(cap, self.ncell))
+        out = np.empty(cap, np.float32)
+        rc = self._L.rna_get_submap(self.h, layer, x, y, length_x, length_y, _ptr(out), out.size, C.byref(info))
+        if rc == 0:
+            return None
+        if rc != 1:
+            self._check(rc)
+        return info, out[:info.size[0] * info.size[1]].copy()
 
     def move(self, x, y):
         m = C.c_int(0)

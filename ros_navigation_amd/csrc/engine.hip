@@ -117,6 +117,20 @@ __global__ void clear_region_kernel(float* __restrict__ p, int rows, int i0, int
   }
 }
 
+// GridMap::getSubmap (gmc/src/GridMap.cpp:287-339): submap cell (r, c) is parent buffer cell
+// ((tl0 + r) mod rows, (tl1 + c) mod cols) -- the reference's <= 4 quadrant blocks are this wrap.
+__global__ void submap_gather_kernel(const float* __restrict__ layer, int rows, int cols, int tl0, int tl1, int sr,
+                                     int sc, float* __restrict__ out) {
+  const size_t n = (size_t)sr * sc;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+    int bi = tl0 + (int)(k % sr), bj = tl1 + (int)(k / sr);
+    if (bi >= rows) bi -= rows;
+    if (bj >= cols) bj -= cols;
+    out[k] = layer[(size_t)bj * rows + bi];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -273,6 +287,47 @@ extern "C" int rna_layer_pack_region(rna_engine* e, int layer, int i0, int ni, i
 extern "C" int rna_layer_unpack_region(rna_engine* e, int layer, int i0, int ni, int j0, int nj,
                                        const float* dense_device) {
   return region_copy(e, layer, i0, ni, j0, nj, const_cast<float*>(dense_device), false);
+}
+
+static int get_submap(rna_engine* e, int layer, double px, double py, double lx, double ly, float* out, size_t cap,
+                      rna_submap_info* info, bool to_host) {
+  if (!e || !info || layer < 0 || layer >= RNA_NUM_LAYERS || (cap > 0 && !out)) return RNA_EINVAL;
+  const double rp[2] = {px, py}, rl[2] = {lx, ly};
+  SubmapInfo si;
+  if (!submap_information(e->geom, rp, rl, si)) return 0;
+  for (int a = 0; a < 2; ++a) {
+    info->length[a] = si.len[a]; info->position[a] = si.pos[a];
+    info->size[a] = si.size[a]; info->top_left[a] = si.top_left[a];
+  }
+  if (si.size[0] <= 0 || si.size[1] <= 0 || si.size[0] > e->geom.size[0] || si.size[1] > e->geom.size[1]) return 0;
+  const size_t n = (size_t)si.size[0] * si.size[1];
+  if (n > cap) return rna::fail(e, RNA_ECAPACITY, "rna_get_submap: output buffer smaller than the submap");
+  RNA_HIP(e, hipSetDevice(e->device));
+  float* dst = out;
+  float* staging = nullptr;
+  if (to_host) {
+    RNA_HIP(e, hipMalloc(&staging, n * sizeof(float)));
+    dst = staging;
+  }
+  hipLaunchKernelGGL(submap_gather_kernel, dim3(grid_for(n, 256)), dim3(256), 0, e->stream, e->layer[layer],
+                     e->geom.size[0], e->geom.size[1], si.top_left[0], si.top_left[1], si.size[0], si.size[1], dst);
+  hipError_t err = hipGetLastError();
+  if (err == hipSuccess && to_host)
+    err = hipMemcpyAsync(out, staging, n * sizeof(float), hipMemcpyDeviceToHost, e->stream);
+  if (err == hipSuccess && to_host) err = hipStreamSynchronize(e->stream);
+  if (staging) (void)hipFree(staging);
+  RNA_HIP(e, err);
+  return 1;
+}
+
+extern "C" int rna_get_submap(rna_engine* e, int layer, double px, double py, double lx, double ly, float* out_host,
+                              size_t cap_cells, rna_submap_info* info) {
+  return get_submap(e, layer, px, py, lx, ly, out_host, cap_cells, info, true);
+}
+
+extern "C" int rna_get_submap_device(rna_engine* e, int layer, double px, double py, double lx, double ly,
+                                     float* out_device, size_t cap_cells, rna_submap_info* info) {
+  return get_submap(e, layer, px, py, lx, ly, out_device, cap_cells, info, false);
 }
 
 extern "C" void* rna_stream(rna_engine* e) { return e ? (void*)e->stream : nullptr; }

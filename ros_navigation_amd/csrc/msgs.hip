@@ -7,6 +7,7 @@
 //   rna_from_occupancy_grid  GridMapRosConverter::fromOccupancyGrid, data part (:238-246)
 //   rna_vfh_hist_msg_batch   Steerer::pubHist -> Histogram.msg (mc/src/steerer.cpp:201-220)
 //   rna_tailor_plan          Nav::taileredPlan (mc/src/nav_node.cpp:192-204), host only
+//   rna_follow_plan          Steerer::acceptPlan / head of Steerer::update (mc/src/steerer.cpp:27-33,222-256), host only
 #include "engine.hpp"
 
 using namespace rna;
@@ -145,4 +146,31 @@ extern "C" int rna_tailor_plan(const double* plan_xy, int n, unsigned stride, do
   }
   *n_out = m;
   return RNA_OK;
+}
+
+// Steerer::update up to the Update_VFH call (mc/src/steerer.cpp:222-256).  deltaX/deltaY/desiredDist/desiredAngle
+// are floats there; map_provider.h:8 has `using namespace std` and the package builds with -std=c++11, so
+// hypot(float, float) and atan2(float, float) resolve to the float overloads (hypotf / atan2f of the host libm).
+extern "C" int rna_follow_plan(const double* plan_xy, int n, int32_t* plan_index, double x, double y, double yaw,
+                               double linear_velocity, double dt, rna_pose* pose) {
+  if (!plan_index || !pose || n < 0 || (n > 0 && !plan_xy) || *plan_index < 0) return RNA_EINVAL;
+  const float tolerance = 250.0f;   // currGoalDistanceTolerance
+  float dx = 0.0f, dy = 0.0f, dist = 0.0f;
+  for (;;) {
+    if (*plan_index >= n) return 0;   // plan finished (reference: ifPlanReady_ = false)
+    dx = (float)((plan_xy[2 * (size_t)*plan_index] - x) * 1000.0);
+    dy = (float)((plan_xy[2 * (size_t)*plan_index + 1] - y) * 1000.0);
+    dist = hypotf(dx, dy);
+    if (dist < tolerance) ++*plan_index;
+    else break;
+  }
+  const double a = (double)atan2f(dy, dx) - yaw + M_PI / 2;
+  const double two_pi = 2.0 * M_PI;
+  const double norm = fmod(fmod(a, two_pi) + two_pi, two_pi);   // angles::normalize_angle_positive
+  pose->x = x; pose->y = y; pose->yaw = yaw; pose->dt = dt;
+  pose->current_speed = (int32_t)(linear_velocity * 1000.0);
+  pose->goal_direction = (float)(norm * 180.0 / M_PI);
+  pose->goal_distance = dist;
+  pose->goal_tolerance = tolerance;
+  return 1;
 }

@@ -109,6 +109,32 @@ class GridMap {
     rna_check(rna_layer_download(e_, layerId(layer), out.data(), out.size()), e_, "GridMap::get");
     return out;
   }
+  // GridMap::getSubmap(position, length, isSuccess) (gmc/src/GridMap.cpp:287-339) for one layer: the submap comes back
+  // as host data with its own geometry (a GridMap on the host side of the boundary; startIndex (0,0)).
+  struct SubMap {
+    Length length; Position position; Size size; double resolution;
+    std::vector<float> data;   // column-major size[0] x size[1]
+    float at(int i, int j) const { return data[(size_t)j * size[0] + i]; }
+  };
+  SubMap getSubmap(const Position& position, const Length& length, bool& isSuccess, const std::string& layer = "master") const {
+    SubMap sm;
+    rna_geometry g = geometry();
+    sm.resolution = g.resolution;
+    size_t cap = ((size_t)std::ceil(length[0] / g.resolution) + 2) * ((size_t)std::ceil(length[1] / g.resolution) + 2);
+    const size_t all = (size_t)g.size[0] * g.size[1];
+    if (cap > all || cap == 0) cap = all;
+    sm.data.resize(cap);
+    rna_submap_info info;
+    const int rc = rna_get_submap(e_, layerId(layer), position[0], position[1], length[0], length[1], sm.data.data(), cap, &info);
+    if (rc < 0) rna_check(rc, e_, "GridMap::getSubmap");
+    isSuccess = rc == 1;
+    if (!isSuccess) { sm.data.clear(); return sm; }
+    sm.length = Length(info.length[0], info.length[1]);
+    sm.position = Position(info.position[0], info.position[1]);
+    sm.size = Size(info.size[0], info.size[1]);
+    sm.data.resize((size_t)info.size[0] * info.size[1]);
+    return sm;
+  }
   rna_engine* engine() const { return e_; }
 
  private:
@@ -186,6 +212,12 @@ class MapProvider {
     msg.data.resize((size_t)g.size[0] * g.size[1]);
     grid_map::rna_check(rna_to_occupancy_grid(map_.engine(), RNA_LAYER_MASTER, 0.0f, 255.0f, msg.data.data()), map_.engine(),
                         "MapProvider::publishMap");
+  }
+  // MapProvider::getSubMap (:93-100)
+  bool getSubMap(GridMap::SubMap& map, const Position& center, const Length& length) {
+    bool ok = false;
+    map = map_.getSubmap(center, length, ok);
+    return ok;
   }
   bool ifCloseToPostion(const Position& robot, const Position& pos, double tolerance) const {  // :102-111
     return std::hypot(pos[0] - robot[0], pos[1] - robot[1]) < tolerance;
@@ -268,6 +300,47 @@ class VFH {
   int robots_;
   float picked_;
   std::vector<float> hist_, origin_;
+};
+
+// Steerer (mc/include/move_control/steerer.h:18-47, mc/src/steerer.cpp): acceptPlan + one update() per VFH period.
+// The ROS side (odometry monitor, velocity / histogram publishers, the 5 Hz thread) stays with the node; update()
+// takes what Steerer::update reads from them (robot pose, odom linear velocity) and returns what pubVel publishes.
+class Steerer {
+ public:
+  Steerer(MapProvider& mapProvider, VFH& vfh) : mapProvider_(mapProvider), vfh_(vfh), ifPlanReady_(false), planIndex_(1) {}
+  void acceptPlan(std::vector<Position>& plan) {   // steerer.cpp:27-33
+    plan_.resize(2 * plan.size());
+    for (size_t k = 0; k < plan.size(); ++k) { plan_[2 * k] = plan[k][0]; plan_[2 * k + 1] = plan[k][1]; }
+    ifPlanReady_ = true;
+    planIndex_ = 1;
+  }
+  bool ifPlanReady() const { return ifPlanReady_; }
+  // steerer.cpp:222-270.  false: no plan / plan finished (nothing published, as in the reference).
+  // linear_x / angular_z are the geometry_msgs/Twist fields of pubVel (steerer.cpp:193-199).
+  bool update(const Position& currentPos, double currentDir, double odomLinearX, double dt, int& chosenSpeed,
+              int& chosenTurnrate, double& linear_x, double& angular_z) {
+    if (!ifPlanReady_) return false;
+    rna_pose pose;
+    const int rc = rna_follow_plan(plan_.data(), (int)(plan_.size() / 2), &planIndex_, currentPos[0], currentPos[1],
+                                   currentDir, odomLinearX, dt, &pose);
+    if (rc < 0) throw std::invalid_argument("Steerer::update");
+    if (rc == 0) { ifPlanReady_ = false; return false; }
+    std::vector<rna_pose> poses(1, pose);
+    std::vector<rna_vfh_out> out;
+    vfh_.Update_VFH(poses, out);        // getRangesFromSubmap + Update_VFH, fused on the device
+    chosenSpeed = out[0].chosen_speed; chosenTurnrate = out[0].chosen_turnrate;
+    linear_x = (float)(chosenSpeed) / 1000.0;
+    angular_z = (chosenTurnrate) * M_PI / 180.0;
+    return true;
+  }
+  int planIndex() const { return planIndex_; }
+
+ private:
+  MapProvider& mapProvider_;
+  VFH& vfh_;
+  std::vector<double> plan_;
+  bool ifPlanReady_;
+  int32_t planIndex_;
 };
 
 // AStarPlanner::makePlan over the reference's hard-coded waypoint graph (astar_planner.cpp:63-127)

@@ -156,6 +156,8 @@ def lib():
         L.og_from_occupancy_grid.restype = None
         L.og_hist_msg.argtypes = [fp, fp, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.og_tailor_plan.argtypes = [d2, C.c_int, C.c_uint, d2]
+        L.og_follow_plan.argtypes = [d2, C.c_int, C.POINTER(C.c_int), C.c_double, C.c_double, C.c_double,
+                                     C.POINTER(C.c_float)]
         _lib = L
     return _lib
 
@@ -412,3 +414,12 @@ def tailor_plan(plan_xy, stride=5):
     m = lib().og_tailor_plan(plan.ctypes.data_as(C.POINTER(C.c_double)), len(plan), stride,
                              out.ctypes.data_as(C.POINTER(C.c_double)))
     return out[:m].copy()
+
+
+def follow_plan(plan_xy, plan_index, x, y, yaw):
+    """(following, plan_index, desiredAngle, desiredDist) of Steerer::update (steerer.cpp:222-256)."""
+    plan = np.ascontiguousarray(plan_xy, np.float64).reshape(-1, 2)
+    idx = C.c_int(plan_index)
+    out = (C.c_float * 2)()
+    ok = lib().og_follow_plan(plan.ctypes.data_as(C.POINTER(C.c_double)), len(plan), C.byref(idx), x, y, yaw, out)
+    return bool(ok), idx.value, np.float32(out[0]), np.float32(out[1])

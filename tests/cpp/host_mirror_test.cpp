@@ -85,6 +85,59 @@ int main() {
     CHECK(occ.data == want);
   }
 
+  {  // MapProvider::getSubMap (map_provider.cpp:93-100) -> GridMap::getSubmap: the Steerer's 1.5 m window and a
+     // planning window that hangs over the map border (nav_node.cpp:141)
+    const double wins[3][4] = {{1.0, -0.5, 1.5, 1.5}, {5.9, -6.1, 4.0, 4.0}, {0.0, 0.0, 100.0, 100.0}};
+    for (int w = 0; w < 3; ++w) {
+      GridMap::SubMap sm;
+      Position c(wins[w][0], wins[w][1]);
+      const bool ok = provider.getSubMap(sm, c, Length(wins[w][2], wins[w][3]));
+      og_geom sg;
+      std::vector<float> want(ref.size());
+      const double p[2] = {wins[w][0], wins[w][1]}, l[2] = {wins[w][2], wins[w][3]};
+      const int ook = og_get_submap(&g, ref.data(), p, l, &sg, want.data(), (int)want.size());
+      CHECK(ok == (ook != 0));
+      if (!ok) continue;
+      CHECK(sm.size[0] == sg.size[0] && sm.size[1] == sg.size[1] && sm.position[0] == sg.pos[0] && sm.position[1] == sg.pos[1]);
+      CHECK(sm.length[0] == sg.len[0] && sm.length[1] == sg.len[1] && sm.data.size() == (size_t)sg.size[0] * sg.size[1]);
+      for (size_t i = 0; i < sm.data.size(); ++i) CHECK(same_bits(sm.data[i], want[i]));
+    }
+  }
+  {  // Steerer::acceptPlan / update (steerer.cpp:27-33,222-270) on a fresh VFH instance, against the oracle
+    VFH svfh(100, 30, 5, 10, 50, 200, 200, 300, 200, 40, 40, 40, 1.0, 2000000.0, 4000000.0, 2000000.0, 4000000.0, 10.0, 1.0);
+    svfh.SetRobotRadius(178.0);
+    svfh.Init(map);
+    Steerer steerer(provider, svfh);
+    std::vector<Position> plan;
+    plan.push_back(Position(1.0, -0.5)); plan.push_back(Position(1.1, -0.45)); plan.push_back(Position(2.0, 0.5));
+    plan.push_back(Position(2.1, 2.0));
+    steerer.acceptPlan(plan);
+    std::vector<double> pxy;
+    for (size_t k = 0; k < plan.size(); ++k) { pxy.push_back(plan[k][0]); pxy.push_back(plan[k][1]); }
+    og_vfh* sv = og_vfh_create(&op);
+    int oidx = 1, steps = 0;
+    double x = 1.0, y = -0.5, yaw = 0.3, vel = 0.0;
+    for (int it = 0; it < 40; ++it) {
+      int cs = 0, ct = 0;
+      double lin = 0, ang = 0;
+      const bool following = steerer.update(Position(x, y), yaw, vel, 0.2, cs, ct, lin, ang);
+      float od[2];
+      const int ofollow = og_follow_plan(pxy.data(), (int)plan.size(), &oidx, x, y, yaw, od);
+      CHECK(following == (ofollow != 0) && steerer.planIndex() == oidx);
+      if (!following) break;
+      int ocs = 0, oct = 0;
+      const double rp[2] = {x, y};
+      og_vfh_step_pose(sv, &g, ref.data(), rp, yaw, (int)(vel * 1000.0), od[0], od[1], 250.0f, 0.2, &ocs, &oct);
+      CHECK(cs == ocs && ct == oct);
+      CHECK(lin == (float)cs / 1000.0 && ang == ct * M_PI / 180.0);
+      vel = lin; yaw += ang * 0.2;
+      x += 0.5 * (plan[oidx][0] - x); y += 0.5 * (plan[oidx][1] - y);   // the robot closes in on its way point
+      ++steps;
+    }
+    CHECK(steps >= 3 && !steerer.ifPlanReady());
+    og_vfh_destroy(sv);
+  }
+
   // ---- planners ----
   Position start(-5.0, -5.0), target(5.5, 4.0);
   std::vector<Position> path;

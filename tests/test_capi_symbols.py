@@ -40,9 +40,10 @@ def test_struct_layouts_match_header(capi):
     #include <stdio.h>
     #include "rna.h"
     int main(void) {
-      printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(rna_geometry), sizeof(rna_ray), sizeof(rna_vfh_params),
+      printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu ", sizeof(rna_geometry), sizeof(rna_ray), sizeof(rna_vfh_params),
              sizeof(rna_pose), sizeof(rna_vfh_out), sizeof(rna_astar_query), sizeof(rna_astar_result),
              sizeof(rna_rrt_query), sizeof(rna_rrt_result), (size_t)RNA_K_COUNT, sizeof(rna_laser_scan));
+      printf("%zu\n", sizeof(rna_submap_info));
       return 0;
     }"""
     exe = "/tmp/rna_layout_check"
@@ -51,7 +52,7 @@ def test_struct_layouts_match_header(capi):
     assert sizes == [C.sizeof(capi.Geometry), capi.RAY_DTYPE.itemsize, C.sizeof(capi.VfhParams),
                      capi.POSE_DTYPE.itemsize, capi.VFH_OUT_DTYPE.itemsize, capi.ASTAR_QUERY_DTYPE.itemsize,
                      capi.ASTAR_RESULT_DTYPE.itemsize, capi.RRT_QUERY_DTYPE.itemsize, capi.RRT_RESULT_DTYPE.itemsize,
-                     len(capi.KERNELS), capi.SCAN_DTYPE.itemsize]
+                     len(capi.KERNELS), capi.SCAN_DTYPE.itemsize, C.sizeof(capi.SubmapInfo)]
     assert src.count("extern \"C\"") == 1
 
 
@@ -75,6 +76,45 @@ def test_tailor_plan_host_entry_point(capi):
         plan = rng.normal(size=(n, 2))
         for stride in (1, 2, 5):
             assert np.array_equal(capi.tailor_plan(plan, stride), O.tailor_plan(plan, stride))
+
+
+def test_follow_plan_host_entry_point(capi):
+    """rna_follow_plan (Steerer::acceptPlan + head of Steerer::update, mc/src/steerer.cpp:27-33,222-256) is host-only:
+    hand-checked cases, then random plans / robot tracks against the oracle, bit for bit."""
+    import numpy as np
+    import _oracle as O
+    plan = np.array([[0.0, 0.0], [1.0, 0.0], [1.0, 2.0], [1.1, 2.0]])
+    # robot at the origin looking along +x: way point 1 is 1000 mm straight ahead = 90 deg
+    ok, idx, pose = capi.follow_plan(plan, 1, 0.0, 0.0, 0.0, linear_velocity=0.3456, dt=0.25)
+    assert ok and idx == 1 and pose["goal_distance"] == np.float32(1000.0) and pose["goal_direction"] == np.float32(90.0)
+    assert pose["current_speed"] == 345 and pose["goal_tolerance"] == 250.0 and pose["dt"] == 0.25
+    # within 250 mm of way point 1: skipped; way point 2 is up-left of a robot looking along +x
+    ok, idx, pose = capi.follow_plan(plan, 1, 0.9, 0.1, 0.0)
+    assert ok and idx == 2 and abs(float(pose["goal_direction"]) - (90.0 + np.degrees(np.arctan2(1.9, 0.1)))) < 1e-4
+    # last two way points both within tolerance: the plan is finished, index runs past the end
+    ok, idx, _ = capi.follow_plan(plan, 2, 1.05, 2.05, 1.0)
+    assert (ok, idx) == (False, 4)
+    for short in (plan[:0], plan[:1]):                       # the reference would read plan_[1] out of bounds
+        assert capi.follow_plan(short, 1, 0.0, 0.0, 0.0)[0] is False
+    with pytest.raises(capi.RnaError):
+        capi.follow_plan(plan, -1, 0.0, 0.0, 0.0)
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        n = int(rng.integers(2, 40))
+        plan = np.cumsum(rng.normal(scale=0.2, size=(n, 2)), 0)
+        idx_c = idx_o = 1
+        pos = plan[0] + rng.normal(scale=0.05, size=2)
+        for step in range(60):
+            yaw = float(rng.uniform(-7, 7))
+            ok, idx_c, pose = capi.follow_plan(plan, idx_c, pos[0], pos[1], yaw, float(rng.uniform(-0.2, 0.7)))
+            ook, idx_o, ang, dist = O.follow_plan(plan, idx_o, pos[0], pos[1], yaw)
+            assert (ok, idx_c) == (ook, idx_o)
+            if not ok:
+                break
+            assert np.float32(pose["goal_direction"]).tobytes() == ang.tobytes()
+            assert np.float32(pose["goal_distance"]).tobytes() == dist.tobytes()
+            assert 0.0 <= pose["goal_direction"] <= 360.0 and pose["goal_distance"] >= 250.0
+            pos = pos + 0.6 * (plan[idx_c] - pos) + rng.normal(scale=0.02, size=2)   # the robot moves towards it
 
 
 def test_product_never_imports_the_oracle():

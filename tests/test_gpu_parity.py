@@ -797,3 +797,121 @@ def test_rrt_config4_sample_matches_oracle(R):
                (ores.status, ores.tree_size, ores.samples, ores.path_len), k
         assert np.allclose(paths[k, :ores.path_len], opath, rtol=0, atol=1e-9), k
     e.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# a7 as an entry point of its own: MapProvider::getSubMap / GridMap::getSubmap
+# ------------------------------------------------------------------------------------------------
+def test_get_submap_matches_oracle_also_on_a_moved_map(R):
+    rng = np.random.default_rng(17)
+    e = R.Engine(12.0, 9.0, 0.05, 1.0, -2.0)           # 240 x 180
+    g = O.make_geom(12.0, 9.0, 0.05, 1.0, -2.0)
+    ref = rng.choice(np.array([np.nan, 0, 30, 60, 180, -1, 7.25], np.float32), e.ncell)
+    for l in range(3):
+        e.upload(l, ref)
+    sub_g = O.Geom()
+    buf = np.empty(e.ncell, np.float32)
+    checked = failed = 0
+    for moved in range(3):
+        if moved:
+            target = (1.0 + rng.uniform(-3, 3), -2.0 + rng.uniform(-3, 3))
+            ptrs = (C.POINTER(C.c_float) * 1)(O.fptr(ref))
+            regs = (O.Region * 4)()
+            mv = C.c_int(0)
+            O.lib().og_move(C.byref(g), ptrs, 1, O.d2(*target), regs, C.byref(mv))
+            e.move(*target)
+            assert tuple(e.geometry().start_index) == tuple(g.start) and g.start[0] + g.start[1] > 0
+        cx, cy = float(g.pos[0]), float(g.pos[1])
+        cases = [(cx, cy, 1.5, 1.5), (cx, cy, 0.0, 0.0), (cx, cy, 1e6, 1e6), (cx + 5.9, cy - 4.4, 1.5, 1.5),
+                 (cx - 6.0, cy + 4.5, 2.0, 2.0), (cx + 40.0, cy, 1.5, 1.5), (cx, cy, 12.0, 9.0), (cx, cy, 0.05, 0.05)]
+        for _ in range(60):
+            cases.append((cx + rng.uniform(-7, 7), cy + rng.uniform(-5.5, 5.5), rng.uniform(0, 11), rng.uniform(0, 11)))
+        for (px, py, lx, ly) in cases:
+            ok = O.lib().og_get_submap(C.byref(g), O.fptr(ref), O.d2(px, py), O.d2(lx, ly), C.byref(sub_g), O.fptr(buf),
+                                       buf.size)
+            got = e.get_submap(R.capi.LAYER_LASER, px, py, lx, ly)
+            assert (got is not None) == bool(ok), (moved, px, py, lx, ly)
+            if not ok:
+                failed += 1
+                continue
+            info, data = got
+            inf = O.SubmapInfo()
+            assert O.lib().og_submap_information(C.byref(g), O.d2(px, py), O.d2(lx, ly), C.byref(inf))
+            assert tuple(info.size) == tuple(sub_g.size) and tuple(info.top_left) == tuple(inf.top_left)
+            assert tuple(info.position) == tuple(sub_g.pos) and tuple(info.length) == tuple(sub_g.len)
+            assert same_f32(data, buf[:sub_g.size[0] * sub_g.size[1]]), (moved, px, py, lx, ly)
+            checked += 1
+    assert checked > 120 and failed > 10     # requested centres outside the clamped window fail, as in the reference
+    # the device variant writes the same cells; a buffer that is too small is an error, not a truncation
+    import torch
+    info = R.capi.SubmapInfo()
+    t = torch.zeros(31 * 31, dtype=torch.float32, device="cuda")
+    cx, cy = float(g.pos[0]), float(g.pos[1])
+    rc = R.capi.lib().rna_get_submap_device(e.h, R.capi.LAYER_LASER, cx, cy, 1.5, 1.5, t.data_ptr(), t.numel(), C.byref(info))
+    e.synchronize()
+    assert rc == 1
+    _, host = e.get_submap(R.capi.LAYER_LASER, cx, cy, 1.5, 1.5)
+    assert same_f32(t.cpu().numpy()[:len(host)], host)
+    rc = R.capi.lib().rna_get_submap_device(e.h, R.capi.LAYER_LASER, cx, cy, 3.0, 3.0, t.data_ptr(), t.numel(), C.byref(info))
+    assert rc == -4 and info.size[0] * info.size[1] > t.numel()      # RNA_ECAPACITY, info still filled
+    e.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# A.6 plan following feeding the VFH+ step: Steerer::acceptPlan + Steerer::update for a fleet
+# ------------------------------------------------------------------------------------------------
+def test_steerer_loop_follow_plan_then_vfh_matches_oracle(R):
+    rng = np.random.default_rng(23)
+    e = R.Engine(20.0, 20.0, 0.05)
+    g = O.make_geom(20.0, 20.0, 0.05)
+    master = R.synth.occupancy_sparse(e.rows, e.cols, seed=8, occupied=0.01)
+    e.upload(R.capi.LAYER_MASTER, master)
+    n = 24
+    e.vfh_init(n)
+    oracles = [O.OracleVfh() for _ in range(n)]
+    plans = [np.cumsum(rng.normal(scale=0.35, size=(int(rng.integers(2, 14)), 2)), 0) + rng.uniform(-6, 6, 2) for _ in range(n)]
+    pos = np.array([p[0] for p in plans]) + rng.normal(scale=0.05, size=(n, 2))
+    yaw = rng.uniform(-np.pi, np.pi, n)
+    idx_c, idx_o = [1] * n, [1] * n                    # acceptPlan: planIndex_ = 1
+    speed = np.zeros(n)
+    active = list(range(n))
+    steps = 0
+    while active and steps < 40:
+        poses = np.zeros(len(active), R.capi.POSE_DTYPE)
+        still = []
+        for k in active:
+            ok, idx_c[k], pose = R.capi.follow_plan(plans[k], idx_c[k], pos[k, 0], pos[k, 1], yaw[k], speed[k] / 1000.0, 0.2)
+            ook, idx_o[k], ang, dist = O.follow_plan(plans[k], idx_o[k], pos[k, 0], pos[k, 1], yaw[k])
+            assert (ok, idx_c[k]) == (ook, idx_o[k])
+            if ok:
+                assert (np.float32(pose["goal_direction"]), np.float32(pose["goal_distance"])) == (ang, dist)
+                poses[len(still)] = pose
+                still.append(k)
+        active = still
+        if not active:
+            break
+        poses = poses[:len(active)]
+        # the engine's VFH instances are addressed by batch position: keep robot k on instance k
+        full = np.zeros(n, R.capi.POSE_DTYPE)
+        full["dt"] = 0.2
+        full["goal_distance"] = 3000.0
+        full["goal_tolerance"] = 250.0
+        full["x"], full["y"], full["yaw"] = pos[:, 0], pos[:, 1], yaw
+        full["goal_direction"] = 90.0
+        full[active] = poses
+        out, origin, hist = e.vfh_step(full)
+        for k in range(n):
+            p = full[k]
+            cs, ct = oracles[k].step_pose(g, master, p["x"], p["y"], p["yaw"], int(p["current_speed"]), p["goal_direction"],
+                                          p["goal_distance"], p["goal_tolerance"], float(p["dt"]))
+            assert (out["chosen_speed"][k], out["chosen_turnrate"][k]) == (cs, ct), (steps, k)
+            assert bits(origin[k]).tobytes() == bits(oracles[k].origin_hist()).tobytes(), (steps, k)
+        # Steerer::pubVel: the robots drive with the chosen command for one period
+        speed = out["chosen_speed"].astype(np.float64)
+        yaw = yaw + np.radians(out["chosen_turnrate"]) * 0.2
+        pos = pos + (speed / 1000.0 * 0.2)[:, None] * np.stack([np.cos(yaw), np.sin(yaw)], 1)
+        for k in active:                                 # and are nudged towards their way point so that plans finish
+            pos[k] += 0.5 * (plans[k][idx_c[k]] - pos[k])
+        steps += 1
+    assert steps >= 3 and len(active) < n
+    e.close()
