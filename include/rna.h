@@ -247,6 +247,17 @@ int rna_scan_to_rays(rna_engine* e, const rna_laser_scan* scans_host, int n_scan
 int rna_scan_to_rays_device(rna_engine* e, const rna_laser_scan* scans_device, int n_scans, const float* ranges_device,
                             int max_beams_per_scan, rna_ray* rays_device, int max_rays, int* n_rays_device);
 
+/* One sensor_msgs/Range reading (sonar) plus the planar sensor pose tf reports for its stamp. */
+typedef struct {
+  float range, max_range;  /* msg->range, msg->max_range */
+  double x, y, yaw;        /* sensor pose in the map frame */
+} rna_range_reading;
+/* RangeMapUpdater::bufferIncomingMsg (mc/src/range_map_updater.cpp:38-76), host only: one RangeSample per reading,
+ * start = T(0,0,0), end = T(range,0,0) (tf::transformPoint in double), ifClearEnd = !(range < max_range).  The rays
+ * go to rna_himm_update(e, RNA_LAYER_RANGE, ...) -- the "range" MapUpdater of MapProvider's factory
+ * (mc/src/map_provider.cpp:12-15,262-266); master is composed from the laser layer only (:216-223). */
+int rna_range_to_rays(const rna_range_reading* readings, int n, rna_ray* rays);
+
 /* ---- message formats either side of the path ------------------------------------------------- */
 /* GridMapRosConverter::toOccupancyGrid (grid_map-master/grid_map_ros/src/GridMapRosConverter.cpp:251-287)
  * as MapProvider::publishMap calls it with (0, 255) (mc/src/map_provider.cpp:113-118,206-213):

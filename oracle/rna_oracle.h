@@ -218,6 +218,8 @@ typedef struct {
 } og_scan;
 int og_simplify_scan(int n, float angle_increment, int* sel, int cap, float* out_increment);
 int og_scan_to_rays(const og_scan* s, const float* ranges, og_ray* out, int cap);   /* returns the number of rays */
+/* sonar: RangeMapUpdater::bufferIncomingMsg (range_map_updater.cpp:38-76) */
+void og_range_to_ray(float range, float max_range, double x, double y, double yaw, og_ray* out);
 
 /* ---- message formats either side of the path (msgs.c) ---- */
 /* GridMapRosConverter::toOccupancyGrid / fromOccupancyGrid (grid_map_ros/src/GridMapRosConverter.cpp:205-287) */

@@ -19,6 +19,7 @@
  * up in the ORIGINAL ranges (laser_map_updater.cpp:62-69); the simplified scan starts with
  * ranges[0] twice over (index 0 is pushed, then the loop starts at i = 0).
  */
+#define _GNU_SOURCE   /* sincos */
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -76,4 +77,21 @@ int og_scan_to_rays(const og_scan* s, const float* ranges, og_ray* out, int cap)
     ++m;
   }
   return m;
+}
+
+/* RangeMapUpdater::bufferIncomingMsg (range_map_updater.cpp:38-76): in.point = (0,0,0) -> start, then
+ * in.point.x = msg->range -> end, both through tf::transformPoint (double; planar pose restated as R(yaw) p + t as
+ * above); ifClearEnd = !(msg->range < msg->max_range) (:52-56).  PARITY UNPINNED like the laser path. */
+void og_range_to_ray(float range, float max_range, double x, double y, double yaw, og_ray* out) {
+  double c, s;
+  sincos(yaw, &s, &c);   /* what gcc makes of cos(yaw), sin(yaw); glibc's sincos and cos differ in the last bit now and then */
+  double px = 0.0, py = 0.0;
+  out->sx = c * px - s * py + x;
+  out->sy = s * px + c * py + y;
+  px = range;
+  out->ex = c * px - s * py + x;
+  out->ey = s * px + c * py + y;
+  if (range < max_range) out->clear_end = 0;
+  else out->clear_end = 1;
+  out->_pad = 0;
 }

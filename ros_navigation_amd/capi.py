@@ -33,7 +33,7 @@ SYMBOLS = [
     "rna_astar_download_nbr_mask",
     "rna_graph_astar_batch", "rna_rrt_batch", "rna_rrt_batch_device",
     "rna_to_occupancy_grid", "rna_to_occupancy_grid_device", "rna_from_occupancy_grid", "rna_vfh_hist_msg_batch",
-    "rna_tailor_plan", "rna_follow_plan", "rna_get_submap", "rna_get_submap_device", "rna_scan_to_rays", "rna_scan_to_rays_device",
+    "rna_tailor_plan", "rna_follow_plan", "rna_get_submap", "rna_get_submap_device", "rna_scan_to_rays", "rna_scan_to_rays_device", "rna_range_to_rays",
     "rna_profile_enable", "rna_profile_reset", "rna_profile_get", "rna_kernel_name",
 ]
 
@@ -71,6 +71,7 @@ VFH_OUT_DTYPE = np.dtype([("chosen_speed", "<i4"), ("chosen_turnrate", "<i4"), (
 SCAN_DTYPE = np.dtype([("angle_min", "<f4"), ("angle_max", "<f4"), ("angle_increment", "<f4"), ("range_min", "<f4"),
                        ("range_max", "<f4"), ("n_ranges", "<i4"), ("ranges_offset", "<i8"), ("x", "<f8"), ("y", "<f8"),
                        ("yaw", "<f8")])
+RANGE_READING_DTYPE = np.dtype([("range", "<f4"), ("max_range", "<f4"), ("x", "<f8"), ("y", "<f8"), ("yaw", "<f8")])
 ASTAR_QUERY_DTYPE = np.dtype([("start", "<i4"), ("goal", "<i4")])
 ASTAR_RESULT_DTYPE = np.dtype([("status", "<i4"), ("path_len", "<i4"), ("cost", "<i4"), ("expanded", "<i4"),
                                ("rounds", "<i4"), ("buckets", "<i4")])
@@ -158,6 +159,7 @@ def lib():
     L.rna_get_submap_device.argtypes = L.rna_get_submap.argtypes
     L.rna_scan_to_rays.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp, C.c_int, C.POINTER(C.c_int)]
     L.rna_scan_to_rays_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
+    L.rna_range_to_rays.argtypes = [vp, C.c_int, vp]
     L.rna_profile_enable.argtypes = [vp, C.c_int]
     L.rna_profile_reset.argtypes = [vp]
     L.rna_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -176,6 +178,17 @@ def tailor_plan(plan_xy, stride=5):
     if rc != 0:
         raise RnaError("rna_tailor_plan failed (%d)" % rc)
     return out[:m.value].copy()
+
+
+def range_to_rays(readings):
+    """RangeMapUpdater::bufferIncomingMsg for a batch of sonar readings (RANGE_READING_DTYPE) -> RAY_DTYPE rays."""
+    readings = np.ascontiguousarray(readings)
+    assert readings.dtype == RANGE_READING_DTYPE
+    rays = np.zeros(len(readings), RAY_DTYPE)
+    rc = lib().rna_range_to_rays(_ptr(readings), len(readings), _ptr(rays))
+    if rc != 0:
+        raise RnaError("rna_range_to_rays failed (%d)" % rc)
+    return rays
 
 
 def follow_plan(plan_xy, plan_index, x, y, yaw, linear_velocity=0.0, dt=0.2):

@@ -186,3 +186,22 @@ extern "C" int rna_scan_to_rays(rna_engine* e, const rna_laser_scan* scans_host,
   if (*n_rays > max_rays) return fail(e, RNA_ECAPACITY, "rna_scan_to_rays: max_rays too small (n_rays holds the required count)");
   return RNA_OK;
 }
+
+// RangeMapUpdater::bufferIncomingMsg (mc/src/range_map_updater.cpp:38-76): two tf::transformPoint calls per sonar
+// reading, in double, for a planar sensor pose.  Host only (five sonars per cycle): cos / sin are the host libm's.
+extern "C" int rna_range_to_rays(const rna_range_reading* readings, int n, rna_ray* rays) {
+  if (n < 0 || (n > 0 && (!readings || !rays))) return RNA_EINVAL;
+  for (int k = 0; k < n; ++k) {
+    const rna_range_reading& m = readings[k];
+    double c, s;
+    sincos(m.yaw, &s, &c);                         // one libm call for both, stated explicitly (host glibc)
+    const double r = (double)m.range;              // in.point.x = msg->range
+    rays[k].sx = c * 0.0 - s * 0.0 + m.x;
+    rays[k].sy = s * 0.0 + c * 0.0 + m.y;
+    rays[k].ex = c * r - s * 0.0 + m.x;
+    rays[k].ey = s * r + c * 0.0 + m.y;
+    rays[k].clear_end = (m.range < m.max_range) ? 0 : 1;
+    rays[k]._pad = 0;
+  }
+  return RNA_OK;
+}

@@ -178,11 +178,20 @@ class MapProvider {
   explicit MapProvider(Length mapLength = Length(30, 30), double resolution = 0.05, int device = 0) {
     map_.setGeometry(mapLength, resolution, Position(0.0, 0.0), device);  // initParameter/initMap, :130-149
   }
-  void bufferSample(const RangeSample& s) {  // LaserMapUpdater::bufferIncomingMsg's push_back, :63-72
+  // typeName selects the MapUpdater as MapProvider's factory does (map_provider.cpp:12-15,262-266): "laser" or "range"
+  void bufferSample(const RangeSample& s, const std::string& typeName = "laser") {  // bufferIncomingMsg's push_back
     rna_ray r;
     r.sx = s.start[0]; r.sy = s.start[1]; r.ex = s.end[0]; r.ey = s.end[1];
     r.clear_end = s.ifClearEnd ? 1 : 0; r._pad = 0;
-    buffer_.push_back(r);
+    if (typeName == "laser") buffer_.push_back(r);
+    else if (typeName == "range") range_buffer_.push_back(r);
+    else throw std::invalid_argument("MapProvider: unknown MapUpdater type '" + typeName + "'");
+  }
+  // RangeMapUpdater::bufferIncomingMsg (range_map_updater.cpp:38-76) for sonar readings with their tf pose
+  void bufferRanges(const std::vector<rna_range_reading>& readings) {
+    std::vector<rna_ray> rays(readings.size());
+    if (rna_range_to_rays(readings.data(), (int)readings.size(), rays.data()) != RNA_OK) throw std::invalid_argument("bufferRanges");
+    range_buffer_.insert(range_buffer_.end(), rays.begin(), rays.end());
   }
   // LaserMapUpdater::bufferIncomingMsg (laser_map_updater.cpp:37-75) for whole scans: decimation,
   // projection and the tf transform run on the device (sensor pose planar and constant over the scan)
@@ -197,6 +206,10 @@ class MapProvider {
   }
   // MapProvider::updateMap: drain the buffer through HIMM, then compose master (fused, dirty tiles)
   void updateMap(bool wholeLayerCopy = false) {
+    // every updater writes its own layer (map_updater.h:12-13); master is composed from "laser" alone (:216-223)
+    grid_map::rna_check(rna_himm_update(map_.engine(), RNA_LAYER_RANGE, range_buffer_.data(), (int)range_buffer_.size()),
+                        map_.engine(), "RangeMapUpdater::updateMap");
+    range_buffer_.clear();
     grid_map::rna_check(rna_update_map(map_.engine(), buffer_.data(), (int)buffer_.size(), wholeLayerCopy ? 1 : 0),
                         map_.engine(), "MapProvider::updateMap");
     buffer_.clear();
@@ -225,7 +238,7 @@ class MapProvider {
 
  private:
   GridMap map_;
-  std::vector<rna_ray> buffer_;
+  std::vector<rna_ray> buffer_, range_buffer_;
 };
 
 // VFH with the reference's constructor signature and Update_VFH contract (vfh.h:185-253).  One

@@ -156,6 +156,8 @@ def lib():
         L.og_from_occupancy_grid.restype = None
         L.og_hist_msg.argtypes = [fp, fp, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.og_tailor_plan.argtypes = [d2, C.c_int, C.c_uint, d2]
+        L.og_range_to_ray.argtypes = [C.c_float, C.c_float, C.c_double, C.c_double, C.c_double, C.c_void_p]
+        L.og_range_to_ray.restype = None
         L.og_follow_plan.argtypes = [d2, C.c_int, C.POINTER(C.c_int), C.c_double, C.c_double, C.c_double,
                                      C.POINTER(C.c_float)]
         _lib = L
@@ -423,3 +425,12 @@ def follow_plan(plan_xy, plan_index, x, y, yaw):
     out = (C.c_float * 2)()
     ok = lib().og_follow_plan(plan.ctypes.data_as(C.POINTER(C.c_double)), len(plan), C.byref(idx), x, y, yaw, out)
     return bool(ok), idx.value, np.float32(out[0]), np.float32(out[1])
+
+
+def range_to_rays(readings):
+    """RangeMapUpdater::bufferIncomingMsg (range_map_updater.cpp:38-76) for a batch of sonar readings."""
+    rays = np.zeros(len(readings), RAY_DTYPE)
+    for k, m in enumerate(readings):
+        lib().og_range_to_ray(float(m["range"]), float(m["max_range"]), float(m["x"]), float(m["y"]), float(m["yaw"]),
+                              rays[k:k + 1].ctypes.data_as(C.c_void_p))
+    return rays

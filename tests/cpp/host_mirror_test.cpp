@@ -37,8 +37,30 @@ int main() {
     og_ray r = {s.start[0], s.start[1], s.end[0], s.end[1], s.ifClearEnd ? 1 : 0, 0};
     rays.push_back(r);
   }
+  // the "range" updater (sonars) works on its own layer and leaves master alone (map_provider.cpp:216-223)
+  std::vector<float> range_ref((size_t)g.size[0] * g.size[1], NAN);
+  {
+    std::vector<rna_range_reading> sonar;
+    std::vector<og_ray> sonar_rays;
+    for (int k = 0; k < 40; ++k) {
+      rna_range_reading m = {0.3f + 0.09f * k, 3.5f, -2.0 + 0.05 * k, 1.0, 0.16 * k};
+      sonar.push_back(m);
+      og_ray r;
+      og_range_to_ray(m.range, m.max_range, m.x, m.y, m.yaw, &r);
+      sonar_rays.push_back(r);
+    }
+    provider.bufferRanges(sonar);
+    og_himm_update(&g, range_ref.data(), sonar_rays.data(), (int)sonar_rays.size(), nullptr);
+    bool bad_type = false;
+    try { provider.bufferSample(RangeSample(), "lidar3d"); } catch (const std::invalid_argument&) { bad_type = true; }
+    CHECK(bad_type);
+  }
   provider.updateMap();
   og_himm_update(&g, ref.data(), rays.data(), (int)rays.size(), nullptr);
+  {
+    std::vector<float> range_layer = map.get("range");
+    for (size_t i = 0; i < range_ref.size(); ++i) CHECK(same_bits(range_layer[i], range_ref[i]));
+  }
   std::vector<float> master = map.get("master");
   for (size_t i = 0; i < ref.size(); ++i) CHECK(same_bits(master[i], ref[i]));
   bool threw = false;

@@ -43,7 +43,7 @@ def test_struct_layouts_match_header(capi):
       printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu ", sizeof(rna_geometry), sizeof(rna_ray), sizeof(rna_vfh_params),
              sizeof(rna_pose), sizeof(rna_vfh_out), sizeof(rna_astar_query), sizeof(rna_astar_result),
              sizeof(rna_rrt_query), sizeof(rna_rrt_result), (size_t)RNA_K_COUNT, sizeof(rna_laser_scan));
-      printf("%zu\n", sizeof(rna_submap_info));
+      printf("%zu %zu\n", sizeof(rna_submap_info), sizeof(rna_range_reading));
       return 0;
     }"""
     exe = "/tmp/rna_layout_check"
@@ -52,7 +52,7 @@ def test_struct_layouts_match_header(capi):
     assert sizes == [C.sizeof(capi.Geometry), capi.RAY_DTYPE.itemsize, C.sizeof(capi.VfhParams),
                      capi.POSE_DTYPE.itemsize, capi.VFH_OUT_DTYPE.itemsize, capi.ASTAR_QUERY_DTYPE.itemsize,
                      capi.ASTAR_RESULT_DTYPE.itemsize, capi.RRT_QUERY_DTYPE.itemsize, capi.RRT_RESULT_DTYPE.itemsize,
-                     len(capi.KERNELS), capi.SCAN_DTYPE.itemsize, C.sizeof(capi.SubmapInfo)]
+                     len(capi.KERNELS), capi.SCAN_DTYPE.itemsize, C.sizeof(capi.SubmapInfo), capi.RANGE_READING_DTYPE.itemsize]
     assert src.count("extern \"C\"") == 1
 
 
@@ -115,6 +115,27 @@ def test_follow_plan_host_entry_point(capi):
             assert np.float32(pose["goal_distance"]).tobytes() == dist.tobytes()
             assert 0.0 <= pose["goal_direction"] <= 360.0 and pose["goal_distance"] >= 250.0
             pos = pos + 0.6 * (plan[idx_c] - pos) + rng.normal(scale=0.02, size=2)   # the robot moves towards it
+
+
+def test_range_to_rays_host_entry_point(capi):
+    """rna_range_to_rays (RangeMapUpdater::bufferIncomingMsg, mc/src/range_map_updater.cpp:38-76), host-only."""
+    import numpy as np
+    import _oracle as O
+    m = np.zeros(4, capi.RANGE_READING_DTYPE)
+    m[0] = (2.0, 4.0, 1.0, -1.0, 0.0)                 # looking along +x: hit 2 m ahead
+    m[1] = (4.0, 4.0, 0.0, 0.0, np.pi / 2)            # range == max_range: nothing seen, clear the end cell too
+    m[2] = (np.inf, 4.0, 0.5, 0.5, 1.0)
+    m[3] = (np.nan, 4.0, 0.5, 0.5, 1.0)               # NaN < max is false -> ifClearEnd
+    r = capi.range_to_rays(m)
+    assert (r["sx"][0], r["sy"][0], r["ex"][0], r["ey"][0], r["clear_end"][0]) == (1.0, -1.0, 3.0, -1.0, 0)
+    assert r["clear_end"].tolist() == [0, 1, 1, 1] and abs(r["ey"][1] - 4.0) < 1e-15 and abs(r["ex"][1]) < 1e-15
+    rng = np.random.default_rng(5)
+    m = np.zeros(5000, capi.RANGE_READING_DTYPE)
+    m["range"] = rng.uniform(0.0, 5.0, len(m))
+    m["max_range"] = rng.choice([3.0, 4.0], len(m))
+    m["x"], m["y"], m["yaw"] = rng.uniform(-20, 20, len(m)), rng.uniform(-20, 20, len(m)), rng.uniform(-7, 7, len(m))
+    assert capi.range_to_rays(m).tobytes() == O.range_to_rays(m).tobytes()
+    assert len(capi.range_to_rays(m[:0])) == 0
 
 
 def test_product_never_imports_the_oracle():
