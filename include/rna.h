@@ -121,6 +121,12 @@ int rna_get_submap(rna_engine* e, int layer, double position_x, double position_
                    float* out_host, size_t cap_cells, rna_submap_info* info);
 int rna_get_submap_device(rna_engine* e, int layer, double position_x, double position_y, double length_x,
                           double length_y, float* out_device, size_t cap_cells, rna_submap_info* info);
+/* The same as a GridMap of its own, which is what GridMap::getSubmap returns: a NEW engine (same device) with the
+ * submap's geometry and all three layers, ready for rna_rrt_batch / rna_astar_batch on the planning window -- the
+ * flow of Nav::makePlan (mc/src/nav_node.cpp:136-152: getSubMap, then RrtPlanner on the submap).  Returns 1 and the
+ * engine in *out (caller destroys it), 0 when the reference's isSuccess is false, < 0 = rna_status. */
+int rna_create_submap(rna_engine* parent, double position_x, double position_y, double length_x, double length_y,
+                      rna_engine** out);
 
 /* ---- VFH+ local avoidance -------------------------------------------------------------------- */
 /* VFH constructor arguments + SetRobotRadius (mc/include/move_control/vfh.h:185-203,235;

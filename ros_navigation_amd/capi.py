@@ -33,7 +33,7 @@ SYMBOLS = [
     "rna_astar_download_nbr_mask",
     "rna_graph_astar_batch", "rna_rrt_batch", "rna_rrt_batch_device",
     "rna_to_occupancy_grid", "rna_to_occupancy_grid_device", "rna_from_occupancy_grid", "rna_vfh_hist_msg_batch",
-    "rna_tailor_plan", "rna_follow_plan", "rna_get_submap", "rna_get_submap_device", "rna_scan_to_rays", "rna_scan_to_rays_device", "rna_range_to_rays",
+    "rna_tailor_plan", "rna_follow_plan", "rna_get_submap", "rna_get_submap_device", "rna_create_submap", "rna_scan_to_rays", "rna_scan_to_rays_device", "rna_range_to_rays",
     "rna_profile_enable", "rna_profile_reset", "rna_profile_get", "rna_kernel_name",
 ]
 
@@ -157,6 +157,7 @@ def lib():
     L.rna_get_submap.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, vp, C.c_size_t,
                                  C.POINTER(SubmapInfo)]
     L.rna_get_submap_device.argtypes = L.rna_get_submap.argtypes
+    L.rna_create_submap.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(vp)]
     L.rna_scan_to_rays.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp, C.c_int, C.POINTER(C.c_int)]
     L.rna_scan_to_rays_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
     L.rna_range_to_rays.argtypes = [vp, C.c_int, vp]
@@ -279,6 +280,23 @@ class Engine:
         out = (C.c_double * 2)()
         ok = self._L.rna_get_position(self.h, i, j, out)
         return (out[0], out[1]) if ok == 1 else None
+
+    def submap_engine(self, x, y, length_x, length_y):
+        """GridMap::getSubmap as a GridMap of its own: a new Engine over the clamped window (all layers), or None."""
+        h = C.c_void_p()
+        rc = self._L.rna_create_submap(self.h, x, y, length_x, length_y, C.byref(h))
+        if rc == 0:
+            return None
+        if rc != 1:
+            self._check(rc)
+        child = Engine.__new__(Engine)
+        child._L, child.h, child.device = self._L, h, self.device
+        g = child.geometry()
+        child.rows, child.cols = g.size[0], g.size[1]
+        child.ncell = child.rows * child.cols
+        child.resolution = g.resolution
+        child.hist_size = None
+        return child
 
     def get_submap(self, layer, x, y, length_x, length_y):
         """GridMap::getSubmap: (info, data) with data column-major info.size[0] x info.size[1], or None when the

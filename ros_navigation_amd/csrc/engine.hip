@@ -320,6 +320,40 @@ static int get_submap(rna_engine* e, int layer, double px, double py, double lx,
   return 1;
 }
 
+// GridMap GridMap::getSubmap(position, length, isSuccess) (gmc/src/GridMap.cpp:287-339) as a GridMap of its own: a new
+// engine with the submap's geometry (startIndex (0,0)) whose layers are gathered from the parent on the device.
+extern "C" int rna_create_submap(rna_engine* parent, double px, double py, double lx, double ly, rna_engine** out) {
+  if (!parent || !out) return RNA_EINVAL;
+  *out = nullptr;
+  const double rp[2] = {px, py}, rl[2] = {lx, ly};
+  SubmapInfo si;
+  if (!submap_information(parent->geom, rp, rl, si)) return 0;
+  if (si.size[0] <= 0 || si.size[1] <= 0 || si.size[0] > parent->geom.size[0] || si.size[1] > parent->geom.size[1]) return 0;
+  rna_engine* c = nullptr;
+  int rc = rna_create(&c, si.len[0], si.len[1], parent->geom.res, si.pos[0], si.pos[1], parent->device);
+  if (rc != RNA_OK) return rna::fail(parent, rc, "rna_create_submap: rna_create failed");
+  if (c->geom.size[0] != si.size[0] || c->geom.size[1] != si.size[1]) {
+    rna_destroy(c);
+    return rna::fail(parent, RNA_EINVAL, "rna_create_submap: geometry does not reproduce the submap size");
+  }
+  hipError_t err = hipSetDevice(parent->device);
+  for (int l = 0; l < RNA_NUM_LAYERS && err == hipSuccess; ++l) {
+    hipLaunchKernelGGL(submap_gather_kernel, dim3(grid_for(c->ncell, 256)), dim3(256), 0, parent->stream, parent->layer[l],
+                       parent->geom.size[0], parent->geom.size[1], si.top_left[0], si.top_left[1], si.size[0], si.size[1],
+                       c->layer[l]);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess) err = hipStreamSynchronize(parent->stream);
+  if (err != hipSuccess) {
+    rna_destroy(c);
+    RNA_HIP(parent, err);
+  }
+  c->nbr_all_dirty = true;
+  c->laser_all_dirty = true;
+  *out = c;
+  return 1;
+}
+
 extern "C" int rna_get_submap(rna_engine* e, int layer, double px, double py, double lx, double ly, float* out_host,
                               size_t cap_cells, rna_submap_info* info) {
   return get_submap(e, layer, px, py, lx, ly, out_host, cap_cells, info, true);

@@ -64,6 +64,11 @@ class GridMap {
   ~GridMap() { if (e_) rna_destroy(e_); }
   GridMap(const GridMap&) = delete;
   GridMap& operator=(const GridMap&) = delete;
+  GridMap(GridMap&& o) : e_(o.e_) { o.e_ = nullptr; }
+  GridMap& operator=(GridMap&& o) {   // `map = map_.getSubmap(...)` of MapProvider::getSubMap (map_provider.cpp:97)
+    if (this != &o) { if (e_) rna_destroy(e_); e_ = o.e_; o.e_ = nullptr; }
+    return *this;
+  }
 
   // GridMap::setGeometry (gmc/src/GridMap.cpp:51-70)
   void setGeometry(const Length& length, double resolution, const Position& position = Position(0.0, 0.0), int device = 0) {
@@ -109,14 +114,22 @@ class GridMap {
     rna_check(rna_layer_download(e_, layerId(layer), out.data(), out.size()), e_, "GridMap::get");
     return out;
   }
-  // GridMap::getSubmap(position, length, isSuccess) (gmc/src/GridMap.cpp:287-339) for one layer: the submap comes back
-  // as host data with its own geometry (a GridMap on the host side of the boundary; startIndex (0,0)).
+  // GridMap::getSubmap(position, length, isSuccess) (gmc/src/GridMap.cpp:287-339): a GridMap of its own (new engine on
+  // the same device, all layers gathered on the device, startIndex (0,0)); an empty GridMap when isSuccess is false.
+  GridMap getSubmap(const Position& position, const Length& length, bool& isSuccess) const {
+    GridMap sub;
+    const int rc = rna_create_submap(e_, position[0], position[1], length[0], length[1], &sub.e_);
+    if (rc < 0) rna_check(rc, e_, "GridMap::getSubmap");
+    isSuccess = rc == 1;
+    return sub;
+  }
+  // One layer of the same submap as host data with its geometry (no new engine)
   struct SubMap {
     Length length; Position position; Size size; double resolution;
     std::vector<float> data;   // column-major size[0] x size[1]
     float at(int i, int j) const { return data[(size_t)j * size[0] + i]; }
   };
-  SubMap getSubmap(const Position& position, const Length& length, bool& isSuccess, const std::string& layer = "master") const {
+  SubMap getSubmapData(const Position& position, const Length& length, bool& isSuccess, const std::string& layer = "master") const {
     SubMap sm;
     rna_geometry g = geometry();
     sm.resolution = g.resolution;
@@ -126,7 +139,7 @@ class GridMap {
     sm.data.resize(cap);
     rna_submap_info info;
     const int rc = rna_get_submap(e_, layerId(layer), position[0], position[1], length[0], length[1], sm.data.data(), cap, &info);
-    if (rc < 0) rna_check(rc, e_, "GridMap::getSubmap");
+    if (rc < 0) rna_check(rc, e_, "GridMap::getSubmapData");
     isSuccess = rc == 1;
     if (!isSuccess) { sm.data.clear(); return sm; }
     sm.length = Length(info.length[0], info.length[1]);
@@ -227,9 +240,14 @@ class MapProvider {
                         "MapProvider::publishMap");
   }
   // MapProvider::getSubMap (:93-100)
-  bool getSubMap(GridMap::SubMap& map, const Position& center, const Length& length) {
+  bool getSubMap(GridMap& map, const Position& center, const Length& length) {
     bool ok = false;
     map = map_.getSubmap(center, length, ok);
+    return ok;
+  }
+  bool getSubMap(GridMap::SubMap& map, const Position& center, const Length& length, const std::string& layer = "master") {
+    bool ok = false;
+    map = map_.getSubmapData(center, length, ok, layer);
     return ok;
   }
   bool ifCloseToPostion(const Position& robot, const Position& pos, double tolerance) const {  // :102-111

@@ -125,6 +125,33 @@ int main() {
       for (size_t i = 0; i < sm.data.size(); ++i) CHECK(same_bits(sm.data[i], want[i]));
     }
   }
+  {  // Nav::makePlan (nav_node.cpp:136-152): planning window as a GridMap of its own, RRT on that window
+    GridMap mapForPlan;
+    Position rstart(1.0, -0.5), rtarget(9.0, 3.0);            // target outside the 8 m window: finish at its border
+    CHECK(provider.getSubMap(mapForPlan, rstart, Length(8.0, 8.0)));
+    og_geom sg;
+    std::vector<float> sub(ref.size());
+    const double p[2] = {rstart[0], rstart[1]}, l[2] = {8.0, 8.0};
+    CHECK(og_get_submap(&g, ref.data(), p, l, &sg, sub.data(), (int)sub.size()));
+    CHECK(mapForPlan.getSize()[0] == sg.size[0] && mapForPlan.getSize()[1] == sg.size[1]);
+    CHECK(mapForPlan.getPosition()[0] == sg.pos[0] && mapForPlan.getPosition()[1] == sg.pos[1]);
+    CHECK(mapForPlan.getLength()[0] == sg.len[0] && mapForPlan.getLength()[1] == sg.len[1]);
+    std::vector<float> got = mapForPlan.get("master"), got_laser = mapForPlan.get("laser");
+    for (size_t i = 0; i < got.size(); ++i) CHECK(same_bits(got[i], sub[i]) && same_bits(got_laser[i], sub[i]));
+    RrtPlanner wplanner(mapForPlan, rstart, rtarget, 0.2);
+    std::vector<Position> wpath;
+    const bool wok = wplanner.makePlan(wpath);
+    std::vector<double> out(2 * 2048);
+    og_rrt_result r;
+    const double a[2] = {rstart[0], rstart[1]}, b[2] = {rtarget[0], rtarget[1]};
+    og_rrt_plan(&sg, sub.data(), a, b, 0.2, 1, 1000000, out.data(), 2048, &r);
+    CHECK(wok == (r.status == 1) && (size_t)r.path_len == wpath.size() && wpath.size() >= 2);
+    for (int k = 0; k < r.path_len; ++k)
+      CHECK(std::fabs(out[2 * k] - wpath[k][0]) < 1e-9 && std::fabs(out[2 * k + 1] - wpath[k][1]) < 1e-9);
+    bool ok_far = true;
+    GridMap none = map.getSubmap(Position(500.0, 500.0), Length(1.0, 1.0), ok_far);   // clamped window does not hold the centre
+    CHECK(!ok_far && none.engine() == nullptr);
+  }
   {  // Steerer::acceptPlan / update (steerer.cpp:27-33,222-270) on a fresh VFH instance, against the oracle
     VFH svfh(100, 30, 5, 10, 50, 200, 200, 300, 200, 40, 40, 40, 1.0, 2000000.0, 4000000.0, 2000000.0, 4000000.0, 10.0, 1.0);
     svfh.SetRobotRadius(178.0);

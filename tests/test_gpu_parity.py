@@ -915,3 +915,50 @@ def test_steerer_loop_follow_plan_then_vfh_matches_oracle(R):
         steps += 1
     assert steps >= 3 and len(active) < n
     e.close()
+
+
+def test_submap_engine_is_getsubmap_as_a_gridmap_and_plans_like_nav_makeplan(R):
+    """Nav::makePlan (mc/src/nav_node.cpp:136-152): getSubMap -> a GridMap of the planning window -> RrtPlanner on it."""
+    rng = np.random.default_rng(29)
+    e = R.Engine(16.0, 12.0, 0.05, -1.0, 2.0)
+    g = O.make_geom(16.0, 12.0, 0.05, -1.0, 2.0)
+    layers = [R.synth.obstacles_rect(e.rows, e.cols, density=0.10, seed=31 + l, side=(2, 10)) for l in range(3)]
+    for l in range(3):
+        e.upload(l, layers[l])
+    ptrs = (C.POINTER(C.c_float) * 3)(*[O.fptr(a) for a in layers])
+    regs = (O.Region * 4)()
+    mv = C.c_int(0)
+    O.lib().og_move(C.byref(g), ptrs, 3, O.d2(1.35, 0.2), regs, C.byref(mv))    # planning on a recentred map
+    assert e.move(1.35, 0.2) and mv.value
+    cx, cy = float(g.pos[0]), float(g.pos[1])
+    for (px, py, lx, ly) in ((cx, cy, 10.0, 10.0), (cx + 6.0, cy - 4.0, 6.0, 6.0), (cx - 7.9, cy + 5.9, 4.0, 3.0)):
+        sub = e.submap_engine(px, py, lx, ly)
+        sg = O.Geom()
+        want = [np.empty(e.ncell, np.float32) for _ in range(3)]
+        for l in range(3):
+            assert O.lib().og_get_submap(C.byref(g), O.fptr(layers[l]), O.d2(px, py), O.d2(lx, ly), C.byref(sg), O.fptr(want[l]), e.ncell)
+        gg = sub.geometry()
+        assert tuple(gg.size) == tuple(sg.size) and tuple(gg.position) == tuple(sg.pos) and tuple(gg.length) == tuple(sg.len)
+        assert tuple(gg.start_index) == (0, 0) and gg.resolution == g.res
+        n = sg.size[0] * sg.size[1]
+        for l in range(3):
+            assert same_f32(sub.download(l), want[l][:n]), (px, py, l)
+        # RrtPlanner(mapForPlan, start, target): targets inside and outside the window (finish at its border)
+        q = np.zeros(6, R.capi.RRT_QUERY_DTYPE)
+        free = np.flatnonzero(~(np.nan_to_num(want[0][:n], nan=0.0) > 0))
+        for k in range(len(q)):
+            c = int(rng.choice(free))
+            q["start"][k] = sub.get_position(c % sg.size[0], c // sg.size[0])
+            q["target"][k] = (px + rng.uniform(-0.8, 0.8) * lx, py + rng.uniform(-0.8, 0.8) * ly)
+        q["close_tolerance"] = 0.2
+        q["seed"] = np.arange(1, len(q) + 1)
+        q["max_samples"] = 20000
+        res, paths = sub.rrt(q)
+        for k in range(len(q)):
+            ores, opath = O.rrt_plan(sg, want[0][:n].copy(), q["start"][k], q["target"][k], 0.2, int(q["seed"][k]), 20000)
+            assert (res["status"][k], res["tree_size"][k], res["samples"][k], res["path_len"][k]) == \
+                   (ores.status, ores.tree_size, ores.samples, ores.path_len), (px, py, k)
+            assert np.allclose(paths[k, :ores.path_len], opath, rtol=0, atol=1e-9)
+        sub.close()
+    assert e.submap_engine(cx + 300.0, cy, 2.0, 2.0) is None      # isSuccess == false
+    e.close()
