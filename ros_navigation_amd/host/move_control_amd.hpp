@@ -229,14 +229,16 @@ class MapProvider {
   }
   GridMap& getMap() { return map_; }
   // MapProvider::publishMap (:113-118,206-213): toOccupancyGrid(map, "master", 0.0, 255.0, msg) on the device
-  void publishMap(OccupancyGrid& msg) {
+  void publishMap(OccupancyGrid& msg) { publishMap(map_, msg); }
+  // MapProvider::publishMap(GridMap&) (:113-118): the "local_map" topic, e.g. the planning window of Nav::makePlan
+  void publishMap(GridMap& map, OccupancyGrid& msg) {
     rna_geometry g;
-    grid_map::rna_check(rna_get_geometry(map_.engine(), &g), map_.engine(), "MapProvider::publishMap");
+    grid_map::rna_check(rna_get_geometry(map.engine(), &g), map.engine(), "MapProvider::publishMap");
     msg.resolution = (float)g.resolution;
     msg.width = (unsigned)g.size[0]; msg.height = (unsigned)g.size[1];
     msg.origin_x = g.position[0] - 0.5 * g.length[0]; msg.origin_y = g.position[1] - 0.5 * g.length[1];
     msg.data.resize((size_t)g.size[0] * g.size[1]);
-    grid_map::rna_check(rna_to_occupancy_grid(map_.engine(), RNA_LAYER_MASTER, 0.0f, 255.0f, msg.data.data()), map_.engine(),
+    grid_map::rna_check(rna_to_occupancy_grid(map.engine(), RNA_LAYER_MASTER, 0.0f, 255.0f, msg.data.data()), map.engine(),
                         "MapProvider::publishMap");
   }
   // MapProvider::getSubMap (:93-100)

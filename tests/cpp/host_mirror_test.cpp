@@ -138,6 +138,14 @@ int main() {
     CHECK(mapForPlan.getLength()[0] == sg.len[0] && mapForPlan.getLength()[1] == sg.len[1]);
     std::vector<float> got = mapForPlan.get("master"), got_laser = mapForPlan.get("laser");
     for (size_t i = 0; i < got.size(); ++i) CHECK(same_bits(got[i], sub[i]) && same_bits(got_laser[i], sub[i]));
+    {  // mapProvider_.publishMap(mapForPlan): the window as the local_map OccupancyGrid (nav_node.cpp:142)
+      OccupancyGrid local;
+      provider.publishMap(mapForPlan, local);
+      std::vector<int8_t> want(got.size());
+      og_to_occupancy_grid(&sg, sub.data(), 0.0f, 255.0f, want.data());
+      CHECK(local.width == (unsigned)sg.size[0] && local.height == (unsigned)sg.size[1] && local.data == want);
+      CHECK(local.origin_x == sg.pos[0] - 0.5 * sg.len[0] && local.origin_y == sg.pos[1] - 0.5 * sg.len[1]);
+    }
     RrtPlanner wplanner(mapForPlan, rstart, rtarget, 0.2);
     std::vector<Position> wpath;
     const bool wok = wplanner.makePlan(wpath);
