@@ -29,6 +29,15 @@ def init(backend, device=None):
     return dist
 
 
+def broadcast_rays(rays, src=0):
+    """Mode 1 in deployment: the rank that owns the sensors hands the ray batch (a uint8 / structured tensor of
+    rna_ray records, 40 B each -- 4 MB for 100 k rays) to every replica before they all apply it.  One
+    broadcast (RCCL over xGMI under "nccl"); the synthetic bench does not need it (every rank derives the batch)."""
+    import torch.distributed as dist
+    dist.broadcast(rays, src=src)
+    return rays
+
+
 def max_over_ranks(value, device="cpu"):
     """MAX all-reduce of a python float (elapsed seconds)."""
     import torch

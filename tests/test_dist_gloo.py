@@ -23,6 +23,14 @@ def _worker(rank, world, port, out):
     q = synth.astar_queries(101, master, 96, 96, seed=2)
     lo, hi = D.shard_bounds(len(q), r, w)
     mine = q[lo:hi]
+    # deployment path of mode 1: rank 0 owns the sensors and broadcasts the ray batch to the replicas
+    import torch
+    rays = synth.rays(3, 50, 4.8, 4.8, seed=4, lmin=0.2, lmax=2.0, margin=0.2)
+    t = torch.from_numpy(np.frombuffer(rays.tobytes(), dtype=np.uint8).copy())
+    if r != 0:
+        t.zero_()
+    D.broadcast_rays(t, src=0)
+    assert t.numpy().tobytes() == rays.tobytes()
     dist.barrier()
     elapsed = 0.25 + 0.5 * rank            # rank 1 is the slow one
     t_max = D.max_over_ranks(elapsed)
