@@ -165,3 +165,50 @@ def test_tiled_loop_two_ranks_on_one_gpu_matches_the_whole_map_oracle():
     assert all(r[2]["vfh"] == 3 * r[3] and r[2]["astar"] == 36 for r in res)
     # 2 x 1 layout: one 16-row strip of 192 columns per rank per round, the other window per gather
     assert all(r[2]["halo_bytes"] == 3 * 16 * 192 * 4 and r[2]["gather_bytes"] == 3 * 128 * 192 * 4 for r in res)
+
+
+def test_config5_full_size_windowed_himm_union_is_the_whole_map_update():
+    """BASELINE config 5 at full size: 8192 x 8192 map tiled 2 x 4 (tile 4096 rows x 2048 cols), the 100 032-ray batch
+    (64 origins x 1563 rays).  Every GPU's windowed update, put together, is the oracle's whole-map update."""
+    import ros_navigation_amd as R
+    from ros_navigation_amd import dist as D
+    n = 8192
+    length = n * 0.05
+    e = R.Engine(length, length, 0.05)
+    g = O.make_geom(length, length, 0.05)
+    L = D.TileLayout.for_world(n, n, 8)
+    assert L.window(0) == (0, 4096, 0, 2048)
+    before = np.zeros(e.ncell, np.float32)
+    before[::7] = 60.0                          # something for the clears to act on
+    before[::11] = np.nan
+    rays = R.synth.rays(64, 1563, length, length, seed=4)
+    # origins drawn over the whole map put most rays inside one window: add rays that cross the window borders
+    cross = R.synth.rays(64, 40, length, length, seed=5, lmin=1.0, lmax=6.0)
+    for k in range(64):
+        i0, ni, j0, nj = L.window(k % 8)
+        x, y = e.get_position(i0 + (ni - 1 if k & 8 else 0), j0 + (nj - 1 if k & 16 else 0))
+        sl = slice(k * 40, (k + 1) * 40)
+        dx, dy = cross["ex"][sl] - cross["sx"][sl], cross["ey"][sl] - cross["sy"][sl]
+        cross["sx"][sl], cross["sy"][sl] = x - 0.5 * dx, y - 0.5 * dy
+        cross["ex"][sl], cross["ey"][sl] = x + 0.5 * dx, y + 0.5 * dy
+    rays = np.concatenate([rays, cross])
+    after = before.copy()
+    O.himm_update(g, after, rays.view(O.RAY_DTYPE))
+    changed = ~((after == before) | (np.isnan(after) & np.isnan(before)))
+    A, B = after.reshape(n, n), before.reshape(n, n)
+    union = np.empty_like(A)
+    touched_windows = 0
+    for rank in range(8):
+        i0, ni, j0, nj = L.window(rank)
+        e.upload(R.capi.LAYER_LASER, before)
+        e.himm_set_window(i0, j0, ni, nj)
+        e.himm_update(R.capi.LAYER_LASER, rays)
+        got = e.download(R.capi.LAYER_LASER).reshape(n, n)
+        win = np.zeros((n, n), bool)
+        win[j0:j0 + nj, i0:i0 + ni] = True
+        assert same_f32(got[~win], B[~win]), rank                 # nothing outside the window
+        union[j0:j0 + nj, i0:i0 + ni] = got[j0:j0 + nj, i0:i0 + ni]
+        touched_windows += bool(changed.reshape(n, n)[win].any())
+    assert same_f32(union, A)
+    assert touched_windows == 8 and int(changed.sum()) > 100000
+    e.close()
