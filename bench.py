@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=4, help="A* batches in flight (rna_astar_set_pipeline_depth)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--tiled-full-gather", action="store_true", help="--tiled: all-gather whole windows instead of dirty tiles")
     ap.add_argument("--tiled", action="store_true",
                     help="SURVEY 8e mode 2 / BASELINE config 5: ONE map tiled 2 x N/2 over the GPUs (windowed HIMM, halo "
                          "exchange for VFH+, all-gather of the owner windows for A*) instead of replicated maps")
@@ -189,10 +190,14 @@ def main():
         step_no[0] += 1
         e.update_map_device(d_rays.data_ptr(), len(rays), compose_mode=0)
         if layout is not None and world > 1:
-            xfer[0] += D.exchange_halo(e, R.capi.LAYER_MASTER, layout, rank, halo, dist)
+            xfer[0] += D.exchange_halo(e, R.capi.LAYER_MASTER, layout, rank, halo, dist, tracked=not args.tiled_full_gather)
         e.vfh_step_device(d_poses.data_ptr(), nq, d_vfh_out.data_ptr())
         if layout is not None and world > 1:
-            xfer[1] += D.gather_layer(e, R.capi.LAYER_MASTER, layout, rank, dist)
+            if args.tiled_full_gather:
+                xfer[1] += D.gather_layer(e, R.capi.LAYER_MASTER, layout, rank, dist)
+            else:   # only the 64 x 64 tiles this update changed travel; their neighbour masks are refreshed, not all
+                xfer[1] += D.gather_dirty(e, (R.capi.LAYER_LASER, R.capi.LAYER_MASTER), layout, rank, dist)
+                e.compose_master(0)
         e.astar_device(d_queries.data_ptr(), nq, d_paths[b].data_ptr(), args.max_path, d_results[b].data_ptr())
         return b
 

@@ -101,6 +101,20 @@ int rna_himm_set_window(rna_engine* e, int i0, int j0, int ni, int nj);
  * halo strips and owner tiles exchanged between GPUs.  Both return after the copy has finished. */
 int rna_layer_pack_region(rna_engine* e, int layer, int i0, int ni, int j0, int nj, float* dense_device);
 int rna_layer_unpack_region(rna_engine* e, int layer, int i0, int ni, int j0, int nj, const float* dense_device);
+/* Incremental hand-over of the tiled mode.  rna_last_dirty_tiles: one byte per 64 x 64 tile (index tj*tiles_i + ti,
+ * tiles_i = ceil(rows/64)) = the tiles the last rna_compose_master consumed, i.e. what the last HIMM batch changed on
+ * this GPU.  rna_layer_pack_tiles / rna_layers_unpack_tiles move the listed tiles, clipped to the window
+ * [i0,i0+ni) x [j0,j0+nj), through a dense device buffer of n slots of 4096 floats; unpack writes layer_a and (if
+ * >= 0) layer_b and flags the tiles for the next rna_compose_master(e, 0), which refreshes their A* neighbour masks
+ * (+ring) instead of rebuilding all of them.  rna_layer_unpack_region_tracked is rna_layer_unpack_region with the
+ * same per-tile bookkeeping.  Precondition of the tracked calls: the laser layer is complete on this GPU (every
+ * owner's changes have been unpacked into laser AND master), so that composing a flagged tile is harmless. */
+int rna_last_dirty_tiles(rna_engine* e, uint8_t* flags_host, size_t n_tiles);
+int rna_layer_pack_tiles(rna_engine* e, int layer, const int32_t* tiles_host, int n, int i0, int ni, int j0, int nj,
+                         float* dense_device);
+int rna_layers_unpack_tiles(rna_engine* e, int layer_a, int layer_b, const int32_t* tiles_host, int n, int i0, int ni,
+                            int j0, int nj, const float* dense_device);
+int rna_layer_unpack_region_tracked(rna_engine* e, int layer, int i0, int ni, int j0, int nj, const float* dense_device);
 /* GridMap::move (gmc/src/GridMap.cpp:346-412): recentre the circular buffer, dropped cells -> NaN */
 int rna_move(rna_engine* e, double position_x, double position_y, int* moved);
 

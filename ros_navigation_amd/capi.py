@@ -26,7 +26,8 @@ SYMBOLS = [
     "rna_layer_upload", "rna_layer_download", "rna_layer_fill", "rna_layer_device_ptr", "rna_stream",
     "rna_synchronize", "rna_get_index", "rna_get_position",
     "rna_himm_update", "rna_himm_update_device", "rna_compose_master", "rna_update_map",
-    "rna_update_map_device", "rna_move", "rna_himm_set_window", "rna_layer_pack_region", "rna_layer_unpack_region",
+    "rna_update_map_device", "rna_move", "rna_himm_set_window", "rna_layer_pack_region", "rna_layer_unpack_region", "rna_last_dirty_tiles", "rna_layer_pack_tiles",
+    "rna_layers_unpack_tiles", "rna_layer_unpack_region_tracked",
     "rna_vfh_default_params", "rna_vfh_init", "rna_vfh_reset", "rna_vfh_hist_size", "rna_vfh_step_batch",
     "rna_vfh_step_batch_device", "rna_vfh_update_batch",
     "rna_astar_configure", "rna_astar_set_pipeline_depth", "rna_astar_batch", "rna_astar_batch_device", "rna_astar_settled_counts",
@@ -130,6 +131,10 @@ def lib():
     L.rna_himm_set_window.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.rna_layer_pack_region.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.rna_layer_unpack_region.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.rna_layer_unpack_region_tracked.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.rna_last_dirty_tiles.argtypes = [vp, vp, C.c_size_t]
+    L.rna_layer_pack_tiles.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.rna_layers_unpack_tiles.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.rna_vfh_default_params.argtypes = [C.POINTER(VfhParams)]
     L.rna_vfh_default_params.restype = None
     L.rna_vfh_init.argtypes = [vp, C.POINTER(VfhParams), C.c_int]
@@ -341,13 +346,49 @@ class Engine:
             self._check(self._L.rna_layer_pack_region(self.h, layer, i0, ni, j0, nj, t.data_ptr()))
         return t
 
-    def unpack_region(self, layer, i0, ni, j0, nj, t):
+    def unpack_region(self, layer, i0, ni, j0, nj, t, tracked=False):
+        """tracked: flag the covered 64 x 64 tiles for the next compose_master(0) instead of "whole layer changed"."""
         if ni <= 0 or nj <= 0:
             return
         assert t.is_cuda and t.dtype.is_floating_point and t.numel() >= ni * nj and t.is_contiguous()
         import torch
         torch.cuda.current_stream(t.device).synchronize()   # the tensor was filled on torch's stream
-        self._check(self._L.rna_layer_unpack_region(self.h, layer, i0, ni, j0, nj, t.data_ptr()))
+        fn = self._L.rna_layer_unpack_region_tracked if tracked else self._L.rna_layer_unpack_region
+        self._check(fn(self.h, layer, i0, ni, j0, nj, t.data_ptr()))
+
+    TILE = 64
+
+    def tile_grid(self):
+        return (self.rows + self.TILE - 1) // self.TILE, (self.cols + self.TILE - 1) // self.TILE
+
+    def last_dirty_tiles(self):
+        """uint8 flag per 64 x 64 tile (index tj * tiles_i + ti): what the last compose_master consumed."""
+        ti, tj = self.tile_grid()
+        f = np.zeros(ti * tj, np.uint8)
+        self._check(self._L.rna_last_dirty_tiles(self.h, _ptr(f), f.size))
+        return f
+
+    def pack_tiles(self, layer, tiles, window):
+        """The listed tiles, clipped to window = (i0, ni, j0, nj), as a dense device tensor of len(tiles) x 4096 floats."""
+        import torch
+        tiles = np.ascontiguousarray(tiles, np.int32)
+        t = torch.empty(len(tiles) * self.TILE * self.TILE, dtype=torch.float32, device=self._torch_device())
+        if len(tiles):
+            i0, ni, j0, nj = window
+            self._check(self._L.rna_layer_pack_tiles(self.h, layer, _ptr(tiles), len(tiles), i0, ni, j0, nj, t.data_ptr()))
+        return t
+
+    def unpack_tiles(self, layers, tiles, window, t):
+        """Inverse of pack_tiles into one or two layers (e.g. (LASER, MASTER)); flags the tiles for compose_master(0)."""
+        tiles = np.ascontiguousarray(tiles, np.int32)
+        if not len(tiles):
+            return
+        import torch
+        assert t.is_cuda and t.is_contiguous() and t.numel() >= len(tiles) * self.TILE * self.TILE
+        torch.cuda.current_stream(t.device).synchronize()
+        la, lb = (layers[0], layers[1]) if len(layers) > 1 else (layers[0], -1)
+        i0, ni, j0, nj = window
+        self._check(self._L.rna_layers_unpack_tiles(self.h, la, lb, _ptr(tiles), len(tiles), i0, ni, j0, nj, t.data_ptr()))
 
     def _torch_device(self):
         import torch

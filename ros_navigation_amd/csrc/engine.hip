@@ -117,6 +117,45 @@ __global__ void clear_region_kernel(float* __restrict__ p, int rows, int i0, int
   }
 }
 
+// Tiled single map, incremental hand-over: the listed 64 x 64 tiles, clipped to a window, <-> fixed 4096-float
+// slots of a dense buffer (slot k = tile k of the list; cells outside the clip are skipped / left alone).
+__global__ void __launch_bounds__(256) pack_tiles_kernel(const float* __restrict__ layer, int rows, int tiles_i,
+                                                         const int32_t* __restrict__ tiles, int wi0, int wi1, int wj0,
+                                                         int wj1, float* __restrict__ dense) {
+  const int t = tiles[blockIdx.x];
+  const int i0 = (t % tiles_i) * TILE, j0 = (t / tiles_i) * TILE;
+  float* out = dense + (size_t)blockIdx.x * (TILE * TILE);
+  for (int k = threadIdx.x; k < TILE * TILE; k += 256) {
+    const int i = i0 + (k & (TILE - 1)), j = j0 + (k >> 6);
+    out[k] = (i >= wi0 && i < wi1 && j >= wj0 && j < wj1) ? layer[(size_t)j * rows + i] : 0.0f;
+  }
+}
+
+__global__ void __launch_bounds__(256) unpack_tiles_kernel(float* __restrict__ layer_a, float* __restrict__ layer_b,
+                                                           int rows, int tiles_i, const int32_t* __restrict__ tiles,
+                                                           int wi0, int wi1, int wj0, int wj1,
+                                                           const float* __restrict__ dense,
+                                                           unsigned* __restrict__ dirty_tiles) {
+  const int t = tiles[blockIdx.x];
+  const int i0 = (t % tiles_i) * TILE, j0 = (t / tiles_i) * TILE;
+  const float* in = dense + (size_t)blockIdx.x * (TILE * TILE);
+  for (int k = threadIdx.x; k < TILE * TILE; k += 256) {
+    const int i = i0 + (k & (TILE - 1)), j = j0 + (k >> 6);
+    if (i >= wi0 && i < wi1 && j >= wj0 && j < wj1) {
+      const float v = in[k];
+      layer_a[(size_t)j * rows + i] = v;
+      if (layer_b) layer_b[(size_t)j * rows + i] = v;
+    }
+  }
+  if (threadIdx.x == 0) reinterpret_cast<volatile unsigned char*>(dirty_tiles)[t] = 1;
+}
+
+__global__ void mark_tiles_kernel(unsigned* __restrict__ dirty_tiles, int tiles_i, int ta0, int ta1, int tb0, int tb1) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int na = ta1 - ta0, n = na * (tb1 - tb0);
+  if (k < n) reinterpret_cast<volatile unsigned char*>(dirty_tiles)[(tb0 + k / na) * tiles_i + ta0 + k % na] = 1;
+}
+
 // GridMap::getSubmap (gmc/src/GridMap.cpp:287-339): submap cell (r, c) is parent buffer cell
 // ((tl0 + r) mod rows, (tl1 + c) mod cols) -- the reference's <= 4 quadrant blocks are this wrap.
 __global__ void submap_gather_kernel(const float* __restrict__ layer, int rows, int cols, int tl0, int tl1, int sr,
@@ -188,6 +227,8 @@ extern "C" int rna_create(rna_engine** out, double length_x, double length_y, do
   const size_t words = ((size_t)e->tiles_i * e->tiles_j + 3) / 4;  // one byte per tile, rounded to words
   if ((rc = dev_alloc(e, &e->dirty_tiles, words)) != RNA_OK) return bail(rc);
   if (hipMemsetAsync(e->dirty_tiles, 0, words * sizeof(unsigned), e->stream) != hipSuccess) return bail(RNA_EHIP);
+  if ((rc = dev_alloc(e, &e->last_dirty, words)) != RNA_OK) return bail(rc);
+  if (hipMemsetAsync(e->last_dirty, 0, words * sizeof(unsigned), e->stream) != hipSuccess) return bail(RNA_EHIP);
   if ((rc = dev_alloc(e, &e->nbr, e->ncell)) != RNA_OK) return bail(rc);
   e->nbr_all_dirty = true;
   if (hipStreamSynchronize(e->stream) != hipSuccess) return bail(RNA_EHIP);
@@ -204,6 +245,8 @@ extern "C" void rna_destroy(rna_engine* e) {
   astar_release(e);
   for (int l = 0; l < RNA_NUM_LAYERS; ++l) dev_free(&e->layer[l]);
   dev_free(&e->dirty_tiles);
+  dev_free(&e->last_dirty);
+  dev_free(&e->tile_list);
   dev_free(&e->nbr);
   (void)profile_flush(e);
   for (hipEvent_t ev : e->free_events) (void)hipEventDestroy(ev);
@@ -262,7 +305,8 @@ extern "C" void* rna_layer_device_ptr(rna_engine* e, int layer) {
 
 // Rectangular block of a layer <-> a dense column-major device buffer (ni fastest): the halo
 // strips and owner tiles of the tiled single-map mode travel through these (ros_navigation_amd/dist.py).
-static int region_copy(rna_engine* e, int layer, int i0, int ni, int j0, int nj, float* dense, bool pack) {
+static int region_copy(rna_engine* e, int layer, int i0, int ni, int j0, int nj, float* dense, bool pack,
+                       bool tracked = false) {
   if (!e || !dense || layer < 0 || layer >= RNA_NUM_LAYERS) return RNA_EINVAL;
   if (ni <= 0 || nj <= 0) return RNA_OK;
   if (i0 < 0 || j0 < 0 || i0 + ni > e->geom.size[0] || j0 + nj > e->geom.size[1])
@@ -274,7 +318,15 @@ static int region_copy(rna_engine* e, int layer, int i0, int ni, int j0, int nj,
     RNA_HIP(e, hipMemcpy2DAsync(dense, dpitch, blk, lpitch, dpitch, (size_t)nj, hipMemcpyDeviceToDevice, e->stream));
   } else {
     RNA_HIP(e, hipMemcpy2DAsync(blk, lpitch, dense, dpitch, dpitch, (size_t)nj, hipMemcpyDeviceToDevice, e->stream));
-    layer_changed(e, layer);
+    if (tracked) {   // per-tile bookkeeping instead of "everything changed": the next compose refreshes these tiles
+      const int ta0 = i0 / TILE, ta1 = (i0 + ni - 1) / TILE + 1, tb0 = j0 / TILE, tb1 = (j0 + nj - 1) / TILE + 1;
+      const int nt = (ta1 - ta0) * (tb1 - tb0);
+      hipLaunchKernelGGL(mark_tiles_kernel, dim3((nt + 255) / 256), dim3(256), 0, e->stream, e->dirty_tiles, e->tiles_i, ta0,
+                         ta1, tb0, tb1);
+      RNA_HIP(e, hipGetLastError());
+    } else {
+      layer_changed(e, layer);
+    }
   }
   RNA_HIP(e, hipStreamSynchronize(e->stream));
   return RNA_OK;
@@ -287,6 +339,11 @@ extern "C" int rna_layer_pack_region(rna_engine* e, int layer, int i0, int ni, i
 extern "C" int rna_layer_unpack_region(rna_engine* e, int layer, int i0, int ni, int j0, int nj,
                                        const float* dense_device) {
   return region_copy(e, layer, i0, ni, j0, nj, const_cast<float*>(dense_device), false);
+}
+
+extern "C" int rna_layer_unpack_region_tracked(rna_engine* e, int layer, int i0, int ni, int j0, int nj,
+                                               const float* dense_device) {
+  return region_copy(e, layer, i0, ni, j0, nj, const_cast<float*>(dense_device), false, true);
 }
 
 static int get_submap(rna_engine* e, int layer, double px, double py, double lx, double ly, float* out, size_t cap,
@@ -318,6 +375,66 @@ static int get_submap(rna_engine* e, int layer, double px, double py, double lx,
   if (staging) (void)hipFree(staging);
   RNA_HIP(e, err);
   return 1;
+}
+
+extern "C" int rna_last_dirty_tiles(rna_engine* e, uint8_t* flags_host, size_t n_tiles) {
+  if (!e || !flags_host || n_tiles != (size_t)e->tiles_i * e->tiles_j) return RNA_EINVAL;
+  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_HIP(e, hipMemcpyAsync(flags_host, e->last_dirty, n_tiles, hipMemcpyDeviceToHost, e->stream));
+  RNA_HIP(e, hipStreamSynchronize(e->stream));
+  return RNA_OK;
+}
+
+static int stage_tile_list(rna_engine* e, const int32_t* tiles_host, int n) {
+  const int ntile = e->tiles_i * e->tiles_j;
+  for (int k = 0; k < n; ++k)
+    if (tiles_host[k] < 0 || tiles_host[k] >= ntile) return rna::fail(e, RNA_EINVAL, "tile index outside the map");
+  if (n > e->tile_list_cap) {
+    int cap = 256;
+    while (cap < n) cap <<= 1;
+    int rc = dev_alloc(e, &e->tile_list, (size_t)cap);
+    if (rc != RNA_OK) { e->tile_list_cap = 0; return rc; }
+    e->tile_list_cap = cap;
+  }
+  RNA_HIP(e, hipMemcpyAsync(e->tile_list, tiles_host, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+  return RNA_OK;
+}
+
+static bool window_ok(const rna_engine* e, int i0, int ni, int j0, int nj) {
+  return i0 >= 0 && j0 >= 0 && ni > 0 && nj > 0 && i0 + ni <= e->geom.size[0] && j0 + nj <= e->geom.size[1];
+}
+
+extern "C" int rna_layer_pack_tiles(rna_engine* e, int layer, const int32_t* tiles_host, int n, int i0, int ni, int j0,
+                                    int nj, float* dense_device) {
+  if (!e || layer < 0 || layer >= RNA_NUM_LAYERS || n < 0 || (n > 0 && (!tiles_host || !dense_device))) return RNA_EINVAL;
+  if (n == 0) return RNA_OK;
+  if (!window_ok(e, i0, ni, j0, nj)) return rna::fail(e, RNA_EINVAL, "window outside the map");
+  RNA_HIP(e, hipSetDevice(e->device));
+  int rc = stage_tile_list(e, tiles_host, n);
+  if (rc != RNA_OK) return rc;
+  hipLaunchKernelGGL(pack_tiles_kernel, dim3(n), dim3(256), 0, e->stream, e->layer[layer], e->geom.size[0], e->tiles_i,
+                     e->tile_list, i0, i0 + ni, j0, j0 + nj, dense_device);
+  RNA_HIP(e, hipGetLastError());
+  RNA_HIP(e, hipStreamSynchronize(e->stream));
+  return RNA_OK;
+}
+
+extern "C" int rna_layers_unpack_tiles(rna_engine* e, int layer_a, int layer_b, const int32_t* tiles_host, int n, int i0,
+                                       int ni, int j0, int nj, const float* dense_device) {
+  if (!e || layer_a < 0 || layer_a >= RNA_NUM_LAYERS || layer_b >= RNA_NUM_LAYERS || layer_b == layer_a || n < 0 ||
+      (n > 0 && (!tiles_host || !dense_device)))
+    return RNA_EINVAL;
+  if (n == 0) return RNA_OK;
+  if (!window_ok(e, i0, ni, j0, nj)) return rna::fail(e, RNA_EINVAL, "window outside the map");
+  RNA_HIP(e, hipSetDevice(e->device));
+  int rc = stage_tile_list(e, tiles_host, n);
+  if (rc != RNA_OK) return rc;
+  hipLaunchKernelGGL(unpack_tiles_kernel, dim3(n), dim3(256), 0, e->stream, e->layer[layer_a],
+                     layer_b >= 0 ? e->layer[layer_b] : (float*)nullptr, e->geom.size[0], e->tiles_i, e->tile_list, i0,
+                     i0 + ni, j0, j0 + nj, dense_device, e->dirty_tiles);
+  RNA_HIP(e, hipGetLastError());
+  RNA_HIP(e, hipStreamSynchronize(e->stream));
+  return RNA_OK;
 }
 
 // GridMap GridMap::getSubmap(position, length, isSuccess) (gmc/src/GridMap.cpp:287-339) as a GridMap of its own: a new
@@ -458,6 +575,12 @@ extern "C" int rna_compose_master(rna_engine* e, int mode) {
                        e->layer[RNA_LAYER_MASTER], e->dirty_tiles, 0, e->geom.size[0], e->geom.size[1], e->tiles_i,
                        e->tiles_j, 0, 0);
     RNA_HIP(e, hipGetLastError());
+  }
+  // what this compose consumed: the tiles a tiled deployment has to hand to the other GPUs (rna_last_dirty_tiles)
+  if (full) {
+    RNA_HIP(e, hipMemsetAsync(e->last_dirty, 1, words * sizeof(unsigned), e->stream));
+  } else {
+    RNA_HIP(e, hipMemcpyAsync(e->last_dirty, e->dirty_tiles, words * sizeof(unsigned), hipMemcpyDeviceToDevice, e->stream));
   }
   RNA_HIP(e, hipMemsetAsync(e->dirty_tiles, 0, words * sizeof(unsigned), e->stream));
   e->laser_all_dirty = false;

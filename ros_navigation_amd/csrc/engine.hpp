@@ -104,6 +104,9 @@ struct rna_engine {
   float* layer[RNA_NUM_LAYERS] = {nullptr, nullptr, nullptr};
   int tiles_i = 0, tiles_j = 0;
   unsigned* dirty_tiles = nullptr;   // one BYTE per TILE x TILE tile: laser changed since last compose
+  unsigned* last_dirty = nullptr;    // the flags the last compose consumed (tiled mode: what this GPU has to hand on)
+  int32_t* tile_list = nullptr;      // staging for rna_layer_pack_tiles / rna_layers_unpack_tiles
+  int tile_list_cap = 0;
   bool laser_all_dirty = false;      // laser uploaded/filled: next compose is a whole-layer copy
   uint8_t* nbr = nullptr;            // A* neighbour masks derived from master
   bool nbr_all_dirty = true;

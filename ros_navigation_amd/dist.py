@@ -135,7 +135,7 @@ def _p2p(dist, sends, recvs):
         t.copy_(h)
 
 
-def exchange_halo(grid, layer, layout, rank, halo, dist):
+def exchange_halo(grid, layer, layout, rank, halo, dist, tracked=False):
     """Bring the `halo`-cell frame around this rank's window up to date from its owners.  Round 1 moves
     row strips (i direction) of the own columns, round 2 column strips that include the rows just
     received, which carries the corners: 4 messages per rank instead of 8.  Returns the bytes received."""
@@ -156,7 +156,10 @@ def exchange_halo(grid, layer, layout, rank, halo, dist):
             into.append((recv_box, buf))
         _p2p(dist, sends, recvs)
         for box, buf in into:
-            grid.unpack_region(layer, box[0], box[1], box[2], box[3], buf)
+            if tracked:     # per-tile bookkeeping (incremental mode, see gather_dirty)
+                grid.unpack_region(layer, box[0], box[1], box[2], box[3], buf, tracked=True)
+            else:
+                grid.unpack_region(layer, box[0], box[1], box[2], box[3], buf)
             got += buf.numel() * 4
 
     up, down = layout.rank_of(a - 1, b), layout.rank_of(a + 1, b)
@@ -201,4 +204,51 @@ def gather_layer(grid, layer, layout, rank, dist):
         part = parts[r][:rni * rnj]
         grid.unpack_region(layer, ri0, rni, rj0, rnj, part.to(mine.device).contiguous() if stage else part.contiguous())
         got += rni * rnj * 4
+    return got
+
+
+def gather_dirty(grid, layers, layout, rank, dist, tile=64):
+    """Incremental form of gather_layer: every rank hands on only the 64 x 64 tiles its last map update changed
+    (grid.last_dirty_tiles(), clipped to its window), and the receivers write them into `layers` (laser and master, so
+    that the laser layer stays complete everywhere) with per-tile bookkeeping -- a following grid.compose_master(0)
+    refreshes the A* neighbour masks of exactly those tiles.  Three small collectives (counts, tile lists) and one
+    all-gather of the tile data, padded to the largest contribution.  Returns the bytes received."""
+    import numpy as np
+    import torch
+    if layout.world == 1:
+        return 0
+    tiles_i = (layout.rows + tile - 1) // tile
+    flags = grid.last_dirty_tiles()
+    win = layout.window(rank)
+    t = np.flatnonzero(flags)
+    ti, tj = t % tiles_i, t // tiles_i
+    i0, ni, j0, nj = win
+    mine = t[(ti * tile < i0 + ni) & (ti * tile + tile > i0) & (tj * tile < j0 + nj) & (tj * tile + tile > j0)].astype(np.int32)
+    probe = grid.pack_tiles(layers[0], mine[:0], win)                   # an empty tensor on the grid's device
+    stage = dist.get_backend() == "gloo" and probe.is_cuda
+    dev = torch.device("cpu") if stage else probe.device
+    count = torch.tensor([len(mine)], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(count) for _ in range(layout.world)]
+    dist.all_gather(counts, count)
+    counts = [int(c.item()) for c in counts]
+    cap = max(counts)
+    if cap == 0:
+        return 0
+    lst = torch.full((cap,), -1, dtype=torch.int32, device=dev)
+    lst[:len(mine)] = torch.from_numpy(mine).to(dev)
+    lists = [torch.empty_like(lst) for _ in range(layout.world)]
+    dist.all_gather(lists, lst)
+    data = grid.pack_tiles(layers[0], mine, win)
+    pad = torch.zeros(cap * tile * tile, dtype=torch.float32, device=dev)
+    pad[:data.numel()] = data.to(dev)
+    parts = [torch.empty_like(pad) for _ in range(layout.world)]
+    dist.all_gather(parts, pad)
+    got = 0
+    for r in range(layout.world):
+        if r == rank or counts[r] == 0:
+            continue
+        tiles_r = lists[r][:counts[r]].cpu().numpy()
+        part = parts[r][:counts[r] * tile * tile]
+        grid.unpack_tiles(layers, tiles_r, layout.window(r), part.to(probe.device).contiguous() if stage else part.contiguous())
+        got += counts[r] * tile * tile * 4
     return got

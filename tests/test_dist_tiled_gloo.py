@@ -28,14 +28,103 @@ class NumpyGrid:
         self.a[j0:j0 + nj, i0:i0 + ni] = t.numpy()[:ni * nj].reshape(nj, ni)
 
 
-def _scene():
+class NumpyTileGrid(NumpyGrid):
+    """The tile-list calls of capi.Engine on host arrays: two layers (0 = laser, 1 = master), 64 x 64 tiles."""
+    T = 64
+
+    def __init__(self, rows, cols, data):
+        super().__init__(rows, cols, data)
+        self.layers = [self.a, self.a.copy()]
+        self.flags = np.zeros(((cols + 63) // 64) * ((rows + 63) // 64), np.uint8)
+        self.marked = set()
+
+    def last_dirty_tiles(self):
+        return self.flags.copy()
+
+    def _clip(self, t, window):
+        tiles_i = (self.rows + 63) // 64
+        i0, ni, j0, nj = window
+        a, b = (t % tiles_i) * 64, (t // tiles_i) * 64
+        return max(a, i0), min(a + 64, i0 + ni, self.rows), max(b, j0), min(b + 64, j0 + nj, self.cols), a, b
+
+    def pack_tiles(self, layer, tiles, window):
+        import torch
+        out = np.zeros((len(tiles), 64, 64), np.float32)          # [slot, lj, li]
+        for k, t in enumerate(tiles):
+            ia, ib, ja, jb, a, b = self._clip(int(t), window)
+            if ia < ib and ja < jb:
+                out[k, ja - b:jb - b, ia - a:ib - a] = self.layers[layer][ja:jb, ia:ib]
+        return torch.from_numpy(out.reshape(-1))
+
+    def unpack_tiles(self, layers, tiles, window, t):
+        data = t.numpy().reshape(-1, 64, 64)
+        for k, tl in enumerate(tiles):
+            ia, ib, ja, jb, a, b = self._clip(int(tl), window)
+            for l in layers:
+                if ia < ib and ja < jb:
+                    self.layers[l][ja:jb, ia:ib] = data[k, ja - b:jb - b, ia - a:ib - a]
+            self.marked.add(int(tl))
+
+
+def _dirty_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from ros_navigation_amd import dist as D
+    dist = D.init("gloo")
+    rows, cols = 200, 150                                   # 4 x 3 tiles of 64, windows cut through tiles
+    before, after = _scene(rows, cols)
+    L = D.TileLayout.for_world(rows, cols, world)
+    i0, ni, j0, nj = L.window(rank)
+    grid = NumpyTileGrid(rows, cols, before)
+    full, old = after.reshape(cols, rows), before.reshape(cols, rows)
+    for lay in grid.layers:                                  # owner-computes, laser == master after compose
+        lay[j0:j0 + nj, i0:i0 + ni] = full[j0:j0 + nj, i0:i0 + ni]
+    ch = ~((full == old) | (np.isnan(full) & np.isnan(old)))
+    win = np.zeros_like(ch)
+    win[j0:j0 + nj, i0:i0 + ni] = True
+    jj, ii = np.nonzero(ch & win)
+    grid.flags[np.unique((jj // 64) * ((rows + 63) // 64) + ii // 64)] = 1     # what HIMM would have flagged
+    got = D.gather_dirty(grid, (0, 1), L, rank, dist)
+    ok = all(np.array_equal(lay, full, equal_nan=True) for lay in grid.layers)
+    # tiles nobody changed were not touched, tiles a peer changed were flagged for the mask refresh
+    peers = ch & ~win
+    jj, ii = np.nonzero(peers)
+    want_marked = set(np.unique((jj // 64) * ((rows + 63) // 64) + ii // 64).tolist())
+    out.put((rank, ok, got, want_marked <= grid.marked, len(grid.marked), int(ch.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tiled_incremental_gather_gloo(world):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_dirty_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, got, marked_ok, n_marked, n_changed in res:
+        assert ok, "rank %d: layers differ from the whole-map update after the incremental gather" % rank
+        assert marked_ok and n_changed > 0
+        assert got >= n_marked * 4096 * 4                                   # a tile two owners changed arrives twice
+        assert got < 4 * 200 * 150 * 2                                      # well under two whole layers
+
+
+def _scene(rows=ROWS, cols=COLS):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
     from ros_navigation_amd import synth
-    g = O.make_geom(ROWS * 0.05, COLS * 0.05, 0.05)
-    before = synth.occupancy_sparse(ROWS, COLS, seed=5)
-    rays = synth.rays(6, 200, ROWS * 0.05, COLS * 0.05, seed=9, lmin=0.3, lmax=3.0, margin=0.3)
+    g = O.make_geom(rows * 0.05, cols * 0.05, 0.05)
+    before = synth.occupancy_sparse(rows, cols, seed=5)
+    rays = synth.rays(6, 200, rows * 0.05, cols * 0.05, seed=9, lmin=0.3, lmax=3.0, margin=0.3)
     after = before.copy()
     O.himm_update(g, after, rays.view(O.RAY_DTYPE))
     return before, after

@@ -69,7 +69,7 @@ def test_windowed_himm_is_the_whole_map_update_inside_the_window():
     e.close()
 
 
-def _tiled_worker(rank, world, port, out):
+def _tiled_worker(rank, world, port, out, mode="full"):
     try:
         sys.path.insert(0, ROOT)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -110,7 +110,7 @@ def _tiled_worker(rank, world, port, out):
             rays = R.synth.rays(10, 700, lx, ly, seed=30 + rnd, lmin=0.3, lmax=6.0, margin=0.4)
             Or.himm_update(g, full, rays.view(Or.RAY_DTYPE))          # whole-map truth (laser == master)
             e.update_map(rays, compose_mode=0)                         # this rank's window only
-            checked["halo_bytes"] += D.exchange_halo(e, R.capi.LAYER_MASTER, L, rank, halo, dist)
+            checked["halo_bytes"] += D.exchange_halo(e, R.capi.LAYER_MASTER, L, rank, halo, dist, tracked=(mode == "dirty"))
             vout, origin, hist = e.vfh_step(mine)
             for k in range(len(mine)):
                 p = mine[k]
@@ -121,7 +121,13 @@ def _tiled_worker(rank, world, port, out):
                 assert hist[k].tobytes() == oracles[k].hist().tobytes(), (rnd, k)
                 checked["vfh"] += 1
             mine["current_speed"] = vout["chosen_speed"]
-            checked["gather_bytes"] += D.gather_layer(e, R.capi.LAYER_MASTER, L, rank, dist)
+            if mode == "dirty":      # only the tiles this update changed travel; masks of exactly those are refreshed
+                checked["gather_bytes"] += D.gather_dirty(e, (R.capi.LAYER_LASER, R.capi.LAYER_MASTER), L, rank, dist)
+                e.compose_master(0)
+                lz = e.download(R.capi.LAYER_LASER)
+                assert np.array_equal(np.isnan(lz), np.isnan(full)) and np.array_equal(lz[~np.isnan(lz)], full[~np.isnan(full)]), rnd
+            else:
+                checked["gather_bytes"] += D.gather_layer(e, R.capi.LAYER_MASTER, L, rank, dist)
             got = e.download(R.capi.LAYER_MASTER)
             assert np.array_equal(np.isnan(got), np.isnan(full)) and np.array_equal(got[~np.isnan(got)], full[~np.isnan(full)]), rnd
             queries = R.synth.astar_queries(24, full, rows, cols, seed=40 + rnd)
@@ -145,7 +151,8 @@ def _tiled_worker(rank, world, port, out):
         out.put((rank, "fail", traceback.format_exc(), repr(ex)))
 
 
-def test_tiled_loop_two_ranks_on_one_gpu_matches_the_whole_map_oracle():
+@pytest.mark.parametrize("mode", ["full", "dirty"])
+def test_tiled_loop_two_ranks_on_one_gpu_matches_the_whole_map_oracle(mode):
     import torch.multiprocessing as mp
     world = 2
     with socket.socket() as s:
@@ -153,7 +160,7 @@ def test_tiled_loop_two_ranks_on_one_gpu_matches_the_whole_map_oracle():
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_tiled_worker, args=(r, world, port, out)) for r in range(world)]
+    procs = [ctx.Process(target=_tiled_worker, args=(r, world, port, out, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(out.get(timeout=600) for _ in range(world))
@@ -164,7 +171,11 @@ def test_tiled_loop_two_ranks_on_one_gpu_matches_the_whole_map_oracle():
     assert sum(r[3] for r in res) == 96                       # every pose served by exactly one rank
     assert all(r[2]["vfh"] == 3 * r[3] and r[2]["astar"] == 36 for r in res)
     # 2 x 1 layout: one 16-row strip of 192 columns per rank per round, the other window per gather
-    assert all(r[2]["halo_bytes"] == 3 * 16 * 192 * 4 and r[2]["gather_bytes"] == 3 * 128 * 192 * 4 for r in res)
+    assert all(r[2]["halo_bytes"] == 3 * 16 * 192 * 4 for r in res)
+    if mode == "full":
+        assert all(r[2]["gather_bytes"] == 3 * 128 * 192 * 4 for r in res)
+    else:                                                     # whole 64 x 64 tiles, and fewer bytes than the windows
+        assert all(r[2]["gather_bytes"] % (4096 * 4) == 0 and 0 < r[2]["gather_bytes"] <= 3 * 128 * 192 * 4 for r in res)
 
 
 def test_config5_full_size_windowed_himm_union_is_the_whole_map_update():
