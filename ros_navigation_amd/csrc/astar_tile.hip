@@ -261,48 +261,37 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
   // 2. tile + halo -> LDS (after the pending bits: every grabbed bit's value is already in L2)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   {
-    // cell r*64 + lane sits 2r rows below cell `lane`: one base address + compile-time offsets
-    unsigned* tp = &W.tile[((lane >> 5) + 1) * TW + (lane & 31) + 1];
-    const uint4 mv = *reinterpret_cast<const uint4*>(nbr_tm + ((size_t)t << 10) + lane * 16);
-    // two batches of eight coalesced loads (each: issue all, one wait, LDS stores): sixteen at once cost 12 more
-    // VGPRs for the whole kernel, and the registers this kernel leaves free per SIMD decide how many wavefronts
-    // of the short map-update kernels can run next to the searches (they gate the next pipelined launch)
-#pragma unroll 1
-    for (int h8 = 0; h8 < 2; ++h8) {
-      unsigned tv[TILE_WORDS / 128];
-#pragma unroll
-      for (int r = 0; r < TILE_WORDS / 128; ++r) tv[r] = ld_l2(&ftile[(h8 * 8 + r) * 64 + lane]);
-#pragma unroll
-      for (int r = 0; r < TILE_WORDS / 128; ++r) tp[(h8 * 8 + r) * 2 * TW] = tv[r];
-    }
-    *reinterpret_cast<uint4*>(&W.mask[lane * 16]) = mv;
-  }
-  {
-    // halo: left/right neighbour columns (contiguous), top/bottom rows (strided), 4 corners
+    // Everything a job reads from HBM is issued before the first wait: the three halo words of a lane (neighbour
+    // column, neighbour row, corner), its 16 tile words (cell r*64 + lane sits 2r rows below cell `lane`: one base
+    // address + compile-time offsets) and its 16 mask bytes -- ONE memory round trip after the pending bits.  (Until
+    // the lane arithmetic of the later phases was cut loose from this one, see lane_b below, the kernel had no
+    // registers for that and loaded in two batches of eight plus the halo: three round trips.)
     const int h = lane & 31;
     const bool second = lane >= 32;
-    // columns: tile (ti, tj-1) column 31 -> LDS jl=-1 ; tile (ti, tj+1) column 0 -> LDS jl=32
-    {
-      const int ntj = second ? tj + 1 : tj - 1;
-      unsigned v = 0xFFFFFF00u;
-      if (ntj >= 0 && ntj < tiles_j) v = ld_l2(&field[((size_t)(ntj * tiles_i + ti) << 10) + ((second ? 0 : 31) << 5) + h]);
-      W.tile[(second ? TS + 1 : 0) * TW + h + 1] = v;
-    }
-    // rows: tile (ti-1, tj) row 31 -> LDS il=-1 ; tile (ti+1, tj) row 0 -> LDS il=32
-    {
-      const int nti = second ? ti + 1 : ti - 1;
-      unsigned v = 0xFFFFFF00u;
-      if (nti >= 0 && nti < tiles_i) v = ld_l2(&field[((size_t)(tj * tiles_i + nti) << 10) + (h << 5) + (second ? 0 : 31)]);
-      W.tile[(h + 1) * TW + (second ? TS + 1 : 0)] = v;
-    }
+    // halo columns: tile (ti, tj-1) column 31 -> LDS jl=-1 ; tile (ti, tj+1) column 0 -> LDS jl=32
+    // halo rows:    tile (ti-1, tj) row 31 -> LDS il=-1 ; tile (ti+1, tj) row 0 -> LDS il=32 ; then the 4 corners
+    const int ntj = second ? tj + 1 : tj - 1;
+    const int nti = second ? ti + 1 : ti - 1;
+    unsigned hv_col = 0xFFFFFF00u, hv_row = 0xFFFFFF00u, hv_cor = 0xFFFFFF00u;
+    if (ntj >= 0 && ntj < tiles_j) hv_col = ld_l2(&field[((size_t)(ntj * tiles_i + ti) << 10) + ((second ? 0 : 31) << 5) + h]);
+    if (nti >= 0 && nti < tiles_i) hv_row = ld_l2(&field[((size_t)(tj * tiles_i + nti) << 10) + (h << 5) + (second ? 0 : 31)]);
+    const int cdi = (lane & 1) ? 1 : -1, cdj = (lane & 2) ? 1 : -1;
     if (lane < 4) {
-      const int di = (lane & 1) ? 1 : -1, dj = (lane & 2) ? 1 : -1;
-      const int nti = ti + di, ntj = tj + dj;
-      unsigned v = 0xFFFFFF00u;
-      if (nti >= 0 && nti < tiles_i && ntj >= 0 && ntj < tiles_j)
-        v = ld_l2(&field[((size_t)(ntj * tiles_i + nti) << 10) + ((dj > 0 ? 0 : 31) << 5) + (di > 0 ? 0 : 31)]);
-      W.tile[(dj > 0 ? TS + 1 : 0) * TW + (di > 0 ? TS + 1 : 0)] = v;
+      const int cti = ti + cdi, ctj = tj + cdj;
+      if (cti >= 0 && cti < tiles_i && ctj >= 0 && ctj < tiles_j)
+        hv_cor = ld_l2(&field[((size_t)(ctj * tiles_i + cti) << 10) + ((cdj > 0 ? 0 : 31) << 5) + (cdi > 0 ? 0 : 31)]);
     }
+    unsigned* tp = &W.tile[((lane >> 5) + 1) * TW + (lane & 31) + 1];
+    unsigned tv[TILE_WORDS / 64];
+#pragma unroll
+    for (int r = 0; r < TILE_WORDS / 64; ++r) tv[r] = ld_l2(&ftile[r * 64 + lane]);
+    const uint4 mv = *reinterpret_cast<const uint4*>(nbr_tm + ((size_t)t << 10) + lane * 16);
+    W.tile[(second ? TS + 1 : 0) * TW + h + 1] = hv_col;
+    W.tile[(h + 1) * TW + (second ? TS + 1 : 0)] = hv_row;
+    if (lane < 4) W.tile[(cdj > 0 ? TS + 1 : 0) * TW + (cdi > 0 ? TS + 1 : 0)] = hv_cor;
+#pragma unroll
+    for (int r = 0; r < TILE_WORDS / 64; ++r) tp[r * 2 * TW] = tv[r];
+    *reinterpret_cast<uint4*>(&W.mask[lane * 16]) = mv;
   }
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -474,20 +463,26 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
   //    atomicMin (a neighbouring tile's job may have improved them in HBM meanwhile).  Only rows that hold a
   //    popped cell can differ from what was loaded (every improved interior cell is queued, hence popped).
   const unsigned dirty = tsa_wave_or(dirty_lane);
+  // Everything after the relaxation loop derives its lane arithmetic from an opaque copy of the lane id, so that no
+  // address or index computed for the tile load stays alive across the loop: 104 -> 86 VGPRs (91 with the one-batch
+  // load above).  The register budget of this kernel decides how many wavefronts of the map-update and VFH kernels
+  // fit next to four searches per SIMD.
+  int lane_b = lane;
+  asm volatile("" : "+v"(lane_b));
   {
-    const unsigned* tp = &W.tile[((lane >> 5) + 1) * TW + (lane & 31) + 1];
-    const int il = lane & 31;
+    const unsigned* tp = &W.tile[((lane_b >> 5) + 1) * TW + (lane_b & 31) + 1];
+    const int il = lane_b & 31;
     const bool edge_col = il == 0 || il == TS - 1;
 #pragma unroll 2
     for (int r = 0; r < TILE_WORDS / 64; ++r) {
       if (((dirty >> (2 * r)) & 3u) == 0u) continue;            // neither row of this pair changed
-      if (!((dirty >> (2 * r + (lane >> 5))) & 1u)) continue;   // this lane's row did not
+      if (!((dirty >> (2 * r + (lane_b >> 5))) & 1u)) continue;   // this lane's row did not
       const unsigned v = tp[r * 2 * TW] & 0xFFFFFF00u;
-      const bool edge = edge_col || (r == 0 && lane < 32) || (r == TILE_WORDS / 64 - 1 && lane >= 32);
+      const bool edge = edge_col || (r == 0 && lane_b < 32) || (r == TILE_WORDS / 64 - 1 && lane_b >= 32);
       if (edge) {
-        if ((v >> 8) != G_INF) (void)atomicMin(&ftile[r * 64 + lane], v);
+        if ((v >> 8) != G_INF) (void)atomicMin(&ftile[r * 64 + lane_b], v);
       } else {
-        ftile[r * 64 + lane] = v;
+        ftile[r * 64 + lane_b] = v;
       }
     }
   }
@@ -497,14 +492,14 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
 #pragma unroll 4
     for (int r = 0; r < TS / 2; ++r) {
       if (((dirty >> (2 * r)) & 3u) == 0u) continue;
-      const int jl = 2 * r + (lane >> 5), il = lane & 31;
+      const int jl = 2 * r + (lane_b >> 5), il = lane_b & 31;
       const bool f = (W.tile[(jl + 1) * TW + il + 1] & 4u) != 0u;
       const unsigned long long bm = __ballot(f);
-      const unsigned word = (unsigned)(bm >> (lane & 32));
-      if ((lane & 31) == 0 && word) { atomicOr(&pend_far[(size_t)t * TS + jl], word); }
+      const unsigned word = (unsigned)(bm >> (lane_b & 32));
+      if ((lane_b & 31) == 0 && word) { atomicOr(&pend_far[(size_t)t * TS + jl], word); }
       anyfar |= bm != 0ull;
     }
-    if (anyfar && lane == 0) sch.act_far(t);
+    if (anyfar && lane_b == 0) sch.act_far(t);
   }
   TSA_T(t_d);
   TSA_ACC(2, t_c, t_d);
@@ -519,7 +514,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
     bool hdo[HK];
 #pragma unroll
     for (int k = 0; k < HK; ++k) {
-      const int hh = lane + 64 * k;
+      const int hh = lane_b + 64 * k;
       hdo[k] = false; hv[k] = 0u; hix[k] = 0u; hfn[k] = 0;
       if (hh < 4 * TW) {
         // ring positions: hh in [0,TW): jl=-1 row; [TW,2TW): jl=32 row; [2TW,3TW): il=-1 col; [3TW,4TW): il=32 col
