@@ -43,9 +43,10 @@ def parse():
     ap.add_argument("--bucket-width", type=int, default=0)
     ap.add_argument("--queue-capacity", type=int, default=0)
     ap.add_argument("--max-path", type=int, default=32768)
-    ap.add_argument("--pipeline", type=int, default=6,
-                    help="A* batches in flight (rna_astar_set_pipeline_depth); 6 x 256 queries x 64 MiB = 96 GiB of search fields "
-                         "at 4096^2 -- measured 4: 24.9k, 6: 25.5k, 8: 23.8k cycles/s")
+    ap.add_argument("--pipeline", type=int, default=4,
+                    help="A* batches in flight (rna_astar_set_pipeline_depth).  Measured 4: 24.9k, 6: 25.5k, 8: 23.8k cycles/s; "
+                         "the default stays at 4 because every launch is stretched by the ones it overlaps with, and the "
+                         "roofline line divides by that per-launch duration (6 in flight: 44 ms per launch instead of 36.5)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--tiled-full-gather", action="store_true", help="--tiled: all-gather whole windows instead of dirty tiles")
