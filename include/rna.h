@@ -200,7 +200,8 @@ int rna_vfh_update_batch(rna_engine* e, const double* ranges_host /* n*361*2 */,
 typedef struct { int32_t start, goal; } rna_astar_query;
 typedef struct {
   int32_t status;      /* 0 found, 1 no path, 2 invalid query, 3 path longer than max_path_len,
-                          4 path cost beyond the 24-bit g range (>= 16.7e6), RNA_ECAPACITY queue overflow */
+                          4 path cost beyond the 24-bit g range (>= 16.7e6), 5 the query's share of search pages is
+                          used up (only after rna_astar_set_page_cap or when HBM is short), RNA_ECAPACITY queue overflow */
   int32_t path_len;    /* cells, start..goal inclusive */
   int32_t cost;        /* 1000/1414 integer cost of the path */
   int32_t expanded;    /* cell expansions the device performed (>= the oracle's settled count) */
@@ -217,6 +218,11 @@ int rna_astar_configure(rna_engine* e, int max_queries, int queue_capacity, int 
  * the next batch and the next map update.  Outputs of a call are valid after rna_synchronize(); the
  * caller must give calls that may be in flight together distinct output buffers.  Default 4. */
 int rna_astar_set_pipeline_depth(rna_engine* e, int depth);
+/* The tile kernel keeps a search's distance field in 4 KiB pages (32 x 32 cells) handed out on first touch.  By
+ * default every query may take one page per tile of the map (it can never run out; HBM is only touched where a
+ * search goes).  A smaller share per query makes room for more queries / pipeline stages in flight; a search that
+ * needs more ends with status 5.  0 = default. */
+int rna_astar_set_page_cap(rna_engine* e, int pages_per_query);
 int rna_astar_batch(rna_engine* e, const rna_astar_query* queries_host, int n, int32_t* paths_host,
                     int max_path_len, rna_astar_result* results_host);
 int rna_astar_batch_device(rna_engine* e, const rna_astar_query* queries_device, int n, int32_t* paths_device,

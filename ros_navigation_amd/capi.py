@@ -30,7 +30,7 @@ SYMBOLS = [
     "rna_layers_unpack_tiles", "rna_layer_unpack_region_tracked",
     "rna_vfh_default_params", "rna_vfh_init", "rna_vfh_reset", "rna_vfh_hist_size", "rna_vfh_step_batch",
     "rna_vfh_step_batch_device", "rna_vfh_update_batch",
-    "rna_astar_configure", "rna_astar_set_pipeline_depth", "rna_astar_batch", "rna_astar_batch_device", "rna_astar_settled_counts",
+    "rna_astar_configure", "rna_astar_set_pipeline_depth", "rna_astar_set_page_cap", "rna_astar_batch", "rna_astar_batch_device", "rna_astar_settled_counts",
     "rna_astar_download_nbr_mask",
     "rna_graph_astar_batch", "rna_rrt_batch", "rna_rrt_batch_device",
     "rna_to_occupancy_grid", "rna_to_occupancy_grid_device", "rna_from_occupancy_grid", "rna_vfh_hist_msg_batch",
@@ -145,6 +145,7 @@ def lib():
     L.rna_vfh_update_batch.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp]
     L.rna_astar_configure.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.rna_astar_set_pipeline_depth.argtypes = [vp, C.c_int]
+    L.rna_astar_set_page_cap.argtypes = [vp, C.c_int]
     L.rna_astar_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
     L.rna_astar_batch_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
     L.rna_astar_download_nbr_mask.argtypes = [vp, vp, C.c_size_t]
@@ -447,6 +448,9 @@ class Engine:
 
     def astar_pipeline_depth(self, depth):
         self._check(self._L.rna_astar_set_pipeline_depth(self.h, depth))
+
+    def astar_page_cap(self, pages_per_query):
+        self._check(self._L.rna_astar_set_page_cap(self.h, pages_per_query))
 
     def astar(self, queries, max_path_len):
         assert queries.dtype == ASTAR_QUERY_DTYPE

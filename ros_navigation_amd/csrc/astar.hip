@@ -310,8 +310,9 @@ int ensure_config(rna_engine* e) {
   AstarDevice& a = e->astar;
   if (a.g[0]) return RNA_OK;
   if (a.max_queries <= 0) a.max_queries = 256;
-  if (const char* t = getenv("RNA_ASTAR_THREADS")) a.threads = atoi(t);  // tuning knob: 256 / 512 / 1024
-  if (const char* k = getenv("RNA_ASTAR_KERNEL")) a.mode = (k[0] == 'p') ? 2 : ((k[0] == 'f') ? 0 : ((k[0] == 'a') ? 3 : 1));  // persist | frontier | async | tile (default)
+  if (const char* t = getenv("RNA_ASTAR_THREADS")) a.threads = atoi(t);  // tuning knob of the frontier kernel: 256 / 512 / 1024
+  a.mode = 1;
+  if (const char* k = getenv("RNA_ASTAR_KERNEL")) a.mode = (k[0] == 'f') ? 0 : 1;  // frontier | tile (default)
   if (a.mode != 0 && !tsa_supported(e)) a.mode = 0;
   if (a.depth < 1) a.depth = 1;
   if (a.depth > AstarDevice::MAX_DEPTH) a.depth = AstarDevice::MAX_DEPTH;
@@ -324,39 +325,41 @@ int ensure_config(rna_engine* e) {
     a.queue_cap = (int)c;
   }
   if (e->ncell >= (1ull << 30)) return fail(e, RNA_EINVAL, "grid A*: more than 2^30 cells");
-  // fit into free HBM (25 % headroom): first fewer pipeline stages, then fewer concurrent queries
+  // fit into free HBM (25 % headroom): first fewer pipeline stages, then (tile kernel) fewer pages per query
+  // -- a search that needs more than its share then ends with status 5 --, then fewer concurrent queries
   size_t free_b = 0, total_b = 0;
   RNA_HIP(e, hipMemGetInfo(&free_b, &total_b));
-  const size_t field_words = a.mode != 0 ? tsa_field_words(e) : e->ncell;
-  const size_t per_query = (field_words + 128) * sizeof(int32_t) +
-                           (a.mode != 0 ? tsa_pend_words(e) * 4 + (size_t)a.rev_cap * 4 + tsa_field_words(e) / 8 / 32
-                                        : (size_t)3 * a.queue_cap * sizeof(int2));
-  while (a.depth > 1 && (double)per_query * a.max_queries * a.depth > 0.75 * (double)free_b) a.depth -= 1;
-  while (a.max_queries > 1 && (double)per_query * a.max_queries * a.depth > 0.75 * (double)free_b) a.max_queries /= 2;
+  const int ntile = a.mode != 0 ? tsa_tiles(e) : 0;
+  a.page_cap = ntile;
+  if (a.page_cap_request > 0 && a.page_cap_request < ntile) a.page_cap = a.page_cap_request;
+  if (const char* c = getenv("RNA_ASTAR_PAGE_CAP")) { const int v = atoi(c); if (v > 0 && v < ntile) a.page_cap = v; }
+  auto stage_bytes = [&]() -> double {
+    if (a.mode != 0)
+      return (double)tsa_pool_bytes(a.max_queries, a.page_cap) + (double)tsa_aux_bytes(e, a.max_queries, a.page_cap) +
+             (double)a.rev_cap * 4.0 * a.max_queries;
+    return ((double)(e->ncell + 128) * 4.0 + 3.0 * a.queue_cap * sizeof(int2)) * a.max_queries;
+  };
+  while (a.depth > 1 && stage_bytes() * a.depth > 0.75 * (double)free_b) a.depth -= 1;
+  while (a.mode != 0 && a.page_cap > 64 && a.page_cap > ntile / 8 && stage_bytes() * a.depth > 0.75 * (double)free_b) a.page_cap /= 2;
+  while (a.max_queries > 1 && stage_bytes() * a.depth > 0.75 * (double)free_b) a.max_queries /= 2;
   int rc;
-  // each query's field is padded (the 3-cell column loads reach one word past either end) and 256-byte aligned
-  a.field_stride = ((field_words + 64 + 63) / 64) * 64;
-  a.pend_stride = ((tsa_pend_words(e) + 63) / 64) * 64;
+  // frontier kernel: each query's field is padded (the 3-cell column loads reach one word past either end) and 256-byte aligned
+  a.field_stride = ((e->ncell + 64 + 63) / 64) * 64;
   for (int d = 0; d < a.depth; ++d) {
-    if ((rc = dev_alloc(e, &a.g[d], a.field_stride * (size_t)a.max_queries + 128)) != RNA_OK) return rc;
     if (a.mode != 0) {
-      if ((rc = dev_alloc(e, &a.pend[d], a.pend_stride * (size_t)a.max_queries)) != RNA_OK) return rc;
-      if ((rc = dev_alloc(e, &a.rev[d], (size_t)a.rev_cap * a.max_queries)) != RNA_OK) return rc;
-      {
-        char* aux = nullptr;
-        const size_t aux_bytes = tsa_aux_bytes(e, a.max_queries);
-        if ((rc = dev_alloc(e, &aux, aux_bytes)) != RNA_OK) return rc;
-        a.tsa_aux[d] = aux;
-        RNA_HIP(e, hipMemsetAsync(aux, 0, aux_bytes, e->stream));   // clean = 0: the first launch writes every field
-      }
-      if (a.mode == 2) {
-        size_t s1 = 0, s2 = 0;
-        char* st = nullptr;
-        if ((rc = dev_alloc(e, &st, tsa_persist_state_bytes(e, a.max_queries, &s1, &s2))) != RNA_OK) return rc;
-        a.pstate[d] = st;
-      }
+      char* pool = nullptr;
+      if ((rc = dev_alloc(e, &pool, tsa_pool_bytes(a.max_queries, a.page_cap))) != RNA_OK) { astar_release(e); return rc; }
+      a.g[d] = reinterpret_cast<int32_t*>(pool);
+      if ((rc = dev_alloc(e, &a.rev[d], (size_t)a.rev_cap * a.max_queries)) != RNA_OK) { astar_release(e); return rc; }
+      char* aux = nullptr;
+      const size_t aux_bytes = tsa_aux_bytes(e, a.max_queries, a.page_cap);
+      if ((rc = dev_alloc(e, &aux, aux_bytes)) != RNA_OK) { astar_release(e); return rc; }
+      a.tsa_aux[d] = aux;
+      RNA_HIP(e, hipMemsetAsync(aux, 0, aux_bytes, e->stream));
+      if ((rc = tsa_stage_prepare(e, d)) != RNA_OK) { astar_release(e); return rc; }
     } else {
-      if ((rc = dev_alloc(e, &a.queues[d], (size_t)3 * a.queue_cap * a.max_queries)) != RNA_OK) return rc;
+      if ((rc = dev_alloc(e, &a.g[d], a.field_stride * (size_t)a.max_queries + 128)) != RNA_OK) { astar_release(e); return rc; }
+      if ((rc = dev_alloc(e, &a.queues[d], (size_t)3 * a.queue_cap * a.max_queries)) != RNA_OK) { astar_release(e); return rc; }
     }
     if (a.depth > 1) {
       RNA_HIP(e, hipStreamCreateWithFlags(&a.side[d], hipStreamNonBlocking));
@@ -366,8 +369,8 @@ int ensure_config(rna_engine* e) {
   }
   if (a.depth > 1) RNA_HIP(e, hipEventCreateWithFlags(&a.ev_init, hipEventDisableTiming));
   a.launches = 0;
-  if ((rc = dev_alloc(e, &a.queries_dev, (size_t)a.max_queries)) != RNA_OK) return rc;
-  if ((rc = dev_alloc(e, &a.results_dev, (size_t)a.max_queries)) != RNA_OK) return rc;
+  if ((rc = dev_alloc(e, &a.queries_dev, (size_t)a.max_queries)) != RNA_OK) { astar_release(e); return rc; }
+  if ((rc = dev_alloc(e, &a.results_dev, (size_t)a.max_queries)) != RNA_OK) { astar_release(e); return rc; }
   return RNA_OK;
 }
 
@@ -377,40 +380,34 @@ int launch_chunk(rna_engine* e, const rna_astar_query* q_dev, int n, int32_t* pa
                  rna_astar_result* res_dev, int* slot_out) {
   AstarDevice& a = e->astar;
   const int slot = (int)(a.launches % (unsigned long long)a.depth);
-  unsigned* field = reinterpret_cast<unsigned*>(a.g[slot]) + 64;
   hipStream_t search_stream = a.depth > 1 ? a.side[slot] : e->stream;
   if (a.depth > 1 && a.busy[slot]) RNA_HIP(e, hipStreamWaitEvent(e->stream, a.done[slot], 0));  // stage is free again
-  if (a.mode == 2) {
-    int rc = tsa_persist_launch(e, e->stream, search_stream, a.depth > 1 ? a.ev_init : nullptr, field, a.field_stride,
-                                a.pend[slot], a.pend_stride, a.tsa_aux[slot], a.pstate[slot], a.max_queries, a.rev[slot], a.rev_cap, q_dev, n,
-                                paths_dev, max_len, res_dev);
-    if (rc != RNA_OK) return rc;
-  } else if (a.mode == 1 || a.mode == 3) {
-    int rc = tsa_launch(e, e->stream, search_stream, a.depth > 1 ? a.ev_init : nullptr, field, a.field_stride, a.pend[slot],
-                        a.pend_stride, a.tsa_aux[slot], a.max_queries, a.rev[slot], a.rev_cap, q_dev, n, paths_dev, max_len, res_dev);
+  if (a.mode != 0) {
+    int rc = tsa_launch(e, slot, e->stream, search_stream, a.depth > 1 ? a.ev_init : nullptr, q_dev, n, paths_dev, max_len, res_dev);
     if (rc != RNA_OK) return rc;
   } else {
-  {
-    KernelTimer kt(e, RNA_K_ASTAR_INIT);
-    hipLaunchKernelGGL(astar_init_kernel, dim3(4096), dim3(256), 0, e->stream, e->nbr, field, a.field_stride, n, e->ncell);
-    RNA_HIP(e, hipGetLastError());
-  }
-  if (a.depth > 1) {
-    RNA_HIP(e, hipEventRecord(a.ev_init, e->stream));
-    RNA_HIP(e, hipStreamWaitEvent(search_stream, a.ev_init, 0));
-  }
-  {
-    KernelTimer kt(e, RNA_K_ASTAR_SEARCH, search_stream);
+    unsigned* field = reinterpret_cast<unsigned*>(a.g[slot]) + 64;
+    {
+      KernelTimer kt(e, RNA_K_ASTAR_INIT);
+      hipLaunchKernelGGL(astar_init_kernel, dim3(4096), dim3(256), 0, e->stream, e->nbr, field, a.field_stride, n, e->ncell);
+      RNA_HIP(e, hipGetLastError());
+    }
+    if (a.depth > 1) {
+      RNA_HIP(e, hipEventRecord(a.ev_init, e->stream));
+      RNA_HIP(e, hipStreamWaitEvent(search_stream, a.ev_init, 0));
+    }
+    {
+      KernelTimer kt(e, RNA_K_ASTAR_SEARCH, search_stream);
 #define RNA_LAUNCH_SEARCH(T)                                                                                        \
   hipLaunchKernelGGL(astar_search_kernel<T>, dim3(n), dim3(T), 0, search_stream, e->geom.size[0], e->geom.size[1], \
                      q_dev, field, a.field_stride, a.queues[slot], a.queue_cap, a.bucket_width, paths_dev, max_len, \
                      res_dev)
-    if (a.threads == 256) RNA_LAUNCH_SEARCH(256);
-    else if (a.threads == 512) RNA_LAUNCH_SEARCH(512);
-    else RNA_LAUNCH_SEARCH(1024);
+      if (a.threads == 256) RNA_LAUNCH_SEARCH(256);
+      else if (a.threads == 512) RNA_LAUNCH_SEARCH(512);
+      else RNA_LAUNCH_SEARCH(1024);
 #undef RNA_LAUNCH_SEARCH
-    RNA_HIP(e, hipGetLastError());
-  }
+      RNA_HIP(e, hipGetLastError());
+    }
   }
   if (a.depth > 1) {
     RNA_HIP(e, hipEventRecord(a.done[slot], search_stream));
@@ -438,8 +435,7 @@ int astar_release(rna_engine* e) {
   if (a.mode == 1) tsa_stats_dump();
 #endif
   for (int d = 0; d < AstarDevice::MAX_DEPTH; ++d) {
-    dev_free(&a.g[d]); dev_free(&a.queues[d]); dev_free(&a.pend[d]); dev_free(&a.rev[d]);
-    if (a.pstate[d]) { (void)hipFree(a.pstate[d]); a.pstate[d] = nullptr; }
+    dev_free(&a.g[d]); dev_free(&a.queues[d]); dev_free(&a.rev[d]);
     if (a.tsa_aux[d]) { (void)hipFree(a.tsa_aux[d]); a.tsa_aux[d] = nullptr; }
     if (a.side[d]) { (void)hipStreamDestroy(a.side[d]); a.side[d] = nullptr; }
     if (a.done[d]) { (void)hipEventDestroy(a.done[d]); a.done[d] = nullptr; }
@@ -476,6 +472,16 @@ extern "C" int rna_astar_set_pipeline_depth(rna_engine* e, int depth) {
   if (depth != e->astar.depth) {
     astar_release(e);
     e->astar.depth = depth;
+  }
+  return RNA_OK;
+}
+
+extern "C" int rna_astar_set_page_cap(rna_engine* e, int pages_per_query) {
+  if (!e || pages_per_query < 0) return RNA_EINVAL;
+  RNA_HIP(e, hipSetDevice(e->device));
+  if (pages_per_query != e->astar.page_cap_request) {
+    astar_release(e);
+    e->astar.page_cap_request = pages_per_query;
   }
   return RNA_OK;
 }
@@ -559,11 +565,11 @@ extern "C" int rna_astar_settled_counts(rna_engine* e, int32_t* counts_host, int
   if (rc != RNA_OK) return rc;
   if ((rc = dev_alloc(e, &d_counts, (size_t)n)) != RNA_OK) return rc;
   if (a.mode != 0)
-    (void)tsa_settled(e, reinterpret_cast<const unsigned*>(a.g[a.last_slot]) + 64, a.field_stride, a.last_queries,
-                      a.last_results, n, d_counts);
+    rc = tsa_settled(e, a.last_slot, a.last_queries, a.last_results, n, d_counts);
   else
     hipLaunchKernelGGL(astar_settled_kernel, dim3(n), dim3(1024), 0, e->stream, e->geom.size[0], e->geom.size[1],
                        a.last_queries, a.last_results, reinterpret_cast<const unsigned*>(a.g[a.last_slot]) + 64, a.field_stride, d_counts);
+  if (rc != RNA_OK) { dev_free(&d_counts); return rc; }
   hipError_t st = hipGetLastError();
   if (st == hipSuccess) st = hipMemcpyAsync(counts_host, d_counts, sizeof(int32_t) * n, hipMemcpyDeviceToHost, e->stream);
   if (st == hipSuccess) st = hipStreamSynchronize(e->stream);

@@ -1,17 +1,10 @@
 // astar_tile.hip -- tile-synchronous grid A* for gfx950 ("TSA"): the same contract and the same
 // label-correcting argument as astar.hip, but the relaxation runs inside LDS.  This file holds the
-// default search kernel of the engine and its variants:
-//   tsa_search_kernel<false>  one workgroup (16 wavefronts) per query, rounds of tile jobs   (default)
-//   tsa_search_kernel<true>   the same without round barriers (RNA_ASTAR_KERNEL=async, experiment)
-//   tsa_multi_kernel<QB>      QB queries share a workgroup (RNA_TSA_QUERIES_PER_BLOCK, experiment)
-//   tsa_persist_kernel        every wavefront of the GPU pulls (query, tile) jobs from per-XCD rings
-//                             (RNA_ASTAR_KERNEL=persist: lowest latency of a single batch)
-// All of them run the same tile job (tsa_job) and pass the same parity tests.
+// default search kernel of the engine: one workgroup (16 wavefronts) per query, rounds of tile jobs.
 //
 // Why tiles: the frontier kernel of astar.hip pays two HBM/L2 round trips plus two workgroup barriers
-// per search GENERATION (~5 us), and a long query has >10^4 generations.  Here the search field is
-// stored TILE-MAJOR (32 x 32 cells = 4 KiB per tile, word = g << 8) and a wavefront owns one tile at a
-// time:
+// per search GENERATION (~5 us), and a long query has >10^4 generations.  Here the search field lives
+// in 32 x 32-cell PAGES (4 KiB, word = g << 8) and a wavefront owns one tile at a time:
 //   1. grab-and-clear the tile's pending bits (cells improved since its last visit),
 //   2. load the tile + a one-cell halo (and the tile's neighbour masks) into LDS with coalesced loads,
 //   3. relax to the tile-local fixed point of the current f-bucket entirely in LDS: a wave-synchronous
@@ -19,12 +12,16 @@
 //   4. write the tile back (inner cells: coalesced stores; edge ring and improved halo cells:
 //      atomicMin, because neighbouring tiles may be in flight on other wavefronts), hand improved
 //      halo cells to their tiles as pending bits and activate those tiles.
-// Two pending bitmaps per query (current bucket / next bucket) replace the frontier queues, so nothing
-// can overflow.  Fields are never initialised wholesale: each search records the tiles it wrote and
-// the next launch on that pipeline stage resets exactly those (tsa_init_kernel).  Exactness: every
-// update is a min over lengths of real paths and the schedule runs every bucket to its fixed point, so
-// at termination g is exact for f <= f*, which is all the canonical backtrace reads (DESIGN.md "Grid A*
-// contract").  Measurements, the ceiling of the design and the experiments that were dropped: DESIGN.md 5.
+// Pages are handed out on first touch: every query owns a contiguous run of `cap` pages and a tile ->
+// page table (tmap), so the 2-4 % of the map a search visits sits in a few MiB of HBM instead of being
+// scattered over a 64 MiB field (TLB reach, L2 hit rate), and the next launch on the same pipeline stage
+// resets exactly the pages that were handed out.  Page 0 is shared, never written and always
+// "unreached": reads of tiles without a page go there.  Two pending bitmaps per page (current bucket /
+// next bucket) replace the frontier queues, so nothing can overflow except the page pool itself
+// (status 5; the pool covers the whole map per query whenever HBM allows, see ensure_config).
+// Exactness: every update is a min over lengths of real paths and the schedule runs every bucket to its
+// fixed point, so at termination g is exact for f <= f*, which is all the canonical backtrace reads
+// (DESIGN.md "Grid A* contract").  Measurements and the experiments that were dropped: DESIGN.md 5.
 #include "engine.hpp"
 #include <algorithm>
 #include <vector>
@@ -49,7 +46,7 @@ constexpr int TSA_WAVES = RNA_TSA_WAVES;
 constexpr int TSA_THREADS = TSA_WAVES * 64;
 constexpr int TSA_MAX_TILE_WORDS = 2048;   // active-tile bitset words -> up to 65536 tiles
 #ifndef RNA_TSA_JOBS
-#define RNA_TSA_JOBS 4096
+#define RNA_TSA_JOBS 2048
 #endif
 constexpr int TSA_JOBS = RNA_TSA_JOBS;             // tile jobs per round (more stay flagged for the next round)
 #ifndef RNA_TSA_LQ
@@ -100,39 +97,39 @@ __device__ __forceinline__ unsigned tsa_wave_or(unsigned v) {
   v = tsa_dpp_or_step<0x143, 0xC>(v);   // row_bcast:31 -> lane 63 holds the OR of the wave
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
-// word index of cell (i, j) in a tile-major field
+// word index of cell (i, j) in a tile-major array (the neighbour-mask snapshot); tile and in-page offset of a cell
 __device__ __forceinline__ size_t tm_index(int i, int j, int tiles_i) {
   return ((size_t)((j >> 5) * tiles_i + (i >> 5)) << 10) + ((j & 31) << 5) + (i & 31);
 }
+__device__ __forceinline__ int tile_of(int i, int j, int tiles_i) { return (j >> 5) * tiles_i + (i >> 5); }
+__device__ __forceinline__ int in_page(int i, int j) { return ((j & 31) << 5) + (i & 31); }
 
-// Per pipeline stage, next to the fields: a tile-major snapshot of the neighbour masks (taken at
-// launch, so a later map update cannot disturb a search in flight), one touched-tile bitset per query,
-// and the `clean` flag.
-//
-// Invariant between launches: every field word is (G_INF << 8) and every pending word is 0, EXCEPT in
-// the tiles flagged in touched[q].  A search flags every tile it wrote (its jobs and the tiles it
-// handed cells to); the next launch on the same stage resets exactly those tiles -- typically a few
-// per cent of the map -- instead of rewriting 64 MiB per query.  clean == 0 (fresh allocation, or a
-// scheduler abort) makes the next launch rewrite everything.
-struct TsaAux {
-  int* clean;
-  uint8_t* nbr_tm;      // [ntile][32][32] neighbour masks, 0 outside the map
-  unsigned* touched;    // [max_queries][nt_words]
+// Device view of one pipeline stage.  Global page index of query q's local page p >= 1 is q*cap + p; page 0 is
+// the shared "unreached" page.  Invariant between launches: every page word is (G_INF << 8), every pending word
+// and every tmap entry is 0, EXCEPT what belongs to the local pages 1..nalloc[q] of each query; the next launch
+// on the stage resets exactly those (tsa_reset_kernel) instead of rewriting 64 MiB per query.
+constexpr unsigned TSA_BUSY = 0xFFFFFFFFu;   // tmap entry while its page is being handed out
+constexpr int PEND_WORDS = 2 * TS;           // per page: two pending bitmaps (current / next bucket) of 32 column words
+struct TsaStage {
+  unsigned* pages;      // [1 + max_queries*cap][1024]
+  unsigned* ppend;      // [1 + max_queries*cap][64]
+  unsigned* tmap;       // [max_queries][ntile] tile -> local page, 0 = none
+  unsigned* owner;      // [max_queries][cap + 1] local page -> tile
+  int* nalloc;          // [max_queries] local pages handed out by the last search
+  uint8_t* nbr_tm;      // [ntile][32][32] neighbour masks of this launch (snapshot), 0 outside the map
   int* perm;            // [max_queries] launch order of this batch: the k-th workgroup to START serves query perm[k]
   int* ticket;          // next position of perm to hand out (reset by every launch's init)
+  int cap;              // pages per query
 };
 __host__ __device__ inline size_t tsa_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-__global__ void tsa_init_kernel(const uint8_t* __restrict__ nbr, int rows, int cols, int tiles_i, int tiles_j,
-                                unsigned* __restrict__ field, size_t field_stride, unsigned* __restrict__ pend,
-                                size_t pend_stride, int max_queries, TsaAux aux, int s0, int s1) {
-  const int ntile = tiles_i * tiles_j;
-  const int nt_words = (ntile + 31) >> 5;
-  const size_t nw = (size_t)ntile * TILE_WORDS;
+// snapshot of the neighbour masks in tile-major MAP-space order (4 cells per thread), taken at launch so that a
+// later map update cannot disturb a search in flight
+__global__ void tsa_snapshot_kernel(const uint8_t* __restrict__ nbr, int rows, int cols, int tiles_i, int tiles_j,
+                                    uint8_t* __restrict__ nbr_tm, int s0, int s1) {
+  const size_t nw = (size_t)tiles_i * tiles_j * TILE_WORDS;
   const size_t step = (size_t)gridDim.x * blockDim.x;
-  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // (a) snapshot of the neighbour masks in tile-major MAP-space order (4 cells per thread)
-  for (size_t w4 = gid; w4 < nw / 4; w4 += step) {
+  for (size_t w4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w4 < nw / 4; w4 += step) {
     const size_t w = w4 * 4;
     const int t = (int)(w >> 10), l = (int)(w & 1023);
     const int i = (t % tiles_i) * TS + (l & 31), j = (t / tiles_i) * TS + (l >> 5);
@@ -146,37 +143,31 @@ __global__ void tsa_init_kernel(const uint8_t* __restrict__ nbr, int rows, int c
           v |= (unsigned)nbr[(size_t)bj * rows + bi] << (8 * k);
         }
     }
-    reinterpret_cast<unsigned*>(aux.nbr_tm)[w4] = v;
-  }
-  if (*aux.clean == 0) {
-    // (b1) everything: fields to "unreached", pending bitmaps and touched bitsets to zero
-    for (int q = 0; q < max_queries; ++q) {
-      uint4* f4 = reinterpret_cast<uint4*>(field + (size_t)q * field_stride);
-      for (size_t w4 = gid; w4 < nw / 4; w4 += step) f4[w4] = make_uint4(0xFFFFFF00u, 0xFFFFFF00u, 0xFFFFFF00u, 0xFFFFFF00u);
-    }
-    for (size_t w = gid; w < (size_t)max_queries * pend_stride; w += step) pend[w] = 0u;
-    for (size_t w = gid; w < (size_t)max_queries * nt_words; w += step) aux.touched[w] = 0u;
-    return;
-  }
-  // (b2) only the tiles the previous launch on this stage wrote: one block per (query, bitset word) pair
-  const size_t pend_words = (size_t)ntile * TS;
-  for (size_t item = blockIdx.x; item < (size_t)max_queries * nt_words; item += gridDim.x) {
-    unsigned bits = aux.touched[item];
-    if (!bits) continue;
-    const int q = (int)(item / nt_words), w = (int)(item % nt_words);
-    unsigned* fq = field + (size_t)q * field_stride;
-    unsigned* pq = pend + (size_t)q * pend_stride;
-    while (bits) {
-      const int t = (w << 5) + (__ffs(bits) - 1);
-      bits &= bits - 1;
-      reinterpret_cast<uint4*>(fq + ((size_t)t << 10))[threadIdx.x] = make_uint4(0xFFFFFF00u, 0xFFFFFF00u, 0xFFFFFF00u, 0xFFFFFF00u);
-      if (threadIdx.x < 2 * TS) pq[(size_t)(threadIdx.x >> 5) * pend_words + (size_t)t * TS + (threadIdx.x & 31)] = 0u;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) aux.touched[item] = 0u;
+    reinterpret_cast<unsigned*>(nbr_tm)[w4] = v;
   }
 }
-__global__ void tsa_mark_clean_kernel(int* clean, int* ticket) { *clean = 1; *ticket = 0; }
+// back to the invariant: the pages the previous launch on this stage handed out.  Block (x, q) takes the local
+// pages 1 + x, 1 + x + gridDim.x, ... of query q (256 threads: one uint4 of the page each).
+__global__ void __launch_bounds__(256) tsa_reset_kernel(TsaStage S, int ntile) {
+  const int q = blockIdx.y;
+  const int used = S.nalloc[q] < S.cap ? S.nalloc[q] : S.cap;
+  for (int p = 1 + (int)blockIdx.x; p <= used; p += (int)gridDim.x) {
+    const size_t gp = (size_t)q * S.cap + p;
+    reinterpret_cast<uint4*>(S.pages + (gp << 10))[threadIdx.x] = make_uint4(0xFFFFFF00u, 0xFFFFFF00u, 0xFFFFFF00u, 0xFFFFFF00u);
+    if (threadIdx.x < PEND_WORDS) S.ppend[gp * PEND_WORDS + threadIdx.x] = 0u;
+    if (threadIdx.x == 0) S.tmap[(size_t)q * ntile + S.owner[(size_t)q * (S.cap + 1) + p]] = 0u;
+  }
+}
+__global__ void tsa_reset_done_kernel(TsaStage S, int max_queries) {
+  for (int q = threadIdx.x; q < max_queries; q += blockDim.x) S.nalloc[q] = 0;
+  if (threadIdx.x == 0) *S.ticket = 0;
+}
+// fresh allocation: every page "unreached" (the zero parts are a hipMemsetAsync)
+__global__ void tsa_fill_pages_kernel(uint4* __restrict__ p, size_t n4) {
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < n4; w += step)
+    p[w] = make_uint4(0xFFFFFF00u, 0xFFFFFF00u, 0xFFFFFF00u, 0xFFFFFF00u);
+}
 
 // Launch order of a batch: longest expected search first (key = Chebyshev distance start -> goal,
 // ties by index).  Workgroups are dispatched in index order and land on the XCDs round-robin, so this
@@ -235,63 +226,115 @@ struct alignas(16) TsaWave {
                                  // improved beyond the current bucket
   unsigned short lq[LQ];         // local queue of LDS positions
   unsigned char mask[TILE_WORDS];    // neighbour masks of the 32 x 32 interior cells, index jl*32 + il
+  unsigned nbpg[8];              // local pages of the eight neighbouring tiles as seen at load time (kept out of the VGPRs)
 #ifdef RNA_TSA_STATS_REEXP
   unsigned char seen[TW * TW + TSA_SCRATCH];   // developer build: cell already expanded in this job
 #endif
 };
 
+// Per-query context of a tile job (wave-uniform).
+struct TsaCtx {
+  int rows, cols, tiles_i, tiles_j;
+  unsigned* pages;            // stage-wide page array
+  unsigned* ppend;            // stage-wide pending bitmaps
+  unsigned* tmap;             // this query's tile -> local page table
+  unsigned* owner;            // this query's local page -> tile list
+  size_t page_base;           // q * cap: global page = page_base + local page (local >= 1)
+  int cap;
+  int* nalloc;                // LDS: local pages handed out so far
+  const uint8_t* nbr_tm;
+  int gi, gj;
+  __device__ __forceinline__ size_t gpage(unsigned local) const { return local ? page_base + local : 0; }
+};
+
+// Make sure tile `nt` of this query has a page; called by ONE lane per tile of a wave (lanes of a wave never ask
+// for the same tile, so a lane only ever waits for another wavefront).  Returns the local page, 0 = pool exhausted.
+__device__ __forceinline__ unsigned tsa_page_get(const TsaCtx& C, int nt, unsigned seen) {
+  unsigned v = seen;
+  if (v == 0u) {
+    const unsigned old = atomicCAS(&C.tmap[nt], 0u, TSA_BUSY);
+    if (old == 0u) {
+      const int p = atomicAdd(C.nalloc, 1) + 1;
+      if (p > C.cap) {
+        __hip_atomic_store(&C.tmap[nt], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0u;
+      }
+      C.owner[p] = (unsigned)nt;
+      __hip_atomic_store(&C.tmap[nt], (unsigned)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return (unsigned)p;
+    }
+    v = old;
+  }
+  while (v == TSA_BUSY) {
+    __builtin_amdgcn_s_sleep(1);
+    v = ld_l2(&C.tmap[nt]);
+  }
+  return v;
+}
+
 // One tile job, executed by one wavefront (lane = this wave's lane id).  `sch` supplies the
 // scheduler-specific pieces: best() / improve_best(g) (upper bound on f*), act_cur(tile) /
-// act_far(tile) (a tile received pending cells for the current / the next bucket), overflow().
-// Returns the number of cell expansions.
+// act_far(tile) (a tile received pending cells for the current / the next bucket), overflow(), pool_exhausted().
+// `pg` is the local page of tile t (a tile only becomes a job after its page exists); `role` selects which of the
+// page's two pending bitmaps is the current bucket's.  Returns the number of cell expansions.
 template <class Sched>
-__device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, const int t, const int rows, const int cols,
-                                       const int tiles_i, const int tiles_j, unsigned* __restrict__ field,
-                                       const uint8_t* __restrict__ nbr_tm, unsigned* __restrict__ pend_cur, unsigned* __restrict__ pend_far,
-                                       const long long bucket_end, const int gi, const int gj TSA_ACC_PARAM) {
+__device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, const int t, const unsigned pg, const TsaCtx& C,
+                                       const int role, const long long bucket_end TSA_ACC_PARAM) {
   int expanded = 0;
+  const int rows = C.rows, cols = C.cols, tiles_i = C.tiles_i, tiles_j = C.tiles_j, gi = C.gi, gj = C.gj;
   const int ti = t % tiles_i, tj = t / tiles_i;
   const int i0 = ti * TS, j0 = tj * TS;
-  unsigned* ftile = field + ((size_t)t << 10);
+  unsigned* ftile = C.pages + (C.gpage(pg) << 10);
+  unsigned* ptile = C.ppend + C.gpage(pg) * PEND_WORDS;
+  unsigned* pend_cur = ptile + role * TS;
+  unsigned* pend_far = ptile + (role ^ 1) * TS;
 
   TSA_T(t_a);
-  // 1. grab-and-clear the pending bits of this tile (lane = column jl)
+  // 1. grab-and-clear the pending bits of this tile (lane = column jl); in the same round trip lane k < 8 looks up
+  //    the page of the neighbouring tile in direction k (0 = none yet, or outside the map)
   unsigned seed = 0u;
-  if (lane < TS) seed = atomicExch(&pend_cur[(size_t)t * TS + lane], 0u);
+  if (lane < TS) seed = atomicExch(&pend_cur[lane], 0u);
+  unsigned nb_pg = 0u;      // lanes 0..7: local page of neighbour tile k as seen now (TSA_BUSY: being handed out)
+  int nb_t = -1;            // lanes 0..7: that tile, -1 outside the map
+  if (lane < 8) {
+    const int kdi = (lane == 0 || lane == 3 || lane == 5) ? -1 : ((lane == 2 || lane == 4 || lane == 7) ? 1 : 0);
+    const int kdj = lane < 3 ? -1 : (lane > 4 ? 1 : 0);
+    const int nti = ti + kdi, ntj = tj + kdj;
+    if (nti >= 0 && ntj >= 0 && nti < tiles_i && ntj < tiles_j) { nb_t = ntj * tiles_i + nti; nb_pg = ld_l2(&C.tmap[nb_t]); }
+  }
   // 2. tile + halo -> LDS (after the pending bits: every grabbed bit's value is already in L2)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   {
     // Everything a job reads from HBM is issued before the first wait: the three halo words of a lane (neighbour
     // column, neighbour row, corner), its 16 tile words (cell r*64 + lane sits 2r rows below cell `lane`: one base
-    // address + compile-time offsets) and its 16 mask bytes -- ONE memory round trip after the pending bits.  (Until
-    // the lane arithmetic of the later phases was cut loose from this one, see lane_b below, the kernel had no
-    // registers for that and loaded in two batches of eight plus the halo: three round trips.)
+    // address + compile-time offsets) and its 16 mask bytes -- ONE memory round trip after the pending bits.
+    // A neighbour whose page is still being handed out has nothing in it yet: read the shared "unreached" page.
+    const unsigned nb_rd = nb_pg == TSA_BUSY ? 0u : nb_pg;
     const int h = lane & 31;
     const bool second = lane >= 32;
     // halo columns: tile (ti, tj-1) column 31 -> LDS jl=-1 ; tile (ti, tj+1) column 0 -> LDS jl=32
     // halo rows:    tile (ti-1, tj) row 31 -> LDS il=-1 ; tile (ti+1, tj) row 0 -> LDS il=32 ; then the 4 corners
-    const int ntj = second ? tj + 1 : tj - 1;
-    const int nti = second ? ti + 1 : ti - 1;
-    unsigned hv_col = 0xFFFFFF00u, hv_row = 0xFFFFFF00u, hv_cor = 0xFFFFFF00u;
-    if (ntj >= 0 && ntj < tiles_j) hv_col = ld_l2(&field[((size_t)(ntj * tiles_i + ti) << 10) + ((second ? 0 : 31) << 5) + h]);
-    if (nti >= 0 && nti < tiles_i) hv_row = ld_l2(&field[((size_t)(tj * tiles_i + nti) << 10) + (h << 5) + (second ? 0 : 31)]);
+    const unsigned* pcol = C.pages + (C.gpage((unsigned)__shfl((int)nb_rd, second ? 6 : 1)) << 10);
+    const unsigned* prow = C.pages + (C.gpage((unsigned)__shfl((int)nb_rd, second ? 4 : 3)) << 10);
+    const unsigned hv_col = ld_l2(&pcol[((second ? 0 : 31) << 5) + h]);
+    const unsigned hv_row = ld_l2(&prow[(h << 5) + (second ? 0 : 31)]);
     const int cdi = (lane & 1) ? 1 : -1, cdj = (lane & 2) ? 1 : -1;
-    if (lane < 4) {
-      const int cti = ti + cdi, ctj = tj + cdj;
-      if (cti >= 0 && cti < tiles_i && ctj >= 0 && ctj < tiles_j)
-        hv_cor = ld_l2(&field[((size_t)(ctj * tiles_i + cti) << 10) + ((cdj > 0 ? 0 : 31) << 5) + (cdi > 0 ? 0 : 31)]);
-    }
+    // corner of lane c < 4: direction (cdi, cdj) = neighbour index {0, 2, 5, 7}[c]
+    const unsigned* pcor = C.pages + (C.gpage((unsigned)__shfl((int)nb_rd, (lane & 2) ? ((lane & 1) ? 7 : 5) : ((lane & 1) ? 2 : 0))) << 10);
+    unsigned hv_cor = 0xFFFFFF00u;
+    if (lane < 4) hv_cor = ld_l2(&pcor[((cdj > 0 ? 0 : 31) << 5) + (cdi > 0 ? 0 : 31)]);
     unsigned* tp = &W.tile[((lane >> 5) + 1) * TW + (lane & 31) + 1];
     unsigned tv[TILE_WORDS / 64];
 #pragma unroll
     for (int r = 0; r < TILE_WORDS / 64; ++r) tv[r] = ld_l2(&ftile[r * 64 + lane]);
-    const uint4 mv = *reinterpret_cast<const uint4*>(nbr_tm + ((size_t)t << 10) + lane * 16);
+    const uint4 mv = *reinterpret_cast<const uint4*>(C.nbr_tm + ((size_t)t << 10) + lane * 16);
     W.tile[(second ? TS + 1 : 0) * TW + h + 1] = hv_col;
     W.tile[(h + 1) * TW + (second ? TS + 1 : 0)] = hv_row;
     if (lane < 4) W.tile[(cdj > 0 ? TS + 1 : 0) * TW + (cdi > 0 ? TS + 1 : 0)] = hv_cor;
 #pragma unroll
     for (int r = 0; r < TILE_WORDS / 64; ++r) tp[r * 2 * TW] = tv[r];
     *reinterpret_cast<uint4*>(&W.mask[lane * 16]) = mv;
+    if (lane < 8) W.nbpg[lane] = nb_pg;
   }
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -496,7 +539,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
       const bool f = (W.tile[(jl + 1) * TW + il + 1] & 4u) != 0u;
       const unsigned long long bm = __ballot(f);
       const unsigned word = (unsigned)(bm >> (lane_b & 32));
-      if ((lane_b & 31) == 0 && word) { atomicOr(&pend_far[(size_t)t * TS + jl], word); }
+      if ((lane_b & 31) == 0 && word) { atomicOr(&pend_far[jl], word); }
       anyfar |= bm != 0ull;
     }
     if (anyfar && lane_b == 0) sch.act_far(t);
@@ -505,17 +548,18 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
   TSA_ACC(2, t_c, t_d);
   //    improved halo cells -> their tiles: value first, then the pending bit, then the activation.  The 136 ring
   //    positions are three cells per lane; each stage is issued for all three before its single wait, so the
-  //    hand-over costs two memory round trips, not two per cell.
+  //    hand-over costs two memory round trips, not two per cell (plus one when a neighbour needs its first page).
   {
     constexpr int HK = (4 * TW + 63) / 64;
     unsigned hv[HK];
-    unsigned hix[HK];
+    unsigned hof[HK];   // (neighbour direction << 10) | word inside its page
     int hfn[HK];
     bool hdo[HK];
+    unsigned need = 0u;   // directions this lane hands cells to
 #pragma unroll
     for (int k = 0; k < HK; ++k) {
       const int hh = lane_b + 64 * k;
-      hdo[k] = false; hv[k] = 0u; hix[k] = 0u; hfn[k] = 0;
+      hdo[k] = false; hv[k] = 0u; hof[k] = 0u; hfn[k] = 0;
       if (hh < 4 * TW) {
         // ring positions: hh in [0,TW): jl=-1 row; [TW,2TW): jl=32 row; [2TW,3TW): il=-1 col; [3TW,4TW): il=32 col
         const int side = hh / TW, u = hh % TW;
@@ -532,20 +576,46 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
           const int fn = (int)(v >> 8) + tsa_octile(ni, nj, gi, gj);
           if (fn <= sch.best()) {                                // else pruned: f > upper bound on f*
             if (ni == gi && nj == gj) sch.improve_best((int)(v >> 8));
-            hdo[k] = true; hv[k] = v; hix[k] = (unsigned)tm_index(ni, nj, tiles_i); hfn[k] = fn;
+            const int idx = ((pjl < 0 ? 0 : (pjl >= TS ? 2 : 1)) * 3) + (pil < 0 ? 0 : (pil >= TS ? 2 : 1));   // 0..8 without 4
+            const unsigned kd = (unsigned)(idx < 4 ? idx : idx - 1);
+            hdo[k] = true; hv[k] = v; hof[k] = (kd << 10) | (unsigned)in_page(ni, nj); hfn[k] = fn;
+            need |= 1u << kd;
           }
         }
       }
     }
+    // first touch of a neighbouring tile: lane k < 8 hands out the page of direction k (other wavefronts of this
+    // workgroup may be doing the same for the same tile: tsa_page_get settles that)
+    need = tsa_wave_or(need);
+    unsigned nb_pg = 0u;
+    if (need) {
+      if (lane_b < 8) nb_pg = W.nbpg[lane_b];
+      if (lane_b < 8 && ((need >> lane_b) & 1u) && (nb_pg == 0u || nb_pg == TSA_BUSY)) {
+        const int kdi = (lane_b == 0 || lane_b == 3 || lane_b == 5) ? -1 : ((lane_b == 2 || lane_b == 4 || lane_b == 7) ? 1 : 0);
+        const int kdj = lane_b < 3 ? -1 : (lane_b > 4 ? 1 : 0);
+        nb_pg = tsa_page_get(C, (tj + kdj) * tiles_i + ti + kdi, nb_pg);
+        if (nb_pg == 0u) sch.pool_exhausted();
+      }
+    }
     unsigned hold[HK];
+    unsigned* hpage[HK];
+    unsigned* hpend[HK];
 #pragma unroll
-    for (int k = 0; k < HK; ++k) hold[k] = hdo[k] ? atomicMin(&field[hix[k]], hv[k]) : 0u;
+    for (int k = 0; k < HK; ++k) {
+      const unsigned lp = (unsigned)__shfl((int)nb_pg, (int)(hof[k] >> 10));
+      hdo[k] = hdo[k] && lp != 0u;   // no page left: the search is being abandoned (status 5)
+      const size_t gp = C.gpage(lp);
+      hpage[k] = C.pages + (gp << 10);
+      hpend[k] = C.ppend + gp * PEND_WORDS;
+    }
+#pragma unroll
+    for (int k = 0; k < HK; ++k) hold[k] = hdo[k] ? atomicMin(&hpage[k][hof[k] & 1023u], hv[k]) : 0u;
 #pragma unroll
     for (int k = 0; k < HK; ++k) {
       hdo[k] = hdo[k] && hv[k] < hold[k];
       if (hdo[k]) {
-        const unsigned nt = hix[k] >> 10, l = hix[k] & 1023u;
-        atomicOr(&(hfn[k] >= bucket_end ? pend_far : pend_cur)[(size_t)nt * TS + (l >> 5)], 1u << (l & 31));
+        const unsigned l = hof[k] & 1023u;
+        atomicOr(&hpend[k][((hfn[k] >= bucket_end) ? (role ^ 1) : role) * TS + (l >> 5)], 1u << (l & 31));
       }
     }
     // the values and their pending bits must be performed at L2 before the tiles can be scheduled
@@ -553,7 +623,10 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
 #pragma unroll
     for (int k = 0; k < HK; ++k)
       if (hdo[k]) {
-        const int nt = (int)(hix[k] >> 10);
+        const unsigned kd = hof[k] >> 10;
+        const int kdi = (kd == 0 || kd == 3 || kd == 5) ? -1 : ((kd == 2 || kd == 4 || kd == 7) ? 1 : 0);
+        const int kdj = kd < 3 ? -1 : (kd > 4 ? 1 : 0);
+        const int nt = (tj + kdj) * tiles_i + ti + kdi;
         if (hfn[k] >= bucket_end) sch.act_far(nt); else sch.act_cur(nt);
       }
   }
@@ -573,100 +646,94 @@ struct TsaLocalSched {
   __device__ __forceinline__ int best() const { return __hip_atomic_load(best_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   __device__ __forceinline__ void improve_best(int g) { atomicMin(best_, g); }
   __device__ __forceinline__ void overflow() { *state_ = 4; }
+  __device__ __forceinline__ void pool_exhausted() { *state_ = 5; }
   __device__ __forceinline__ void act_cur(int t) { atomicOr(&act_cur_[t >> 5], 1u << (t & 31)); }
   __device__ __forceinline__ void act_far(int t) { atomicOr(&act_far_[t >> 5], 1u << (t & 31)); }
 };
 
-// Barrier-free variant of the same kernel: the active-tile set is a bitset in LDS that every
-// wavefront scans and claims from on its own; `outstanding` = active bits + running jobs, and the
-// wave that brings it to zero owns the query alone and opens the next bucket (or ends the search).
-struct TsaAsyncSched {
-  int* best_;
-  int* state_;
-  unsigned* act_;
-  unsigned* far_;
-  int* outstanding_;
-  __device__ __forceinline__ int best() const { return __hip_atomic_load(best_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-  __device__ __forceinline__ void improve_best(int g) { atomicMin(best_, g); }
-  __device__ __forceinline__ void overflow() { *state_ = 4; }
-  __device__ __forceinline__ void act_cur(int t) {
-    const unsigned bit = 1u << (t & 31);
-    if (__hip_atomic_load(&act_[t >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & bit) return;   // already active
-    // count the tile BEFORE it can be claimed: a claimer that finishes first must not see the sum at 0
-    atomicAdd(outstanding_, 1);
-    if (atomicOr(&act_[t >> 5], bit) & bit) atomicSub(outstanding_, 1);   // lost the race to another activator
-  }
-  __device__ __forceinline__ void act_far(int t) { atomicOr(&far_[t >> 5], 1u << (t & 31)); }
-};
 __device__ __forceinline__ unsigned lds_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int lds_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-template <bool ASYNC>
-__global__ void __launch_bounds__(TSA_THREADS)
-tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_query* __restrict__ queries,
-                  unsigned* __restrict__ field_all, size_t field_stride, unsigned* __restrict__ pend_all,
-                  size_t pend_stride, const uint8_t* __restrict__ nbr_tm, unsigned* __restrict__ touched_all,
-                  int bucket_width, int32_t* __restrict__ paths, int max_path_len,
-                  int32_t* __restrict__ rev_all, int rev_cap, rna_astar_result* __restrict__ results, int s0, int s1,
-                  const int* __restrict__ perm, int* __restrict__ ticket) {
+// Kernel arguments that are the same for every query of a launch.
+struct TsaLaunch {
+  int rows, cols, tiles_i, tiles_j, s0, s1;
+  const rna_astar_query* queries;
+  TsaStage S;
+  int bucket_width;
+  int32_t* paths;
+  int max_path_len;
+  int32_t* rev_all;
+  int rev_cap;
+  rna_astar_result* results;
+};
+
+__global__ void __launch_bounds__(TSA_THREADS) tsa_search_kernel(const TsaLaunch A) {
   __shared__ TsaWave s_w[TSA_WAVES];
-  extern __shared__ unsigned s_dyn[];   // tile bitsets, sized by the launch: (ASYNC ? 4 : 3) x ((ntile + 31) / 32) words
-  __shared__ unsigned short s_jobs[ASYNC ? 2 : TSA_JOBS];
-  __shared__ int s_njobs, s_first_fail, s_job_next, s_best, s_state, s_bucket, s_bucket0, s_rounds, s_role, s_expanded, s_len;
-  __shared__ int s_outstanding;
+  extern __shared__ unsigned s_dyn[];   // tile bitsets, sized by the launch: 2 x ((ntile + 31) / 32) words
+  __shared__ unsigned short s_jobs[TSA_JOBS];
+  __shared__ unsigned s_jobpg[TSA_JOBS];   // local page of each job's tile (looked up once per round by the list builders)
+  __shared__ int s_njobs, s_first_fail, s_job_next, s_best, s_state, s_bucket, s_bucket0, s_rounds, s_role, s_expanded, s_len, s_nalloc;
 
   // Workgroups take their query when they START (a ticket), not by blockIdx: the hardware deals workgroup
   // indices round-robin to the XCDs, so a fixed mapping lets one XCD with several long searches hold back
   // its share of the batch while the other XCDs idle.  With tickets a free CU anywhere takes the next
   // (longest remaining) query.
   __shared__ int s_q;
-  if (threadIdx.x == 0) s_q = perm[atomicAdd(ticket, 1)];
+  if (threadIdx.x == 0) s_q = A.S.perm[atomicAdd(A.S.ticket, 1)];
   __syncthreads();
   const int q = s_q;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  rna_astar_query qu = queries[q];   // buffer linear indices; the search itself runs in map space
+  const int rows = A.rows, cols = A.cols, tiles_i = A.tiles_i, tiles_j = A.tiles_j;
+  rna_astar_query qu = A.queries[q];   // buffer linear indices; the search itself runs in map space
   const int ncell = rows * cols;
   const int ntile = tiles_i * tiles_j;
   const int nt_words = (ntile + 31) >> 5;
   unsigned* const s_act[2] = {s_dyn, s_dyn + nt_words};   // [0] current bucket (next round), [1] next bucket
-  unsigned* const s_touched = s_dyn + 2 * nt_words;        // every tile that ever became a job
-  unsigned* const s_running = s_dyn + 3 * nt_words;        // ASYNC only: a wavefront is inside a job of this tile
-  unsigned* field = field_all + (size_t)q * field_stride;
-  unsigned* pend0 = pend_all + (size_t)q * pend_stride;   // two bitmaps of ntile*32 words each
-  const size_t pend_words = (size_t)ntile * TS;
+  rna_astar_result* const results = A.results;
 
   const bool valid = qu.start >= 0 && qu.goal >= 0 && qu.start < ncell && qu.goal < ncell;
   if (!valid) {
     if (tid == 0) results[q] = rna_astar_result{2, 0, INF, 0, 0, 0};
     return;
   }
-  qu.start = tsa_unwrap_lin(qu.start, rows, cols, s0, s1);
-  qu.goal = tsa_unwrap_lin(qu.goal, rows, cols, s0, s1);
+  qu.start = tsa_unwrap_lin(qu.start, rows, cols, A.s0, A.s1);
+  qu.goal = tsa_unwrap_lin(qu.goal, rows, cols, A.s0, A.s1);
   const int si = qu.start % rows, sj = qu.start / rows;
   const int gi = qu.goal % rows, gj = qu.goal / rows;
 
-  for (int w = tid; w < nt_words; w += TSA_THREADS) {
-    s_act[0][w] = 0u; s_act[1][w] = 0u; s_touched[w] = 0u;
-    if (ASYNC) s_running[w] = 0u;
-  }
+  TsaCtx C;
+  C.rows = rows; C.cols = cols; C.tiles_i = tiles_i; C.tiles_j = tiles_j;
+  C.pages = A.S.pages; C.ppend = A.S.ppend;
+  C.tmap = A.S.tmap + (size_t)q * ntile;
+  C.owner = A.S.owner + (size_t)q * (A.S.cap + 1);
+  C.page_base = (size_t)q * A.S.cap;
+  C.cap = A.S.cap;
+  C.nalloc = &s_nalloc;
+  C.nbr_tm = A.S.nbr_tm;
+  C.gi = gi; C.gj = gj;
+
+  for (int w = tid; w < nt_words; w += TSA_THREADS) { s_act[0][w] = 0u; s_act[1][w] = 0u; }
   // a goal without a single traversable neighbour cannot be reached (blocked or walled in); nothing
-  // has been written yet, so the field stays clean
-  if (qu.goal != qu.start && nbr_tm[tm_index(gi, gj, tiles_i)] == 0) {
+  // has been written yet, so no page is in use
+  if (qu.goal != qu.start && C.nbr_tm[tm_index(gi, gj, tiles_i)] == 0) {
     if (tid == 0) results[q] = rna_astar_result{1, 0, INF, 0, 0, 0};
     return;
   }
   if (tid == 0) {
-    s_best = INF; s_state = 0; s_rounds = 0; s_role = 0; s_expanded = 0; s_outstanding = 1;
-    s_bucket = tsa_octile(si, sj, gi, gj) / bucket_width;
+    s_best = INF; s_state = 0; s_rounds = 0; s_role = 0; s_expanded = 0;
+    s_bucket = tsa_octile(si, sj, gi, gj) / A.bucket_width;
     s_bucket0 = s_bucket;
-    const size_t ws = tm_index(si, sj, tiles_i);
-    __hip_atomic_store(&field[ws], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // g(start) = 0
-    const int ts = (sj >> 5) * tiles_i + (si >> 5);
-    atomicOr(&pend0[(size_t)ts * TS + (sj & 31)], 1u << (si & 31));
+    // the start tile takes local page 1: g(start) = 0, pending in the current bucket
+    const int ts = tile_of(si, sj, tiles_i);
+    s_nalloc = 1;
+    C.owner[1] = (unsigned)ts;
+    __hip_atomic_store(&C.tmap[ts], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&C.pages[(C.gpage(1u) << 10) + in_page(si, sj)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicOr(&C.ppend[C.gpage(1u) * PEND_WORDS + (sj & 31)], 1u << (si & 31));
   }
   __syncthreads();
   if (tid == 0) {
-    const int ts = (sj >> 5) * tiles_i + (si >> 5);
+    const int ts = tile_of(si, sj, tiles_i);
     s_act[0][ts >> 5] = 1u << (ts & 31);
   }
   __syncthreads();
@@ -677,77 +744,6 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
   unsigned long long tsa_acc[16] = {};
   const unsigned long long t_life0 = wall_clock64();
 #endif
-  if constexpr (ASYNC) {
-    TsaAsyncSched sch{&s_best, &s_state, s_act[0], s_act[1], &s_outstanding};
-    int cursor = (int)(((long long)wv * nt_words) / TSA_WAVES);   // the waves start their sweeps at different words
-    for (;;) {
-      if (lds_ld(&s_state) != 0) break;
-      // ---- find and claim an active tile: sweep the bitset from `cursor`, 64 words per step ----
-      int t = -1;
-      for (int base = 0; base < nt_words && t < 0; base += 64) {
-        int w = cursor + base + lane;
-        if (w >= nt_words) w -= nt_words;
-        const unsigned bits = (base + lane < nt_words) ? lds_ld(&s_act[0][w]) : 0u;
-        unsigned long long m = __ballot(bits != 0u);
-        while (m && t < 0) {
-          const int src = __ffsll((long long)m) - 1;
-          m &= m - 1;
-          const unsigned cb = __shfl(bits, src);
-          const int cw = __shfl(w, src);
-          int got = -1;
-          if (lane == 0) {
-            unsigned rem = cb;
-            while (rem) {
-              const int b = __ffs(rem) - 1;
-              rem &= rem - 1;
-              const unsigned bit = 1u << b;
-              if (atomicOr(&s_running[cw], bit) & bit) continue;        // a job of this tile is in flight: it stays active
-              if (atomicAnd(&s_act[0][cw], ~bit) & bit) { got = (cw << 5) + b; break; }   // claimed: active -> running
-              atomicAnd(&s_running[cw], ~bit);                           // somebody else took it meanwhile
-            }
-          }
-          got = __shfl(got, 0);
-          if (got >= 0) t = got;
-        }
-      }
-      if (t < 0) { __builtin_amdgcn_s_sleep(8); continue; }
-      cursor = (t >> 5) + 1;
-      if (cursor >= nt_words) cursor = 0;
-      const int role = lds_ld(&s_role), bucket = lds_ld(&s_bucket);
-      unsigned* pend_cur = pend0 + (size_t)role * pend_words;
-      unsigned* pend_far = pend0 + (size_t)(role ^ 1) * pend_words;
-      const long long bucket_end = ((long long)bucket + 1) * bucket_width;
-      if (lane == 0) atomicOr(&s_touched[t >> 5], 1u << (t & 31));
-      TSA_CNT(7, 1);
-      my_expanded += tsa_job(sch, W, lane, t, rows, cols, tiles_i, tiles_j, field, nbr_tm, pend_cur, pend_far, bucket_end, gi, gj TSA_ACC_ARG);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // everything this job wrote is at L2 before the tile is released
-      int left = 1;
-      if (lane == 0) {
-        atomicAnd(&s_running[t >> 5], ~(1u << (t & 31)));
-        atomicAdd(&s_rounds, 1);
-        left = atomicSub(&s_outstanding, 1) - 1;
-      }
-      left = __shfl(left, 0);
-      if (left != 0) continue;
-      // ---- this wave emptied the bucket: no tile is active or running, it owns the query alone ----
-      if (lds_ld(&s_state) != 0) break;   // overflow was flagged
-      const int best = lds_ld(&s_best);
-      const long long done_below = ((long long)bucket + 1) * bucket_width;
-      if (best != INF && (long long)best < done_below) { if (lane == 0) s_state = 1; break; }   // goal settled, ties included
-      int cnt = 0;
-      for (int w = lane; w < nt_words; w += 64) cnt += __popc(lds_ld(&s_act[1][w]));
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
-      if (cnt == 0) { if (lane == 0) s_state = (best != INF) ? 1 : 2; break; }   // nothing left anywhere
-      if (lane == 0) { s_bucket = bucket + 1; s_role = role ^ 1; s_outstanding = cnt; }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      for (int w = lane; w < nt_words; w += 64) {   // publish the next bucket's tiles (count and role are in place)
-        const unsigned b = s_act[1][w];
-        if (b) { s_act[1][w] = 0u; atomicOr(&s_act[0][w], b); }
-      }
-    }
-  } else {
   TsaLocalSched sch{&s_best, &s_state, s_act[0], s_act[1]};
 
   for (;;) {
@@ -762,9 +758,15 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
       const int base = atomicAdd(&s_njobs, cnt);
       if (base + cnt <= TSA_JOBS) {
         s_act[0][w] = 0u;
-        s_touched[w] |= bits;
         int k = base;
-        while (bits) { const int b = __ffs(bits) - 1; bits &= bits - 1; s_jobs[k++] = (unsigned short)((w << 5) + b); }
+        while (bits) {
+          const int b = __ffs(bits) - 1;
+          bits &= bits - 1;
+          const int t = (w << 5) + b;
+          s_jobs[k] = (unsigned short)t;
+          s_jobpg[k] = ld_l2(&C.tmap[t]);   // final: a tile is activated only after its page was published
+          ++k;
+        }
       } else {
         atomicMin(&s_first_fail, base);   // job list full: these tiles stay flagged for the next round
       }
@@ -782,7 +784,7 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
       // bucket k is at its fixed point: every cell with f < (k+1)*B has its exact g
       __syncthreads();
       if (tid == 0) {
-        const long long done_below = ((long long)s_bucket + 1) * bucket_width;
+        const long long done_below = ((long long)s_bucket + 1) * A.bucket_width;
         if (s_best != INF && (long long)s_best < done_below) s_state = 1;
         else s_state = -1;  // try the next bucket
       }
@@ -807,9 +809,7 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
     }
 
     const int role = s_role;
-    unsigned* pend_cur = pend0 + (size_t)role * pend_words;
-    unsigned* pend_far = pend0 + (size_t)(role ^ 1) * pend_words;
-    const long long bucket_end = ((long long)s_bucket + 1) * bucket_width;
+    const long long bucket_end = ((long long)s_bucket + 1) * A.bucket_width;
 
     // ---- tile jobs: one wavefront per job ----
     TSA_T(t_r1);
@@ -821,37 +821,35 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
       job = __shfl(job, 0);
       if (job >= njobs) break;
       const int t = s_jobs[job];
+      const unsigned pg = s_jobpg[job];
       TSA_CNT(7, 1);
-      my_expanded += tsa_job(sch, W, lane, t, rows, cols, tiles_i, tiles_j, field, nbr_tm, pend_cur, pend_far, bucket_end, gi, gj TSA_ACC_ARG);
+      my_expanded += tsa_job(sch, W, lane, t, pg, C, role, bucket_end TSA_ACC_ARG);
     }
     // all stores / atomics of this round are performed before any wave loads tiles in the next one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int stop = __syncthreads_or(s_state == 4);
+    const int stop = __syncthreads_or(s_state >= 4);
     if (tid == 0) s_rounds += 1;
     if (stop) break;
   }
-  }   // !ASYNC
   atomicAdd(&s_expanded, my_expanded);
   __syncthreads();
 #ifdef RNA_TSA_STATS
   tsa_acc[5] = wall_clock64() - t_life0;   // wave lifetime inside the search loop
   if (lane == 0) for (int k = 0; k < 16; ++k) atomicAdd(&g_tsa_stat[k], tsa_acc[k]);
 #endif
-  // every tile this search wrote: its jobs plus the tiles that were handed cells but never ran
-  {
-    unsigned* touched = touched_all + (size_t)q * nt_words;
-    for (int w = tid; w < nt_words; w += TSA_THREADS) touched[w] = s_touched[w] | s_act[0][w] | s_act[1][w];
-  }
+  // what the next launch on this stage has to reset
+  if (tid == 0) A.S.nalloc[q] = s_nalloc < C.cap ? s_nalloc : C.cap;
 
   const int state = s_state;
   const int n_buckets = s_bucket - s_bucket0 + 1;
   if (state != 1) {
-    if (tid == 0) results[q] = rna_astar_result{state == 4 ? 4 : 1, 0, INF, s_expanded, s_rounds, n_buckets};
+    if (tid == 0) results[q] = rna_astar_result{state >= 4 ? state : 1, 0, INF, s_expanded, s_rounds, n_buckets};
     return;
   }
 
   // ---- canonical backtrace by the first wavefront (lane k probes neighbour k) ----
-  int* rev = rev_all + (size_t)q * rev_cap;
+  int* rev = A.rev_all + (size_t)q * A.rev_cap;
+  const int rev_cap = A.rev_cap;
   if (tid < 64) {
     int ci = gi, cj = gj;
     int len = 0;
@@ -867,10 +865,14 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
       if (len > ncell) { ok = false; break; }
       const int ni = ci + di, nj = cj + dj;
       const bool inb = ni >= 0 && nj >= 0 && ni < rows && nj < cols;
-      const unsigned wc = ld_l2(&field[tm_index(ci, cj, tiles_i)]);
-      const unsigned mc = nbr_tm[tm_index(ci, cj, tiles_i)];
-      const unsigned wn = ld_l2(&field[inb ? tm_index(ni, nj, tiles_i) : tm_index(ci, cj, tiles_i)]);
-      const bool hit = tid < 8 && inb && ((mc >> k) & 1u) && ((wn >> 8) != G_INF) && ((wn >> 8) + (unsigned)w == (wc >> 8));
+      // lane k: page of its neighbour's tile, lane 8: page of the current cell's tile (settled cells always have one)
+      const int li = (tid == 8 || !inb) ? ci : ni, lj = (tid == 8 || !inb) ? cj : nj;
+      unsigned lp = ld_l2(&C.tmap[tile_of(li, lj, tiles_i)]);
+      if (lp == TSA_BUSY) lp = 0u;
+      const unsigned wl = ld_l2(&C.pages[(C.gpage(lp) << 10) + in_page(li, lj)]);
+      const unsigned wc = (unsigned)__shfl((int)wl, 8);
+      const unsigned mc = C.nbr_tm[tm_index(ci, cj, tiles_i)];
+      const bool hit = tid < 8 && inb && ((mc >> k) & 1u) && ((wl >> 8) != G_INF) && ((wl >> 8) + (unsigned)w == (wc >> 8));
       const unsigned long long mask = __ballot(hit);
       if (!mask) { ok = false; break; }
       const int src = __ffsll((long long)mask) - 1;
@@ -885,258 +887,18 @@ tsa_search_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_
     if (tid == 0) results[q] = rna_astar_result{1, 0, INF, s_expanded, s_rounds, n_buckets};
     return;
   }
-  if (len > max_path_len || len > rev_cap) {
+  if (len > A.max_path_len || len > rev_cap) {
     if (tid == 0) results[q] = rna_astar_result{3, len, s_best, s_expanded, s_rounds, n_buckets};
     return;
   }
-  int32_t* path = paths + (size_t)q * max_path_len;
-  for (int i = tid; i < len; i += TSA_THREADS) path[i] = tsa_buffer_lin(rev[len - 1 - i], rows, cols, s0, s1);
+  int32_t* path = A.paths + (size_t)q * A.max_path_len;
+  for (int i = tid; i < len; i += TSA_THREADS) path[i] = tsa_buffer_lin(rev[len - 1 - i], rows, cols, A.s0, A.s1);
   if (tid == 0) results[q] = rna_astar_result{0, len, s_best, s_expanded, s_rounds, n_buckets};
 }
 
-// -------------------------------------------------------------------------------------------------
-// Several queries per workgroup.  Profiling the kernel above shows 61 % of its rounds holding <= 16 tile
-// jobs for 16 wavefronts (they carry 16 % of the jobs but 30 % of the time): a single query rarely has
-// enough active tiles to keep a CU's wavefronts busy.  Here QB queries share the 16 wavefronts of one
-// workgroup: every round's job list is the union of their active tiles, so thin rounds of one query are
-// filled by the others.  Each query keeps its own bucket, role, bound and bitsets; a query whose current
-// bucket ran dry opens its next bucket at the start of the round, independently of its neighbours.
-// -------------------------------------------------------------------------------------------------
-constexpr int TSA_MQ_JOBS = 2048;   // job list entries per round: (local query << 16) | tile
-
-template <int QB>
-__global__ void __launch_bounds__(TSA_THREADS)
-tsa_multi_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_query* __restrict__ queries, int n_queries,
-                 unsigned* __restrict__ field_all, size_t field_stride, unsigned* __restrict__ pend_all, size_t pend_stride,
-                 const uint8_t* __restrict__ nbr_tm, unsigned* __restrict__ touched_all, int bucket_width,
-                 int32_t* __restrict__ paths, int max_path_len, int32_t* __restrict__ rev_all, int rev_cap,
-                 rna_astar_result* __restrict__ results, int s0, int s1, const int* __restrict__ perm) {
-  __shared__ TsaWave s_w[TSA_WAVES];
-  extern __shared__ unsigned s_dyn[];   // [QB][3][nt_words]: active (current bucket), active (next bucket), touched
-  __shared__ unsigned s_jobs[TSA_MQ_JOBS];
-  __shared__ int s_njobs, s_first_fail, s_job_next, s_running;
-  // per-query state: 0 searching, 1 goal settled, 2 no path, 4 cost overflow, 5 never started (invalid / walled-in goal)
-  __shared__ int s_state[QB], s_best[QB], s_bucket[QB], s_bucket0[QB], s_role[QB], s_rounds[QB], s_expanded[QB], s_len[QB];
-  __shared__ int s_any[QB], s_adv[QB], s_si[QB], s_sj[QB], s_gi[QB], s_gj[QB], s_q[QB];   // s_q: global query index, -1 = none
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int ncell = rows * cols;
-  const int ntile = tiles_i * tiles_j;
-  const int nt_words = (ntile + 31) >> 5;
-  const size_t pend_words = (size_t)ntile * TS;
-  auto act = [&](int ql, int which) -> unsigned* { return s_dyn + (size_t)(ql * 3 + which) * nt_words; };
-
-  for (int w = tid; w < QB * 3 * nt_words; w += TSA_THREADS) s_dyn[w] = 0u;
-  if (tid < QB) {
-    const int ql = tid;
-    // queries are dealt round-robin in launch order, so each workgroup gets a mix of long and short searches
-    const int slot = ql * (int)gridDim.x + (int)blockIdx.x;
-    const int q = slot < n_queries ? perm[slot] : -1;
-    s_q[ql] = q;
-    s_best[ql] = INF; s_rounds[ql] = 0; s_role[ql] = 0; s_expanded[ql] = 0; s_bucket[ql] = 0; s_bucket0[ql] = 0; s_len[ql] = 0;
-    s_state[ql] = 5;
-    if (q >= 0) {
-      rna_astar_query qu = queries[q];
-      if (!(qu.start >= 0 && qu.goal >= 0 && qu.start < ncell && qu.goal < ncell)) {
-        results[q] = rna_astar_result{2, 0, INF, 0, 0, 0};
-      } else {
-        qu.start = tsa_unwrap_lin(qu.start, rows, cols, s0, s1);
-        qu.goal = tsa_unwrap_lin(qu.goal, rows, cols, s0, s1);
-        const int si = qu.start % rows, sj = qu.start / rows, gi = qu.goal % rows, gj = qu.goal / rows;
-        s_si[ql] = si; s_sj[ql] = sj; s_gi[ql] = gi; s_gj[ql] = gj;
-        if (qu.goal != qu.start && nbr_tm[tm_index(gi, gj, tiles_i)] == 0) {
-          results[q] = rna_astar_result{1, 0, INF, 0, 0, 0};   // walled-in goal: nothing written
-        } else {
-          s_state[ql] = 0;
-          s_bucket[ql] = s_bucket0[ql] = tsa_octile(si, sj, gi, gj) / bucket_width;
-          unsigned* field = field_all + (size_t)q * field_stride;
-          unsigned* pend0 = pend_all + (size_t)q * pend_stride;
-          __hip_atomic_store(&field[tm_index(si, sj, tiles_i)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // g(start) = 0
-          const int ts = (sj >> 5) * tiles_i + (si >> 5);
-          atomicOr(&pend0[(size_t)ts * TS + (sj & 31)], 1u << (si & 31));
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (tid < QB && s_state[tid] == 0) {
-    const int ts = (s_sj[tid] >> 5) * tiles_i + (s_si[tid] >> 5);
-    act(tid, 0)[ts >> 5] = 1u << (ts & 31);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  TsaWave& W = s_w[wv];
-  int my_expanded[QB];
-#pragma unroll
-  for (int k = 0; k < QB; ++k) my_expanded[k] = 0;
-#ifdef RNA_TSA_STATS
-  unsigned long long tsa_acc[16] = {};
-  const unsigned long long t_life0 = wall_clock64();
-#endif
-
-  for (;;) {
-    // ---- 1. which searching queries still have tiles in their current bucket? ----
-    if (tid < QB) { s_any[tid] = 0; s_adv[tid] = 0; }
-    if (tid == 0) { s_njobs = 0; s_job_next = 0; s_first_fail = TSA_MQ_JOBS; s_running = 0; }
-    __syncthreads();
-#pragma unroll
-    for (int ql = 0; ql < QB; ++ql) {
-      if (s_state[ql] != 0) continue;
-      const unsigned* a = act(ql, 0);
-      unsigned any = 0u;
-      for (int w = tid; w < nt_words; w += TSA_THREADS) any |= a[w];
-      if (__ballot(any != 0u) && lane == 0) s_any[ql] = 1;
-    }
-    __syncthreads();
-    // ---- 2. a query whose bucket ran dry is at that bucket's fixed point: finish it or open the next bucket ----
-    if (tid < QB && s_state[tid] == 0 && !s_any[tid]) {
-      const int ql = tid;
-      const long long done_below = ((long long)s_bucket[ql] + 1) * bucket_width;
-      if (s_best[ql] != INF && (long long)s_best[ql] < done_below) s_state[ql] = 1;   // goal settled, ties included
-      else s_adv[ql] = 1;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ql = 0; ql < QB; ++ql) {
-      if (!s_adv[ql]) continue;
-      unsigned* a0 = act(ql, 0);
-      unsigned* a1 = act(ql, 1);
-      unsigned any = 0u;
-      for (int w = tid; w < nt_words; w += TSA_THREADS) {
-        const unsigned b = a1[w];
-        a0[w] = b;
-        a1[w] = 0u;
-        any |= b;
-      }
-      if (__ballot(any != 0u) && lane == 0) s_any[ql] = 1;
-    }
-    __syncthreads();
-    if (tid < QB && s_adv[tid]) {
-      const int ql = tid;
-      if (!s_any[ql]) s_state[ql] = (s_best[ql] != INF) ? 1 : 2;   // nothing left anywhere
-      else { s_bucket[ql] += 1; s_role[ql] ^= 1; }
-    }
-    __syncthreads();
-    // ---- 3. this round's job list: the active tiles of every searching query ----
-#pragma unroll
-    for (int ql = 0; ql < QB; ++ql) {
-      if (s_state[ql] != 0) continue;
-      if (tid == 0) s_running = 1;
-      unsigned* a0 = act(ql, 0);
-      unsigned* tch = act(ql, 2);
-      for (int w = tid; w < nt_words; w += TSA_THREADS) {
-        unsigned bits = a0[w];
-        if (!bits) continue;
-        const int cnt = __popc(bits);
-        const int base = atomicAdd(&s_njobs, cnt);
-        if (base + cnt <= TSA_MQ_JOBS) {
-          a0[w] = 0u;
-          tch[w] |= bits;
-          int k = base;
-          while (bits) { const int b = __ffs(bits) - 1; bits &= bits - 1; s_jobs[k++] = ((unsigned)ql << 16) | (unsigned)((w << 5) + b); }
-        } else {
-          atomicMin(&s_first_fail, base);   // job list full: these tiles stay flagged for the next round
-        }
-      }
-    }
-    __syncthreads();
-    if (!s_running) break;
-    const int njobs = s_njobs < s_first_fail ? s_njobs : s_first_fail;
-    if (tid < QB && s_state[tid] == 0) s_rounds[tid] += 1;
-
-    // ---- 4. tile jobs: one wavefront per job ----
-    for (;;) {
-      int job = 0;
-      if (lane == 0) job = atomicAdd(&s_job_next, 1);
-      job = __shfl(job, 0);
-      if (job >= njobs) break;
-      const unsigned je = s_jobs[job];
-      const int ql = (int)(je >> 16), t = (int)(je & 0xffffu);
-      const int q = s_q[ql];
-      unsigned* field = field_all + (size_t)q * field_stride;
-      unsigned* pend0 = pend_all + (size_t)q * pend_stride;
-      const int role = s_role[ql];
-      const long long bucket_end = ((long long)s_bucket[ql] + 1) * bucket_width;
-      TsaLocalSched sch{&s_best[ql], &s_state[ql], act(ql, 0), act(ql, 1)};
-      TSA_CNT(7, 1);
-      const int ex = tsa_job(sch, W, lane, t, rows, cols, tiles_i, tiles_j, field, nbr_tm, pend0 + (size_t)role * pend_words,
-                             pend0 + (size_t)(role ^ 1) * pend_words, bucket_end, s_gi[ql], s_gj[ql] TSA_ACC_ARG);
-#pragma unroll
-      for (int k = 0; k < QB; ++k) my_expanded[k] += (k == ql) ? ex : 0;
-    }
-    // all stores / atomics of this round are performed before any wave loads tiles in the next one
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-#pragma unroll
-  for (int k = 0; k < QB; ++k) atomicAdd(&s_expanded[k], my_expanded[k]);
-  __syncthreads();
-#ifdef RNA_TSA_STATS
-  tsa_acc[5] = wall_clock64() - t_life0;
-  if (lane == 0) for (int k = 0; k < 16; ++k) atomicAdd(&g_tsa_stat[k], tsa_acc[k]);
-#endif
-  // every tile a search wrote: its jobs plus the tiles that were handed cells but never ran
-  for (int ql = 0; ql < QB; ++ql) {
-    if (s_q[ql] < 0) continue;
-    unsigned* touched = touched_all + (size_t)s_q[ql] * nt_words;
-    const unsigned *a0 = act(ql, 0), *a1 = act(ql, 1), *tch = act(ql, 2);
-    for (int w = tid; w < nt_words; w += TSA_THREADS) touched[w] = tch[w] | a0[w] | a1[w];
-  }
-
-  // ---- canonical backtrace: wavefront ql serves query ql (lane k probes neighbour k) ----
-  if (wv < QB && s_q[wv] >= 0 && s_state[wv] != 5) {
-    const int ql = wv, q = s_q[ql];
-    const int state = s_state[ql];
-    const int n_buckets = s_bucket[ql] - s_bucket0[ql] + 1;
-    const unsigned* field = field_all + (size_t)q * field_stride;
-    if (state != 1) {
-      if (lane == 0) results[q] = rna_astar_result{state == 4 ? 4 : 1, 0, INF, s_expanded[ql], s_rounds[ql], n_buckets};
-    } else {
-      const int si = s_si[ql], sj = s_sj[ql];
-      int* rev = rev_all + (size_t)q * rev_cap;
-      int ci = s_gi[ql], cj = s_gj[ql];
-      int len = 0;
-      bool ok = true;
-      const int k = lane & 7;
-      const int w = (k == 1 || k == 3 || k == 4 || k == 6) ? COST_S : COST_D;
-      const int di = (k == 0 || k == 3 || k == 5) ? -1 : ((k == 2 || k == 4 || k == 7) ? 1 : 0);
-      const int dj = k < 3 ? -1 : (k > 4 ? 1 : 0);
-      for (;;) {
-        if (lane == 0 && len < rev_cap) rev[len] = cj * rows + ci;
-        ++len;
-        if (ci == si && cj == sj) break;
-        if (len > ncell) { ok = false; break; }
-        const int ni = ci + di, nj = cj + dj;
-        const bool inb = ni >= 0 && nj >= 0 && ni < rows && nj < cols;
-        const unsigned wc = ld_l2(&field[tm_index(ci, cj, tiles_i)]);
-        const unsigned mc = nbr_tm[tm_index(ci, cj, tiles_i)];
-        const unsigned wn = ld_l2(&field[inb ? tm_index(ni, nj, tiles_i) : tm_index(ci, cj, tiles_i)]);
-        const bool hit = lane < 8 && inb && ((mc >> k) & 1u) && ((wn >> 8) != G_INF) && ((wn >> 8) + (unsigned)w == (wc >> 8));
-        const unsigned long long mask = __ballot(hit);
-        if (!mask) { ok = false; break; }
-        const int src = __ffsll((long long)mask) - 1;
-        ci = __shfl(ni, src);
-        cj = __shfl(nj, src);
-      }
-      if (!ok) {
-        if (lane == 0) results[q] = rna_astar_result{1, 0, INF, s_expanded[ql], s_rounds[ql], n_buckets};
-      } else if (len > max_path_len || len > rev_cap) {
-        if (lane == 0) results[q] = rna_astar_result{3, len, s_best[ql], s_expanded[ql], s_rounds[ql], n_buckets};
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        int32_t* path = paths + (size_t)q * max_path_len;
-        for (int i = lane; i < len; i += 64) path[i] = tsa_buffer_lin(rev[len - 1 - i], rows, cols, s0, s1);
-        if (lane == 0) results[q] = rna_astar_result{0, len, s_best[ql], s_expanded[ql], s_rounds[ql], n_buckets};
-      }
-    }
-  }
-}
-
-// |{n : g(n) + h(n) <= f*}| per query from the resident tile-major fields (measurement utility)
+// |{n : g(n) + h(n) <= f*}| per query from the pages still resident in HBM (measurement utility)
 __global__ void tsa_settled_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_query* __restrict__ queries,
-                                   const rna_astar_result* __restrict__ results, const unsigned* __restrict__ field_all,
-                                   size_t field_stride, int32_t* __restrict__ counts, int s0, int s1) {
+                                   const rna_astar_result* __restrict__ results, TsaStage S, int32_t* __restrict__ counts, int s0, int s1) {
   __shared__ int s_cnt;
   const int q = blockIdx.x;
   if (threadIdx.x == 0) s_cnt = 0;
@@ -1146,12 +908,12 @@ __global__ void tsa_settled_kernel(int rows, int cols, int tiles_i, int tiles_j,
   if (r.status == 0 || r.status == 3) {
     const int goal = tsa_unwrap_lin(queries[q].goal, rows, cols, s0, s1);
     const int gi = goal % rows, gj = goal / rows;
-    const unsigned* field = field_all + (size_t)q * field_stride;
-    const size_t nw = (size_t)tiles_i * tiles_j * TILE_WORDS;
-    for (size_t w = threadIdx.x; w < nw; w += blockDim.x) {
-      const int t = (int)(w >> 10), l = (int)(w & 1023);
+    const int used = S.nalloc[q];
+    for (size_t w = threadIdx.x; w < ((size_t)used << 10); w += blockDim.x) {
+      const int p = 1 + (int)(w >> 10), l = (int)(w & 1023);
+      const int t = (int)S.owner[(size_t)q * (S.cap + 1) + p];
       const int i = (t % tiles_i) * TS + (l & 31), j = (t / tiles_i) * TS + (l >> 5);
-      const unsigned gv = field[w] >> 8;
+      const unsigned gv = S.pages[(((size_t)q * S.cap + p) << 10) + l] >> 8;
       if (gv != G_INF && i < rows && j < cols && (int)gv + tsa_octile(i, j, gi, gj) <= r.cost) ++cnt;
     }
   }
@@ -1160,443 +922,69 @@ __global__ void tsa_settled_kernel(int rows, int cols, int tiles_i, int tiles_j,
   if (threadIdx.x == 0) counts[q] = s_cnt;
 }
 
-// =================================================================================================
-// Persistent, cross-CU scheduler ("TSA-P"): every wavefront of the whole GPU is a worker that pulls
-// (query, tile) jobs from a queue.  A long query is therefore served by many CUs at once and the
-// batch is load-balanced at tile granularity -- the one-workgroup-per-query kernels above finish
-// only when their slowest query does (the mean query is 5x shorter than the longest one).
-//
-//  * Queries are bound to the XCD whose worker first picks them and all their jobs stay on that
-//    XCD's queue: a query's field, pending bitmaps and tile states are then only touched through ONE
-//    L2 (L2s of different XCDs are not coherent); L1 is bypassed with sc1 loads and every hand-over
-//    is "s_waitcnt vmcnt(0), then a device-scope atomic".  The XCD id is read from HW_REG_XCC_ID, so
-//    nothing depends on the block -> XCD placement.
-//  * Tile state machine (2 bits per tile): IDLE -> QUEUED -> RUNNING -> IDLE, or RUNNING ->
-//    RUNNING_DIRTY (re-activated while in flight) -> QUEUED.  A tile is never run by two waves.
-//  * outstanding[q] counts queued + running jobs of the current bucket; the wave that brings it to 0
-//    owns the query alone and either finishes it or opens the next bucket (tiles flagged in far_act).
-//  * No worker ever waits for a particular other worker: it waits for queue entries, which any
-//    resident worker of that XCD can produce/consume, so co-residency of the grid is not required.
-//    Every spin is bounded; on timeout the abort flag ends the launch and the host reports it.
-// =================================================================================================
-constexpr int TSA_QN = 1 << 16;         // ring entries per XCD
-constexpr unsigned TSA_NOJOB = 0xFFFFFFFFu;
-constexpr int TSA_SPIN_LIMIT = 1 << 22;
-
-struct TsaQ {   // per-query state (one 64-byte line)
-  int best, bucket, bucket0, role, outstanding, status, xcc, expanded, jobs, overflow, start, goal, pad[4];
-};
-struct TsaCtl {
-  int next_query, remaining, abort, n, pad[12];
-  unsigned head[8][16];   // one 64-byte line per XCD
-  unsigned tail[8][16];
-};
-
-__device__ __forceinline__ int ld_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_i32(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long ld_u64(const unsigned long long* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_u64(unsigned long long* p, unsigned long long v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ int read_xcc_id() {
-  int x;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-  return x & 7;
-}
-
-// Consecutive ring positions are spread 264 B apart (odd multiplier = bijection on the ring): the
-// waiting workers of an XCD then poll different L2 channels instead of one cache line.
-__device__ __forceinline__ unsigned tsa_slot(unsigned pos) { return (pos * 33u) & (unsigned)(TSA_QN - 1); }
-// bounded MPMC ring: entry = (sequence << 32) | job; the slot of position i starts with sequence i
-__device__ bool tsa_enqueue(TsaCtl* ctl, unsigned long long* ring, int x, unsigned job) {
-  const unsigned pos = atomicAdd(&ctl->tail[x][0], 1u);
-  unsigned long long* slot = &ring[(size_t)x * TSA_QN + tsa_slot(pos)];
-  for (int spin = 0;; ++spin) {
-    if ((unsigned)(ld_u64(slot) >> 32) == pos) break;          // slot is free for this lap
-    if (spin > TSA_SPIN_LIMIT || ((spin & 1023) == 1023 && ld_i32(&ctl->abort))) { atomicCAS(&ctl->abort, 0, 1); return false; }
-    __builtin_amdgcn_s_sleep(1);
-  }
-  st_u64(slot, ((unsigned long long)(pos + 1u) << 32) | job);  // one 64-bit store publishes job + sequence
-  return true;
-}
-// Ticket dequeue: one atomicAdd takes the next position of this XCD's ring, then the worker waits
-// for that slot to be published (a CAS-on-head dequeue collapsed under 512 contending wavefronts).
-// Returns TSA_NOJOB only when the launch is over (no query left unfinished) or aborted.
-__device__ unsigned tsa_dequeue(TsaCtl* ctl, unsigned long long* ring, int x) {
-  const unsigned pos = atomicAdd(&ctl->head[x][0], 1u);
-  unsigned long long* slot = &ring[(size_t)x * TSA_QN + tsa_slot(pos)];
-  for (int spin = 0;; ++spin) {
-    const unsigned long long v = ld_u64(slot);
-    if ((unsigned)(v >> 32) == pos + 1u) {
-      st_u64(slot, (unsigned long long)(pos + (unsigned)TSA_QN) << 32);   // free the slot for the next lap
-      return (unsigned)v;
-    }
-    if ((spin & 15) == 15) {
-      if (ld_i32(&ctl->remaining) <= 0 || ld_i32(&ctl->abort)) return TSA_NOJOB;
-      if (spin > 400000) { atomicCAS(&ctl->abort, 0, 5); return TSA_NOJOB; }   // ~5 s without work
-    }
-    if (spin < 64) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(RNA_TSA_POLL_SLEEP);
-  }
-}
-
-struct TsaGlobalSched {
-  TsaQ* qs;
-  TsaCtl* ctl;
-  unsigned long long* ring;
-  unsigned* tstate;     // 2 bits per tile of this query
-  unsigned* far_act;    // bit per tile: has next-bucket pending cells
-  int q, xcc, best_cache;
-  __device__ __forceinline__ int best() const { return best_cache; }
-  __device__ __forceinline__ void improve_best(int g) { atomicMin(&qs->best, g); if (g < best_cache) best_cache = g; }
-  __device__ __forceinline__ void overflow() { st_i32(&qs->overflow, 1); }
-  __device__ __forceinline__ void act_far(int t) { atomicOr(&far_act[t >> 5], 1u << (t & 31)); }
-  __device__ void act_cur(int t) {
-    unsigned* w = &tstate[t >> 4];
-    const int sh = (t & 15) * 2;
-    for (int spin = 0; spin < TSA_SPIN_LIMIT; ++spin) {
-      const unsigned old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned st = (old >> sh) & 3u;
-      if (st == 1u || st == 3u) return;                               // already scheduled to run (again)
-      const unsigned nw = (st == 0u) ? (old | (1u << sh)) : (old | (3u << sh));   // IDLE->QUEUED, RUNNING->RUNNING_DIRTY
-      if (atomicCAS(w, old, nw) == old) {
-        if (st == 0u) {
-          atomicAdd(&qs->outstanding, 1);                            // count the job BEFORE it becomes visible
-          tsa_enqueue(ctl, ring, xcc, ((unsigned)q << 16) | (unsigned)t);
-        }
-        return;
-      }
-    }
-    atomicCAS(&ctl->abort, 0, 2);
-  }
-};
-
-struct TsaPersistArgs {
-  int rows, cols, tiles_i, tiles_j, n, bucket_width;
-  int s0, s1;                  // circular-buffer start index: queries/paths are buffer indices, the search is in map space
-  const rna_astar_query* queries;
-  unsigned* field; size_t field_stride;
-  unsigned* pend; size_t pend_stride;
-  TsaQ* qstate; TsaCtl* ctl; unsigned long long* ring;
-  unsigned* tstate; size_t tstate_stride;
-  unsigned* far_act; size_t far_stride;
-  const uint8_t* nbr_tm;       // tile-major neighbour masks (snapshot of this launch)
-  unsigned* touched;           // [n][nt_words] tiles written by each query
-  int* clean;                  // cleared on abort: the next launch rewrites every field
-  const int* perm;             // launch order (longest expected search first)
-};
-
-__global__ void tsa_persist_init_kernel(TsaPersistArgs A) {
-  const size_t step = (size_t)gridDim.x * blockDim.x;
-  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (size_t w = gid; w < (size_t)A.n * A.tstate_stride; w += step) A.tstate[w] = 0u;
-  for (size_t w = gid; w < (size_t)A.n * A.far_stride; w += step) A.far_act[w] = 0u;
-  for (size_t w = gid; w < (size_t)8 * TSA_QN; w += step)
-    A.ring[(w & ~(size_t)(TSA_QN - 1)) + tsa_slot((unsigned)w & (TSA_QN - 1))] = (unsigned long long)(w & (TSA_QN - 1)) << 32;
-  for (size_t w = gid; w < (size_t)A.n * (sizeof(TsaQ) / 4); w += step)
-    reinterpret_cast<int*>(A.qstate)[w] = ((w % (sizeof(TsaQ) / 4)) == 5) ? -2 : 0;   // status = -2: not started
-  if (gid == 0) {
-    A.ctl->next_query = 0; A.ctl->remaining = A.n; A.ctl->abort = 0; A.ctl->n = A.n;
-    for (int x = 0; x < 8; ++x) { A.ctl->head[x][0] = 0u; A.ctl->tail[x][0] = 0u; }
-  }
-}
-
-__global__ void __launch_bounds__(TSA_THREADS) tsa_persist_kernel(TsaPersistArgs A) {
-  __shared__ TsaWave s_w[TSA_WAVES];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  TsaWave& W = s_w[wv];
-  const int xcc = read_xcc_id();
-  const int ntile = A.tiles_i * A.tiles_j;
-  const int nt_words = (ntile + 31) >> 5;
-  const size_t pend_words = (size_t)ntile * TS;
-#ifdef RNA_TSA_STATS
-  unsigned long long tsa_acc[16] = {};
-#endif
-  for (;;) {
-    // ---- unstarted queries first: the worker that starts a query binds it to its own XCD ----
-    int qn = -1;
-    if (lane == 0 && ld_i32(&A.ctl->next_query) < A.n) {
-      qn = atomicAdd(&A.ctl->next_query, 1);   // caller's order: longest-first (A.perm) measured slower here
-      if (qn >= A.n) qn = -1;
-    }
-    qn = __shfl(qn, 0);
-    if (qn >= 0) {
-      if (lane == 0) {
-        TsaQ* qs = &A.qstate[qn];
-        rna_astar_query qu = A.queries[qn];
-        const int ncell = A.rows * A.cols;
-        unsigned* field = A.field + (size_t)qn * A.field_stride;
-        int status = -1;
-        if (!(qu.start >= 0 && qu.goal >= 0 && qu.start < ncell && qu.goal < ncell)) status = 2;
-        else {
-          qu.start = tsa_unwrap_lin(qu.start, A.rows, A.cols, A.s0, A.s1);
-          qu.goal = tsa_unwrap_lin(qu.goal, A.rows, A.cols, A.s0, A.s1);
-          const int si = qu.start % A.rows, sj = qu.start / A.rows, gi = qu.goal % A.rows, gj = qu.goal / A.rows;
-          const int b0 = tsa_octile(si, sj, gi, gj) / A.bucket_width;
-          qs->best = INF; qs->bucket = b0; qs->bucket0 = b0; qs->role = 0; qs->outstanding = 1; qs->xcc = xcc;
-          qs->expanded = 0; qs->jobs = 0; qs->overflow = 0; qs->start = qu.start; qs->goal = qu.goal;
-#ifdef RNA_TSA_STATS
-          qs->pad[0] = (int)(wall_clock64() & 0x7fffffff);
-#endif
-          if (qu.goal != qu.start && A.nbr_tm[tm_index(gi, gj, A.tiles_i)] == 0) status = 1;  // walled-in goal: nothing written
-          else {
-            __hip_atomic_store(&field[tm_index(si, sj, A.tiles_i)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // g(start) = 0
-            const int ts = (sj >> 5) * A.tiles_i + (si >> 5);
-            unsigned* pend0 = A.pend + (size_t)qn * A.pend_stride;
-            atomicOr(&pend0[(size_t)ts * TS + (sj & 31)], 1u << (si & 31));
-            atomicOr(&(A.tstate + (size_t)qn * A.tstate_stride)[ts >> 4], 1u << ((ts & 15) * 2));     // QUEUED
-            st_i32(&qs->status, -1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            tsa_enqueue(A.ctl, A.ring, xcc, ((unsigned)qn << 16) | (unsigned)ts);
-          }
-        }
-        if (status >= 0) {
-          st_i32(&qs->status, status);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          atomicSub(&A.ctl->remaining, 1);
-        }
-      }
-      continue;
-    }
-    // ---- next job of this XCD (blocks until one is published or the launch is over) ----
-    unsigned job = TSA_NOJOB;
-    TSA_T(t_w0);
-    if (lane == 0) job = tsa_dequeue(A.ctl, A.ring, xcc);
-    job = __shfl(job, 0);
-    TSA_T(t_w1);
-    TSA_ACC(4, t_w0, t_w1);
-    if (job == TSA_NOJOB) break;
-    TSA_CNT(7, 1);
-
-    // ---- run one tile job ----
-    const int q = (int)(job >> 16), t = (int)(job & 0xffffu);
-    TsaQ* qs = &A.qstate[q];
-    unsigned* tstate = A.tstate + (size_t)q * A.tstate_stride;
-    unsigned* far_act = A.far_act + (size_t)q * A.far_stride;
-    unsigned* tw = &tstate[t >> 4];
-    const int sh = (t & 15) * 2;
-    if (lane == 0) {   // QUEUED -> RUNNING
-      atomicOr(&A.touched[(size_t)q * nt_words + (t >> 5)], 1u << (t & 31));   // this search writes tile t
-      for (int spin = 0;; ++spin) {
-        const unsigned old = __hip_atomic_load(tw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (((old >> sh) & 3u) == 1u && atomicCAS(tw, old, (old & ~(3u << sh)) | (2u << sh)) == old) break;
-        if (spin > TSA_SPIN_LIMIT) { atomicCAS(&A.ctl->abort, 0, 3); break; }
-      }
-    }
-    const int bucket = ld_i32(&qs->bucket), role = ld_i32(&qs->role);
-    const int goal = ld_i32(&qs->goal);
-    const int gi = goal % A.rows, gj = goal / A.rows;
-    unsigned* field = A.field + (size_t)q * A.field_stride;
-    unsigned* pend0 = A.pend + (size_t)q * A.pend_stride;
-    TsaGlobalSched sch{qs, A.ctl, A.ring, tstate, far_act, q, xcc, ld_i32(&qs->best)};
-    const long long bucket_end = ((long long)bucket + 1) * A.bucket_width;
-    int exp = tsa_job(sch, W, lane, t, A.rows, A.cols, A.tiles_i, A.tiles_j, field, A.nbr_tm, pend0 + (size_t)role * pend_words,
-                      pend0 + (size_t)(role ^ 1) * pend_words, bucket_end, gi, gj TSA_ACC_ARG);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // everything this job wrote is at L2 before the tile is released
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) exp += __shfl_xor(exp, o);
-    int last = 0;
-    if (lane == 0) {
-      atomicAdd(&qs->expanded, exp);
-      atomicAdd(&qs->jobs, 1);
-      for (int spin = 0;; ++spin) {
-        const unsigned old = __hip_atomic_load(tw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned st = (old >> sh) & 3u;
-        if (st == 2u) {            // RUNNING -> IDLE
-          if (atomicCAS(tw, old, old & ~(3u << sh)) == old) { last = (atomicSub(&qs->outstanding, 1) == 1); break; }
-        } else if (st == 3u) {     // re-activated while running: RUNNING_DIRTY -> QUEUED, same job count
-          if (atomicCAS(tw, old, (old & ~(3u << sh)) | (1u << sh)) == old) { tsa_enqueue(A.ctl, A.ring, xcc, job); break; }
-        }
-        if (spin > TSA_SPIN_LIMIT) { atomicCAS(&A.ctl->abort, 0, 4); break; }
-      }
-    }
-    last = __shfl(last, 0);
-    TSA_T(t_w2);
-    TSA_ACC(5, t_w1, t_w2);
-    if (!last) continue;
-
-    // ---- this wave emptied the bucket: it owns the query alone until it enqueues new jobs ----
-    const int best = ld_i32(&qs->best);
-    const long long done_below = ((long long)bucket + 1) * A.bucket_width;
-    int status = -1;
-    if (ld_i32(&qs->overflow)) status = 4;
-    else if (best != INF && (long long)best < done_below) status = 0;   // goal settled, ties included
-    else {
-      unsigned* scratch = W.tile;   // grabbed far bits (nt_words <= TW*TW)
-      int cnt = 0;
-      for (int w = lane; w < nt_words; w += 64) {
-        const unsigned bits = atomicExch(&far_act[w], 0u);
-        scratch[w] = bits;
-        cnt += __popc(bits);
-      }
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
-      if (cnt == 0) status = (best != INF) ? 0 : 1;   // nothing left anywhere
-      else {
-        if (lane == 0) { st_i32(&qs->bucket, bucket + 1); st_i32(&qs->role, role ^ 1); st_i32(&qs->outstanding, cnt); }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        // pass 1: every tile of the new bucket becomes QUEUED before the first job is visible (a job
-        // that is already running may otherwise activate -- and enqueue -- one of them a second time)
-        for (int w = lane; w < nt_words; w += 64) {
-          unsigned bits = scratch[w];
-          while (bits) {
-            const int b = __ffs(bits) - 1;
-            bits &= bits - 1;
-            const int tt = (w << 5) + b;
-            atomicOr(&tstate[tt >> 4], 1u << ((tt & 15) * 2));   // IDLE -> QUEUED (all tiles are idle here)
-          }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        // pass 2: publish the jobs
-        for (int w = lane; w < nt_words; w += 64) {
-          unsigned bits = scratch[w];
-          while (bits) {
-            const int b = __ffs(bits) - 1;
-            bits &= bits - 1;
-            tsa_enqueue(A.ctl, A.ring, xcc, ((unsigned)q << 16) | (unsigned)((w << 5) + b));
-          }
-        }
-      }
-    }
-    if (status >= 0) {   // tiles that were handed next-bucket cells but never ran were written as well
-      for (int w = lane; w < nt_words; w += 64) {
-        const unsigned bits = ld_l2(&far_act[w]);
-        if (bits) atomicOr(&A.touched[(size_t)q * nt_words + w], bits);
-      }
-    }
-    if (status >= 0 && lane == 0) {
-#ifdef RNA_TSA_STATS
-      qs->pad[1] = (int)(wall_clock64() & 0x7fffffff);
-#endif
-      st_i32(&qs->status, status);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      atomicSub(&A.ctl->remaining, 1);
-    }
-    TSA_T(t_w3);
-    TSA_ACC(6, t_w2, t_w3);
-  }
-#ifdef RNA_TSA_STATS
-  if (lane == 0) for (int k = 0; k < 16; ++k) atomicAdd(&g_tsa_stat[k], tsa_acc[k]);
-#endif
-}
-
-// canonical backtrace + result records for the persistent scheduler: one wavefront per query
-__global__ void tsa_backtrace_kernel(int rows, int cols, int s0, int s1, int tiles_i, const unsigned* __restrict__ field_all, size_t field_stride,
-                                     const uint8_t* __restrict__ nbr_tm, int* __restrict__ clean,
-                                     const TsaQ* __restrict__ qstate, const TsaCtl* __restrict__ ctl, int32_t* __restrict__ paths,
-                                     int max_path_len, int32_t* __restrict__ rev_all, int rev_cap,
-                                     rna_astar_result* __restrict__ results) {
-  const int q = blockIdx.x, tid = threadIdx.x;
-  const TsaQ qs = qstate[q];
-  const unsigned* field = field_all + (size_t)q * field_stride;
-  const int n_buckets = qs.bucket - qs.bucket0 + 1;
-  if (ctl->abort || qs.status < 0) {   // scheduler timeout: report it as a capacity/scheduling failure
-    if (tid == 0) *clean = 0;          // queued tiles were never recorded: rewrite every field next time
-    if (tid == 0) results[q] = rna_astar_result{(int)RNA_ECAPACITY, ctl->abort, qs.status, qs.expanded, qs.jobs, qs.outstanding};
-    return;
-  }
-  if (qs.status != 0) {
-    if (tid == 0) results[q] = rna_astar_result{qs.status, 0, INF, qs.expanded, qs.jobs, qs.status == 2 ? 0 : n_buckets};
-    return;
-  }
-  const int ncell = rows * cols;
-  const int si = qs.start % rows, sj = qs.start / rows, gi = qs.goal % rows, gj = qs.goal / rows;
-  int* rev = rev_all + (size_t)q * rev_cap;
-  int ci = gi, cj = gj, len = 0;
-  bool ok = true;
-  const int k = tid & 7;
-  const int w = (k == 1 || k == 3 || k == 4 || k == 6) ? COST_S : COST_D;
-  const int di = (k == 0 || k == 3 || k == 5) ? -1 : ((k == 2 || k == 4 || k == 7) ? 1 : 0);
-  const int dj = k < 3 ? -1 : (k > 4 ? 1 : 0);
-  for (;;) {
-    if (tid == 0 && len < rev_cap) rev[len] = cj * rows + ci;
-    ++len;
-    if (ci == si && cj == sj) break;
-    if (len > ncell) { ok = false; break; }
-    const int ni = ci + di, nj = cj + dj;
-    const bool inb = ni >= 0 && nj >= 0 && ni < rows && nj < cols;
-    const unsigned wc = field[tm_index(ci, cj, tiles_i)];
-    const unsigned mc = nbr_tm[tm_index(ci, cj, tiles_i)];
-    const unsigned wn = field[inb ? tm_index(ni, nj, tiles_i) : tm_index(ci, cj, tiles_i)];
-    const bool hit = tid < 8 && inb && ((mc >> k) & 1u) && ((wn >> 8) != G_INF) && ((wn >> 8) + (unsigned)w == (wc >> 8));
-    const unsigned long long mask = __ballot(hit);
-    if (!mask) { ok = false; break; }
-    const int src = __ffsll((long long)mask) - 1;
-    ci = __shfl(ni, src);
-    cj = __shfl(nj, src);
-  }
-  if (!ok) { if (tid == 0) results[q] = rna_astar_result{1, 0, INF, qs.expanded, qs.jobs, n_buckets}; return; }
-  if (len > max_path_len || len > rev_cap) {
-    if (tid == 0) results[q] = rna_astar_result{3, len, qs.best, qs.expanded, qs.jobs, n_buckets};
-    return;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  int32_t* path = paths + (size_t)q * max_path_len;
-  for (int i = tid; i < len; i += 64) path[i] = tsa_buffer_lin(rev[len - 1 - i], rows, cols, s0, s1);
-  if (tid == 0) results[q] = rna_astar_result{0, len, qs.best, qs.expanded, qs.jobs, n_buckets};
-}
-
 // ---- host entry points used by astar.hip ----
-size_t tsa_field_words(const rna_engine* e) {
-  const size_t ti = (e->geom.size[0] + TS - 1) / TS, tj = (e->geom.size[1] + TS - 1) / TS;
-  return ti * tj * TILE_WORDS;
+static inline int tsa_ntile(const rna_engine* e) {
+  return ((e->geom.size[0] + TS - 1) / TS) * ((e->geom.size[1] + TS - 1) / TS);
 }
-size_t tsa_pend_words(const rna_engine* e) {
-  const size_t ti = (e->geom.size[0] + TS - 1) / TS, tj = (e->geom.size[1] + TS - 1) / TS;
-  return 2 * ti * tj * TS;
+bool tsa_supported(const rna_engine* e) { return (size_t)tsa_ntile(e) <= (size_t)TSA_MAX_TILE_WORDS * 32; }
+int tsa_tiles(const rna_engine* e) { return tsa_ntile(e); }
+// HBM of one pipeline stage: pages and pending bitmaps (cap per query + the shared page 0) ...
+size_t tsa_pool_bytes(int max_queries, int cap) { return ((size_t)max_queries * cap + 1) * (TILE_WORDS + PEND_WORDS) * sizeof(unsigned); }
+// ... and one allocation that must start zeroed: ticket | nalloc | perm | mask snapshot | tmap | owner
+size_t tsa_aux_bytes(const rna_engine* e, int max_queries, int cap) {
+  const size_t ntile = (size_t)tsa_ntile(e);
+  return 256 + 2 * tsa_align256((size_t)max_queries * sizeof(int)) + tsa_align256(ntile * TILE_WORDS) +
+         tsa_align256((size_t)max_queries * ntile * sizeof(unsigned)) + tsa_align256((size_t)max_queries * ((size_t)cap + 1) * sizeof(unsigned));
 }
-bool tsa_supported(const rna_engine* e) {
-  const size_t ti = (e->geom.size[0] + TS - 1) / TS, tj = (e->geom.size[1] + TS - 1) / TS;
-  return ti * tj <= (size_t)TSA_MAX_TILE_WORDS * 32;
+static TsaStage tsa_stage_view(const rna_engine* e, int slot) {
+  const AstarDevice& a = e->astar;
+  const size_t ntile = (size_t)tsa_ntile(e);
+  char* base = static_cast<char*>(a.tsa_aux[slot]);
+  TsaStage S;
+  S.cap = a.page_cap;
+  S.pages = reinterpret_cast<unsigned*>(a.g[slot]);
+  S.ppend = S.pages + (((size_t)a.max_queries * S.cap + 1) << 10);
+  S.ticket = reinterpret_cast<int*>(base);
+  base += 256;
+  S.nalloc = reinterpret_cast<int*>(base);
+  base += tsa_align256((size_t)a.max_queries * sizeof(int));
+  S.perm = reinterpret_cast<int*>(base);
+  base += tsa_align256((size_t)a.max_queries * sizeof(int));
+  S.nbr_tm = reinterpret_cast<uint8_t*>(base);
+  base += tsa_align256(ntile * TILE_WORDS);
+  S.tmap = reinterpret_cast<unsigned*>(base);
+  base += tsa_align256((size_t)a.max_queries * ntile * sizeof(unsigned));
+  S.owner = reinterpret_cast<unsigned*>(base);
+  return S;
 }
-
-// one allocation per pipeline stage: clean flag | tile-major neighbour masks | touched bitsets.
-// It must start zeroed (clean == 0: the first launch writes every field).
-size_t tsa_aux_bytes(const rna_engine* e, int max_queries) {
-  const size_t ti = (e->geom.size[0] + TS - 1) / TS, tj = (e->geom.size[1] + TS - 1) / TS;
-  const size_t ntile = ti * tj;
-  return 256 + tsa_align256(ntile * TILE_WORDS) + tsa_align256((size_t)max_queries * ((ntile + 31) / 32) * 4) +
-         tsa_align256((size_t)max_queries * sizeof(int));
-}
-static TsaAux tsa_aux_view(const rna_engine* e, void* aux) {
-  const size_t ti = (e->geom.size[0] + TS - 1) / TS, tj = (e->geom.size[1] + TS - 1) / TS;
-  char* base = static_cast<char*>(aux);
-  TsaAux v;
-  v.clean = reinterpret_cast<int*>(base);
-  v.ticket = reinterpret_cast<int*>(base + 64);
-  v.nbr_tm = reinterpret_cast<uint8_t*>(base + 256);
-  v.touched = reinterpret_cast<unsigned*>(base + 256 + tsa_align256(ti * tj * TILE_WORDS));
-  v.perm = reinterpret_cast<int*>(base + 256 + tsa_align256(ti * tj * TILE_WORDS) +
-                                  tsa_align256((size_t)e->astar.max_queries * ((ti * tj + 31) / 32) * 4));
-  return v;
-}
-// snapshot the neighbour masks and bring every field of this stage back to "unreached"
-static void tsa_launch_init(rna_engine* e, hipStream_t stream, unsigned* field, size_t field_stride, unsigned* pend,
-                            size_t pend_stride, int max_queries, const TsaAux& aux, const rna_astar_query* q_dev, int n) {
-  const int rows = e->geom.size[0], cols = e->geom.size[1];
-  const int ti = (rows + TS - 1) / TS, tj = (cols + TS - 1) / TS;
-  hipLaunchKernelGGL(tsa_init_kernel, dim3(4096), dim3(256), 0, stream, e->nbr, rows, cols, ti, tj, field, field_stride, pend,
-                     pend_stride, max_queries, aux, e->geom.start[0], e->geom.start[1]);
-  hipLaunchKernelGGL(tsa_mark_clean_kernel, dim3(1), dim3(1), 0, stream, aux.clean, aux.ticket);
-  if (n <= 2048)   // the ranking is O(n^2 / 256) per thread: beyond this the caller order is kept
-    // one small workgroup: it has to fit next to the search workgroups that fill every CU when batches are pipelined
-    hipLaunchKernelGGL(tsa_order_kernel, dim3(1), dim3(256), (size_t)n * sizeof(int), stream, q_dev, n, rows, cols, aux.perm);
-  else
-    hipLaunchKernelGGL(tsa_identity_order_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, aux.perm);
+// fresh stage: pages "unreached" (everything else was zeroed by the caller's hipMemsetAsync)
+int tsa_stage_prepare(rna_engine* e, int slot) {
+  const TsaStage S = tsa_stage_view(e, slot);
+  const size_t pages = (size_t)e->astar.max_queries * S.cap + 1;
+  RNA_HIP(e, hipMemsetAsync(S.ppend, 0, pages * PEND_WORDS * sizeof(unsigned), e->stream));
+  hipLaunchKernelGGL(tsa_fill_pages_kernel, dim3(8192), dim3(256), 0, e->stream, reinterpret_cast<uint4*>(S.pages), pages * TILE_WORDS / 4);
+  RNA_HIP(e, hipGetLastError());
+  return RNA_OK;
 }
 
-int tsa_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init, unsigned* field,
-               size_t field_stride, unsigned* pend, size_t pend_stride, void* aux_mem, int max_queries, int32_t* rev,
-               int rev_cap, const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len, rna_astar_result* res_dev) {
+int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init,
+               const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len, rna_astar_result* res_dev) {
+  AstarDevice& a = e->astar;
   const int rows = e->geom.size[0], cols = e->geom.size[1];
   const int ti = (rows + TS - 1) / TS, tj = (cols + TS - 1) / TS;
-  const TsaAux aux = tsa_aux_view(e, aux_mem);
+  const TsaStage S = tsa_stage_view(e, slot);
   {
+    // snapshot the neighbour masks and bring the pages the last search on this stage used back to "unreached"
     KernelTimer kt(e, RNA_K_ASTAR_INIT, init_stream);
-    tsa_launch_init(e, init_stream, field, field_stride, pend, pend_stride, max_queries, aux, q_dev, n);
+    hipLaunchKernelGGL(tsa_snapshot_kernel, dim3(2048), dim3(256), 0, init_stream, e->nbr, rows, cols, ti, tj, S.nbr_tm,
+                       e->geom.start[0], e->geom.start[1]);
+    hipLaunchKernelGGL(tsa_reset_kernel, dim3(32, a.max_queries), dim3(256), 0, init_stream, S, ti * tj);
+    hipLaunchKernelGGL(tsa_reset_done_kernel, dim3(1), dim3(256), 0, init_stream, S, a.max_queries);
+    if (n <= 2048)   // the ranking is O(n^2 / 256) per thread: beyond this the caller order is kept
+      // one small workgroup: it has to fit next to the search workgroups that fill every CU when batches are pipelined
+      hipLaunchKernelGGL(tsa_order_kernel, dim3(1), dim3(256), (size_t)n * sizeof(int), init_stream, q_dev, n, rows, cols, S.perm);
+    else
+      hipLaunchKernelGGL(tsa_identity_order_kernel, dim3((n + 255) / 256), dim3(256), 0, init_stream, n, S.perm);
     RNA_HIP(e, hipGetLastError());
   }
   if (ev_init) {
@@ -1606,29 +994,11 @@ int tsa_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream
   {
     KernelTimer kt(e, RNA_K_ASTAR_SEARCH, search_stream);
     const size_t nt_bytes = (size_t)((ti * tj + 31) / 32) * sizeof(unsigned);
-    // queries per workgroup: as many (<= 4) as the three bitsets per query leave room for in the 160 KB of LDS
-    int qb = 1;
-    if (const char* m = getenv("RNA_TSA_QUERIES_PER_BLOCK")) qb = atoi(m);
-    if (qb > 1) {   // opt-in: several queries per workgroup (fills thin rounds, but measured no faster when pipelined)
-      const size_t fixed = sizeof(TsaWave) * TSA_WAVES + sizeof(unsigned) * TSA_MQ_JOBS + 1024;
-      if (qb > 4) qb = 4;
-      if (qb == 3) qb = 2;
-      while (qb > 1 && fixed + 3 * nt_bytes * qb > 160 * 1024) qb >>= 1;
-    }
-#define RNA_LAUNCH_MQ(QB)                                                                                               \
-  hipLaunchKernelGGL(tsa_multi_kernel<QB>, dim3((n + QB - 1) / QB), dim3(TSA_THREADS), 3 * nt_bytes * QB, search_stream, rows,   \
-                     cols, ti, tj, q_dev, n, field, field_stride, pend, pend_stride, aux.nbr_tm, aux.touched,          \
-                     e->astar.bucket_width, paths_dev, max_len, rev, rev_cap, res_dev, e->geom.start[0], e->geom.start[1], aux.perm)
-    if (e->astar.mode == 1 && qb == 4) RNA_LAUNCH_MQ(4);
-    else if (e->astar.mode == 1 && qb == 2) RNA_LAUNCH_MQ(2);
-    else if (e->astar.mode == 3)
-      hipLaunchKernelGGL(tsa_search_kernel<true>, dim3(n), dim3(TSA_THREADS), 4 * nt_bytes, search_stream, rows, cols, ti, tj, q_dev,
-                         field, field_stride, pend, pend_stride, aux.nbr_tm, aux.touched, e->astar.bucket_width, paths_dev, max_len,
-                         rev, rev_cap, res_dev, e->geom.start[0], e->geom.start[1], aux.perm, aux.ticket);
-    else
-      hipLaunchKernelGGL(tsa_search_kernel<false>, dim3(n), dim3(TSA_THREADS), 3 * nt_bytes, search_stream, rows, cols, ti, tj, q_dev,
-                         field, field_stride, pend, pend_stride, aux.nbr_tm, aux.touched, e->astar.bucket_width, paths_dev, max_len,
-                         rev, rev_cap, res_dev, e->geom.start[0], e->geom.start[1], aux.perm, aux.ticket);
+    TsaLaunch A;
+    A.rows = rows; A.cols = cols; A.tiles_i = ti; A.tiles_j = tj; A.s0 = e->geom.start[0]; A.s1 = e->geom.start[1];
+    A.queries = q_dev; A.S = S; A.bucket_width = a.bucket_width; A.paths = paths_dev; A.max_path_len = max_len;
+    A.rev_all = a.rev[slot]; A.rev_cap = a.rev_cap; A.results = res_dev;
+    hipLaunchKernelGGL(tsa_search_kernel, dim3(n), dim3(TSA_THREADS), 2 * nt_bytes, search_stream, A);
     RNA_HIP(e, hipGetLastError());
   }
   return RNA_OK;
@@ -1657,95 +1027,12 @@ void tsa_stats_dump() {
 }
 #endif
 
-int tsa_settled(rna_engine* e, const unsigned* field, size_t field_stride, const rna_astar_query* q, const rna_astar_result* r,
-                int n, int32_t* d_counts) {
+int tsa_settled(rna_engine* e, int slot, const rna_astar_query* q, const rna_astar_result* r, int n, int32_t* d_counts) {
   const int rows = e->geom.size[0], cols = e->geom.size[1];
   const int ti = (rows + TS - 1) / TS, tj = (cols + TS - 1) / TS;
-  hipLaunchKernelGGL(tsa_settled_kernel, dim3(n), dim3(1024), 0, e->stream, rows, cols, ti, tj, q, r, field, field_stride,
+  hipLaunchKernelGGL(tsa_settled_kernel, dim3(n), dim3(1024), 0, e->stream, rows, cols, ti, tj, q, r, tsa_stage_view(e, slot),
                      d_counts, e->geom.start[0], e->geom.start[1]);
   RNA_HIP(e, hipGetLastError());
-  return RNA_OK;
-}
-
-
-size_t tsa_persist_state_bytes(const rna_engine* e, int max_queries, size_t* tstate_stride, size_t* far_stride) {
-  const size_t ti = (e->geom.size[0] + TS - 1) / TS, tj = (e->geom.size[1] + TS - 1) / TS;
-  const size_t ntile = ti * tj;
-  *tstate_stride = ((ntile + 15) / 16 + 15) / 16 * 16;
-  *far_stride = ((ntile + 31) / 32 + 15) / 16 * 16;
-  return sizeof(TsaCtl) + (size_t)max_queries * sizeof(TsaQ) + (size_t)8 * TSA_QN * 8 +
-         (size_t)max_queries * (*tstate_stride + *far_stride) * 4;
-}
-
-// persistent launch: init (field + scheduler state) on init_stream, then the worker grid and the
-// backtrace on search_stream.  `state` is one allocation laid out as ctl | qstate | ring | tstate | far_act.
-int tsa_persist_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init, unsigned* field,
-                       size_t field_stride, unsigned* pend, size_t pend_stride, void* aux_mem, void* state, int max_queries,
-                       int32_t* rev, int rev_cap, const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len,
-                       rna_astar_result* res_dev) {
-  const int rows = e->geom.size[0], cols = e->geom.size[1];
-  const int ti = (rows + TS - 1) / TS, tj = (cols + TS - 1) / TS;
-  if (n > 32767 || (size_t)ti * tj > 65536) return fail(e, RNA_EINVAL, "persistent A*: too many queries or tiles");
-  TsaPersistArgs A{};
-  A.rows = rows; A.cols = cols; A.tiles_i = ti; A.tiles_j = tj; A.n = n; A.bucket_width = e->astar.bucket_width;
-  A.s0 = e->geom.start[0]; A.s1 = e->geom.start[1];
-  A.queries = q_dev; A.field = field; A.field_stride = field_stride; A.pend = pend; A.pend_stride = pend_stride;
-  size_t ts_stride = 0, far_stride = 0;
-  (void)tsa_persist_state_bytes(e, max_queries, &ts_stride, &far_stride);
-  char* base = static_cast<char*>(state);
-  A.ctl = reinterpret_cast<TsaCtl*>(base); base += sizeof(TsaCtl);
-  A.qstate = reinterpret_cast<TsaQ*>(base); base += (size_t)max_queries * sizeof(TsaQ);
-  A.ring = reinterpret_cast<unsigned long long*>(base); base += (size_t)8 * TSA_QN * 8;
-  A.tstate = reinterpret_cast<unsigned*>(base); A.tstate_stride = ts_stride; base += (size_t)max_queries * ts_stride * 4;
-  A.far_act = reinterpret_cast<unsigned*>(base); A.far_stride = far_stride;
-  const TsaAux aux = tsa_aux_view(e, aux_mem);
-  A.nbr_tm = aux.nbr_tm; A.touched = aux.touched; A.clean = aux.clean; A.perm = aux.perm;
-  {
-    KernelTimer kt(e, RNA_K_ASTAR_INIT, init_stream);
-    tsa_launch_init(e, init_stream, field, field_stride, pend, pend_stride, max_queries, aux, q_dev, n);
-    hipLaunchKernelGGL(tsa_persist_init_kernel, dim3(512), dim3(256), 0, init_stream, A);
-    RNA_HIP(e, hipGetLastError());
-  }
-  if (ev_init) {
-    RNA_HIP(e, hipEventRecord(ev_init, init_stream));
-    RNA_HIP(e, hipStreamWaitEvent(search_stream, ev_init, 0));
-  }
-  {
-    KernelTimer kt(e, RNA_K_ASTAR_SEARCH, search_stream);
-    int cus = 0;
-    RNA_HIP(e, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
-    if (cus <= 0) cus = 256;
-    if (const char* m = getenv("RNA_TSA_BLOCKS_PER_CU")) cus *= std::max(1, atoi(m));
-    hipLaunchKernelGGL(tsa_persist_kernel, dim3(cus), dim3(TSA_THREADS), 0, search_stream, A);
-    hipLaunchKernelGGL(tsa_backtrace_kernel, dim3(n), dim3(64), 0, search_stream, rows, cols, A.s0, A.s1, ti, field, field_stride,
-                       aux.nbr_tm, aux.clean, A.qstate, A.ctl, paths_dev, max_len, rev, rev_cap, res_dev);
-    RNA_HIP(e, hipGetLastError());
-  }
-#ifdef RNA_TSA_STATS
-  {
-    RNA_HIP(e, hipStreamSynchronize(search_stream));
-    unsigned long long st[32];
-    RNA_HIP(e, hipMemcpyFromSymbol(st, HIP_SYMBOL(g_tsa_stat), sizeof(st)));
-    static const unsigned long long zero[32] = {};
-    RNA_HIP(e, hipMemcpyToSymbol(HIP_SYMBOL(g_tsa_stat), zero, sizeof(zero)));
-    std::vector<TsaQ> qh(n);
-    RNA_HIP(e, hipMemcpy(qh.data(), A.qstate, (size_t)n * sizeof(TsaQ), hipMemcpyDeviceToHost));
-    int t0 = 0x7fffffff;
-    for (auto& qq : qh) if (qq.status != 2 && qq.pad[0] < t0) t0 = qq.pad[0];
-    std::vector<double> fin;
-    for (auto& qq : qh) if (qq.status != 2) fin.push_back((qq.pad[1] - t0) * 1e-5);
-    std::sort(fin.begin(), fin.end());
-    const double jobs = (double)st[7];
-    fprintf(stderr, "[tsa stats] jobs %.0f | per job us: load %.2f relax %.2f wb %.2f handover %.2f finish %.2f advance %.2f | wait total %.1f ms-waves | relax iters/job %.1f cells/iter %.1f\n",
-            jobs, st[0] * 0.01 / jobs, st[1] * 0.01 / jobs, st[2] * 0.01 / jobs, st[3] * 0.01 / jobs, (st[5] - st[0] - st[1] - st[2] - st[3]) * 0.01 / jobs,
-            st[6] * 0.01 / jobs, st[4] * 1e-5, st[8] / jobs, st[9] / (double)std::max<unsigned long long>(1, st[8]));
-    fprintf(stderr, "[tsa stats] jobs by expansions: 0: %.1f%%  1-15: %.1f%%  16-63: %.1f%%  64-255: %.1f%%  256-1023: %.1f%%  1024+: %.1f%%\n",
-            100.0 * st[10] / jobs, 100.0 * st[11] / jobs, 100.0 * st[12] / jobs, 100.0 * st[13] / jobs, 100.0 * st[14] / jobs, 100.0 * st[15] / jobs);
-    if (!fin.empty())
-      fprintf(stderr, "[tsa stats] query finish ms: p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f | busy wave-ms %.1f\n", fin[fin.size() / 10],
-              fin[fin.size() / 2], fin[fin.size() * 9 / 10], fin[fin.size() * 99 / 100], fin.back(), (st[5] + st[6]) * 1e-5);
-  }
-#endif
   return RNA_OK;
 }
 

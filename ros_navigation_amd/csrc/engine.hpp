@@ -63,15 +63,15 @@ struct AstarDevice {
   // stream, so the tail of batch k (few long queries) overlaps the head of batch k+1.
   static constexpr int MAX_DEPTH = 8;
   int depth = 4;
-  int32_t* g[MAX_DEPTH] = {};      // [max_queries][field_stride] search fields: (g << 8) | mask (frontier kernel), g << 8 (tile kernels)
+  int32_t* g[MAX_DEPTH] = {};      // frontier kernel: [max_queries][field_stride] search fields (g << 8) | mask;
+                                   // tile kernel: the stage's page pool (pages, then pending bitmaps), see astar_tile.hip
   int2* queues[MAX_DEPTH] = {};    // [max_queries][3][queue_cap] (cell, g)
-  unsigned* pend[MAX_DEPTH] = {};  // tile kernel: two pending bitmaps per query
   int32_t* rev[MAX_DEPTH] = {};    // tile kernel: reversed-path staging per query
-  size_t pend_stride = 0;
   int rev_cap = 16800;             // g < 2^24 at >= 1000 per step bounds a path to 16 777 cells
-  int mode = 1;                    // 0 = frontier kernel (astar.hip), 1 = tile kernel (default), 2 = persistent cross-CU tile scheduler
-  void* pstate[MAX_DEPTH] = {};    // mode 2: scheduler state (control block, per-query state, job rings, tile states)
-  void* tsa_aux[MAX_DEPTH] = {};   // modes 1/2: clean flag, tile-major neighbour-mask snapshot, touched-tile bitsets
+  int mode = 1;                    // 0 = frontier kernel (astar.hip, fallback for maps beyond 65 536 tiles), 1 = tile kernel (default)
+  int page_cap = 0;                // tile kernel: 4 KiB pages per query (0 = one per tile: a search can never run out)
+  int page_cap_request = 0;        // rna_astar_set_page_cap
+  void* tsa_aux[MAX_DEPTH] = {};   // tile kernel: ticket, page counts, launch order, neighbour-mask snapshot, tile -> page tables
   hipStream_t side[MAX_DEPTH] = {};
   hipEvent_t done[MAX_DEPTH] = {}; // search of the batch that last used this set has finished
   bool busy[MAX_DEPTH] = {};
@@ -186,19 +186,13 @@ int astar_release(rna_engine* e);
 int map_prepare_nbr(rna_engine* e);   // make e->nbr consistent with the master layer
 int sync_all(rna_engine* e);          // main stream + every A* side stream
 // tile-synchronous A* (astar_tile.hip)
-size_t tsa_field_words(const rna_engine* e);
-size_t tsa_pend_words(const rna_engine* e);
 bool tsa_supported(const rna_engine* e);
-size_t tsa_aux_bytes(const rna_engine* e, int max_queries);   // per pipeline stage, must start zeroed
-int tsa_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init, unsigned* field,
-               size_t field_stride, unsigned* pend, size_t pend_stride, void* aux, int max_queries, int32_t* rev, int rev_cap,
+int tsa_tiles(const rna_engine* e);                                   // 32 x 32 tiles of the map
+size_t tsa_pool_bytes(int max_queries, int cap);                      // pages + pending bitmaps of one pipeline stage
+size_t tsa_aux_bytes(const rna_engine* e, int max_queries, int cap);  // per stage, must start zeroed
+int tsa_stage_prepare(rna_engine* e, int slot);                       // fresh stage: every page "unreached"
+int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init,
                const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len, rna_astar_result* res_dev);
-size_t tsa_persist_state_bytes(const rna_engine* e, int max_queries, size_t* tstate_stride, size_t* far_stride);
-int tsa_persist_launch(rna_engine* e, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init, unsigned* field,
-                       size_t field_stride, unsigned* pend, size_t pend_stride, void* aux, void* state, int max_queries,
-                       int32_t* rev, int rev_cap, const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len,
-                       rna_astar_result* res_dev);
-int tsa_settled(rna_engine* e, const unsigned* field, size_t field_stride, const rna_astar_query* q,
-                const rna_astar_result* r, int n, int32_t* d_counts);
+int tsa_settled(rna_engine* e, int slot, const rna_astar_query* q, const rna_astar_result* r, int n, int32_t* d_counts);
 
 }  // namespace rna

@@ -276,13 +276,11 @@ def test_astar_paths_bit_identical(R, rows, cols, density, seed):
     e.close()
 
 
-@pytest.mark.parametrize("env", [{"RNA_ASTAR_KERNEL": "frontier"}, {"RNA_ASTAR_KERNEL": "persist"}, {"RNA_ASTAR_KERNEL": "async"},
-                                 {"RNA_TSA_QUERIES_PER_BLOCK": "2"}, {"RNA_TSA_QUERIES_PER_BLOCK": "4"}])
-def test_astar_opt_in_kernels_keep_the_contract(R, env):
-    """The default is the tile-synchronous kernel; the fallback frontier kernel, the persistent cross-CU scheduler,
-    the barrier-free variant and the several-queries-per-workgroup kernel are selected by environment variables
-    read when an engine first plans.  All of them must reproduce the oracle's paths, costs and settled counts, also
-    when the same engine is reused for a second, different batch (the lazy field reset)."""
+@pytest.mark.parametrize("env", [{"RNA_ASTAR_KERNEL": "frontier"}])
+def test_astar_fallback_kernel_keeps_the_contract(R, env):
+    """The default is the tile-synchronous kernel; the frontier kernel (the fallback for maps beyond 65 536 tiles) is
+    selected by an environment variable read when an engine first plans.  It must reproduce the oracle's paths, costs
+    and settled counts, also when the same engine is reused for a second, different batch."""
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -300,6 +298,38 @@ def test_astar_opt_in_kernels_keep_the_contract(R, env):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_astar_page_pool(R):
+    """The tile kernel hands search pages out on first touch.  (a) Reuse: the same engine serves batches whose
+    searches cover different parts of the map, back to back and through every pipeline stage -- the lazy reset must
+    return every page to 'unreached'.  (b) A share per query that is too small ends a search loudly with status 5 and
+    leaves the engine usable; queries that fit their share still match the oracle."""
+    e = R.Engine(320 * 0.05, 256 * 0.05, 0.05)
+    master = R.synth.obstacles_rect(e.rows, e.cols, density=0.25, seed=21, side=(3, 24))
+    e.upload(R.capi.LAYER_MASTER, master)
+    e.astar_pipeline_depth(2)
+    for seed in (1, 2, 3, 4, 5):
+        q = R.synth.astar_queries(24, master, e.rows, e.cols, seed=seed)
+        check_astar(R, e, master, q, e.ncell, max_queries=32)
+    # (b) 80 tiles in the map, 6 pages per query
+    e.astar_page_cap(6)
+    q = R.synth.astar_queries(48, master, e.rows, e.cols, seed=9)
+    res, paths = e.astar(q, e.ncell)
+    _, nbr = O.astar_masks(master, e.rows, e.cols)
+    n5 = 0
+    for k in range(len(q)):
+        ores, opath, _ = O.astar_query(nbr, e.rows, e.cols, q["start"][k], q["goal"][k])
+        if res["status"][k] == 5:
+            n5 += 1
+            continue
+        assert res["status"][k] == ores.status
+        if ores.status == 0:
+            assert res["cost"][k] == ores.cost and np.array_equal(paths[k, :ores.path_len], opath)
+    assert 0 < n5 < len(q)
+    e.astar_page_cap(0)
+    check_astar(R, e, master, q, e.ncell, max_queries=64)
+    e.close()
 
 
 class _Hip:
