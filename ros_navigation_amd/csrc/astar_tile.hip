@@ -666,13 +666,21 @@ struct TsaLaunch {
   int rev_cap;
   rna_astar_result* results;
 };
+constexpr int TSA_FOUND = -1000;        // provisional status between the search and the backtrace kernel
 
+// One workgroup of 16 wavefronts per query.  The kernel ends with the exact distance field in HBM and a provisional
+// result; the path is traced by tsa_backtrace_kernel (one wavefront per query, next kernel on the stream), which
+// needs none of this kernel's LDS and therefore overlaps with the searches of the other batches in flight.
+// (Several queries per workgroup -- the union of their active tiles as one job list per round -- was measured again
+// on the paged fields: wavefronts spend 83 % instead of 53 % of their life inside jobs, but four relaxing wavefronts
+// per SIMD already fill its VALU issue slots, every job gets slower by the same factor and the kernel needs 26 more
+// VGPRs, which starves the map-update kernels: 20.9 k / 18.0 k / 13.6 k cycles/s for 1 / 2 / 4 queries per workgroup.)
 __global__ void __launch_bounds__(TSA_THREADS) tsa_search_kernel(const TsaLaunch A) {
   __shared__ TsaWave s_w[TSA_WAVES];
   extern __shared__ unsigned s_dyn[];   // tile bitsets, sized by the launch: 2 x ((ntile + 31) / 32) words
   __shared__ unsigned short s_jobs[TSA_JOBS];
   __shared__ unsigned s_jobpg[TSA_JOBS];   // local page of each job's tile (looked up once per round by the list builders)
-  __shared__ int s_njobs, s_first_fail, s_job_next, s_best, s_state, s_bucket, s_bucket0, s_rounds, s_role, s_expanded, s_len, s_nalloc;
+  __shared__ int s_njobs, s_first_fail, s_job_next, s_best, s_state, s_bucket, s_bucket0, s_rounds, s_role, s_expanded, s_nalloc;
 
   // Workgroups take their query when they START (a ticket), not by blockIdx: the hardware deals workgroup
   // indices round-robin to the XCDs, so a fixed mapping lets one XCD with several long searches hold back
@@ -818,7 +826,7 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_search_kernel(const TsaLaunch
     for (;;) {
       int job = 0;
       if (lane == 0) job = atomicAdd(&s_job_next, 1);
-      job = __shfl(job, 0);
+      job = __builtin_amdgcn_readfirstlane(job);   // wave-uniform: the loop is a scalar branch
       if (job >= njobs) break;
       const int t = s_jobs[job];
       const unsigned pg = s_jobpg[job];
@@ -840,60 +848,116 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_search_kernel(const TsaLaunch
   // what the next launch on this stage has to reset
   if (tid == 0) A.S.nalloc[q] = s_nalloc < C.cap ? s_nalloc : C.cap;
 
-  const int state = s_state;
-  const int n_buckets = s_bucket - s_bucket0 + 1;
-  if (state != 1) {
-    if (tid == 0) results[q] = rna_astar_result{state >= 4 ? state : 1, 0, INF, s_expanded, s_rounds, n_buckets};
-    return;
+  // provisional result: the backtrace kernel (next on the stream) finishes the found ones
+  if (tid == 0) {
+    const int state = s_state;
+    results[q] = rna_astar_result{state == 1 ? TSA_FOUND : (state >= 4 ? state : 1), 0, state == 1 ? s_best : INF, s_expanded, s_rounds,
+                                  s_bucket - s_bucket0 + 1};
   }
+}
 
-  // ---- canonical backtrace by the first wavefront (lane k probes neighbour k) ----
+// Canonical backtrace, one wavefront per query: walk from the goal to the neighbour n with g[n] + w(n, c) == g[c],
+// lowest linear index first (lane k probes neighbour k).  The walk runs in LDS: the 32 x 32 tile of the current
+// cell plus its halo ring and the tile's neighbour masks are loaded once, then every step is one LDS round trip
+// until the path leaves the tile's interior -- a path of 2 000 cells is ~70 tile loads instead of 2 000 dependent
+// HBM round trips (which held a whole CU for 2-4 ms per query while the search kernel still did this itself).
+__global__ void __launch_bounds__(64) tsa_backtrace_kernel(const TsaLaunch A) {
+  __shared__ unsigned s_tile[TW * TW];
+  __shared__ unsigned char s_mask[TILE_WORDS];
+  const int q = blockIdx.x, lane = threadIdx.x;
+  const rna_astar_result r = A.results[q];
+  if (r.status != TSA_FOUND) return;
+  const int rows = A.rows, cols = A.cols, tiles_i = A.tiles_i, tiles_j = A.tiles_j;
+  const int ncell = rows * cols, ntile = tiles_i * tiles_j;
+  const unsigned* tmap = A.S.tmap + (size_t)q * ntile;
+  const size_t page_base = (size_t)q * A.S.cap;
+  const int start = tsa_unwrap_lin(A.queries[q].start, rows, cols, A.s0, A.s1);
+  const int goal = tsa_unwrap_lin(A.queries[q].goal, rows, cols, A.s0, A.s1);
+  const int si = start % rows, sj = start / rows;
+  int ci = goal % rows, cj = goal / rows;
   int* rev = A.rev_all + (size_t)q * A.rev_cap;
-  const int rev_cap = A.rev_cap;
-  if (tid < 64) {
-    int ci = gi, cj = gj;
-    int len = 0;
-    bool ok = true;
-    const int k = tid & 7;
-    const int w = (k == 1 || k == 3 || k == 4 || k == 6) ? COST_S : COST_D;
-    const int di = (k == 0 || k == 3 || k == 5) ? -1 : ((k == 2 || k == 4 || k == 7) ? 1 : 0);
-    const int dj = k < 3 ? -1 : (k > 4 ? 1 : 0);
-    for (;;) {
-      if (tid == 0 && len < rev_cap) rev[len] = cj * rows + ci;
-      ++len;
-      if (ci == si && cj == sj) break;
-      if (len > ncell) { ok = false; break; }
-      const int ni = ci + di, nj = cj + dj;
-      const bool inb = ni >= 0 && nj >= 0 && ni < rows && nj < cols;
-      // lane k: page of its neighbour's tile, lane 8: page of the current cell's tile (settled cells always have one)
-      const int li = (tid == 8 || !inb) ? ci : ni, lj = (tid == 8 || !inb) ? cj : nj;
-      unsigned lp = ld_l2(&C.tmap[tile_of(li, lj, tiles_i)]);
-      if (lp == TSA_BUSY) lp = 0u;
-      const unsigned wl = ld_l2(&C.pages[(C.gpage(lp) << 10) + in_page(li, lj)]);
-      const unsigned wc = (unsigned)__shfl((int)wl, 8);
-      const unsigned mc = C.nbr_tm[tm_index(ci, cj, tiles_i)];
-      const bool hit = tid < 8 && inb && ((mc >> k) & 1u) && ((wl >> 8) != G_INF) && ((wl >> 8) + (unsigned)w == (wc >> 8));
-      const unsigned long long mask = __ballot(hit);
-      if (!mask) { ok = false; break; }
-      const int src = __ffsll((long long)mask) - 1;
-      ci = __shfl(ni, src);
-      cj = __shfl(nj, src);
+  const int k = lane & 7;
+  const int wk = (k == 1 || k == 3 || k == 4 || k == 6) ? COST_S : COST_D;
+  const int di = (k == 0 || k == 3 || k == 5) ? -1 : ((k == 2 || k == 4 || k == 7) ? 1 : 0);
+  const int dj = k < 3 ? -1 : (k > 4 ? 1 : 0);
+  const int off = di + dj * TW;
+  int len = 0;
+  bool ok = true, done = false;
+  while (ok && !done) {
+    // ---- tile of the current cell + halo ring + masks -> LDS ----
+    const int ti = ci >> 5, tj = cj >> 5;
+    const int t = tj * tiles_i + ti;
+    unsigned pgl = 0u;   // lane k < 8: page of the neighbouring tile in direction k; lane 8: page of this tile
+    {
+      const int nti = lane < 8 ? ti + di : ti, ntj = lane < 8 ? tj + dj : tj;
+      if (lane < 9 && nti >= 0 && ntj >= 0 && nti < tiles_i && ntj < tiles_j) pgl = ld_l2(&tmap[ntj * tiles_i + nti]);
+      if (pgl == TSA_BUSY) pgl = 0u;
     }
-    if (tid == 0) s_len = ok ? len : -1;
+    auto page = [&](int src) -> const unsigned* {
+      const unsigned lp = (unsigned)__shfl((int)pgl, src);
+      return A.S.pages + ((lp ? page_base + lp : (size_t)0) << 10);
+    };
+    {
+      const int h = lane & 31;
+      const bool second = lane >= 32;
+      const unsigned* pcol = page(second ? 6 : 1);
+      const unsigned* prow = page(second ? 4 : 3);
+      const unsigned* pcor = page((lane & 2) ? ((lane & 1) ? 7 : 5) : ((lane & 1) ? 2 : 0));
+      const unsigned* pown = page(8);
+      const int cdi = (lane & 1) ? 1 : -1, cdj = (lane & 2) ? 1 : -1;
+      const unsigned hv_col = ld_l2(&pcol[((second ? 0 : 31) << 5) + h]);
+      const unsigned hv_row = ld_l2(&prow[(h << 5) + (second ? 0 : 31)]);
+      unsigned hv_cor = 0xFFFFFF00u;
+      if (lane < 4) hv_cor = ld_l2(&pcor[((cdj > 0 ? 0 : 31) << 5) + (cdi > 0 ? 0 : 31)]);
+      unsigned tv[TILE_WORDS / 64];
+#pragma unroll
+      for (int rr = 0; rr < TILE_WORDS / 64; ++rr) tv[rr] = ld_l2(&pown[rr * 64 + lane]);
+      const uint4 mv = *reinterpret_cast<const uint4*>(A.S.nbr_tm + ((size_t)t << 10) + lane * 16);
+      __builtin_amdgcn_wave_barrier();   // the previous tile's walk has finished reading the LDS image
+      s_tile[(second ? TS + 1 : 0) * TW + h + 1] = hv_col;
+      s_tile[(h + 1) * TW + (second ? TS + 1 : 0)] = hv_row;
+      if (lane < 4) s_tile[(cdj > 0 ? TS + 1 : 0) * TW + (cdi > 0 ? TS + 1 : 0)] = hv_cor;
+      unsigned* tp = &s_tile[((lane >> 5) + 1) * TW + (lane & 31) + 1];
+#pragma unroll
+      for (int rr = 0; rr < TILE_WORDS / 64; ++rr) tp[rr * 2 * TW] = tv[rr];
+      *reinterpret_cast<uint4*>(&s_mask[lane * 16]) = mv;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // ---- walk inside the tile ----
+    int il = ci & 31, jl = cj & 31;
+    unsigned gc = s_tile[(jl + 1) * TW + il + 1] >> 8;
+    for (;;) {
+      if (lane == 0 && len < A.rev_cap) rev[len] = cj * rows + ci;
+      ++len;
+      if (ci == si && cj == sj) { done = true; break; }
+      if (len > ncell || gc == G_INF) { ok = false; break; }
+      const unsigned mc = s_mask[jl * TS + il];
+      const unsigned gn = s_tile[(jl + 1) * TW + il + 1 + off] >> 8;
+      const bool hit = lane < 8 && ((mc >> k) & 1u) && gn != G_INF && gn + (unsigned)wk == gc;
+      const unsigned long long m = __ballot(hit);
+      if (!m) { ok = false; break; }
+      const int src = __ffsll((long long)m) - 1;
+      gc = (unsigned)__shfl((int)gn, src);
+      const int sdi = (src == 0 || src == 3 || src == 5) ? -1 : ((src == 2 || src == 4 || src == 7) ? 1 : 0);
+      const int sdj = src < 3 ? -1 : (src > 4 ? 1 : 0);
+      ci += sdi; cj += sdj; il += sdi; jl += sdj;
+      if (il < 0 || jl < 0 || il >= TS || jl >= TS) break;   // left the interior: load that tile
+    }
   }
-  __syncthreads();
-  const int len = s_len;
-  if (len < 0) {
-    if (tid == 0) results[q] = rna_astar_result{1, 0, INF, s_expanded, s_rounds, n_buckets};
+  if (!ok) {
+    if (lane == 0) A.results[q] = rna_astar_result{1, 0, INF, r.expanded, r.rounds, r.buckets};
     return;
   }
-  if (len > A.max_path_len || len > rev_cap) {
-    if (tid == 0) results[q] = rna_astar_result{3, len, s_best, s_expanded, s_rounds, n_buckets};
+  if (len > A.max_path_len || len > A.rev_cap) {
+    if (lane == 0) A.results[q] = rna_astar_result{3, len, r.cost, r.expanded, r.rounds, r.buckets};
     return;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
   int32_t* path = A.paths + (size_t)q * A.max_path_len;
-  for (int i = tid; i < len; i += TSA_THREADS) path[i] = tsa_buffer_lin(rev[len - 1 - i], rows, cols, A.s0, A.s1);
-  if (tid == 0) results[q] = rna_astar_result{0, len, s_best, s_expanded, s_rounds, n_buckets};
+  for (int i = lane; i < len; i += 64) path[i] = tsa_buffer_lin(rev[len - 1 - i], rows, cols, A.s0, A.s1);
+  if (lane == 0) A.results[q] = rna_astar_result{0, len, r.cost, r.expanded, r.rounds, r.buckets};
 }
 
 // |{n : g(n) + h(n) <= f*}| per query from the pages still resident in HBM (measurement utility)
@@ -999,6 +1063,7 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     A.queries = q_dev; A.S = S; A.bucket_width = a.bucket_width; A.paths = paths_dev; A.max_path_len = max_len;
     A.rev_all = a.rev[slot]; A.rev_cap = a.rev_cap; A.results = res_dev;
     hipLaunchKernelGGL(tsa_search_kernel, dim3(n), dim3(TSA_THREADS), 2 * nt_bytes, search_stream, A);
+    hipLaunchKernelGGL(tsa_backtrace_kernel, dim3(n), dim3(64), 0, search_stream, A);
     RNA_HIP(e, hipGetLastError());
   }
   return RNA_OK;
