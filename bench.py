@@ -6,36 +6,45 @@ One "step" = one pass of the hot path over one batch of synthetic input, all res
     -> VFH+ step for 256 robot poses -> grid A* for 256 (start, goal) queries.
 A "replan cycle" is one (pose -> VFH command, start/goal -> A* path) pair served against the map
 that has received its HIMM batch, so one step = 256 cycles with the ray batch amortised over them
-(SURVEY.md section 8d).  N > 1: one process per GPU, each with its own replicated grid and its own
-shard of poses/queries (weak scaling, no data-path collective); value = all ranks' cycles / max time.
+(SURVEY.md section 8d).  The steps rotate through ROTATE pre-generated ray batches, pose sets and
+query sets, so no step repeats its predecessor's input (HIMM clears really write, every A* batch is
+a different one).
+
+N > 1 (`--gpus N`): one process per GPU, each with its own replicated grid and its own shard of
+poses/queries (weak scaling, no data-path collective); value = all ranks' cycles / max time.  Started
+without torchrun, the parent spawns the N ranks itself (before anything touches a GPU) and exits with
+their status; under `torch.distributed.run` (RANK/WORLD_SIZE set) WORLD_SIZE must equal --gpus.
 
 Prints ONE JSON line on rank 0 (see the task contract) including
-  roofline:     dominant kernel (astar_search) algorithmic GB/s vs the 8 TB/s HBM peak
-  cpu_baseline: the CPU oracle ("port") timed on a bounded sample of the same workload, 1 core
+  roofline:      dominant kernel (astar_search) algorithmic GB/s vs the 8 TB/s HBM peak
+  roofline_rows: the same for himm_raster and vfh_step, from the same run
+  cpu_baseline:  the CPU oracle ("port") timed on a bounded sample of the same workload
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 # pipelined A* batches run on several HIP streams; give the runtime enough hardware queues
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 ASTAR_BYTES_PER_SETTLED = 44   # SURVEY.md 8d: 8 neighbour occupancy reads x 4 B + 12 B g/parent/flag RMW
+VFH_BYTES_PER_POSE = 4 * 31 * 31 + 2 * 72 * 4 + 32   # SURVEY.md 8d
+ROTATE = int(os.environ.get("RNA_BENCH_ROTATE", "4"))   # distinct ray batches / pose sets / query sets the steps cycle through (developer override)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default: about 2 s on one MI355X)")
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--grid", type=int, default=4096)
     ap.add_argument("--queries", type=int, default=256, help="A* queries == VFH poses per step (cycles per step)")
     ap.add_argument("--ray-poses", type=int, default=64)
@@ -43,10 +52,11 @@ def parse():
     ap.add_argument("--bucket-width", type=int, default=0)
     ap.add_argument("--queue-capacity", type=int, default=0)
     ap.add_argument("--max-path", type=int, default=32768)
-    ap.add_argument("--pipeline", type=int, default=4,
-                    help="A* batches in flight (rna_astar_set_pipeline_depth).  Measured 4: 24.9k, 6: 25.5k, 8: 23.8k cycles/s; "
-                         "the default stays at 4 because every launch is stretched by the ones it overlaps with, and the "
-                         "roofline line divides by that per-launch duration (6 in flight: 44 ms per launch instead of 36.5)")
+    ap.add_argument("--pipeline", type=int, default=6,
+                    help="A* batches in flight (rna_astar_set_pipeline_depth).  With rotating query sets the batches' tails "
+                         "differ and four stages leave CUs idle (measured 4: 17.4k, 6: 25.4k, 8: 25.0k cycles/s).  Every "
+                         "launch is stretched by the ones it overlaps with, and the roofline line divides by that "
+                         "per-launch duration")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--tiled-full-gather", action="store_true", help="--tiled: all-gather whole windows instead of dirty tiles")
@@ -56,8 +66,33 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """`--gpus N` without a launcher: start the N ranks as fresh child processes (this process has not touched a GPU
+    and never will) and exit with their status."""
+    share = os.environ.get("RNA_BENCH_SHARE_GPU") == "1"
+    if not share:
+        import torch   # device_count() does not initialise the GPU on this image
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    raise SystemExit(rc)
+
+
 def cpu_baseline(args, R, master, rays, poses, queries, rows, cols, length):
     """Oracle (CPU restatement of the reference path) on a bounded sample: 1 thread, then one thread per host core."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
     g = O.make_geom(length, length, 0.05)
@@ -104,23 +139,40 @@ def cpu_baseline(args, R, master, rays, poses, queries, rows, cols, length):
     per_cycle = t_himm / len(queries) + t_vfh + t_mt
     return {"value": 1.0 / per_cycle, "unit": "replan cycles/s", "cores": cores, "kind": "port",
             "value_1core": 1.0 / per_cycle_1,
-            "sample": "oracle (C, -O2): full %d-ray HIMM batch + compose (1 thread, %.3f s, amortised over %d cycles), "
-                      "%d VFH+ poses (%.1f us each on one core), A*: first %d queries on 1 thread (%.3f s each, %.0f cells "
-                      "settled each) and first %d queries on %d threads (%.4f s per query wall)"
-                      % (len(rays), t_himm, len(queries), n_vfh, t_vfh * 1e6, n_a, t_a / n_a, settled / n_a, n_mt, cores, t_mt)}
+            "sample": "oracle (C, -O2) on the first of the %d rotating input sets: full %d-ray HIMM batch + compose (1 thread, "
+                      "%.3f s, amortised over %d cycles), %d VFH+ poses (%.1f us each on one core), A*: first %d queries on 1 "
+                      "thread (%.3f s each, %.0f cells settled each) and first %d queries on %d threads (%.4f s per query wall)"
+                      % (ROTATE, len(rays), t_himm, len(queries), n_vfh, t_vfh * 1e6, n_a, t_a / n_a, settled / n_a, n_mt,
+                         cores, t_mt)}
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (None when absent)."""
+def pmc_traffic(kernel, args, world):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes, as the range [TCC_EA0 requests x 64 B,
+    reads doubled] (MI355X_MICROARCH.md: FETCH_SIZE reports half of the bytes of 16 B/lane streaming reads; this
+    kernel's dword accesses are uncalibrated).  None unless the passes were taken on this very configuration."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+        with open(PMC_SUMMARY) as f:
+            d = json.load(f)
+        c = d["config"]
+        if (c["grid"], c["queries"], c["pipeline"], c["ray_poses"], c["rays_per_pose"]) != \
+                (args.grid, args.queries, args.pipeline, args.ray_poses, args.rays_per_pose) or world != 1 or args.tiled:
+            return None, "PMC passes in profiles/ were taken on another configuration"
+        k = d["kernels"][kernel]
+        lo = (k["fetch_size_kb_avg"] + k["write_size_kb_avg"]) * 1024.0
+        hi = (2.0 * k["fetch_size_kb_avg"] + k["write_size_kb_avg"]) * 1024.0
+        return [lo, hi], "profiles/r02_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " \
+                         "[(FETCH+WRITE), (2*FETCH+WRITE)] x 1024 B per launch"
     except Exception:
-        return None
+        return None, "no PMC summary committed for this kernel"
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
+    import numpy as np
     import torch
     from ros_navigation_amd import capi as _capi
     if os.environ.get("RNA_LIB"):  # developer switch: alternative build of librna.so
@@ -128,6 +180,9 @@ def main():
     import ros_navigation_amd as R
     from ros_navigation_amd import dist as D
     rank, local_rank, world = D.env_rank_world()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d or drop the launcher)"
+                         % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
     # developer switch: RNA_BENCH_SHARE_GPU=1 runs every rank on cuda:0 with a gloo barrier, to exercise the
@@ -135,6 +190,8 @@ def main():
     share = os.environ.get("RNA_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -148,34 +205,50 @@ def main():
     master0 = R.synth.obstacles_rect(n, n, density=0.30, seed=2)
     e.upload(R.capi.LAYER_LASER, master0)
     e.compose_master(1)
-    rays = R.synth.rays(args.ray_poses, args.rays_per_pose, length, length, seed=4)  # same batch on every replica
-    # untimed setup: the map receives the ray batch once, so that the (start, goal) pairs are drawn
-    # from cells that stay free while the same batch is re-applied every step (ray end points are
-    # marked as obstacles by HIMM; a query ending on one would be a trivial "no path")
-    e.update_map(rays, compose_mode=0)
+    # ROTATE ray batches (different origins and bearings; the same on every replica).  Untimed setup: the map receives
+    # every batch a few times, so that the (start, goal) pairs are drawn from cells of the map the timed steps work on
+    ray_sets = [R.synth.rays(args.ray_poses, args.rays_per_pose, length, length, seed=4 + k) for k in range(ROTATE)]
+    for _ in range(3):
+        for rays in ray_sets:
+            e.update_map(rays, compose_mode=0)
     master = e.download(R.capi.LAYER_MASTER)
+    # cells a ray of any batch ends on are marked and cleared over and over: keep query end points off them
+    avoid = master.copy()
+    for rays in ray_sets:
+        for x, y in ((rays["ex"], rays["ey"]), (rays["sx"], rays["sy"])):
+            i = np.floor((length / 2 - x) / 0.05).astype(np.int64)
+            j = np.floor((length / 2 - y) / 0.05).astype(np.int64)
+            ok = (i >= 1) & (j >= 1) & (i < n - 1) & (j < n - 1)
+            for di in (-1, 0, 1):
+                for dj in (-1, 0, 1):
+                    avoid[(j[ok] + dj) * n + i[ok] + di] = 180.0
     # weak scaling: the global batch holds `queries` cycles per GPU; each rank serves its own shard
     lo, hi = D.shard_bounds(args.queries * world, rank, world)
-    poses = R.synth.poses(args.queries * world, length, length, seed=1)[lo:hi]
+    nq = hi - lo
+    pose_sets = [R.synth.poses(args.queries * world, length, length, seed=1 + k)[lo:hi] for k in range(ROTATE)]
     layout = halo = None
     if args.tiled:
         # one map, one window per GPU: a pose is served by the GPU that owns its cell
         layout = D.TileLayout.for_world(n, n, world)
         halo = D.vfh_halo(0.05)
         e.himm_set_window(*[layout.window(rank)[k] for k in (0, 2, 1, 3)])
-        cand = R.synth.poses(args.queries * world * 4, length, length, seed=1)
-        idx = np.array([e.get_index(p["x"], p["y"]) for p in cand])
-        poses = cand[layout.owner(idx[:, 0], idx[:, 1]) == rank][:hi - lo].copy()
-        assert len(poses) == hi - lo, "not enough synthetic poses inside this rank's window"
-    queries = R.synth.astar_queries(args.queries * world, master, n, n, seed=2)[lo:hi]
-    nq = hi - lo
+        pose_sets = []
+        for k in range(ROTATE):
+            cand = R.synth.poses(args.queries * world * 4, length, length, seed=1 + k)
+            idx = np.array([e.get_index(p["x"], p["y"]) for p in cand])
+            own = cand[layout.owner(idx[:, 0], idx[:, 1]) == rank][:nq].copy()
+            assert len(own) == nq, "not enough synthetic poses inside this rank's window"
+            pose_sets.append(own)
+    query_sets = [R.synth.astar_queries(args.queries * world, avoid, n, n, seed=2 + k)[lo:hi] for k in range(ROTATE)]
 
     dev = torch.device("cuda", local_rank)
 
     def to_dev(a):
         return torch.from_numpy(np.frombuffer(a.tobytes(), dtype=np.uint8).copy()).to(dev)
 
-    d_rays, d_poses, d_queries = to_dev(rays), to_dev(poses), to_dev(queries)
+    d_rays = [to_dev(r) for r in ray_sets]
+    d_poses = [to_dev(p) for p in pose_sets]
+    d_queries = [to_dev(q) for q in query_sets]
     d_vfh_out = torch.zeros(nq * R.capi.VFH_OUT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     # one output set per batch that may be in flight (pipelined searches write them asynchronously)
     d_paths = [torch.zeros(nq * args.max_path, dtype=torch.int32, device=dev) for _ in range(args.pipeline)]
@@ -190,32 +263,44 @@ def main():
 
     def step():
         b = step_no[0] % args.pipeline
+        k = step_no[0] % ROTATE
         step_no[0] += 1
-        e.update_map_device(d_rays.data_ptr(), len(rays), compose_mode=0)
+        e.update_map_device(d_rays[k].data_ptr(), len(ray_sets[k]), compose_mode=0)
         if layout is not None and world > 1:
             xfer[0] += D.exchange_halo(e, R.capi.LAYER_MASTER, layout, rank, halo, dist, tracked=not args.tiled_full_gather)
-        e.vfh_step_device(d_poses.data_ptr(), nq, d_vfh_out.data_ptr())
+        e.vfh_step_device(d_poses[k].data_ptr(), nq, d_vfh_out.data_ptr())
         if layout is not None and world > 1:
             if args.tiled_full_gather:
                 xfer[1] += D.gather_layer(e, R.capi.LAYER_MASTER, layout, rank, dist)
             else:   # only the 64 x 64 tiles this update changed travel; their neighbour masks are refreshed, not all
                 xfer[1] += D.gather_dirty(e, (R.capi.LAYER_LASER, R.capi.LAYER_MASTER), layout, rank, dist)
                 e.compose_master(0)
-        e.astar_device(d_queries.data_ptr(), nq, d_paths[b].data_ptr(), args.max_path, d_results[b].data_ptr())
+        e.astar_device(d_queries[k].data_ptr(), nq, d_paths[b].data_ptr(), args.max_path, d_results[b].data_ptr())
         return b
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    last = 0
+    def check_results(what):
+        """every result buffer that may hold a batch: all queries answered (0 found / 1 no path), nothing else"""
+        found = answered = total = 0
+        for buf in d_results[:min(args.pipeline, step_no[0])]:
+            st = buf.cpu().numpy().reshape(nq, 6)[:, 0]
+            bad = sorted(set(st[(st != 0) & (st != 1)].tolist()))
+            if bad:
+                raise SystemExit("A* batch did not complete %s: statuses %s (3 = path buffer too small, 4 = cost beyond 24 bits, "
+                                 "5 = search pages used up, < 0 = frontier queue overflow)" % (what, bad))
+            found += int((st == 0).sum())
+            answered += int(((st == 0) | (st == 1)).sum())
+            total += nq
+        return found, answered, total
+
     for _ in range(args.warmup):
-        last = step()
+        step()
     e.synchronize()
     torch.cuda.synchronize()
-    res = d_results[last].cpu().numpy().reshape(nq, 6)
-    if (res[:, 0] < 0).any():
-        raise SystemExit("A* frontier queue overflow during warm-up: pass a larger --queue-capacity")
+    check_results("during warm-up")
 
     e.profile(True)
     e.profile_reset()
@@ -224,27 +309,42 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        last = step()
+        step()
     e.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
     prof = e.profile_get()
     e.profile(False)
+    found, answered, total = check_results("in the timed region")
 
-    res = d_results[last].cpu().numpy().reshape(nq, 6)
-    found = int((res[:, 0] == 0).sum())
-    if (res[:, 0] < 0).any() or (res[:, 0] == 3).any():
-        raise SystemExit("A* batch did not complete (status %s)" % sorted(set(res[:, 0].tolist())))
-    settled = e.astar_settled(nq)          # E per query of the last launch, from the resident g fields
+    # E per query set (settled cells, from the pages still resident after a launch), on the map as the timed region left it
+    settled_sets = []
+    for k in range(ROTATE):
+        e.astar_device(d_queries[k].data_ptr(), nq, d_paths[0].data_ptr(), args.max_path, d_results[0].data_ptr())
+        e.synchronize()
+        settled_sets.append(float(e.astar_settled(nq).astype(np.int64).sum()))
+    settled_per_launch = float(np.mean(settled_sets))
 
     t_max = D.max_over_ranks(elapsed, "cpu" if share else dev) if world > 1 else elapsed
 
     if rank == 0:
         cycles = args.queries * world * args.steps
         ms_search = prof["astar_search"][0] / max(1, prof["astar_search"][1])
-        alg_bytes = float(settled.astype(np.int64).sum()) * ASTAR_BYTES_PER_SETTLED
+        alg_bytes = settled_per_launch * ASTAR_BYTES_PER_SETTLED
         achieved = alg_bytes / (ms_search * 1e-3) / 1e9 if ms_search > 0 else 0.0
+        traffic, traffic_src = pmc_traffic("tsa_search_kernel", args, world)
+
+        def row(kernel_key, pmc_name, alg):
+            ms = prof[kernel_key][0] / max(1, prof[kernel_key][1])
+            gbs = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            tr, src = pmc_traffic(pmc_name, args, world)
+            return {"kernel": pmc_name, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                    "traffic": tr, "traffic_source": src, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms,
+                    "launches": prof[kernel_key][1]}
+
+        himm_alg = float(np.mean([(8.0 * np.hypot(r["ex"] - r["sx"], r["ey"] - r["sy"]) / 0.05 + 8.0 * (r["clear_end"] == 0) + 40.0).sum()
+                                  for r in ray_sets]))
         out = {
             "metric": "replan cycles/sec (HIMM+VFH++A*) on %dx%d grid" % (n, n),
             "value": cycles / t_max, "unit": "replan cycles/s", "n_gpus": world, "steps": args.steps,
@@ -252,22 +352,26 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "full replan loop on %dx%d f32 grid (res 0.05 m): %d-ray HIMM batch + fused "
                                    "compose -> %d VFH+ poses -> %d grid-A* queries per step; 30%% rectangle "
-                                   "obstacles (seed 2)" % (n, n, len(rays), nq, nq),
-                       "cycles_per_step": nq, "rays_per_step": int(len(rays)), "astar_paths_found": found,
+                                   "obstacles (seed 2); %d ray batches / pose sets / query sets in rotation"
+                                   % (n, n, len(ray_sets[0]), nq, nq, ROTATE),
+                       "cycles_per_step": nq, "rays_per_step": int(len(ray_sets[0])), "rotating_input_sets": ROTATE,
+                       "astar_queries_checked": total, "astar_queries_answered": answered, "astar_paths_found": found,
                        "astar_bucket_width": args.bucket_width or 16000, "astar_pipeline_depth": args.pipeline,
+                       "timed_seconds": t_max,
                        "parallelism": ("query-sharded x%d" % world) if layout is None else
                                       ("one map tiled %d x %d (windowed HIMM, %d-cell halo exchange, all-gather of owner "
                                        "windows), A* query-sharded x%d" % (layout.ti, layout.tj, halo, world))},
             "roofline": {"bound": "hbm", "kernel": "tsa_search_kernel (astar_search)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("rna::tsa_search_kernel<false>"),
-                         "traffic_source": "profiles/r01_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                           "of this command (2*FETCH+WRITE)*1024 B per launch, see MI355X_MICROARCH.md",
-                         "algorithmic_bytes_per_launch": alg_bytes, "settled_cells_per_launch": int(settled.sum()),
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg_bytes, "settled_cells_per_launch": settled_per_launch,
+                         "settled_cells_by_query_set": settled_sets,
                          "avg_launch_ms": ms_search, "launches": prof["astar_search"][1],
                          # pipelined launches overlap on the GPU: each one's duration is stretched by the others, so
                          # the whole-step figure (algorithmic bytes of one launch / wall time of one step) is given too
                          "overlapped_launches": ms_search / (1e3 * t_max / args.steps),
                          "achieved_per_step_wall": alg_bytes / (t_max / args.steps) / 1e9},
+            "roofline_rows": [row("himm_raster", "himm_raster_kernel", himm_alg),
+                              row("vfh_step", "vfh_step_kernel", float(nq * VFH_BYTES_PER_POSE))],
             "kernel_ms_per_step": {k: (v[0] / args.steps) for k, v in prof.items() if v[1]},
         }
         if layout is not None:
@@ -275,7 +379,7 @@ def main():
                             "halo_bytes_per_step_rank0": xfer[0] / args.steps,
                             "gather_bytes_per_step_rank0": xfer[1] / args.steps}
         if not args.no_cpu and world == 1:   # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args, R, master, rays, poses, queries, n, n, length)
+            out["cpu_baseline"] = cpu_baseline(args, R, master, ray_sets[0], pose_sets[0], query_sets[0], n, n, length)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -26,6 +26,14 @@ float og_himm_mark(float v) {
   return v;
 }
 
+/* A ray with a non-finite coordinate, or longer than 2^20 cells, makes the reference's clipping march
+ * (LineIterator.cpp:92-104) spin forever / for minutes.  Defined (here and in csrc/himm.hip): dropped whole. */
+int og_ray_well_formed(const og_geom* g, const og_ray* r) {
+  if (!(isfinite(r->sx) && isfinite(r->sy) && isfinite(r->ex) && isfinite(r->ey))) return 0;
+  double vx = r->ex - r->sx, vy = r->ey - r->sy;
+  return sqrt(vx * vx + vy * vy) <= 1048576.0 * g->res;
+}
+
 /* map_updater.h:38-50 (lineOnMap) for each buffered sample in order (laser_map_updater.cpp:14-20) */
 void og_himm_update(const og_geom* g, float* layer, const og_ray* rays, int n, double bbox[4]) {
   int cap = 2 * (g->size[0] + g->size[1]) + 8;
@@ -33,6 +41,7 @@ void og_himm_update(const og_geom* g, float* layer, const og_ray* rays, int n, d
   size_t rows = (size_t)g->size[0];
   for (int r = 0; r < n; ++r) {
     double s[2] = { rays[r].sx, rays[r].sy }, e[2] = { rays[r].ex, rays[r].ey };
+    if (!og_ray_well_formed(g, &rays[r])) continue;
     int nc = og_line_cells(g, s, e, cells, cap);
     for (int k = 0; k < nc; ++k) {
       float* c = &layer[(size_t)cells[2 * k + 1] * rows + (size_t)cells[2 * k]];

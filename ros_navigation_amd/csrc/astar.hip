@@ -362,7 +362,14 @@ int ensure_config(rna_engine* e) {
       if ((rc = dev_alloc(e, &a.queues[d], (size_t)3 * a.queue_cap * a.max_queries)) != RNA_OK) { astar_release(e); return rc; }
     }
     if (a.depth > 1) {
-      RNA_HIP(e, hipStreamCreateWithFlags(&a.side[d], hipStreamNonBlocking));
+      {
+        // searches run at the lowest queue priority, the engine stream (map update, VFH+, field reset) at the highest:
+        // its short kernels gate the next search launch and must not queue behind 1000 waiting search workgroups
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (getenv("RNA_NO_STREAM_PRIORITY")) prio_lo = prio_hi = 0;
+        RNA_HIP(e, hipStreamCreateWithPriority(&a.side[d], hipStreamNonBlocking, prio_lo));
+      }
       RNA_HIP(e, hipEventCreateWithFlags(&a.done[d], hipEventDisableTiming));
     }
     a.busy[d] = false;

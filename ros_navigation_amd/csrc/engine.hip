@@ -218,7 +218,12 @@ extern "C" int rna_create(rna_engine** out, double length_x, double length_y, do
   int rc = RNA_OK;
   auto bail = [&](int code) { rna_destroy(e); return code; };
   if (hipSetDevice(device_id) != hipSuccess) return bail(RNA_EHIP);
-  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(RNA_EHIP);
+  {
+    int prio_lo = 0, prio_hi = 0;   // numerically lower = higher priority
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (getenv("RNA_NO_STREAM_PRIORITY")) prio_lo = prio_hi = 0;
+    if (hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return bail(RNA_EHIP);
+  }
   for (int l = 0; l < RNA_NUM_LAYERS; ++l) {
     if ((rc = dev_alloc(e, &e->layer[l], e->ncell)) != RNA_OK) return bail(rc);
     // GridMap::setGeometry -> clearAll(): every layer starts as NaN (gmc/src/GridMap.cpp:62)
@@ -268,7 +273,9 @@ extern "C" int rna_get_geometry(const rna_engine* e, rna_geometry* o) {
 }
 
 static void layer_changed(rna_engine* e, int layer) {
-  if (layer == RNA_LAYER_MASTER) e->nbr_all_dirty = true;
+  // master written directly (upload, fill, fromOccupancyGrid, a caller's device pointer): it no longer equals laser
+  // outside the dirty tiles, so the next compose has to be the reference's whole-layer copy (map_provider.cpp:221)
+  if (layer == RNA_LAYER_MASTER) { e->nbr_all_dirty = true; e->master_diverged = true; }
   if (layer == RNA_LAYER_LASER) e->laser_all_dirty = true;
 }
 
@@ -550,7 +557,7 @@ extern "C" int rna_compose_master(rna_engine* e, int mode) {
   if (!e || (mode != 0 && mode != 1)) return RNA_EINVAL;
   RNA_HIP(e, hipSetDevice(e->device));
   const size_t words = ((size_t)e->tiles_i * e->tiles_j + 3) / 4;  // one byte per tile, rounded to words
-  const bool full = (mode == 1) || e->laser_all_dirty;
+  const bool full = (mode == 1) || e->laser_all_dirty || e->master_diverged;
   {
     KernelTimer kt(e, RNA_K_COMPOSE);
     if (full) {
@@ -563,8 +570,8 @@ extern "C" int rna_compose_master(rna_engine* e, int mode) {
       RNA_HIP(e, hipGetLastError());
     }
   }
-  if (e->laser_all_dirty) {
-    // the laser layer was replaced wholesale: nothing is known about which masks are still valid
+  if (e->laser_all_dirty || e->master_diverged) {
+    // a layer was replaced wholesale: nothing is known about which masks are still valid
     e->nbr_all_dirty = true;
   } else if (e->geom.start[0] != 0 || e->geom.start[1] != 0) {
     e->nbr_all_dirty = true;   // moved map: dirty tiles (buffer space) do not line up with mask tiles (map space)
@@ -584,6 +591,7 @@ extern "C" int rna_compose_master(rna_engine* e, int mode) {
   }
   RNA_HIP(e, hipMemsetAsync(e->dirty_tiles, 0, words * sizeof(unsigned), e->stream));
   e->laser_all_dirty = false;
+  e->master_diverged = false;
   return RNA_OK;
 }
 

@@ -108,6 +108,7 @@ struct rna_engine {
   int32_t* tile_list = nullptr;      // staging for rna_layer_pack_tiles / rna_layers_unpack_tiles
   int tile_list_cap = 0;
   bool laser_all_dirty = false;      // laser uploaded/filled: next compose is a whole-layer copy
+  bool master_diverged = false;      // master written directly: next compose is a whole-layer copy
   uint8_t* nbr = nullptr;            // A* neighbour masks derived from master
   bool nbr_all_dirty = true;
   rna::HimmScratch himm;

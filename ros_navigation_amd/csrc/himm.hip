@@ -52,6 +52,17 @@ __device__ __forceinline__ unsigned hash_cell(unsigned c) {
   return c;
 }
 
+// A ray the reference could not digest either: a non-finite coordinate makes its clipping march
+// (LineIterator.cpp:92-104) spin forever, a start millions of cells away makes it spin for minutes.  Defined here
+// and in oracle/himm.c: such a ray is dropped whole (no clears, no mark).  HIMM_MAX_RAY_CELLS cells is 52 km at
+// the reference's 0.05 m resolution; the march below needs at most length / step + 1 iterations.
+constexpr double HIMM_MAX_RAY_CELLS = 1048576.0;
+__device__ __forceinline__ bool ray_well_formed(const Geom& g, const rna_ray& r) {
+  if (!(isfinite(r.sx) && isfinite(r.sy) && isfinite(r.ex) && isfinite(r.ey))) return false;
+  const double vx = r.ex - r.sx, vy = r.ey - r.sy;
+  return sqrt(vx * vx + vy * vy) <= HIMM_MAX_RAY_CELLS * g.res;
+}
+
 // LineIterator::getIndexLimitedToMapRange (LineIterator.cpp:92-104): march `start` towards `end`
 // in (res - eps) steps until it is inside the map.
 __device__ bool index_limited_to_map(const Geom& g, double sx, double sy, double ex, double ey, int idx[2]) {
@@ -84,6 +95,11 @@ __global__ void himm_prep_kernel(Geom g, const rna_ray* __restrict__ rays, int n
   const rna_ray ray = rays[r];
   int s[2], t[2];
   int nc = 0;
+  if (!ray_well_formed(g, ray)) {
+    ncells[r] = 0;
+    next[r] = -1;
+    return;
+  }
   if (index_limited_to_map(g, ray.sx, ray.sy, ray.ex, ray.ey, s) &&
       index_limited_to_map(g, ray.ex, ray.ey, ray.sx, ray.sy, t)) {
     const int dx = abs(t[0] - s[0]), dy = abs(t[1] - s[1]);
@@ -182,7 +198,7 @@ __global__ void himm_raster_kernel(int rows, const int4* __restrict__ desc, cons
     if (i < win.x || i >= win.y || j < win.z || j >= win.w) continue;
     const int cell = j * rows + i;
     const int tile = (j >> 6) * tiles_i + (i >> 6);
-    if (tile != last_tile) {
+    if (tile != last_tile && dirty_tiles) {   // flags exist for the laser layer only: "laser differs from master here"
       // one byte per tile, plain load + plain store of the same value by every first toucher: no
       // atomics (a bit-packed atomicOr here serialised the whole batch on four cache lines)
       volatile unsigned char* flag = reinterpret_cast<volatile unsigned char*>(dirty_tiles) + tile;
@@ -234,7 +250,7 @@ __global__ void himm_apply_kernel(int rows, const HimmSlot* __restrict__ slots, 
   atomicAnd(&mark_bitmap[sl.cell >> 5], ~(1u << (sl.cell & 31)));  // leave the bitmap all-zero
   const int i = sl.cell % rows, j = sl.cell / rows;
   const int tile = (j >> 6) * tiles_i + (i >> 6);
-  reinterpret_cast<volatile unsigned char*>(dirty_tiles)[tile] = 1;
+  if (dirty_tiles) reinterpret_cast<volatile unsigned char*>(dirty_tiles)[tile] = 1;
 }
 
 int ensure_scratch(rna_engine* e, int n) {
@@ -250,15 +266,19 @@ int ensure_scratch(rna_engine* e, int n) {
   int cap = 1024;
   while (cap < n) cap <<= 1;
   RNA_HIP(e, hipStreamSynchronize(e->stream));
-  if ((rc = dev_alloc(e, &s.rays_dev, (size_t)cap)) != RNA_OK) return rc;
-  if ((rc = dev_alloc(e, &s.desc, (size_t)cap)) != RNA_OK) return rc;
-  if ((rc = dev_alloc(e, &s.ncells, (size_t)cap)) != RNA_OK) return rc;
-  if ((rc = dev_alloc(e, &s.next, (size_t)cap)) != RNA_OK) return rc;
-  if ((rc = dev_alloc(e, &s.seqs, (size_t)cap)) != RNA_OK) return rc;
-  if ((rc = dev_alloc(e, &s.before, (size_t)cap)) != RNA_OK) return rc;
-  if ((rc = dev_alloc(e, &s.after, (size_t)cap)) != RNA_OK) return rc;
+  // a failed regrow leaves no half-sized scratch behind: the next call starts from nothing again
+  s.cap_rays = 0;
+  s.n_slots = 0;
+  if ((rc = dev_alloc(e, &s.rays_dev, (size_t)cap)) != RNA_OK || (rc = dev_alloc(e, &s.desc, (size_t)cap)) != RNA_OK ||
+      (rc = dev_alloc(e, &s.ncells, (size_t)cap)) != RNA_OK || (rc = dev_alloc(e, &s.next, (size_t)cap)) != RNA_OK ||
+      (rc = dev_alloc(e, &s.seqs, (size_t)cap)) != RNA_OK || (rc = dev_alloc(e, &s.before, (size_t)cap)) != RNA_OK ||
+      (rc = dev_alloc(e, &s.after, (size_t)cap)) != RNA_OK || (rc = dev_alloc(e, &s.slots, (size_t)cap * 2)) != RNA_OK) {
+    const std::string why = e->err;
+    (void)himm_release(e);
+    e->err = why;
+    return rc;
+  }
   s.n_slots = cap * 2;
-  if ((rc = dev_alloc(e, &s.slots, (size_t)s.n_slots)) != RNA_OK) return rc;
   s.cap_rays = cap;
   return RNA_OK;
 }
@@ -287,16 +307,16 @@ int himm_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n) {
     const long long threads = (long long)n * LANES_PER_RAY;
     hipLaunchKernelGGL(himm_raster_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream,
                        g.size[0], s.desc, s.ncells, n, e->layer[layer], s.mark_bitmap, s.slots, n_slots - 1,
-                       s.seqs, s.before, s.after, e->dirty_tiles, e->tiles_i, win);
+                       s.seqs, s.before, s.after, layer == RNA_LAYER_LASER ? e->dirty_tiles : nullptr, e->tiles_i, win);
     RNA_HIP(e, hipGetLastError());
   }
   {
     KernelTimer kt(e, RNA_K_HIMM_APPLY);
     hipLaunchKernelGGL(himm_apply_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, e->stream, g.size[0], s.slots,
-                       n_slots, s.before, s.after, e->layer[layer], s.mark_bitmap, e->dirty_tiles, e->tiles_i);
+                       n_slots, s.before, s.after, e->layer[layer], s.mark_bitmap, layer == RNA_LAYER_LASER ? e->dirty_tiles : nullptr, e->tiles_i);
     RNA_HIP(e, hipGetLastError());
   }
-  if (layer == RNA_LAYER_MASTER) e->nbr_all_dirty = true;
+  if (layer == RNA_LAYER_MASTER) { e->nbr_all_dirty = true; e->master_diverged = true; }
   return RNA_OK;
 }
 

@@ -103,7 +103,7 @@ extern "C" int rna_from_occupancy_grid(rna_engine* e, int layer, const int8_t* d
   if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
   dev_free(&d);
   if (st != hipSuccess) return fail(e, RNA_EHIP, hipGetErrorString(st));
-  if (layer == RNA_LAYER_MASTER) e->nbr_all_dirty = true;
+  if (layer == RNA_LAYER_MASTER) { e->nbr_all_dirty = true; e->master_diverged = true; }
   if (layer == RNA_LAYER_LASER) e->laser_all_dirty = true;
   return RNA_OK;
 }

@@ -8,25 +8,52 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--grid", "512", "--queries", "32", "--steps", "5", "--warmup", "2", "--ray-poses", "8", "--rays-per-pose", "200"]
 
 
-def test_bench_line_contract_on_a_small_grid():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--grid", "512", "--queries", "32", "--steps", "3",
-                          "--warmup", "2", "--ray-poses", "8", "--rays-per-pose", "200", "--cpu-seconds", "0.5"],
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+def run_bench(extra, env=None):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + extra, capture_output=True, text=True,
+                         timeout=600, cwd=ROOT, env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract_on_a_small_grid():
+    d = run_bench(["--cpu-seconds", "0.5"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "roofline_rows", "cpu_baseline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
-    assert d["value"] > 0 and abs(d["value"] - 32 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert d["value"] > 0 and abs(d["value"] - 32 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert r["achieved"] > 0 and r["launches"] == 3
+    assert r["achieved"] > 0 and r["launches"] == 5
+    assert r["traffic"] is None      # the committed PMC passes belong to the default configuration, not to this one
+    rows = {x["kernel"]: x for x in d["roofline_rows"]}
+    assert set(rows) == {"himm_raster_kernel", "vfh_step_kernel"}
+    for x in rows.values():
+        assert x["achieved"] > 0 and x["launches"] == 5 and abs(x["frac"] - x["achieved"] / 8000.0) < 1e-12
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
-    assert d["config"]["astar_paths_found"] == 32      # every query of the batch was served
+    cfg = d["config"]
+    # every query of every batch still in a result buffer was answered (found / no path), none failed
+    assert cfg["astar_queries_checked"] == 32 * 4 and cfg["astar_queries_answered"] == cfg["astar_queries_checked"]
+    assert cfg["astar_paths_found"] > 0 and cfg["rotating_input_sets"] == 4
+
+
+def test_bench_gpus_2_spawns_two_ranks():
+    """`--gpus 2` without a launcher: the parent starts both ranks itself (here on the one GPU of the test box, gloo
+    barrier) and rank 0 reports n_gpus == 2 with both ranks' cycles in `value`."""
+    d = run_bench(["--gpus", "2", "--no-cpu"], env={"RNA_BENCH_SHARE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["cpu_baseline"] is None
+    assert abs(d["value"] - 2 * 32 * 5 / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]
+    assert "query-sharded x2" in d["config"]["parallelism"]
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--gpus", "2"], capture_output=True, text=True,
+                         timeout=120, cwd=ROOT, env=dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"))
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr

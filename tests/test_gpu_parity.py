@@ -132,6 +132,58 @@ def test_himm_zero_length_and_outside_rays(R):
     e.close()
 
 
+def test_himm_malformed_rays_are_dropped_not_spun_on(R):
+    """A non-finite coordinate makes the reference's clipping march (LineIterator.cpp:92-104) spin forever, a start
+    10^9 m away makes it spin for minutes.  Defined in oracle/himm.c and himm.hip alike: the ray is dropped whole; its
+    neighbours in the batch are applied as usual, and the call returns."""
+    e = R.Engine(2.0, 2.0, 0.05)
+    g = O.make_geom(2.0, 2.0, 0.05)
+    rays = np.zeros(9, O.RAY_DTYPE)
+    rays[0] = (0.3, 0.3, -0.4, 0.2, 0, 0)
+    rays[1] = (np.inf, 0.0, 0.0, 0.0, 0, 0)
+    rays[2] = (0.0, 0.0, 0.0, -np.inf, 0, 0)
+    rays[3] = (np.nan, 0.1, 0.2, 0.2, 0, 0)
+    rays[4] = (0.1, 0.1, np.nan, np.nan, 1, 0)
+    rays[5] = (1e9, 0.0, 0.0, 0.0, 0, 0)        # would be 2e10 steps of the march
+    rays[6] = (0.0, 0.0, 0.0, 1e12, 1, 0)
+    rays[7] = (-0.5, 0.6, 0.7, -0.1, 0, 0)
+    rays[8] = (0.0, 0.0, 5e4, 0.0, 1, 0)        # long but legal (10^6 cells): clipped and cleared
+    ref = np.full(1600, 40.0, np.float32)
+    O.himm_update(g, ref, rays)
+    e.fill(R.capi.LAYER_LASER, 40.0)
+    e.himm_update(R.capi.LAYER_LASER, rays.view(R.capi.RAY_DTYPE))
+    assert same_f32(e.download(R.capi.LAYER_LASER), ref)
+    assert (ref != 40.0).sum() > 40          # the well-formed rays did their work
+    e.close()
+
+
+def test_compose_after_master_was_written_directly(R):
+    """compose mode 0 copies only the tiles HIMM flagged -- unless master was written behind its back (upload, fill,
+    fromOccupancyGrid, HIMM on the master layer): the reference's `master = laser` (map_provider.cpp:221) replaces
+    such content on the next update, so the engine falls back to the whole-layer copy once."""
+    e = R.Engine(12.8, 12.8, 0.05)
+    g = O.make_geom(12.8, 12.8, 0.05)
+    rng = np.random.default_rng(8)
+    laser = np.full(e.ncell, np.nan, np.float32)
+    rays = random_rays(rng, 300, 3.0, outside=0.0)
+    O.himm_update(g, laser, rays)
+    e.update_map(rays.view(R.capi.RAY_DTYPE), compose_mode=0)
+    junk = rng.integers(0, 7, e.ncell).astype(np.float32) * 30.0
+    e.upload(R.capi.LAYER_MASTER, junk)                       # e.g. GridMap::set("master", ...)
+    rays = random_rays(rng, 50, 1.0, outside=0.0)             # touches a few tiles only
+    O.himm_update(g, laser, rays)
+    e.update_map(rays.view(R.capi.RAY_DTYPE), compose_mode=0)
+    assert same_f32(e.download(R.capi.LAYER_MASTER), laser)
+    _, nbr = O.astar_masks(laser, e.rows, e.cols)
+    assert np.array_equal(e.nbr_mask(), nbr)
+    # HIMM on the range layer does not flag laser tiles: the following compose leaves master alone
+    e.himm_update(R.capi.LAYER_RANGE, random_rays(rng, 50, 2.0, outside=0.0).view(R.capi.RAY_DTYPE))
+    e.compose_master(0)
+    assert same_f32(e.download(R.capi.LAYER_MASTER), laser)
+    assert not e.last_dirty_tiles().any()
+    e.close()
+
+
 def test_update_map_compose_modes(R):
     rng = np.random.default_rng(5)
     for mode in (0, 1):

@@ -195,3 +195,24 @@ def test_rrt_reaches_goal_and_is_collision_free():
     assert np.array_equal(path, path2)
     res3, path3 = O.rrt_plan(g, m, (3.0, 3.0), (-3.0, -3.0), seed=2)
     assert not np.array_equal(path, path3)
+
+
+def test_oracle_himm_drops_malformed_rays():
+    """oracle/himm.c: a ray with a non-finite coordinate or longer than 2^20 cells is dropped whole (the reference's
+    clipping march, LineIterator.cpp:92-104, would spin on it); everything else in the batch is applied."""
+    g = O.make_geom(2.0, 2.0, 0.05)
+    good = np.zeros(2, O.RAY_DTYPE)
+    good[0] = (0.3, 0.3, -0.4, 0.2, 0, 0)
+    good[1] = (-0.5, 0.6, 0.7, -0.1, 0, 0)
+    bad = np.zeros(5, O.RAY_DTYPE)
+    bad[0] = (np.inf, 0.0, 0.0, 0.0, 0, 0)
+    bad[1] = (0.1, 0.1, np.nan, np.nan, 1, 0)
+    bad[2] = (1e9, 0.0, 0.0, 0.0, 0, 0)
+    bad[3] = (0.0, 0.0, 0.0, -np.inf, 0, 0)
+    bad[4] = (0.0, 0.0, 0.0, 1e12, 1, 0)
+    a = np.full(1600, 40.0, np.float32)
+    b = a.copy()
+    O.himm_update(g, a, good)
+    mixed = np.concatenate([bad[:2], good[:1], bad[2:4], good[1:], bad[4:]])
+    O.himm_update(g, b, mixed)
+    assert np.array_equal(a, b) and (a != 40.0).any()
