@@ -72,6 +72,21 @@ int rna_synchronize(rna_engine* e);
 int rna_get_index(const rna_engine* e, double x, double y, int32_t index[2]);   /* 1 inside, 0 outside */
 int rna_get_position(const rna_engine* e, int32_t i, int32_t j, double position[2]);
 
+/* The same math over a geometry alone -- no engine, no GPU (host iterators of the C++ mirror, callers that only
+ * need indices).  1 inside / in range, 0 outside, < 0 = rna_status. */
+int rna_geometry_index(const rna_geometry* g, double x, double y, int32_t index[2]);
+int rna_geometry_position(const rna_geometry* g, int32_t i, int32_t j, double position[2]);
+/* grid_map_core's iterators as cell lists ((i, j) buffer-index pairs in visiting order; return value = length of
+ * the walk, only the first cap cells are written): LineIterator (gmc/src/iterators/LineIterator.cpp:16-150; the
+ * cells a HIMM ray clears), CircleIterator (CircleIterator.cpp:16-93; the blocked-disc scan of GlobalPlanner::
+ * ifBlocked), SubmapIterator (SubmapIterator.cpp:28-83). */
+int rna_line_cells(const rna_geometry* g, double sx, double sy, double ex, double ey, int32_t* cells, int cap);
+int rna_circle_cells(const rna_geometry* g, double cx, double cy, double radius, int32_t* cells, int cap);
+int rna_submap_cells(const rna_geometry* g, const int32_t top_left[2], const int32_t size[2], int32_t* cells, int cap);
+/* GridMap copy-assignment (`map = map_`, MapProvider::getMap, mc/src/map_provider.cpp:120-125): a new engine with
+ * the same geometry, start index and layer contents; the caller destroys it. */
+int rna_clone(rna_engine* src, rna_engine** out);
+
 /* ---- HIMM map update ------------------------------------------------------------------------- */
 /* RangeSample (mc/include/move_control/map_updater.h:28-32) */
 typedef struct {
@@ -115,6 +130,15 @@ int rna_layer_pack_tiles(rna_engine* e, int layer, const int32_t* tiles_host, in
 int rna_layers_unpack_tiles(rna_engine* e, int layer_a, int layer_b, const int32_t* tiles_host, int n, int i0, int ni,
                             int j0, int nj, const float* dense_device);
 int rna_layer_unpack_region_tracked(rna_engine* e, int layer, int i0, int ni, int j0, int nj, const float* dense_device);
+/* The same with the tile lists resident on the device (a C/C++ host that drives RCCL itself, include/rna_rccl.h):
+ * rna_last_dirty_tiles_device compacts the flagged tiles that intersect the window into list_device (room for every
+ * tile of the map) and their number into *count_device; the pack / unpack forms take device lists.  Asynchronous on
+ * the engine's stream. */
+int rna_last_dirty_tiles_device(rna_engine* e, int i0, int ni, int j0, int nj, int32_t* list_device, int* count_device);
+int rna_layer_pack_tiles_device(rna_engine* e, int layer, const int32_t* tiles_device, int n, int i0, int ni, int j0, int nj,
+                                float* dense_device);
+int rna_layers_unpack_tiles_device(rna_engine* e, int layer_a, int layer_b, const int32_t* tiles_device, int n, int i0, int ni,
+                                   int j0, int nj, const float* dense_device);
 /* GridMap::move (gmc/src/GridMap.cpp:346-412): recentre the circular buffer, dropped cells -> NaN */
 int rna_move(rna_engine* e, double position_x, double position_y, int* moved);
 

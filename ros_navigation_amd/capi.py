@@ -24,10 +24,12 @@ KERNELS = ["himm_prep", "himm_raster", "himm_apply", "compose_master", "nbr_mask
 SYMBOLS = [
     "rna_create", "rna_destroy", "rna_last_error", "rna_abi_version", "rna_get_geometry",
     "rna_layer_upload", "rna_layer_download", "rna_layer_fill", "rna_layer_device_ptr", "rna_stream",
-    "rna_synchronize", "rna_get_index", "rna_get_position",
+    "rna_synchronize", "rna_get_index", "rna_get_position", "rna_geometry_index", "rna_geometry_position", "rna_line_cells",
+    "rna_circle_cells", "rna_submap_cells", "rna_clone",
     "rna_himm_update", "rna_himm_update_device", "rna_compose_master", "rna_update_map",
     "rna_update_map_device", "rna_move", "rna_himm_set_window", "rna_layer_pack_region", "rna_layer_unpack_region", "rna_last_dirty_tiles", "rna_layer_pack_tiles",
-    "rna_layers_unpack_tiles", "rna_layer_unpack_region_tracked",
+    "rna_layers_unpack_tiles", "rna_layer_unpack_region_tracked", "rna_last_dirty_tiles_device", "rna_layer_pack_tiles_device",
+    "rna_layers_unpack_tiles_device",
     "rna_vfh_default_params", "rna_vfh_init", "rna_vfh_reset", "rna_vfh_hist_size", "rna_vfh_step_batch",
     "rna_vfh_step_batch_device", "rna_vfh_update_batch",
     "rna_astar_configure", "rna_astar_set_pipeline_depth", "rna_astar_set_page_cap", "rna_astar_batch", "rna_astar_batch_device", "rna_astar_settled_counts",
@@ -122,6 +124,13 @@ def lib():
     L.rna_synchronize.argtypes = [vp]
     L.rna_get_index.argtypes = [vp, C.c_double, C.c_double, C.POINTER(C.c_int32)]
     L.rna_get_position.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    gp, ip = C.POINTER(Geometry), C.POINTER(C.c_int32)
+    L.rna_geometry_index.argtypes = [gp, C.c_double, C.c_double, ip]
+    L.rna_geometry_position.argtypes = [gp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    L.rna_line_cells.argtypes = [gp, C.c_double, C.c_double, C.c_double, C.c_double, ip, C.c_int]
+    L.rna_circle_cells.argtypes = [gp, C.c_double, C.c_double, C.c_double, ip, C.c_int]
+    L.rna_submap_cells.argtypes = [gp, ip, ip, ip, C.c_int]
+    L.rna_clone.argtypes = [vp, C.POINTER(vp)]
     L.rna_himm_update.argtypes = [vp, C.c_int, vp, C.c_int]
     L.rna_himm_update_device.argtypes = [vp, C.c_int, vp, C.c_int]
     L.rna_compose_master.argtypes = [vp, C.c_int]
@@ -218,6 +227,56 @@ def default_vfh_params():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def make_geometry(length_x, length_y, resolution, position=(0.0, 0.0), start_index=(0, 0)):
+    """rna_geometry as GridMap::setGeometry derives it (size = round(length / resolution), length = size * resolution)"""
+    g = Geometry()
+    g.size[0], g.size[1] = int(round(length_x / resolution)), int(round(length_y / resolution))
+    g.resolution = resolution
+    g.length[0], g.length[1] = g.size[0] * resolution, g.size[1] * resolution
+    g.position[0], g.position[1] = position
+    g.start_index[0], g.start_index[1] = start_index
+    return g
+
+
+def _cells(fn, *args):
+    import numpy as _np
+    cap = 4096
+    while True:
+        out = _np.zeros(2 * cap, _np.int32)
+        n = fn(*args, out.ctypes.data_as(C.POINTER(C.c_int32)), cap)
+        if n < 0:
+            raise RnaError(STATUS.get(n, n))
+        if n <= cap:
+            return out[:2 * n].reshape(-1, 2).copy()
+        cap = n
+
+
+def line_cells(g, sx, sy, ex, ey):
+    """LineIterator(map, start, end) as a cell list (host only; the cells a HIMM ray clears)"""
+    return _cells(lib().rna_line_cells, C.byref(g), sx, sy, ex, ey)
+
+
+def circle_cells(g, cx, cy, radius):
+    return _cells(lib().rna_circle_cells, C.byref(g), cx, cy, radius)
+
+
+def submap_cells(g, top_left, size):
+    tl, sz = (C.c_int32 * 2)(*top_left), (C.c_int32 * 2)(*size)
+    return _cells(lib().rna_submap_cells, C.byref(g), tl, sz)
+
+
+def geometry_index(g, x, y):
+    o = (C.c_int32 * 2)()
+    rc = lib().rna_geometry_index(C.byref(g), x, y, o)
+    return (o[0], o[1]) if rc == 1 else None
+
+
+def geometry_position(g, i, j):
+    o = (C.c_double * 2)()
+    rc = lib().rna_geometry_position(C.byref(g), i, j, o)
+    return (o[0], o[1]) if rc == 1 else None
 
 
 class Engine:

@@ -150,6 +150,15 @@ __global__ void __launch_bounds__(256) unpack_tiles_kernel(float* __restrict__ l
   if (threadIdx.x == 0) reinterpret_cast<volatile unsigned char*>(dirty_tiles)[t] = 1;
 }
 
+// the flagged tiles that intersect a window, as a device list (order arbitrary) + count
+__global__ void dirty_list_kernel(const unsigned* __restrict__ flags, int tiles_i, int ntile, int wi0, int wi1, int wj0, int wj1,
+                                  int32_t* __restrict__ list, int* __restrict__ count) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntile || !reinterpret_cast<const unsigned char*>(flags)[t]) return;
+  const int i0 = (t % tiles_i) * TILE, j0 = (t / tiles_i) * TILE;
+  if (i0 < wi1 && i0 + TILE > wi0 && j0 < wj1 && j0 + TILE > wj0) list[atomicAdd(count, 1)] = t;
+}
+
 __global__ void mark_tiles_kernel(unsigned* __restrict__ dirty_tiles, int tiles_i, int ta0, int ta1, int tb0, int tb1) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   const int na = ta1 - ta0, n = na * (tb1 - tb0);
@@ -444,6 +453,47 @@ extern "C" int rna_layers_unpack_tiles(rna_engine* e, int layer_a, int layer_b, 
   return RNA_OK;
 }
 
+// Device-side forms of the three calls above for hosts that drive the exchange themselves (csrc/rccl_tiled.hip): no
+// tile flags or lists cross PCIe.  All asynchronous on the engine's stream.
+extern "C" int rna_last_dirty_tiles_device(rna_engine* e, int i0, int ni, int j0, int nj, int32_t* list_device, int* count_device) {
+  if (!e || !list_device || !count_device) return RNA_EINVAL;
+  if (!window_ok(e, i0, ni, j0, nj)) return rna::fail(e, RNA_EINVAL, "window outside the map");
+  RNA_HIP(e, hipSetDevice(e->device));
+  const int ntile = e->tiles_i * e->tiles_j;
+  RNA_HIP(e, hipMemsetAsync(count_device, 0, sizeof(int), e->stream));
+  hipLaunchKernelGGL(dirty_list_kernel, dim3((ntile + 255) / 256), dim3(256), 0, e->stream, e->last_dirty, e->tiles_i, ntile, i0,
+                     i0 + ni, j0, j0 + nj, list_device, count_device);
+  RNA_HIP(e, hipGetLastError());
+  return RNA_OK;
+}
+
+extern "C" int rna_layer_pack_tiles_device(rna_engine* e, int layer, const int32_t* tiles_device, int n, int i0, int ni, int j0,
+                                           int nj, float* dense_device) {
+  if (!e || layer < 0 || layer >= RNA_NUM_LAYERS || n < 0 || (n > 0 && (!tiles_device || !dense_device))) return RNA_EINVAL;
+  if (n == 0) return RNA_OK;
+  if (!window_ok(e, i0, ni, j0, nj)) return rna::fail(e, RNA_EINVAL, "window outside the map");
+  RNA_HIP(e, hipSetDevice(e->device));
+  hipLaunchKernelGGL(pack_tiles_kernel, dim3(n), dim3(256), 0, e->stream, e->layer[layer], e->geom.size[0], e->tiles_i,
+                     tiles_device, i0, i0 + ni, j0, j0 + nj, dense_device);
+  RNA_HIP(e, hipGetLastError());
+  return RNA_OK;
+}
+
+extern "C" int rna_layers_unpack_tiles_device(rna_engine* e, int layer_a, int layer_b, const int32_t* tiles_device, int n, int i0,
+                                              int ni, int j0, int nj, const float* dense_device) {
+  if (!e || layer_a < 0 || layer_a >= RNA_NUM_LAYERS || layer_b >= RNA_NUM_LAYERS || layer_b == layer_a || n < 0 ||
+      (n > 0 && (!tiles_device || !dense_device)))
+    return RNA_EINVAL;
+  if (n == 0) return RNA_OK;
+  if (!window_ok(e, i0, ni, j0, nj)) return rna::fail(e, RNA_EINVAL, "window outside the map");
+  RNA_HIP(e, hipSetDevice(e->device));
+  hipLaunchKernelGGL(unpack_tiles_kernel, dim3(n), dim3(256), 0, e->stream, e->layer[layer_a],
+                     layer_b >= 0 ? e->layer[layer_b] : (float*)nullptr, e->geom.size[0], e->tiles_i, tiles_device, i0,
+                     i0 + ni, j0, j0 + nj, dense_device, e->dirty_tiles);
+  RNA_HIP(e, hipGetLastError());
+  return RNA_OK;
+}
+
 // GridMap GridMap::getSubmap(position, length, isSuccess) (gmc/src/GridMap.cpp:287-339) as a GridMap of its own: a new
 // engine with the submap's geometry (startIndex (0,0)) whose layers are gathered from the parent on the device.
 extern "C" int rna_create_submap(rna_engine* parent, double px, double py, double lx, double ly, rna_engine** out) {
@@ -476,6 +526,34 @@ extern "C" int rna_create_submap(rna_engine* parent, double px, double py, doubl
   c->laser_all_dirty = true;
   *out = c;
   return 1;
+}
+
+// GridMap copy (`map = map_` of MapProvider::getMap, mc/src/map_provider.cpp:120-125): a new engine on the same
+// device with the same geometry, circular-buffer start index and layer contents.
+extern "C" int rna_clone(rna_engine* src, rna_engine** out) {
+  if (!src || !out) return RNA_EINVAL;
+  *out = nullptr;
+  rna_engine* c = nullptr;
+  const Geom& g = src->geom;
+  int rc = rna_create(&c, g.len[0], g.len[1], g.res, g.pos[0], g.pos[1], src->device);
+  if (rc != RNA_OK) return rna::fail(src, rc, "rna_clone: rna_create failed");
+  if (c->geom.size[0] != g.size[0] || c->geom.size[1] != g.size[1]) {
+    rna_destroy(c);
+    return rna::fail(src, RNA_EINVAL, "rna_clone: geometry does not reproduce the size");
+  }
+  c->geom = g;   // position / length / start index exactly as they are
+  hipError_t err = hipSetDevice(src->device);
+  for (int l = 0; l < RNA_NUM_LAYERS && err == hipSuccess; ++l)
+    err = hipMemcpyAsync(c->layer[l], src->layer[l], src->ncell * sizeof(float), hipMemcpyDeviceToDevice, src->stream);
+  if (err == hipSuccess) err = hipStreamSynchronize(src->stream);
+  if (err != hipSuccess) {
+    rna_destroy(c);
+    RNA_HIP(src, err);
+  }
+  c->nbr_all_dirty = true;
+  c->laser_all_dirty = true;
+  *out = c;
+  return RNA_OK;
 }
 
 extern "C" int rna_get_submap(rna_engine* e, int layer, double px, double py, double lx, double ly, float* out_host,

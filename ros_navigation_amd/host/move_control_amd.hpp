@@ -19,6 +19,7 @@
 
 #include <array>
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <limits>
 #include <stdexcept>
@@ -57,18 +58,75 @@ inline void rna_check(int rc, rna_engine* e, const char* what) {
   if (rc != RNA_OK) throw std::runtime_error(std::string(what) + ": " + (e ? rna_last_error(e) : "rna error"));
 }
 
+// grid_map::Matrix stand-in: a host copy of one layer (column-major, linear = i + j*rows as Eigen::MatrixXf),
+// what GridMap::operator[] hands out here (copy-out; write a changed copy back with GridMap::set).
+class Matrix {
+ public:
+  Matrix() : rows_(0), cols_(0) {}
+  Matrix(int rows, int cols, float v = std::numeric_limits<float>::quiet_NaN()) : rows_(rows), cols_(cols), d_((size_t)rows * cols, v) {}
+  int rows() const { return rows_; }
+  int cols() const { return cols_; }
+  size_t size() const { return d_.size(); }
+  float& operator()(int i, int j) { return d_[(size_t)j * rows_ + i]; }
+  float operator()(int i, int j) const { return d_[(size_t)j * rows_ + i]; }
+  float& operator()(size_t linear) { return d_[linear]; }
+  float operator()(size_t linear) const { return d_[linear]; }
+  void setConstant(float v) { d_.assign(d_.size(), v); }
+  const float* data() const { return d_.data(); }
+  float* data() { return d_.data(); }
+  const std::vector<float>& values() const { return d_; }
+ private:
+  int rows_, cols_;
+  std::vector<float> d_;
+};
+
 // GridMap: geometry + the three layers MapProvider uses ("master", "laser", "range"), resident in HBM.
 class GridMap {
  public:
-  GridMap() : e_(nullptr) {}
+  GridMap() : e_(nullptr), frameId_() {}
+  // GridMap(const std::vector<std::string>& layers) (gmc/src/GridMap.cpp:27-40): the engine always carries the three
+  // layers of move_control; any other name is refused as GridMap::get refuses it
+  explicit GridMap(const std::vector<std::string>& layers) : e_(nullptr), frameId_() {
+    for (size_t k = 0; k < layers.size(); ++k) (void)layerId(layers[k]);
+  }
   ~GridMap() { if (e_) rna_destroy(e_); }
-  GridMap(const GridMap&) = delete;
-  GridMap& operator=(const GridMap&) = delete;
-  GridMap(GridMap&& o) : e_(o.e_) { o.e_ = nullptr; }
-  GridMap& operator=(GridMap&& o) {   // `map = map_.getSubmap(...)` of MapProvider::getSubMap (map_provider.cpp:97)
-    if (this != &o) { if (e_) rna_destroy(e_); e_ = o.e_; o.e_ = nullptr; }
+  // copy = deep copy (`map = map_` of MapProvider::getMap, map_provider.cpp:120-125)
+  GridMap(const GridMap& o) : e_(nullptr), frameId_(o.frameId_) {
+    if (o.e_) rna_check(rna_clone(o.e_, &e_), o.e_, "GridMap copy");
+  }
+  GridMap& operator=(const GridMap& o) {
+    if (this != &o) {
+      rna_engine* c = nullptr;
+      if (o.e_) rna_check(rna_clone(o.e_, &c), o.e_, "GridMap copy");
+      if (e_) rna_destroy(e_);
+      e_ = c;
+      frameId_ = o.frameId_;
+    }
     return *this;
   }
+  GridMap(GridMap&& o) : e_(o.e_), frameId_(o.frameId_) { o.e_ = nullptr; }
+  GridMap& operator=(GridMap&& o) {   // `map = map_.getSubmap(...)` of MapProvider::getSubMap (map_provider.cpp:97)
+    if (this != &o) { if (e_) rna_destroy(e_); e_ = o.e_; o.e_ = nullptr; frameId_ = o.frameId_; }
+    return *this;
+  }
+  void setFrameId(const std::string& frameId) { frameId_ = frameId; }
+  const std::string& getFrameId() const { return frameId_; }
+  // GridMap::add(layer, value) (gmc/src/GridMap.cpp:77-95) for the layers the engine carries
+  void add(const std::string& layer, float value = std::numeric_limits<float>::quiet_NaN()) {
+    rna_check(rna_layer_fill(e_, layerId(layer), value), e_, "GridMap::add");
+  }
+  // GridMap::operator[] / get (gmc/src/GridMap.cpp:125-151): std::out_of_range for unknown layers; copy-out
+  Matrix operator[](const std::string& layer) const {
+    const int id = layerId(layer);
+    rna_geometry g = geometry();
+    Matrix m(g.size[0], g.size[1]);
+    rna_check(rna_layer_download(e_, id, m.data(), m.size()), e_, "GridMap::operator[]");
+    return m;
+  }
+  void set(const std::string& layer, const Matrix& m) {
+    rna_check(rna_layer_upload(e_, layerId(layer), m.data(), m.size()), e_, "GridMap::set");
+  }
+  Index getStartIndex() const { rna_geometry g = geometry(); return Index(g.start_index[0], g.start_index[1]); }
 
   // GridMap::setGeometry (gmc/src/GridMap.cpp:51-70)
   void setGeometry(const Length& length, double resolution, const Position& position = Position(0.0, 0.0), int device = 0) {
@@ -152,11 +210,79 @@ class GridMap {
 
  private:
   rna_engine* e_;
+  std::string frameId_;
+};
+
+// grid_map_core's iterators over a GridMap's geometry (host side; the same walks the kernels do, through
+// rna_line_cells / rna_circle_cells / rna_submap_cells).  Usage as in the reference:
+//   for (LineIterator it(map, start, end); !it.isPastEnd(); ++it) { const Index& index = *it; ... }
+class CellListIterator {
+ public:
+  bool isPastEnd() const { return k_ >= n_; }
+  CellListIterator& operator++() { ++k_; return *this; }
+  const Index& operator*() const { cur_ = Index(cells_[2 * k_], cells_[2 * k_ + 1]); return cur_; }
+  bool operator!=(const CellListIterator& o) const { return k_ != o.k_; }
+  size_t size() const { return n_; }
+ protected:
+  CellListIterator() : k_(0), n_(0) {}
+  template <class F> void fill(F&& walk) {
+    int cap = 1024;
+    for (;;) {
+      cells_.resize(2 * (size_t)cap);
+      const int n = walk(cells_.data(), cap);
+      if (n < 0) throw std::invalid_argument("grid_map iterator: bad geometry");
+      if (n <= cap) { n_ = (size_t)n; return; }
+      cap = n;
+    }
+  }
+  std::vector<int32_t> cells_;
+  size_t k_, n_;
+  mutable Index cur_;
+};
+class LineIterator : public CellListIterator {      // gmc/src/iterators/LineIterator.cpp:16-150
+ public:
+  LineIterator(const GridMap& map, const Position& start, const Position& end) {
+    const rna_geometry g = map.geometry();
+    fill([&](int32_t* c, int cap) { return rna_line_cells(&g, start[0], start[1], end[0], end[1], c, cap); });
+  }
+};
+class CircleIterator : public CellListIterator {    // gmc/src/iterators/CircleIterator.cpp:16-93
+ public:
+  CircleIterator(const GridMap& map, const Position& center, double radius) {
+    const rna_geometry g = map.geometry();
+    fill([&](int32_t* c, int cap) { return rna_circle_cells(&g, center[0], center[1], radius, c, cap); });
+  }
+};
+class SubmapIterator : public CellListIterator {    // gmc/src/iterators/SubmapIterator.cpp:28-83
+ public:
+  SubmapIterator(const GridMap& map, const Index& submapStartIndex, const Size& submapSize) {
+    const rna_geometry g = map.geometry();
+    const int32_t tl[2] = {submapStartIndex[0], submapStartIndex[1]}, sz[2] = {submapSize[0], submapSize[1]};
+    fill([&](int32_t* c, int cap) { return rna_submap_cells(&g, tl, sz, c, cap); });
+  }
+};
+class GridMapIterator {                             // gmc/src/iterators/GridMapIterator.cpp:14-83: linear order of the buffer
+ public:
+  explicit GridMapIterator(const GridMap& map) : k_(0) { const Size s = map.getSize(); rows_ = s[0]; n_ = (size_t)s[0] * s[1]; }
+  bool isPastEnd() const { return k_ >= n_; }
+  GridMapIterator& operator++() { ++k_; return *this; }
+  const Index& operator*() const { cur_ = Index((int)(k_ % rows_), (int)(k_ / rows_)); return cur_; }
+  size_t getLinearIndex() const { return k_; }
+ private:
+  size_t k_, n_;
+  int rows_;
+  mutable Index cur_;
 };
 
 }  // namespace grid_map
 
+// With RNA_REFERENCE_SIGNATURES (set by move_control_api.hpp) the compute cores below live in move_control::core and
+// move_control itself holds the classes with the reference's exact constructor / method signatures.
+#ifdef RNA_REFERENCE_SIGNATURES
+namespace move_control { namespace core {
+#else
 namespace move_control {
+#endif
 
 using grid_map::GridMap;
 using grid_map::Length;
@@ -471,4 +597,7 @@ class RrtPlanner {
   unsigned seed_;
 };
 
+#ifdef RNA_REFERENCE_SIGNATURES
+}  // namespace core
+#endif
 }  // namespace move_control

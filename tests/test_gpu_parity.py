@@ -827,6 +827,65 @@ def test_astar_large_grid_properties(R):
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json's full sizes for the rows whose oracle is fast enough to run them whole
 # ------------------------------------------------------------------------------------------------
+def oracle_pool(fn, n):
+    """fn(k) for k < n on every host core (the C oracle releases the GIL)"""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, min(32, len(os.sched_getaffinity(0))))) as ex:
+        return list(ex.map(fn, range(n)))
+
+
+def test_astar_config3_every_bench_query_matches_oracle(R):
+    """Config 3 as bench.py serves it: the 4096 x 4096 rectangle map (seed 2) and ALL 256 (start, goal) pairs of a
+    batch, through the asynchronous device entry point with batches in flight: path, cost and settled count E of
+    every query against the CPU oracle."""
+    n = 4096
+    e = R.Engine(n * 0.05, n * 0.05, 0.05)
+    master = R.synth.obstacles_rect(n, n, density=0.30, seed=2)
+    e.upload(R.capi.LAYER_MASTER, master)
+    q = R.synth.astar_queries(256, master, n, n, seed=2)
+    e.astar_configure(max_queries=256)
+    res, paths = e.astar(q, 32768)
+    settled = e.astar_settled(len(q))
+    _, onbr = O.astar_masks(master, n, n)
+    assert np.array_equal(onbr, e.nbr_mask())
+
+    def one(k):
+        ores, opath, _ = O.astar_query(onbr, n, n, q["start"][k], q["goal"][k])
+        assert ores.status == res["status"][k] == 0, k
+        assert ores.cost == res["cost"][k] and ores.settled == settled[k] and ores.path_len == res["path_len"][k], k
+        assert np.array_equal(opath, paths[k, :ores.path_len]), k
+        return ores.settled
+    total = sum(oracle_pool(one, len(q)))
+    assert total > 5e7
+    e.close()
+
+
+def test_rrt_config4_one_gpu_share_matches_oracle(R):
+    """Config 4: 2048 x 2048, 30 % rectangles (seed 3), one GPU's share of the 4096 trees = 512 queries (the reference's
+    2000 extendTree iterations, rrt_planner.cpp:6, each bounded to the batch's 100 000 samples in total): status, tree
+    size, sample count and path length exact, way points at 1e-9 m."""
+    n = 2048
+    L = n * 0.05
+    e = R.Engine(L, L, 0.05)
+    g = O.make_geom(L, L, 0.05)
+    master = R.synth.obstacles_rect(n, n, density=0.30, seed=3)
+    e.upload(R.capi.LAYER_MASTER, master)
+    q = R.synth.rrt_queries(512, master, n, n, e.get_position, seed=3, max_samples=100000)
+    res, paths = e.rrt(q)
+
+    def one(k):
+        ores, opath = O.rrt_plan(g, master, tuple(q["start"][k]), tuple(q["target"][k]), tol=0.2,
+                                 seed=int(q["seed"][k]), max_samples=int(q["max_samples"][k]))
+        assert (res["status"][k], res["tree_size"][k], res["samples"][k], res["path_len"][k]) == \
+               (ores.status, ores.tree_size, ores.samples, ores.path_len), k
+        assert np.allclose(paths[k, :ores.path_len], opath, rtol=0, atol=1e-9), k
+        return ores.status
+    st = oracle_pool(one, len(q))
+    assert 0 in st                       # some trees reach their target within the budget
+    e.close()
+
+
+
 def test_himm_full_ray_batch_on_4096_matches_oracle(R):
     """Config 5's ray batch (100 032 rays from 64 origins, 1-6 m, 80 % hits) on the 4096 x 4096 bench map, applied
     three times in a row (steady state: marks saturate, clears and marks interleave on shared cells): bit-exact."""

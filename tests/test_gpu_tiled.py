@@ -69,7 +69,15 @@ def test_windowed_himm_is_the_whole_map_update_inside_the_window():
     e.close()
 
 
-def _tiled_worker(rank, world, port, out, mode="full"):
+SMALL = dict(rows=256, cols=192, rounds=3, ray_poses=10, rays_per_pose=700, lmin=0.3, margin=0.4, density=0.12, side=(2, 10),
+             poses=64, edge_poses=32, queries=24, max_path=4096)
+# BASELINE config 5 at full size, two of its ranks: 8192 x 8192, the 100 032-ray batch, 64 VFH+ poses (half of them on
+# the window border, so their 1.5 m submaps reach into the halo), 16 A* queries after the dirty-tile gather
+CONFIG5 = dict(rows=8192, cols=8192, rounds=1, ray_poses=64, rays_per_pose=1563, lmin=1.0, margin=6.5, density=0.30, side=(4, 64),
+               poses=32, edge_poses=32, queries=16, max_path=32768)
+
+
+def _tiled_worker(rank, world, port, out, mode="full", cfg=None):
     try:
         sys.path.insert(0, ROOT)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -81,20 +89,23 @@ def _tiled_worker(rank, world, port, out, mode="full"):
         from ros_navigation_amd import dist as D
         torch.cuda.set_device(0)
         dist = D.init("gloo")
-        rows, cols, res = 256, 192, 0.05
+        cfg = cfg or SMALL
+        rows, cols, res = cfg["rows"], cfg["cols"], 0.05
         lx, ly = rows * res, cols * res
         e = R.Engine(lx, ly, res)
+        e.astar_pipeline_depth(1)
+        e.astar_configure(max_queries=8)
         g = Or.make_geom(lx, ly, res)
         L = D.TileLayout.for_world(rows, cols, world)
         halo = D.vfh_halo(res)
         i0, ni, j0, nj = L.window(rank)
-        full = R.synth.obstacles_rect(rows, cols, density=0.12, seed=21, side=(2, 10))
+        full = R.synth.obstacles_rect(rows, cols, density=cfg["density"], seed=21, side=cfg["side"])
         e.upload(R.capi.LAYER_LASER, full)
         e.compose_master(1)
         e.himm_set_window(i0, j0, ni, nj)
         # poses: uniform ones plus a row of robots right on both sides of every window border
-        poses = R.synth.poses(64, lx, ly, seed=3, margin=0.9)
-        edge = R.synth.poses(32, lx, ly, seed=4, margin=0.9)
+        poses = R.synth.poses(cfg["poses"], lx, ly, seed=3, margin=0.9)
+        edge = R.synth.poses(cfg["edge_poses"], lx, ly, seed=4, margin=0.9)
         for k in range(len(edge)):                      # the same poses on every rank
             wi0, wni = L.window(k % world)[:2]
             bi = (wi0 if k % 2 else wi0 + wni - 1) + (k % 5) - 2
@@ -106,8 +117,9 @@ def _tiled_worker(rank, world, port, out, mode="full"):
         e.vfh_init(len(mine))
         oracles = [Or.OracleVfh() for _ in range(len(mine))]
         checked = {"vfh": 0, "astar": 0, "halo_bytes": 0, "gather_bytes": 0}
-        for rnd in range(3):
-            rays = R.synth.rays(10, 700, lx, ly, seed=30 + rnd, lmin=0.3, lmax=6.0, margin=0.4)
+        for rnd in range(cfg["rounds"]):
+            rays = R.synth.rays(cfg["ray_poses"], cfg["rays_per_pose"], lx, ly, seed=30 + rnd, lmin=cfg["lmin"], lmax=6.0,
+                                margin=cfg["margin"])
             Or.himm_update(g, full, rays.view(Or.RAY_DTYPE))          # whole-map truth (laser == master)
             e.update_map(rays, compose_mode=0)                         # this rank's window only
             checked["halo_bytes"] += D.exchange_halo(e, R.capi.LAYER_MASTER, L, rank, halo, dist, tracked=(mode == "dirty"))
@@ -130,9 +142,9 @@ def _tiled_worker(rank, world, port, out, mode="full"):
                 checked["gather_bytes"] += D.gather_layer(e, R.capi.LAYER_MASTER, L, rank, dist)
             got = e.download(R.capi.LAYER_MASTER)
             assert np.array_equal(np.isnan(got), np.isnan(full)) and np.array_equal(got[~np.isnan(got)], full[~np.isnan(full)]), rnd
-            queries = R.synth.astar_queries(24, full, rows, cols, seed=40 + rnd)
+            queries = R.synth.astar_queries(cfg["queries"], full, rows, cols, seed=40 + rnd)
             lo, hi = D.shard_bounds(len(queries), rank, world)
-            res_, paths = e.astar(queries[lo:hi], 4096)
+            res_, paths = e.astar(queries[lo:hi], cfg["max_path"])
             _, nbr = Or.astar_masks(full, rows, cols)
             assert np.array_equal(e.nbr_mask(), nbr), rnd
             gw = np.empty(rows * cols, np.int32)
@@ -176,6 +188,32 @@ def test_tiled_loop_two_ranks_on_one_gpu_matches_the_whole_map_oracle(mode):
         assert all(r[2]["gather_bytes"] == 3 * 128 * 192 * 4 for r in res)
     else:                                                     # whole 64 x 64 tiles, and fewer bytes than the windows
         assert all(r[2]["gather_bytes"] % (4096 * 4) == 0 and 0 < r[2]["gather_bytes"] <= 3 * 128 * 192 * 4 for r in res)
+
+
+def test_config5_full_size_two_ranks_vfh_and_astar_legs():
+    """BASELINE config 5's VFH+ and A* legs at the full 8192 x 8192 size: two of the ranks (2 x 1 windows of 4096 x 8192,
+    sharing the test box's GPU) run windowed HIMM of the 100 032-ray batch + compose -> 16-cell halo exchange -> VFH+ for
+    their 64 poses (half of them on the window border) -> dirty-tile gather -> 16 sharded A* queries; every output
+    against the whole-map oracle, and laser / master / neighbour masks equal on both ranks after the gather."""
+    import torch.multiprocessing as mp
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_tiled_worker, args=(r, world, port, out, "dirty", CONFIG5)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", r[2]
+    assert sum(r[3] for r in res) == 64 and all(r[3] >= 16 for r in res)
+    assert all(r[2]["vfh"] == r[3] and r[2]["astar"] == 8 for r in res)
+    assert all(r[2]["halo_bytes"] == 16 * 8192 * 4 for r in res)          # one 16-row strip of 8192 columns
+    assert all(0 < r[2]["gather_bytes"] < 4096 * 8192 * 4 // 8 for r in res)   # dirty tiles only: far less than a window
 
 
 def test_config5_full_size_windowed_himm_union_is_the_whole_map_update():
