@@ -356,7 +356,7 @@ def main():
                                    % (n, n, len(ray_sets[0]), nq, nq, ROTATE),
                        "cycles_per_step": nq, "rays_per_step": int(len(ray_sets[0])), "rotating_input_sets": ROTATE,
                        "astar_queries_checked": total, "astar_queries_answered": answered, "astar_paths_found": found,
-                       "astar_bucket_width": args.bucket_width or 16000, "astar_pipeline_depth": args.pipeline,
+                       "astar_bucket_width": args.bucket_width or 8000, "astar_pipeline_depth": args.pipeline,
                        "timed_seconds": t_max,
                        "parallelism": ("query-sharded x%d" % world) if layout is None else
                                       ("one map tiled %d x %d (windowed HIMM, %d-cell halo exchange, all-gather of owner "

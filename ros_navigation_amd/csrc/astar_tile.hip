@@ -485,6 +485,11 @@ __device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, c
       } else {
         lq_full = true;   // the stored words carry the in-queue flag: the rescan picks these cells up
       }
+      // Direction k + 1 must read what direction k stored: another lane's neighbour may be the same cell.  Within
+      // one lane the eight addresses are distinct, so without this the compiler may hoist the later reads above the
+      // store (seen once the code between them became straight-line); the hardware itself executes a wavefront's
+      // LDS instructions in order.
+      asm volatile("" ::: "memory");
     }
     tail = (int)__builtin_amdgcn_readfirstlane(tail_v);
     __builtin_amdgcn_wave_barrier();
