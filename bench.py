@@ -333,7 +333,7 @@ def main():
         ms_search = prof["astar_search"][0] / max(1, prof["astar_search"][1])
         alg_bytes = settled_per_launch * ASTAR_BYTES_PER_SETTLED
         achieved = alg_bytes / (ms_search * 1e-3) / 1e9 if ms_search > 0 else 0.0
-        traffic, traffic_src = pmc_traffic("tsa_search_kernel", args, world)
+        traffic, traffic_src = pmc_traffic("rna::tsa_search_kernel", args, world)
 
         def row(kernel_key, pmc_name, alg):
             ms = prof[kernel_key][0] / max(1, prof[kernel_key][1])

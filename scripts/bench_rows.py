@@ -67,17 +67,29 @@ L = n * 0.05
 e = R.Engine(L, L, 0.05)
 master = R.synth.obstacles_rect(n, n, density=0.30, seed=2)
 e.upload(R.capi.LAYER_LASER, master)
-rays = R.synth.rays(64, 1563, L, L, seed=4)
-d_rays = dev(rays)
-for _ in range(3):
-    e.update_map_device(d_rays.data_ptr(), len(rays), 0)
-wall, prof = timed(e, lambda: e.update_map_device(d_rays.data_ptr(), len(rays), 0), 20)
-ln = np.hypot(rays["ex"] - rays["sx"], rays["ey"] - rays["sy"]) / 0.05
-alg = float((8 * ln + 8 * (rays["clear_end"] == 0) + 40).sum())
+# four different batches in rotation, so that the clears of a step really write (a batch re-applied to its own result
+# finds most cells already at 0 and skips the store)
+ray_sets = [R.synth.rays(64, 1563, L, L, seed=4 + k) for k in range(4)]
+d_sets = [dev(r) for r in ray_sets]
+rays, d_rays = ray_sets[0], d_sets[0]
+turn = [0]
+
+
+def himm_step():
+    k = turn[0] % 4
+    turn[0] += 1
+    e.update_map_device(d_sets[k].data_ptr(), len(ray_sets[k]), 0)
+
+
+for _ in range(8):
+    himm_step()
+wall, prof = timed(e, himm_step, 20)
+alg = float(np.mean([(8 * np.hypot(r["ex"] - r["sx"], r["ey"] - r["sy"]) / 0.05 + 8 * (r["clear_end"] == 0) + 40).sum() for r in ray_sets]))
 k_ms = sum(prof.get(k, 0.0) for k in ("himm_prep", "himm_raster", "himm_apply"))
-out["himm_batch"] = dict(workload="100032 rays (64 origins x 1563, 1-6 m) on 4096x4096, fused compose (dirty tiles)",
+out["himm_batch"] = dict(workload="100032 rays (64 origins x 1563, 1-6 m) on 4096x4096, four batches in rotation, fused compose (dirty tiles)",
                          rays_per_s=len(rays) / wall, kernels_ms=prof, algorithmic_bytes=alg,
-                         achieved_gbs=alg / (k_ms * 1e-3) / 1e9, frac=alg / (k_ms * 1e-3) / 1e9 / PEAK)
+                         achieved_gbs=alg / (k_ms * 1e-3) / 1e9, frac=alg / (k_ms * 1e-3) / 1e9 / PEAK,
+                         raster_gbs=alg / (prof["himm_raster"] * 1e-3) / 1e9, raster_frac=alg / (prof["himm_raster"] * 1e-3) / 1e9 / PEAK)
 wall1, prof1 = timed(e, lambda: e.update_map_device(d_rays.data_ptr(), len(rays), 1), 10)
 out["himm_batch"]["compose_full_copy_ms"] = prof1.get("compose_master")
 out["himm_batch"]["compose_full_copy_gbs"] = 8.0 * n * n / (prof1.get("compose_master", 1) * 1e-3) / 1e9

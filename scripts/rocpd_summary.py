@@ -60,10 +60,12 @@ def main():
         out["pmc"] = summ
         with open(os.path.join(dst, "%s_pmc_summary.json" % tag), "w") as f:
             json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py "
-                                "--steps 2 --warmup 1 --no-cpu --pipeline 1`; hbm_bytes_per_launch = (2*FETCH_SIZE + "
-                                "WRITE_SIZE) * 1024 (FETCH_SIZE doubled: gfx950 reports half of coalesced read bytes; "
-                                "calibrated here on astar_settled_kernel, which streams 256 x 64 MiB = 17.18 GB and "
-                                "reports FETCH_SIZE 8.39e6 KiB)", kernels=summ), f, indent=1)
+                                "--steps 8 --warmup 4 --no-cpu` (the default configuration below); per launch: "
+                                "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (FETCH_SIZE doubled: gfx950 "
+                                "reports half of the bytes of 16 B/lane streaming reads, MI355X_MICROARCH.md; dword "
+                                "accesses are uncalibrated, so bench.py quotes the range from (FETCH + WRITE) * 1024)",
+                           config=dict(grid=4096, queries=256, pipeline=6, ray_poses=64, rays_per_pose=1563),
+                           kernels=summ), f, indent=1)
     print(json.dumps({k: (v if k == "pmc" else [(short(r["name"]), r["calls"], round(r["avg_ns"] / 1e3, 1)) for r in v][:8])
                       for k, v in out.items()}, indent=1)[:3000])
 
