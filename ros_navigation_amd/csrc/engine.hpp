@@ -30,6 +30,8 @@ struct HimmScratch {
   unsigned* after = nullptr;     // clears after the last mark of the cell
   int* total = nullptr;          // allocation cursor into seqs
   unsigned* mark_bitmap = nullptr;  // 1 bit per cell: cell holds >= 1 mark in the current batch
+  int* pairs = nullptr;          // (tile, ray) pairs grouped by tile: the rays each 64 x 64 tile has to rasterise
+  int* tile_bins = nullptr;      // [3][ntile]: pair count, offset and fill cursor per tile
   int win[4] = {0, 0, 0, 0};     // owner window [i0, i1) x [j0, j1) in buffer indices; i1 == 0: whole map
 };
 

@@ -16,15 +16,22 @@
 //
 // Kernels: himm_prep (1 thread/ray: double-precision clipping, mark registration),
 //          himm_collect (1 thread/hash slot: gather + sort that cell's marks),
-//          himm_raster (16 lanes/ray, closed-form Bresenham cell k, HBM read-modify-write),
+//          himm_bin_count / himm_bin_scan / himm_bin_fill (rays -> the 64 x 64 tiles they cross),
+//          himm_tile_raster (one workgroup per touched tile: its rays' clears are COUNTED per cell in LDS --
+//              k clears are clear^k, whatever their order -- then every touched line of the layer is read once,
+//              coalesced, and written once; clears of marked cells go to the interval counters instead),
 //          himm_apply (1 thread/hash slot: ordered replay on marked cells).
+// Round 1 rasterised ray by ray with a 4-byte compare-and-swap per cell straight on HBM: 295 MB of traffic for the
+// 61 MB the batch needs (rays from one origin re-touch the same lines hundreds of times).  Per tile it is at most
+// one read and one write of 16 KB.
 #include "engine.hpp"
+
+#include <algorithm>
 
 using namespace rna;
 
 namespace {
 
-constexpr int LANES_PER_RAY = 16;
 
 __device__ __forceinline__ float himm_clear(float v) {  // map_updater.h:61-71
   if (v <= 0.0f || v != v) v = 0.0f;
@@ -167,68 +174,254 @@ __global__ void himm_collect_kernel(HimmSlot* __restrict__ slots, int n_slots, c
   for (int i = 0; i < len; ++i) { before[off + i] = 0; after[off + i] = 0; }
 }
 
-__global__ void himm_raster_kernel(int rows, const int4* __restrict__ desc, const int* __restrict__ ncells, int n,
-                                   float* __restrict__ layer, const unsigned* __restrict__ mark_bitmap,
-                                   const HimmSlot* __restrict__ slots, int slot_mask,
-                                   const int* __restrict__ seqs, unsigned* __restrict__ before,
-                                   unsigned* __restrict__ after, unsigned* __restrict__ dirty_tiles, int tiles_i,
-                                   int4 win) {
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int r = gid / LANES_PER_RAY;
-  const int lane = gid % LANES_PER_RAY;
-  if (r >= n) return;
-  const int nc = ncells[r];
-  if (nc == 0) return;
-  const int4 d = desc[r];
-  const int adx = abs(d.z - d.x), ady = abs(d.w - d.y);
-  const int sx = d.z >= d.x ? 1 : -1, sy = d.w >= d.y ? 1 : -1;
-  const bool xmajor = adx >= ady;           // LineIterator.cpp:133-149
-  const int den = xmajor ? adx : ady;
-  const int add = xmajor ? ady : adx;
-  const int num0 = den / 2;
-  int last_tile = -1;
-  for (int k = lane; k < nc; k += LANES_PER_RAY) {
-    // cell k of the Bresenham walk in closed form: the minor axis has stepped
-    // floor((num0 + k*add) / den) times after k increments (LineIterator.cpp:60-70).
-    const int m = den > 0 ? (int)(((long long)num0 + (long long)k * add) / den) : 0;
-    const int i = d.x + (xmajor ? k : m) * sx;
-    const int j = d.y + (xmajor ? m : k) * sy;
-    // tiled single map (SURVEY 8e mode 2): the line is rasterised on the GLOBAL geometry and only
-    // the cells of this GPU's window are written, so every cell sees exactly the full batch's ops
-    if (i < win.x || i >= win.y || j < win.z || j >= win.w) continue;
-    const int cell = j * rows + i;
-    const int tile = (j >> 6) * tiles_i + (i >> 6);
-    if (tile != last_tile && dirty_tiles) {   // flags exist for the laser layer only: "laser differs from master here"
-      // one byte per tile, plain load + plain store of the same value by every first toucher: no
-      // atomics (a bit-packed atomicOr here serialised the whole batch on four cache lines)
-      volatile unsigned char* flag = reinterpret_cast<volatile unsigned char*>(dirty_tiles) + tile;
-      if (!*flag) *flag = 1;
-      last_tile = tile;
+// ---- rays -> tiles ------------------------------------------------------------------------------------------------
+// A ray is walked over its major axis in 64-cell tile columns; inside one it changes the minor tile at most once
+// (slope <= 1), so it is registered with <= 2 tiles per column -- exactly the tiles that hold one of its cells.
+struct RayWalk {
+  int M0, m0, s, sm, den, add, num0, nc;
+  bool xmajor;
+  __device__ __forceinline__ RayWalk(const int4 d, int ncells) {
+    const int adx = abs(d.z - d.x), ady = abs(d.w - d.y);
+    xmajor = adx >= ady;                      // LineIterator.cpp:133-149
+    den = xmajor ? adx : ady;
+    add = xmajor ? ady : adx;
+    num0 = den / 2;
+    nc = ncells;
+    const int sx = d.z >= d.x ? 1 : -1, sy = d.w >= d.y ? 1 : -1;
+    M0 = xmajor ? d.x : d.y; m0 = xmajor ? d.y : d.x;
+    s = xmajor ? sx : sy; sm = xmajor ? sy : sx;
+  }
+  // cell k of the Bresenham walk in closed form: the minor axis has stepped floor((num0 + k*add) / den) times
+  // after k increments (LineIterator.cpp:60-70)
+  __device__ __forceinline__ int minor(int k) const {
+    // k, add, den < 46 341 (rows * cols < 2^31): the numerator fits 32 unsigned bits; a 32-bit division is a
+    // handful of instructions, the 64-bit one a subroutine of ~200
+    return m0 + (den > 0 ? (int)(((unsigned)num0 + (unsigned)k * (unsigned)add) / (unsigned)den) : 0) * sm;
+  }
+  __device__ __forceinline__ int major(int k) const { return M0 + k * s; }
+  // Lock-step form for a whole wavefront (lanes without a ray pass nc = 0): f(active, tile) is called by ALL lanes the
+  // same number of times, so that f can combine the lanes that name the same tile (wave_tile_add below).
+  template <class F>
+  __device__ __forceinline__ void for_each_tile_lockstep(int tiles_i, F f) const {
+    int k = 0;
+    while (__builtin_amdgcn_ballot_w64(k < nc)) {
+      const bool act = k < nc;
+      const int M = major(act ? k : 0), tM = M >> 6;
+      int kend = s > 0 ? k + ((tM << 6) + 63 - M) : k + (M - (tM << 6));
+      if (kend > nc - 1) kend = nc - 1;
+      const int ta = minor(act ? k : 0) >> 6, tb = minor(act ? kend : 0) >> 6;
+      f(act, xmajor ? ta * tiles_i + tM : tM * tiles_i + ta);
+      f(act && tb != ta, xmajor ? tb * tiles_i + tM : tM * tiles_i + tb);
+      if (act) k = kend + 1;
     }
-    if ((mark_bitmap[cell >> 5] >> (cell & 31)) & 1u) {
-      // marked cell: count this clear in the interval before the first mark with seq >= r
-      unsigned h = hash_cell((unsigned)cell) & (unsigned)slot_mask;
-      while (slots[h].cell != cell) h = (h + 1) & (unsigned)slot_mask;
-      const int off = slots[h].offset, len = slots[h].len;
-      int lo = 0, hi = len;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (seqs[off + mid] < r) lo = mid + 1; else hi = mid;
-      }
-      if (lo < len) atomicAdd(&before[off + lo], 1u);
-      else atomicAdd(&after[off + len - 1], 1u);
-    } else {
-      // unmarked cell: clears commute -> lock-free read-modify-write on the float bits
-      int* p = reinterpret_cast<int*>(&layer[cell]);
-      int old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (;;) {
-        const int nv = __float_as_int(himm_clear(__int_as_float(old)));
-        if (nv == old) break;
-        const int seen = atomicCAS(p, old, nv);
-        if (seen == old) break;
-        old = seen;
-      }
+  }
+};
+
+// counters[t] += 1 for every active lane, one atomic per DISTINCT tile of the wavefront; returns the lane's own slot
+// (old value + its rank among the lanes of the same tile).  Rays of one scan are consecutive and start in the same
+// tile: without this the 1563 rays of an origin queue up on one L2 atomic unit per tile they share.
+__device__ __forceinline__ int wave_tile_add(int* __restrict__ counters, bool active, int t) {
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
+  int slot = 0;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int lt = __shfl(t, leader);
+    const unsigned long long same = __builtin_amdgcn_ballot_w64(active && t == lt);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&counters[lt], __popcll(same));
+    base = __shfl(base, leader);
+    if (active && t == lt) slot = base + __popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  return slot;
+}
+
+__global__ void himm_bin_count_kernel(const int4* __restrict__ desc, const int* __restrict__ ncells, int n, int tiles_i,
+                                      int* __restrict__ tile_count) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nc = r < n ? ncells[r] : 0;
+  const RayWalk w(nc ? desc[r] : make_int4(0, 0, 0, 0), nc);
+  w.for_each_tile_lockstep(tiles_i, [&](bool act, int t) { (void)wave_tile_add(tile_count, act, t); });
+}
+
+// exclusive prefix sum of the tile counts (one workgroup; ntile <= 65536 at 4096 x 4096 cells per 64 x 64 tile)
+__global__ void __launch_bounds__(1024) himm_bin_scan_kernel(const int* __restrict__ tile_count, int ntile, int* __restrict__ tile_off,
+                                                             int* __restrict__ tile_cursor) {
+  __shared__ int s_part[1024];
+  const int per = (ntile + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = min(ntile, lo + per);
+  int sum = 0;
+  for (int t = lo; t < hi; ++t) sum += tile_count[t];
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+    __syncthreads();
+    s_part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = s_part[threadIdx.x] - sum;
+  for (int t = lo; t < hi; ++t) { tile_off[t] = run; tile_cursor[t] = 0; run += tile_count[t]; }
+}
+
+__global__ void himm_bin_fill_kernel(const int4* __restrict__ desc, const int* __restrict__ ncells, int n, int tiles_i,
+                                     const int* __restrict__ tile_off, int* __restrict__ tile_cursor, int* __restrict__ pairs) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nc = r < n ? ncells[r] : 0;
+  const RayWalk w(nc ? desc[r] : make_int4(0, 0, 0, 0), nc);
+  w.for_each_tile_lockstep(tiles_i, [&](bool act, int t) {
+    const int slot = wave_tile_add(tile_cursor, act, t);
+    if (act) pairs[tile_off[t] + slot] = r;
+  });
+}
+
+// Two workgroups per 64 x 64 tile that at least one ray crosses, one per half (32 columns j): 8 KB of counters each, so
+// that they fit into the LDS a resident A* search workgroup leaves free on its CU (tests/test_kernel_budgets.py).
+// One LANE per ray: the lane loads its ray (256 independent loads per round instead of a dependent chain per ray),
+// steps along its cells inside the tile with the integer Bresenham recurrence and counts clears in LDS.  A clear that
+// lands on a MARKED cell (ray end points) belongs to an interval between that cell's marks.  The half tile's marked
+// cells are looked up once (hash probe per cell, all threads in parallel) into an LDS table; a cell with a single
+// mark -- almost all of them -- then takes its clears as two more LDS counters (before / after that mark), flushed
+// with one global add each at the end.  Only cells with several marks, or beyond the table, walk the interval
+// counters in HBM (hash probe + binary search: a chain of dependent loads).
+constexpr int HIMM_MTAB = 256;   // marked cells per half tile with an LDS entry
+
+__device__ __forceinline__ void himm_count_marked_clear(int cell, int r, const HimmSlot* __restrict__ slots, int slot_mask,
+                                                        const int* __restrict__ seqs, unsigned* __restrict__ before,
+                                                        unsigned* __restrict__ after) {
+  // count this clear in the interval before the first mark with seq >= r
+  unsigned h = hash_cell((unsigned)cell) & (unsigned)slot_mask;
+  while (slots[h].cell != cell) h = (h + 1) & (unsigned)slot_mask;
+  const int off = slots[h].offset, len = slots[h].len;
+  int lo = 0, hi = len;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (seqs[off + mid] < r) lo = mid + 1; else hi = mid;
+  }
+  if (lo < len) atomicAdd(&before[off + lo], 1u);
+  else atomicAdd(&after[off + len - 1], 1u);
+}
+
+constexpr int HIMM_TR_THREADS = 512;   // 8 wavefronts: two per SIMD next to the four of a resident search workgroup
+__global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int rows, int cols, int tiles_i, const int4* __restrict__ desc,
+                                                               const int* __restrict__ ncells, const int* __restrict__ tile_count,
+                                                               const int* __restrict__ tile_off, const int* __restrict__ pairs,
+                                                               float* __restrict__ layer, const unsigned* __restrict__ mark_bitmap,
+                                                               const HimmSlot* __restrict__ slots, int slot_mask,
+                                                               const int* __restrict__ seqs, unsigned* __restrict__ before,
+                                                               unsigned* __restrict__ after, unsigned* __restrict__ dirty_tiles, int4 win) {
+  __shared__ unsigned s_cnt[32 * 64];   // clears per cell of this half tile, index (j & 31) * 64 + (i & 63)
+  __shared__ unsigned s_mark[64];       // mark bits of the half tile: word lc >> 5, bit lc & 31
+  __shared__ unsigned short s_mrank[64];   // marked cells in the words before this one
+  __shared__ int s_moff[HIMM_MTAB];     // per marked cell (by rank): offset of its marks in seqs / before / after, -1: not a single-mark cell
+  __shared__ int s_mseq[HIMM_MTAB];     // ... the ray sequence number of its one mark
+  __shared__ unsigned s_mcnt[2 * HIMM_MTAB];   // ... clears before / after that mark
+  __shared__ int s_touched;
+  const int t = blockIdx.x >> 1, half = blockIdx.x & 1;
+  const int np = tile_count[t];
+  if (np == 0) return;
+  const int ti = t % tiles_i, tj = t / tiles_i;
+  const int i0 = ti << 6, j0 = (tj << 6) + (half << 5);
+  for (int c = threadIdx.x; c < 32 * 64; c += HIMM_TR_THREADS) s_cnt[c] = 0u;
+  for (int c = threadIdx.x; c < 2 * HIMM_MTAB; c += HIMM_TR_THREADS) s_mcnt[c] = 0u;
+  if (threadIdx.x < HIMM_MTAB) s_moff[threadIdx.x] = -1;
+  if (threadIdx.x < 64) {
+    // the tile's 64 cells of column j are two words of the bitmap when rows is a multiple of 32; gathered bit by
+    // bit otherwise
+    const int jl = threadIdx.x >> 1, wi = threadIdx.x & 1;
+    const int j = j0 + jl, ib = i0 + (wi << 5);
+    unsigned bits = 0u;
+    if (j < cols && ib < rows) {
+      const size_t cell = (size_t)j * rows + ib;
+      if ((cell & 31) == 0 && ib + 32 <= rows) bits = mark_bitmap[cell >> 5];
+      else
+        for (int b = 0; b < 32 && ib + b < rows; ++b) bits |= ((mark_bitmap[(cell + b) >> 5] >> ((cell + b) & 31)) & 1u) << b;
     }
+    s_mark[threadIdx.x] = bits;
+  }
+  if (threadIdx.x == 0) s_touched = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int w = 0; w < 64; ++w) { s_mrank[w] = (unsigned short)run; run += __popc(s_mark[w]); }
+  }
+  __syncthreads();
+  // one hash probe per marked cell of the half tile
+  for (int w = threadIdx.x >> 5, b = threadIdx.x & 31; w < 64; w += HIMM_TR_THREADS / 32) {
+    if (!((s_mark[w] >> b) & 1u)) continue;
+    const int rank = s_mrank[w] + __popc(s_mark[w] & ((1u << b) - 1u));
+    if (rank >= HIMM_MTAB) continue;
+    const int lc = (w << 5) + b;
+    const int cell = (j0 + (lc >> 6)) * rows + i0 + (lc & 63);
+    unsigned h = hash_cell((unsigned)cell) & (unsigned)slot_mask;
+    while (slots[h].cell != cell) h = (h + 1) & (unsigned)slot_mask;
+    if (slots[h].len == 1) { s_moff[rank] = slots[h].offset; s_mseq[rank] = seqs[slots[h].offset]; }
+  }
+  __syncthreads();
+  const int* mine = pairs + tile_off[t];
+  bool touched = false;
+  for (int base = 0; base < np; base += HIMM_TR_THREADS) {
+    const int p = base + (int)threadIdx.x;
+    if (p >= np) break;
+    const int r = mine[p];
+    const RayWalk w(desc[r], ncells[r]);
+    // the ray's cells whose major coordinate lies in this tile
+    const int tM = w.xmajor ? ti : tj;
+    int k_lo = w.s > 0 ? (tM << 6) - w.M0 : w.M0 - ((tM << 6) + 63);
+    int k_hi = w.s > 0 ? (tM << 6) + 63 - w.M0 : w.M0 - (tM << 6);
+    if (k_lo < 0) k_lo = 0;
+    if (k_hi > w.nc - 1) k_hi = w.nc - 1;
+    if (k_lo > k_hi) continue;
+    // integer Bresenham from cell k_lo on (LineIterator.cpp:133-149): minor steps when the numerator passes den
+    // (starting every lane at a different cell of its range, to keep the rays of one scan from piling their first
+    // clears onto the same LDS words, was measured: the second pair of 64-bit divisions costs more than it saves)
+    const unsigned acc = (unsigned)w.num0 + (unsigned)k_lo * (unsigned)w.add;   // < 2^32, see RayWalk::minor
+    const unsigned q = w.den > 0 ? acc / (unsigned)w.den : 0u;
+    int m = w.m0 + (int)q * w.sm;
+    int num = w.den > 0 ? (int)(acc - q * (unsigned)w.den) : 0;
+    int M = w.major(k_lo);
+    for (int k = k_lo; k <= k_hi; ++k) {
+      const int i = w.xmajor ? M : m, j = w.xmajor ? m : M;
+      // the other tile of this tile column / the other half are somebody else's; tiled single map (SURVEY 8e mode
+      // 2): the line is rasterised on the GLOBAL geometry and only the cells of this GPU's window are written
+      if ((i >> 6) == ti && (j >> 5) == (j0 >> 5) && i >= win.x && i < win.y && j >= win.z && j < win.w) {
+        touched = true;
+        const int lc = ((j & 31) << 6) + (i & 63);
+        const unsigned mw = s_mark[lc >> 5];
+        if ((mw >> (lc & 31)) & 1u) {
+          const int rank = s_mrank[lc >> 5] + __popc(mw & ((1u << (lc & 31)) - 1u));
+          const int off = rank < HIMM_MTAB ? s_moff[rank] : -1;
+          // the clear belongs to the interval before the first mark with seq >= r
+          if (off >= 0) atomicAdd(&s_mcnt[2 * rank + (s_mseq[rank] < r ? 1 : 0)], 1u);
+          else himm_count_marked_clear(j * rows + i, r, slots, slot_mask, seqs, before, after);
+        } else {
+          atomicAdd(&s_cnt[lc], 1u);   // unmarked cell: clears commute, only their number matters
+        }
+      }
+      num += w.add;
+      if (num >= w.den && w.den > 0) { num -= w.den; m += w.sm; }
+      M += w.s;
+    }
+  }
+  if (touched) s_touched = 1;
+  __syncthreads();
+  if (!s_touched) return;
+  // flags exist for the laser layer only ("laser differs from master here")
+  if (threadIdx.x == 0 && dirty_tiles) reinterpret_cast<volatile unsigned char*>(dirty_tiles)[t] = 1;
+  if (threadIdx.x < HIMM_MTAB && s_moff[threadIdx.x] >= 0) {
+    const unsigned kb = s_mcnt[2 * threadIdx.x], ka = s_mcnt[2 * threadIdx.x + 1];
+    if (kb) atomicAdd(&before[s_moff[threadIdx.x]], kb);
+    if (ka) atomicAdd(&after[s_moff[threadIdx.x]], ka);
+  }
+  // apply: lanes run along i (contiguous in the column-major layer); only lines that hold a counted cell are touched
+  for (int c = threadIdx.x; c < 32 * 64; c += HIMM_TR_THREADS) {
+    const unsigned k = s_cnt[c];
+    if (k == 0u) continue;
+    const int i = i0 + (c & 63), j = j0 + (c >> 6);
+    float* p = &layer[(size_t)j * rows + i];
+    const float v = *p, nv = himm_clear_n(v, k);
+    if (__float_as_int(nv) != __float_as_int(v)) *p = nv;
   }
 }
 
@@ -261,6 +454,7 @@ int ensure_scratch(rna_engine* e, int n) {
     if ((rc = dev_alloc(e, &s.mark_bitmap, words)) != RNA_OK) return rc;
     RNA_HIP(e, hipMemsetAsync(s.mark_bitmap, 0, words * sizeof(unsigned), e->stream));
     if ((rc = dev_alloc(e, &s.total, 1)) != RNA_OK) return rc;
+    if ((rc = dev_alloc(e, &s.tile_bins, (size_t)3 * e->tiles_i * e->tiles_j)) != RNA_OK) return rc;
   }
   if (n <= s.cap_rays) return RNA_OK;
   int cap = 1024;
@@ -272,7 +466,9 @@ int ensure_scratch(rna_engine* e, int n) {
   if ((rc = dev_alloc(e, &s.rays_dev, (size_t)cap)) != RNA_OK || (rc = dev_alloc(e, &s.desc, (size_t)cap)) != RNA_OK ||
       (rc = dev_alloc(e, &s.ncells, (size_t)cap)) != RNA_OK || (rc = dev_alloc(e, &s.next, (size_t)cap)) != RNA_OK ||
       (rc = dev_alloc(e, &s.seqs, (size_t)cap)) != RNA_OK || (rc = dev_alloc(e, &s.before, (size_t)cap)) != RNA_OK ||
-      (rc = dev_alloc(e, &s.after, (size_t)cap)) != RNA_OK || (rc = dev_alloc(e, &s.slots, (size_t)cap * 2)) != RNA_OK) {
+      (rc = dev_alloc(e, &s.after, (size_t)cap)) != RNA_OK || (rc = dev_alloc(e, &s.slots, (size_t)cap * 2)) != RNA_OK ||
+      // a ray is registered with at most two tiles per 64-cell tile column it crosses
+      (rc = dev_alloc(e, &s.pairs, (size_t)cap * (size_t)(2 * ((std::max(e->geom.size[0], e->geom.size[1]) + 63) / 64) + 2))) != RNA_OK) {
     const std::string why = e->err;
     (void)himm_release(e);
     e->err = why;
@@ -304,10 +500,18 @@ int himm_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n) {
   }
   {
     KernelTimer kt(e, RNA_K_HIMM_RASTER);
-    const long long threads = (long long)n * LANES_PER_RAY;
-    hipLaunchKernelGGL(himm_raster_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream,
-                       g.size[0], s.desc, s.ncells, n, e->layer[layer], s.mark_bitmap, s.slots, n_slots - 1,
-                       s.seqs, s.before, s.after, layer == RNA_LAYER_LASER ? e->dirty_tiles : nullptr, e->tiles_i, win);
+    const int ntile = e->tiles_i * e->tiles_j;
+    int* count = s.tile_bins;
+    int* off = s.tile_bins + ntile;
+    int* cursor = s.tile_bins + 2 * ntile;
+    RNA_HIP(e, hipMemsetAsync(count, 0, (size_t)ntile * sizeof(int), e->stream));
+    hipLaunchKernelGGL(himm_bin_count_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, s.desc, s.ncells, n, e->tiles_i, count);
+    hipLaunchKernelGGL(himm_bin_scan_kernel, dim3(1), dim3(1024), 0, e->stream, count, ntile, off, cursor);
+    hipLaunchKernelGGL(himm_bin_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, s.desc, s.ncells, n, e->tiles_i, off,
+                       cursor, s.pairs);
+    hipLaunchKernelGGL(himm_tile_raster_kernel, dim3(2 * ntile), dim3(HIMM_TR_THREADS), 0, e->stream, g.size[0], g.size[1], e->tiles_i, s.desc,
+                       s.ncells, count, off, s.pairs, e->layer[layer], s.mark_bitmap, s.slots, n_slots - 1, s.seqs, s.before,
+                       s.after, layer == RNA_LAYER_LASER ? e->dirty_tiles : nullptr, win);
     RNA_HIP(e, hipGetLastError());
   }
   {
@@ -327,6 +531,7 @@ int himm_release(rna_engine* e) {
   HimmScratch& s = e->himm;
   dev_free(&s.rays_dev); dev_free(&s.desc); dev_free(&s.ncells); dev_free(&s.next); dev_free(&s.slots);
   dev_free(&s.seqs); dev_free(&s.before); dev_free(&s.after); dev_free(&s.total); dev_free(&s.mark_bitmap);
+  dev_free(&s.pairs); dev_free(&s.tile_bins);
   s.cap_rays = 0;
   s.n_slots = 0;
   return RNA_OK;

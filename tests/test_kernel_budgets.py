@@ -51,7 +51,8 @@ def test_engine_stream_kernels_fit_next_to_the_search_workgroups():
     for src in ("vfh.hip", "himm.hip", "engine.hip"):
         side.update(resources(src))
     side.update({k: v for k, v in tile.items() if "tsa_search_kernel" not in k})
-    hot = ("vfh_step_kernel", "himm_prep_kernel", "himm_raster_kernel", "himm_apply_kernel", "himm_collect_kernel",
+    hot = ("vfh_step_kernel", "himm_prep_kernel", "himm_tile_raster_kernel", "himm_bin_count_kernel", "himm_bin_scan_kernel",
+           "himm_bin_fill_kernel", "himm_apply_kernel", "himm_collect_kernel",
            "compose_dirty_tiles_kernel", "nbr_mask_tiles_kernel", "tsa_reset_kernel", "tsa_snapshot_kernel", "tsa_backtrace_kernel")
     seen = 0
     for name, r in side.items():
@@ -60,4 +61,4 @@ def test_engine_stream_kernels_fit_next_to_the_search_workgroups():
         seen += 1
         assert alloc(r["VGPRs"]) <= free_vgprs, "%s: %d VGPRs, %d left beside four search wavefronts" % (name, r["VGPRs"], free_vgprs)
         assert r["LDS"] <= free_lds, "%s: %d B of LDS, %d B left beside a search workgroup" % (name, r["LDS"], free_lds)
-    assert seen >= 9
+    assert seen >= 12
