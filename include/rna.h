@@ -280,13 +280,22 @@ int rna_rrt_batch_device(rna_engine* e, const rna_rrt_query* queries_device, int
                          int max_path_len, rna_rrt_result* results_device);
 
 /* ---- laser ingestion ------------------------------------------------------------------------- */
-/* One sensor_msgs/LaserScan plus the sensor pose tf reports for it (planar, constant over the scan). */
+/* One sensor_msgs/LaserScan plus the planar sensor poses tf reports for it: at header.stamp, and at the end time
+ * laser_geometry's high-fidelity projection asks for, stamp + (beams - 1) * time_increment, where `beams` counts the
+ * beams of the scan that is projected -- the decimated one when angle_increment < 0.017 (rna_scan_projected_beams).
+ * Every beam is transformed with the pose interpolated for its index (position linearly, yaw along the shortest arc),
+ * as transformLaserScanToPointCloud does with tf's start / end transforms.  End pose == start pose: a pose that is
+ * constant over the scan. */
 typedef struct {
   float angle_min, angle_max, angle_increment, range_min, range_max;
   int32_t n_ranges;
   int64_t ranges_offset;   /* first range of this scan in the concatenated ranges array */
-  double x, y, yaw;        /* sensor pose in the map frame */
+  double x, y, yaw;        /* sensor pose in the map frame at header.stamp (also the origin of every ray) */
+  double x_end, y_end, yaw_end;   /* sensor pose at the end time */
 } rna_laser_scan;
+/* number of beams of the scan LaserMapUpdater hands to the projector (simplifyLaserScan, mc/src/laser_map_updater.cpp:
+ * 118-143, when angle_increment < 0.017; else n_ranges): the end time above is stamp + (this - 1) * time_increment */
+int rna_scan_projected_beams(int n_ranges, float angle_increment);
 /* LaserMapUpdater::bufferIncomingMsg (mc/src/laser_map_updater.cpp:37-75): simplifyLaserScan
  * (:118-143), laser_geometry's projection + tf transform of every valid beam (:78-99), ray origin
  * (:101-116) -> RangeSamples in scan order, beam order.  n_rays receives the number of rays produced;

@@ -214,7 +214,8 @@ typedef struct {
   float angle_min, angle_max, angle_increment, range_min, range_max;   /* sensor_msgs/LaserScan fields */
   int32_t n_ranges;
   int64_t ranges_offset;   /* first range of this scan in the concatenated ranges array */
-  double x, y, yaw;        /* sensor pose in the map frame (tf), constant over the scan */
+  double x, y, yaw;        /* sensor pose in the map frame (tf) at header.stamp */
+  double x_end, y_end, yaw_end;   /* ... at stamp + (projected beams - 1) * time_increment */
 } og_scan;
 int og_simplify_scan(int n, float angle_increment, int* sel, int cap, float* out_increment);
 int og_scan_to_rays(const og_scan* s, const float* ranges, og_ray* out, int cap);   /* returns the number of rays */

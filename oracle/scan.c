@@ -9,11 +9,16 @@
  * laser_geometry and tf are ROS packages that are NOT under /root/reference and are not
  * version-pinned by it (move_control/package.xml:16-29 lists them without versions; ROS Indigo
  * ships laser_geometry 1.6.x, tf 1.11.x).  Their published algorithm is restated here for the case
- * the engine supports: a planar sensor pose (x, y, yaw) in the map frame that is constant over the
- * scan (so tf's start/end interpolation of the high-fidelity projection is the identity):
+ * the engine supports: planar sensor poses (x, y, yaw) in the map frame at the scan's start time (header.stamp)
+ * and end time (stamp + (beams - 1) * time_increment, beams of the PROJECTED scan), as
+ * transformLaserScanToPointCloud looks them up:
  *   projectLaser_:  x = r*cos(angle_min + i*angle_increment), y = r*sin(...) in double, a point is
  *                   emitted iff r < range_max && r >= range_min, stored as float32 with its index;
- *   transform:      p' = R(yaw) p + t in double on the float32 point, stored as float32 again.
+ *   per point:      ratio = index / (beams - 1); origin = (1 - ratio) * t_start + ratio * t_end
+ *                   (tf::Vector3::setInterpolate3), rotation = slerp(q_start, q_end, ratio) -- for rotations about z
+ *                   the yaw interpolated along the shortest arc;
+ *   transform:      p' = R(yaw_i) p + t_i in double on the float32 point, stored as float32 again.
+ * (A scan of one beam divides by zero there; defined here: ratio = 0.)
  * PARITY UNPINNED: no reference test covers this path and the dependencies cannot be built here.
  * Reference quirks kept: the point's index refers to the SIMPLIFIED scan but ifClearEnd looks it
  * up in the ORIGINAL ranges (laser_map_updater.cpp:62-69); the simplified scan starts with
@@ -57,16 +62,23 @@ int og_scan_to_rays(const og_scan* s, const float* ranges, og_ray* out, int cap)
     if (n > (1 << 16)) n = 1 << 16;
     sel = sel_buf;
   }
-  const double cy = cos(s->yaw), sy = sin(s->yaw);
   const double range_cutoff = s->range_max;
+  double dyaw = fmod(s->yaw_end - s->yaw, 2.0 * M_PI);   /* shortest arc, as a quaternion slerp turns */
+  if (dyaw > M_PI) dyaw -= 2.0 * M_PI;
+  if (dyaw < -M_PI) dyaw += 2.0 * M_PI;
+  const double ranges_norm = n > 1 ? 1.0 / ((double)n - 1.0) : 0.0;
   int m = 0;
   for (int i = 0; i < n; ++i) {
     const float range = r[sel ? sel[i] : i];
     if (!(range < range_cutoff && range >= s->range_min)) continue;
     const double a = s->angle_min + (double)i * inc;
     const float px = (float)(range * cos(a)), py = (float)(range * sin(a));
-    const float gx = (float)(cy * (double)px - sy * (double)py + s->x);
-    const float gy = (float)(sy * (double)px + cy * (double)py + s->y);
+    const double ratio = (double)i * ranges_norm, keep = 1.0 - ratio;
+    const double yaw_i = s->yaw + ratio * dyaw;
+    const double cy = cos(yaw_i), sy = sin(yaw_i);
+    const double tx = keep * s->x + ratio * s->x_end, ty = keep * s->y + ratio * s->y_end;
+    const float gx = (float)(cy * (double)px - sy * (double)py + tx);
+    const float gy = (float)(sy * (double)px + cy * (double)py + ty);
     const float orig = i < s->n_ranges ? r[i] : r[s->n_ranges - 1];   /* msg->ranges[index] of the ORIGINAL scan */
     if (m < cap) {
       out[m].sx = s->x; out[m].sy = s->y;

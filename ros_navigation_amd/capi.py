@@ -36,7 +36,7 @@ SYMBOLS = [
     "rna_astar_download_nbr_mask",
     "rna_graph_astar_batch", "rna_rrt_batch", "rna_rrt_batch_device",
     "rna_to_occupancy_grid", "rna_to_occupancy_grid_device", "rna_from_occupancy_grid", "rna_vfh_hist_msg_batch",
-    "rna_tailor_plan", "rna_follow_plan", "rna_get_submap", "rna_get_submap_device", "rna_create_submap", "rna_scan_to_rays", "rna_scan_to_rays_device", "rna_range_to_rays",
+    "rna_tailor_plan", "rna_follow_plan", "rna_get_submap", "rna_get_submap_device", "rna_create_submap", "rna_scan_to_rays", "rna_scan_to_rays_device", "rna_scan_projected_beams", "rna_range_to_rays",
     "rna_profile_enable", "rna_profile_reset", "rna_profile_get", "rna_kernel_name",
 ]
 
@@ -73,7 +73,7 @@ VFH_OUT_DTYPE = np.dtype([("chosen_speed", "<i4"), ("chosen_turnrate", "<i4"), (
                           ("emergency", "<i4")])
 SCAN_DTYPE = np.dtype([("angle_min", "<f4"), ("angle_max", "<f4"), ("angle_increment", "<f4"), ("range_min", "<f4"),
                        ("range_max", "<f4"), ("n_ranges", "<i4"), ("ranges_offset", "<i8"), ("x", "<f8"), ("y", "<f8"),
-                       ("yaw", "<f8")])
+                       ("yaw", "<f8"), ("x_end", "<f8"), ("y_end", "<f8"), ("yaw_end", "<f8")])
 RANGE_READING_DTYPE = np.dtype([("range", "<f4"), ("max_range", "<f4"), ("x", "<f8"), ("y", "<f8"), ("yaw", "<f8")])
 ASTAR_QUERY_DTYPE = np.dtype([("start", "<i4"), ("goal", "<i4")])
 ASTAR_RESULT_DTYPE = np.dtype([("status", "<i4"), ("path_len", "<i4"), ("cost", "<i4"), ("expanded", "<i4"),
@@ -131,6 +131,7 @@ def lib():
     L.rna_circle_cells.argtypes = [gp, C.c_double, C.c_double, C.c_double, ip, C.c_int]
     L.rna_submap_cells.argtypes = [gp, ip, ip, ip, C.c_int]
     L.rna_clone.argtypes = [vp, C.POINTER(vp)]
+    L.rna_scan_projected_beams.argtypes = [C.c_int, C.c_float]
     L.rna_himm_update.argtypes = [vp, C.c_int, vp, C.c_int]
     L.rna_himm_update_device.argtypes = [vp, C.c_int, vp, C.c_int]
     L.rna_compose_master.argtypes = [vp, C.c_int]

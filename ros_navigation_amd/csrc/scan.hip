@@ -54,8 +54,13 @@ scan_to_rays_kernel(const rna_laser_scan* __restrict__ scans, const float* __res
   __syncthreads();
   const int n = s_n;
   const float inc = s_inc;
-  const double cy = cos(sc.yaw), sy = sin(sc.yaw);
   const double range_cutoff = sc.range_max;
+  // tf's start / end transforms interpolated per beam (laser_geometry's high-fidelity projection): position linearly,
+  // yaw along the shortest arc; a constant pose (end == start) reduces to one rotation
+  double dyaw = fmod(sc.yaw_end - sc.yaw, 2.0 * M_PI);
+  if (dyaw > M_PI) dyaw -= 2.0 * M_PI;
+  if (dyaw < -M_PI) dyaw += 2.0 * M_PI;
+  const double ranges_norm = n > 1 ? 1.0 / ((double)n - 1.0) : 0.0;
   rna_ray* out = staged + (size_t)blockIdx.x * max_rays_per_scan;
   for (int i0 = 0; i0 < n; i0 += SCAN_THREADS) {
     const int i = i0 + tid;
@@ -67,9 +72,13 @@ scan_to_rays_kernel(const rna_laser_scan* __restrict__ scans, const float* __res
       if (valid) {
         const double a = sc.angle_min + (double)i * inc;
         const float px = (float)(range * cos(a)), py = (float)(range * sin(a));   // projectLaser_: float32 point
+        const double ratio = (double)i * ranges_norm, keep = 1.0 - ratio;
+        const double yaw_i = sc.yaw + ratio * dyaw;
+        const double cy = cos(yaw_i), sy = sin(yaw_i);
+        const double tx = keep * sc.x + ratio * sc.x_end, ty = keep * sc.y + ratio * sc.y_end;
         ray.sx = sc.x; ray.sy = sc.y;
-        ray.ex = (double)(float)(cy * (double)px - sy * (double)py + sc.x);       // tf transform, float32 again
-        ray.ey = (double)(float)(sy * (double)px + cy * (double)py + sc.y);
+        ray.ex = (double)(float)(cy * (double)px - sy * (double)py + tx);         // tf transform, float32 again
+        ray.ey = (double)(float)(sy * (double)px + cy * (double)py + ty);
         const float orig = r[i < sc.n_ranges ? i : sc.n_ranges - 1];              // ORIGINAL ranges[index], :62-69
         ray.clear_end = (isinf(orig) || orig == sc.range_max) ? 1 : 0;
         ray._pad = 0;
@@ -112,6 +121,18 @@ __global__ void __launch_bounds__(256) scan_pack_kernel(const rna_ray* __restric
 }
 
 }  // namespace
+
+extern "C" int rna_scan_projected_beams(int n_ranges, float angle_increment) {
+  if (n_ranges <= 0) return 0;
+  if (!(angle_increment < 0.017)) return n_ranges;   // laser_map_updater.cpp:82
+  int m = 1;                                          // simplifyLaserScan (:118-143)
+  float increment = 0.0f;
+  for (int i = 0; i < n_ranges; ++i) {
+    increment += angle_increment;
+    if (increment >= 0.017) { increment = 0.0f; ++m; }
+  }
+  return m;
+}
 
 extern "C" int rna_scan_to_rays_device(rna_engine* e, const rna_laser_scan* scans_device, int n_scans,
                                        const float* ranges_device, int max_beams_per_scan, rna_ray* rays_device, int max_rays,

@@ -110,10 +110,11 @@ def rrt_queries(n, master, rows, cols, engine_get_position, seed=3, max_samples=
     return q
 
 
-def laser_scans(n_scans, n_beams, length_x, length_y, seed=6, angle_increment=None, range_max=6.0, hit=0.8):
+def laser_scans(n_scans, n_beams, length_x, length_y, seed=6, angle_increment=None, range_max=6.0, hit=0.8, moving=0.5):
     """Synthetic sensor_msgs/LaserScan batch (capi.SCAN_DTYPE descriptors + concatenated float32 ranges): sensor
     poses inside the map, 270-degree fans, ranges uniform in [range_min, range_max) for hits, range_max or +inf for
-    misses, a few NaN / below-range_min returns (all dropped by the projection as in laser_geometry)."""
+    misses, a few NaN / below-range_min returns (all dropped by the projection as in laser_geometry).  A share `moving`
+    of the scans carries an end pose that differs from the start pose (the high-fidelity projection interpolates)."""
     from .capi import SCAN_DTYPE
     rng = np.random.default_rng(seed)
     scans = np.zeros(n_scans, SCAN_DTYPE)
@@ -128,7 +129,11 @@ def laser_scans(n_scans, n_beams, length_x, length_y, seed=6, angle_increment=No
         r[rng.random(n_beams) < 0.01] = np.nan
         r[rng.random(n_beams) < 0.01] = np.float32(0.01)
         ranges[k * n_beams:(k + 1) * n_beams] = r
+        x, y, yaw = rng.uniform(-0.4, 0.4) * length_x, rng.uniform(-0.4, 0.4) * length_y, rng.uniform(-np.pi, np.pi)
+        xe, ye, yawe = x, y, yaw
+        if rng.random() < moving:     # the sensor moved during the scan: tf's end transform differs (yaw may cross +-pi)
+            xe, ye = x + rng.uniform(-0.05, 0.05), y + rng.uniform(-0.05, 0.05)
+            yawe = (yaw + rng.uniform(-0.2, 0.2) + np.pi) % (2 * np.pi) - np.pi
         scans[k] = (np.float32(-0.5 * fan), np.float32(-0.5 * fan + inc * n_beams), inc, np.float32(0.1), np.float32(range_max),
-                    n_beams, k * n_beams, rng.uniform(-0.4, 0.4) * length_x, rng.uniform(-0.4, 0.4) * length_y,
-                    rng.uniform(-np.pi, np.pi))
+                    n_beams, k * n_beams, x, y, yaw, xe, ye, yawe)
     return scans, ranges

@@ -362,7 +362,7 @@ def rrt_plan(g, master, start, target, tol=0.2, seed=1, max_samples=200000, cap=
 
 SCAN_DTYPE = np.dtype([("angle_min", "<f4"), ("angle_max", "<f4"), ("angle_increment", "<f4"), ("range_min", "<f4"),
                        ("range_max", "<f4"), ("n_ranges", "<i4"), ("ranges_offset", "<i8"), ("x", "<f8"), ("y", "<f8"),
-                       ("yaw", "<f8")])
+                       ("yaw", "<f8"), ("x_end", "<f8"), ("y_end", "<f8"), ("yaw_end", "<f8")])
 
 
 def scan_to_rays(scans, ranges):

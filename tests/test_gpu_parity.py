@@ -705,7 +705,8 @@ def test_hist_msg_matches_oracle(R):
 
 
 def test_scan_to_rays_matches_oracle_and_feeds_himm(R):
-    """LaserScan batches -> RangeSamples on the device.  Ray counts, order, origins and
+    """LaserScan batches -> RangeSamples on the device, every beam transformed with the sensor pose
+    interpolated between tf's start and end transforms (half of the scans move while they sweep).  Ray counts, order, origins and
     ifClearEnd flags are exact; end points are float32 values built from device cos/sin (f64), so they may
     differ from the oracle's libm by one float32 ulp -- compared at 1e-6 m, and bit-exactly for the
     overwhelming majority."""
@@ -713,6 +714,9 @@ def test_scan_to_rays_matches_oracle_and_feeds_himm(R):
     g = O.make_geom(25.6, 25.6, 0.05)
     for inc, beams in ((None, 1081), (np.float32(0.02), 200), (np.float32(0.0005), 4000)):
         scans, ranges = R.synth.laser_scans(24, beams, 25.6, 25.6, seed=beams, angle_increment=inc)
+        assert (scans["yaw_end"] != scans["yaw"]).any() and (scans["yaw_end"] == scans["yaw"]).any()   # moving and resting sensors
+        n_proj = R.capi.lib().rna_scan_projected_beams(beams, float(scans["angle_increment"][0]))
+        assert n_proj == (beams if scans["angle_increment"][0] >= 0.017 else len(O.simplify_scan(beams, scans["angle_increment"][0])[0]))
         want = O.scan_to_rays(scans, ranges)
         got = e.scan_to_rays(scans, ranges)
         assert len(got) == len(want) > 0

@@ -24,12 +24,12 @@ def test_scan_to_rays_projection_filter_and_quirks():
     scans = np.zeros(2, O.SCAN_DTYPE)
     # scan 0: coarse increment (no decimation), sensor at (1, 2) looking along +y
     r0 = np.array([0.05, 1.0, 2.0, np.inf, 6.0, np.nan, 3.0], np.float32)
-    scans[0] = (np.float32(-0.3), 0, np.float32(0.1), np.float32(0.1), np.float32(6.0), len(r0), 0, 1.0, 2.0, np.pi / 2)
+    scans[0] = (np.float32(-0.3), 0, np.float32(0.1), np.float32(0.1), np.float32(6.0), len(r0), 0, 1.0, 2.0, np.pi / 2, 1.0, 2.0, np.pi / 2)
     # scan 1: fine increment -> decimated; index quirk: clear_end looks up the ORIGINAL ranges at the simplified index
     n1 = 40
     r1 = np.full(n1, 2.5, np.float32)
     r1[3] = 6.0         # original beam 3 == range_max: simplified beam 3 (a different beam) is flagged ifClearEnd
-    scans[1] = (np.float32(0.0), 0, np.float32(0.004), np.float32(0.1), np.float32(6.0), n1, len(r0), -1.0, 0.5, 0.0)
+    scans[1] = (np.float32(0.0), 0, np.float32(0.004), np.float32(0.1), np.float32(6.0), n1, len(r0), -1.0, 0.5, 0.0, -1.0, 0.5, 0.0)
     rays = O.scan_to_rays(scans, np.concatenate([r0, r1]))
     sel, inc = O.simplify_scan(n1, np.float32(0.004))
     n0 = 3                                             # beams 1, 2 and 6 of scan 0 survive (0.05 < range_min, inf/max/NaN dropped)
@@ -44,3 +44,29 @@ def test_scan_to_rays_projection_filter_and_quirks():
     assert second["clear_end"].tolist() == [1 if k == 3 else 0 for k in range(len(sel))]
     ang = np.float64(0.0) + np.arange(len(sel)) * np.float64(np.float32(inc))
     assert np.allclose(second["ex"], -1.0 + 2.5 * np.cos(ang), atol=1e-6) and np.allclose(second["ey"], 0.5 + 2.5 * np.sin(ang), atol=1e-6)
+
+
+def test_scan_pose_is_interpolated_between_tf_start_and_end():
+    """laser_geometry's high-fidelity projection: beam i of n is transformed with the pose at ratio i / (n - 1) between
+    tf's start and end transforms -- position linearly, yaw along the shortest arc (here across +-pi); the ray origin
+    stays the start pose (getLaserOriginOnGlobal transforms (0, 0, 0) at header.stamp)."""
+    n = 5
+    r = np.full(n, 2.0, np.float32)
+    scans = np.zeros(1, O.SCAN_DTYPE)
+    y0, y1 = np.pi - 0.05, -np.pi + 0.07          # 0.12 rad apart through pi
+    scans[0] = (np.float32(0.0), 0, np.float32(0.1), np.float32(0.1), np.float32(6.0), n, 0, 1.0, -2.0, y0, 1.4, -2.2, y1)
+    rays = O.scan_to_rays(scans, r)
+    assert len(rays) == n and np.all(rays["sx"] == 1.0) and np.all(rays["sy"] == -2.0)
+    for i in range(n):
+        ratio = i / (n - 1)
+        yaw = y0 + ratio * 0.12
+        a = i * np.float64(np.float32(0.1))
+        px, py = np.float32(2.0 * np.cos(a)), np.float32(2.0 * np.sin(a))
+        tx, ty = (1 - ratio) * 1.0 + ratio * 1.4, (1 - ratio) * -2.0 + ratio * -2.2
+        ex = np.cos(yaw) * np.float64(px) - np.sin(yaw) * np.float64(py) + tx
+        ey = np.sin(yaw) * np.float64(px) + np.cos(yaw) * np.float64(py) + ty
+        assert abs(rays["ex"][i] - ex) < 1e-6 and abs(rays["ey"][i] - ey) < 1e-6
+    # a single beam: ratio 0 (the reference divides by zero there)
+    scans["n_ranges"] = 1
+    one = O.scan_to_rays(scans, r[:1])
+    assert len(one) == 1 and abs(one["ex"][0] - (np.cos(y0) * 2.0 + 1.0)) < 1e-6
