@@ -290,6 +290,13 @@ def test_vfh_update_matches_reference_golden(R, pi):
 # ------------------------------------------------------------------------------------------------
 # grid A*
 # ------------------------------------------------------------------------------------------------
+def oracle_pool(fn, n):
+    """fn(k) for k < n on every host core (the C oracle releases the GIL)"""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, min(32, len(os.sched_getaffinity(0))))) as ex:
+        return list(ex.map(fn, range(n)))
+
+
 def check_astar(R, e, master, queries, max_len, settled_counts=True, **cfg):
     if cfg:
         e.astar_configure(**cfg)
@@ -456,6 +463,77 @@ def test_astar_pipelined_batches_with_map_updates_in_between(R):
     assert same_f32(e.download(R.capi.LAYER_MASTER), ref)
     for p in bufs:
         hip.free(p)
+    e.close()
+
+
+def test_bench_loop_at_full_size_matches_oracle_every_step(R):
+    """bench.py's timed loop as it runs, at BASELINE's size: 4096 x 4096 map, per step a 100 032-ray HIMM batch (four
+    batches in rotation) + fused compose -> VFH+ for 256 poses (four pose sets, the robots' VFH state carried from step
+    to step) -> 256 grid-A* queries (four query sets) through the asynchronous device entry points with six batches in
+    flight, nothing waited for in between.  Every step's map, VFH+ commands and histograms, and A* statuses / costs /
+    paths against the oracle fed with the same sequence."""
+    hip = _Hip()
+    n, nq, steps, rot, depth, max_len = 4096, 256, 7, 4, 6, 32768
+    L = n * 0.05
+    e = R.Engine(L, L, 0.05)
+    g = O.make_geom(L, L, 0.05)
+    ref = R.synth.obstacles_rect(n, n, density=0.30, seed=2)
+    e.upload(R.capi.LAYER_LASER, ref)
+    e.compose_master(1)
+    ray_sets = [R.synth.rays(64, 1563, L, L, seed=4 + k) for k in range(rot)]
+    pose_sets = [R.synth.poses(nq, L, L, seed=1 + k) for k in range(rot)]
+    query_sets = [R.synth.astar_queries(nq, ref, n, n, seed=2 + k) for k in range(rot)]
+    d_rays = [hip.upload(r) for r in ray_sets]
+    d_poses = [hip.upload(p) for p in pose_sets]
+    d_q = [hip.upload(q) for q in query_sets]
+    e.vfh_init(nq)
+    e.astar_pipeline_depth(depth)
+    e.astar_configure(max_queries=nq)
+    outs = []
+    for s in range(steps):
+        k = s % rot
+        d_vfh, d_origin, d_hist = hip.alloc(nq * 16), hip.alloc(nq * 72 * 4), hip.alloc(nq * 72 * 4)
+        d_paths, d_res = hip.alloc(nq * max_len * 4), hip.alloc(nq * 24)
+        e.update_map_device(d_rays[k], len(ray_sets[k]), compose_mode=0)
+        e.vfh_step_device(d_poses[k], nq, d_vfh, d_origin, d_hist)
+        e.astar_device(d_q[k], nq, d_paths, max_len, d_res)
+        outs.append((d_vfh, d_origin, d_hist, d_paths, d_res))
+    e.synchronize()
+    oracles = [O.OracleVfh() for _ in range(nq)]
+    found = 0
+    for s in range(steps):
+        k = s % rot
+        O.himm_update(g, ref, ray_sets[k].view(O.RAY_DTYPE))
+        vout = hip.download(outs[s][0], np.uint8, nq * 16).view(R.capi.VFH_OUT_DTYPE)
+        origin = hip.download(outs[s][1], np.float32, nq * 72).reshape(nq, 72)
+        hist = hip.download(outs[s][2], np.float32, nq * 72).reshape(nq, 72)
+        poses = pose_sets[k].copy()
+        for r in range(nq):
+            p = poses[r]
+            cs, ct = oracles[r].step_pose(g, ref, p["x"], p["y"], p["yaw"], int(p["current_speed"]), p["goal_direction"],
+                                          p["goal_distance"], p["goal_tolerance"], float(p["dt"]))
+            assert (vout["chosen_speed"][r], vout["chosen_turnrate"][r]) == (cs, ct), (s, r)
+            assert origin[r].tobytes() == oracles[r].origin_hist().tobytes() and hist[r].tobytes() == oracles[r].hist().tobytes(), (s, r)
+        res = hip.download(outs[s][4], np.int32, nq * 6).reshape(nq, 6)
+        paths = hip.download(outs[s][3], np.int32, nq * max_len).reshape(nq, max_len)
+        _, nbr = O.astar_masks(ref, n, n)
+        q = query_sets[k]
+
+        def one(i):
+            ores, opath, _ = O.astar_query(nbr, n, n, q["start"][i], q["goal"][i])
+            assert res[i, 0] == (0 if ores.status == 0 else 1), (s, i)
+            if ores.status == 0:
+                assert res[i, 1] == ores.path_len and res[i, 2] == ores.cost, (s, i)
+                assert np.array_equal(paths[i, :ores.path_len], opath), (s, i)
+            return ores.status == 0
+        found += sum(oracle_pool(one, nq))
+    assert found > steps * nq * 0.9
+    assert same_f32(e.download(R.capi.LAYER_MASTER), ref) and same_f32(e.download(R.capi.LAYER_LASER), ref)
+    for t in outs:
+        for p_ in t:
+            hip.free(p_)
+    for p_ in d_rays + d_poses + d_q:
+        hip.free(p_)
     e.close()
 
 
@@ -831,13 +909,6 @@ def test_astar_large_grid_properties(R):
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json's full sizes for the rows whose oracle is fast enough to run them whole
 # ------------------------------------------------------------------------------------------------
-def oracle_pool(fn, n):
-    """fn(k) for k < n on every host core (the C oracle releases the GIL)"""
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max(1, min(32, len(os.sched_getaffinity(0))))) as ex:
-        return list(ex.map(fn, range(n)))
-
-
 def test_astar_config3_every_bench_query_matches_oracle(R):
     """Config 3 as bench.py serves it: the 4096 x 4096 rectangle map (seed 2) and ALL 256 (start, goal) pairs of a
     batch, through the asynchronous device entry point with batches in flight: path, cost and settled count E of
