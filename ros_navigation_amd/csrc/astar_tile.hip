@@ -1047,7 +1047,7 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     KernelTimer kt(e, RNA_K_ASTAR_INIT, init_stream);
     hipLaunchKernelGGL(tsa_snapshot_kernel, dim3(2048), dim3(256), 0, init_stream, e->nbr, rows, cols, ti, tj, S.nbr_tm,
                        e->geom.start[0], e->geom.start[1]);
-    hipLaunchKernelGGL(tsa_reset_kernel, dim3(32, a.max_queries), dim3(256), 0, init_stream, S, ti * tj);
+    hipLaunchKernelGGL(tsa_reset_kernel, dim3(128, a.max_queries), dim3(256), 0, init_stream, S, ti * tj);   // ~5 pages per block at 4096^2
     hipLaunchKernelGGL(tsa_reset_done_kernel, dim3(1), dim3(256), 0, init_stream, S, a.max_queries);
     if (n <= 2048)   // the ranking is O(n^2 / 256) per thread: beyond this the caller order is kept
       // one small workgroup: it has to fit next to the search workgroups that fill every CU when batches are pipelined
