@@ -146,8 +146,13 @@ def cpu_baseline(args, R, master, rays, poses, queries, rows, cols, length):
                          cores, t_mt)}
 
 
+# the kernels timed as the "himm_raster" slot (himm.hip: rays binned to 64 x 64 tiles, then rasterised per tile in LDS);
+# the 16 KiB memset of the bin counters in front of them is not attributed
+HIMM_RASTER_CHAIN = ["himm_bin_count_kernel", "himm_bin_scan_kernel", "himm_bin_fill_kernel", "himm_tile_raster_kernel"]
+
+
 def pmc_traffic(kernel, args, world):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes, as the range [TCC_EA0 requests x 64 B,
+    """HBM bytes per launch of `kernel` (or of a chain of kernels timed as one slot) from the committed rocprofv3 PMC passes, as the range [TCC_EA0 requests x 64 B,
     reads doubled] (MI355X_MICROARCH.md: FETCH_SIZE reports half of the bytes of 16 B/lane streaming reads; this
     kernel's dword accesses are uncalibrated).  None unless the passes were taken on this very configuration."""
     try:
@@ -157,9 +162,9 @@ def pmc_traffic(kernel, args, world):
         if (c["grid"], c["queries"], c["pipeline"], c["ray_poses"], c["rays_per_pose"]) != \
                 (args.grid, args.queries, args.pipeline, args.ray_poses, args.rays_per_pose) or world != 1 or args.tiled:
             return None, "PMC passes in profiles/ were taken on another configuration"
-        k = d["kernels"][kernel]
-        lo = (k["fetch_size_kb_avg"] + k["write_size_kb_avg"]) * 1024.0
-        hi = (2.0 * k["fetch_size_kb_avg"] + k["write_size_kb_avg"]) * 1024.0
+        ks = [d["kernels"][name] for name in ([kernel] if isinstance(kernel, str) else kernel)]   # a slot's chain: one launch each
+        lo = sum(k["fetch_size_kb_avg"] + k["write_size_kb_avg"] for k in ks) * 1024.0
+        hi = sum(2.0 * k["fetch_size_kb_avg"] + k["write_size_kb_avg"] for k in ks) * 1024.0
         return [lo, hi], "profiles/r02_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " \
                          "[(FETCH+WRITE), (2*FETCH+WRITE)] x 1024 B per launch"
     except Exception:
@@ -339,7 +344,7 @@ def main():
             ms = prof[kernel_key][0] / max(1, prof[kernel_key][1])
             gbs = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             tr, src = pmc_traffic(pmc_name, args, world)
-            return {"kernel": pmc_name, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            return {"kernel": pmc_name if isinstance(pmc_name, str) else " + ".join(pmc_name), "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                     "traffic": tr, "traffic_source": src, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms,
                     "launches": prof[kernel_key][1]}
 
@@ -370,7 +375,7 @@ def main():
                          # the whole-step figure (algorithmic bytes of one launch / wall time of one step) is given too
                          "overlapped_launches": ms_search / (1e3 * t_max / args.steps),
                          "achieved_per_step_wall": alg_bytes / (t_max / args.steps) / 1e9},
-            "roofline_rows": [row("himm_raster", "himm_raster_kernel", himm_alg),
+            "roofline_rows": [row("himm_raster", HIMM_RASTER_CHAIN, himm_alg),
                               row("vfh_step", "vfh_step_kernel", float(nq * VFH_BYTES_PER_POSE))],
             "kernel_ms_per_step": {k: (v[0] / args.steps) for k, v in prof.items() if v[1]},
         }
