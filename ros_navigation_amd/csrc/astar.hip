@@ -368,7 +368,19 @@ int ensure_config(rna_engine* e) {
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         if (getenv("RNA_NO_STREAM_PRIORITY")) prio_lo = prio_hi = 0;
-        RNA_HIP(e, hipStreamCreateWithPriority(&a.side[d], hipStreamNonBlocking, prio_lo));
+        // RNA_SEARCH_CU_SKIP=n: the searches may not use the first n CUs of the queue's CU mask (ROCr deals the mask bits
+        // round-robin to the XCDs, so n = 8 is one CU per XCD), which leaves those to the engine stream
+        if (const char* m = getenv("RNA_SEARCH_CU_SKIP")) {
+          uint32_t mask[8];
+          const int skip = atoi(m);
+          for (int k = 0; k < 8; ++k) {
+            const int lo = skip - 32 * k;
+            mask[k] = lo <= 0 ? 0xffffffffu : (lo >= 32 ? 0u : (0xffffffffu << lo));
+          }
+          RNA_HIP(e, hipExtStreamCreateWithCUMask(&a.side[d], 8, mask));
+        } else {
+          RNA_HIP(e, hipStreamCreateWithPriority(&a.side[d], hipStreamNonBlocking, prio_lo));
+        }
       }
       RNA_HIP(e, hipEventCreateWithFlags(&a.done[d], hipEventDisableTiming));
     }

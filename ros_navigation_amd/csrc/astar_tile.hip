@@ -1,27 +1,28 @@
 // astar_tile.hip -- tile-synchronous grid A* for gfx950 ("TSA"): the same contract and the same
-// label-correcting argument as astar.hip, but the relaxation runs inside LDS.  This file holds the
+// label-correcting argument as astar.hip, but the relaxation runs in REGISTERS.  This file holds the
 // default search kernel of the engine: one workgroup (16 wavefronts) per query, rounds of tile jobs.
 //
-// Why tiles: the frontier kernel of astar.hip pays two HBM/L2 round trips plus two workgroup barriers
-// per search GENERATION (~5 us), and a long query has >10^4 generations.  Here the search field lives
-// in 32 x 32-cell PAGES (4 KiB, word = g << 8) and a wavefront owns one tile at a time:
-//   1. grab-and-clear the tile's pending bits (cells improved since its last visit),
-//   2. load the tile + a one-cell halo (and the tile's neighbour masks) into LDS with coalesced loads,
-//   3. relax to the tile-local fixed point of the current f-bucket entirely in LDS: a wave-synchronous
-//      queue, one lane per popped cell, plain LDS reads and writes (no LDS atomics), ~1 us per generation,
-//   4. write the tile back (inner cells: coalesced stores; edge ring and improved halo cells:
-//      atomicMin, because neighbouring tiles may be in flight on other wavefronts), hand improved
-//      halo cells to their tiles as pending bits and activate those tiles.
-// Pages are handed out on first touch: every query owns a contiguous run of `cap` pages and a tile ->
-// page table (tmap), so the 2-4 % of the map a search visits sits in a few MiB of HBM instead of being
-// scattered over a 64 MiB field (TLB reach, L2 hit rate), and the next launch on the same pipeline stage
-// resets exactly the pages that were handed out.  Page 0 is shared, never written and always
-// "unreached": reads of tiles without a page go there.  Two pending bitmaps per page (current bucket /
-// next bucket) replace the frontier queues, so nothing can overflow except the page pool itself
-// (status 5; the pool covers the whole map per query whenever HBM allows, see ensure_config).
-// Exactness: every update is a min over lengths of real paths and the schedule runs every bucket to its
-// fixed point, so at termination g is exact for f <= f*, which is all the canonical backtrace reads
-// (DESIGN.md "Grid A* contract").  Measurements and the experiments that were dropped: DESIGN.md 5.
+// The search field lives in PAGES of one 64 x 16-cell tile each (4 KiB; word = KU - g, 0 = unreached, so that a
+// fresh page is all zeros and "better" is "larger").  A wavefront owns one tile at a time: lane = column (the
+// contiguous axis i), register = row (j), i.e. the whole tile is 16 VGPRs.  A tile job
+//   1. loads its page, the two neighbouring rows, the two neighbouring columns (kept by their owners as a copy in
+//      the page's aux words, so they are one 64-byte read) and four corners -- ONE memory round trip after the page
+//      table look-up -- and applies what those halo cells can contribute once (they do not change during the job),
+//   2. relaxes the tile to the fixed point of the current f-bucket with alternating down / up sweeps: a row takes its
+//      three vertical candidates from the row before it (one in-lane, two through DPP wave shifts by one lane) and
+//      its two horizontal ones through the same shifts; ~16 VALU instructions per 64 cells, no LDS, no atomics, no
+//      divergence.  Rows whose sources did not change since their last evaluation are skipped (three 16-bit flag
+//      words on the scalar unit), so a job costs what its moving front costs, not 1024 cells per sweep,
+//   3. stores the rows that changed (it is the only writer of its page: plain coalesced stores), and activates the
+//      neighbouring tiles whose halo it improved.  Neighbours PULL: nothing is ever written into another tile.
+// Pages are handed out by the job that first changes a tile; every query owns a contiguous run of `cap` pages and a
+// tile -> page table (tmap), so the 2-4 % of the map a search visits sits in a few MiB of HBM, and the next launch on
+// the same pipeline stage resets exactly the pages that were handed out.  Page 0 is shared, never written and always
+// "unreached": reads of tiles without a page go there.
+// Exactness: every update is a max over (KU - length) of real paths and the schedule runs every bucket to its fixed
+// point, so at termination g is exact for f <= f*, which is all the canonical backtrace reads (DESIGN.md "Grid A*
+// contract").  scripts/sim_dense2.c is a CPU model of exactly this schedule (checked against the oracle's cost and E).
+// The round-1/2 worklist-in-LDS kernel this replaces, and the measurements behind the switch: DESIGN.md 5.
 #include "engine.hpp"
 #include <algorithm>
 #include <vector>
@@ -30,17 +31,18 @@ using namespace rna;
 
 namespace rna {
 
-constexpr int TS = 32;                 // tile edge (cells)
-constexpr int TW = TS + 2;             // LDS row pitch incl. halo
-constexpr int TILE_WORDS = TS * TS;    // 1024
+constexpr int TI = 64, TJ = 16;               // tile: 64 cells along i (lanes) x 16 along j (registers)
+constexpr int TILE_WORDS = TI * TJ;           // 1024
+constexpr int AUX_WORDS = 64;                 // per page: [0..15] copy of column 0, [16..31] copy of column 63
+constexpr int MASK_STRIDE = TILE_WORDS + 32;  // snapshot bytes per tile: lane-major masks + the two edge columns again
 #ifndef RNA_TSA_WAVES
 #define RNA_TSA_WAVES 16
 #endif
-#ifndef RNA_TSA_POLL_SLEEP
-#define RNA_TSA_POLL_SLEEP 32
+#ifndef RNA_TSA_HPASS
+#define RNA_TSA_HPASS 4   // extra passes of a changed row along itself
 #endif
-#ifndef RNA_TSA_UNR
-#define RNA_TSA_UNR 1
+#ifndef RNA_TSA_WAVES_PER_EU
+#define RNA_TSA_WAVES_PER_EU 8   // two workgroups per CU: the kernel must fit 64 VGPRs
 #endif
 constexpr int TSA_WAVES = RNA_TSA_WAVES;
 constexpr int TSA_THREADS = TSA_WAVES * 64;
@@ -48,15 +50,11 @@ constexpr int TSA_MAX_TILE_WORDS = 2048;   // active-tile bitset words -> up to 
 #ifndef RNA_TSA_JOBS
 #define RNA_TSA_JOBS 2048
 #endif
-constexpr int TSA_JOBS = RNA_TSA_JOBS;             // tile jobs per round (more stay flagged for the next round)
-#ifndef RNA_TSA_LQ
-#define RNA_TSA_LQ 1024
-#endif
-constexpr int LQ = RNA_TSA_LQ;   // per-wave local queue (u16 LDS positions, power of two).  Live entries are distinct interior cells
-                                 // (in-queue flag), so 1024 can never overflow; a smaller queue falls back to a rescan of the flags
+constexpr int TSA_JOBS = RNA_TSA_JOBS;     // tile jobs per round (more stay flagged for the next round)
 constexpr int COST_S = 1000, COST_D = 1414;
 constexpr int INF = 0x7fffffff;
-constexpr unsigned G_INF = 0xFFFFFFu;
+constexpr int KU = 0x40000000;             // field word u = KU - g; 0 = unreached
+constexpr int SCR_WORDS = 84;              // per-wave LDS scratch (column transposition): 68 + a zero tail of 16
 
 __device__ __forceinline__ int tsa_octile(int i, int j, int gi, int gj) {
   const int dx = abs(i - gi), dy = abs(j - gj);
@@ -65,10 +63,6 @@ __device__ __forceinline__ int tsa_octile(int i, int j, int gi, int gj) {
 }
 __device__ __forceinline__ unsigned ld_l2(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// number of set bits of a wave mask below this lane (v_mbcnt_lo/hi)
-__device__ __forceinline__ unsigned tsa_rank(unsigned long long m, unsigned base = 0u) {   // base + rank: v_mbcnt adds for free
-  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, base));
 }
 // buffer linear index <-> map-space (unwrapped) linear index (gmc/src/GridMapMath.cpp:467-476, 70-81)
 __device__ __forceinline__ int tsa_unwrap_lin(int lin, int rows, int cols, int s0, int s1) {
@@ -83,67 +77,73 @@ __device__ __forceinline__ int tsa_buffer_lin(int lin, int rows, int cols, int s
   if (j >= cols) j -= cols;
   return j * rows + i;
 }
-// wave-wide OR with DPP row shifts / row broadcasts; every lane receives the result (all 64 lanes active)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned tsa_dpp_or_step(unsigned v) {
-  return v | (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+// DPP wave shifts by one lane (all 64 lanes active).  from_below(v)[l] = v[l-1], lane 0 receives `edge`;
+// from_above(v)[l] = v[l+1], lane 63 receives `edge`.
+__device__ __forceinline__ int lane_m1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true); }    // wave_shr:1
+__device__ __forceinline__ int lane_p1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, true); }    // wave_shl:1
+__device__ __forceinline__ int lane_m1(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ int lane_p1(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x130, 0xF, 0xF, false); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+// all ones if bit `bit` of m is set, else 0.  Opaque to the optimiser on purpose: left to itself it hoists the 64 tests
+// of a tile job (16 rows x 4 diagonal moves) out of the sweeps as 64-bit lane masks, 128 SGPRs that it then spills into
+// VGPR lanes and from there into scratch.
+#define TSA_OPEN(m, bit) ({ int r_; asm volatile("v_bfe_i32 %0, %1, %2, 1" : "=v"(r_) : "v"(m), "i"(bit)); r_; })
+// octile heuristic from max / min of the two offsets with full-rate 24-bit multiplies (left to itself the compiler
+// emits two quarter-rate v_mul_lo_u32 here, in the hottest recompute of the sweeps)
+__device__ __forceinline__ int tsa_h24(int mx, int mn) {
+  int a, r;
+  asm("v_mul_u32_u24 %0, %2, %1" : "=v"(a) : "v"(mx), "s"(COST_S));
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(mn), "s"(COST_D - COST_S), "v"(a));
+  return r;
 }
-__device__ __forceinline__ unsigned tsa_wave_or(unsigned v) {
-  v = tsa_dpp_or_step<0x111, 0xF>(v);   // row_shr:1
-  v = tsa_dpp_or_step<0x112, 0xF>(v);   // row_shr:2
-  v = tsa_dpp_or_step<0x114, 0xF>(v);   // row_shr:4
-  v = tsa_dpp_or_step<0x118, 0xF>(v);   // row_shr:8
-  v = tsa_dpp_or_step<0x142, 0xA>(v);   // row_bcast:15
-  v = tsa_dpp_or_step<0x143, 0xC>(v);   // row_bcast:31 -> lane 63 holds the OR of the wave
-  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-// word index of cell (i, j) in a tile-major array (the neighbour-mask snapshot); tile and in-page offset of a cell
-__device__ __forceinline__ size_t tm_index(int i, int j, int tiles_i) {
-  return ((size_t)((j >> 5) * tiles_i + (i >> 5)) << 10) + ((j & 31) << 5) + (i & 31);
-}
-__device__ __forceinline__ int tile_of(int i, int j, int tiles_i) { return (j >> 5) * tiles_i + (i >> 5); }
-__device__ __forceinline__ int in_page(int i, int j) { return ((j & 31) << 5) + (i & 31); }
+// u if the cell may pass its value on in this bucket (f < lim  <=>  u - h >= thr), else "unreached"
+__device__ __forceinline__ int tsa_prop(int u, int h, int thr) { return (u - h >= thr) ? u : 0; }
+
+__device__ __forceinline__ int tile_of(int i, int j, int tiles_i) { return (j >> 4) * tiles_i + (i >> 6); }
+__device__ __forceinline__ int in_page(int i, int j) { return ((j & 15) << 6) + (i & 63); }
+// neighbouring tile k (same numbering as the neighbour-mask bits): offsets along i and j
+__device__ __forceinline__ int kdi_of(int k) { return (k == 0 || k == 3 || k == 5) ? -1 : ((k == 2 || k == 4 || k == 7) ? 1 : 0); }
+__device__ __forceinline__ int kdj_of(int k) { return k < 3 ? -1 : (k > 4 ? 1 : 0); }
 
 // Device view of one pipeline stage.  Global page index of query q's local page p >= 1 is q*cap + p; page 0 is
-// the shared "unreached" page.  Invariant between launches: every page word is (G_INF << 8), every pending word
-// and every tmap entry is 0, EXCEPT what belongs to the local pages 1..nalloc[q] of each query; the next launch
-// on the stage resets exactly those (tsa_reset_kernel) instead of rewriting 64 MiB per query.
-constexpr unsigned TSA_BUSY = 0xFFFFFFFFu;   // tmap entry while its page is being handed out
-constexpr int PEND_WORDS = 2 * TS;           // per page: two pending bitmaps (current / next bucket) of 32 column words
+// the shared "unreached" page.  Invariant between launches: every page word, aux word and tmap entry is 0, EXCEPT
+// what belongs to the local pages 1..nalloc[q] of each query; the next launch on the stage resets exactly those
+// (tsa_reset_kernel) instead of rewriting 64 MiB per query.
 struct TsaStage {
   unsigned* pages;      // [1 + max_queries*cap][1024]
-  unsigned* ppend;      // [1 + max_queries*cap][64]
+  unsigned* paux;       // [1 + max_queries*cap][64]
   unsigned* tmap;       // [max_queries][ntile] tile -> local page, 0 = none
   unsigned* owner;      // [max_queries][cap + 1] local page -> tile
   int* nalloc;          // [max_queries] local pages handed out by the last search
-  uint8_t* nbr_tm;      // [ntile][32][32] neighbour masks of this launch (snapshot), 0 outside the map
+  uint8_t* nbr_tm;      // [ntile][MASK_STRIDE] neighbour masks of this launch (snapshot), 0 outside the map
   int* perm;            // [max_queries] launch order of this batch: the k-th workgroup to START serves query perm[k]
   int* ticket;          // next position of perm to hand out (reset by every launch's init)
   int cap;              // pages per query
 };
 __host__ __device__ inline size_t tsa_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// snapshot of the neighbour masks in tile-major MAP-space order (4 cells per thread), taken at launch so that a
-// later map update cannot disturb a search in flight
-__global__ void tsa_snapshot_kernel(const uint8_t* __restrict__ nbr, int rows, int cols, int tiles_i, int tiles_j,
-                                    uint8_t* __restrict__ nbr_tm, int s0, int s1) {
-  const size_t nw = (size_t)tiles_i * tiles_j * TILE_WORDS;
-  const size_t step = (size_t)gridDim.x * blockDim.x;
-  for (size_t w4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w4 < nw / 4; w4 += step) {
-    const size_t w = w4 * 4;
-    const int t = (int)(w >> 10), l = (int)(w & 1023);
-    const int i = (t % tiles_i) * TS + (l & 31), j = (t / tiles_i) * TS + (l >> 5);
+// snapshot of the neighbour masks, taken at launch so that a later map update cannot disturb a search in flight.
+// Per tile (MAP-space, unwrapped indices): byte a*16 + b = mask of cell (a, b) -- the 16 rows of a lane are one
+// 16-byte load --, then the 16 masks of column 0 and the 16 of column 63 once more for the halo step.
+__global__ void __launch_bounds__(256) tsa_snapshot_kernel(const uint8_t* __restrict__ nbr, int rows, int cols, int tiles_i, int tiles_j,
+                                                             uint8_t* __restrict__ nbr_tm, int s0, int s1) {
+  const int a = threadIdx.x & 63, bq = threadIdx.x >> 6;
+  for (int t = blockIdx.x; t < tiles_i * tiles_j; t += gridDim.x) {
+    const int i = (t % tiles_i) * TI + a, j0 = (t / tiles_i) * TJ + bq * 4;
     unsigned v = 0u;   // (i, j) is a MAP-space (unwrapped) index; nbr is stored at buffer indices
-    if (j < cols) {
-      const int bj = j + s1 >= cols ? j + s1 - cols : j + s1;
+    if (i < rows) {
+      const int bi = i + s0 >= rows ? i + s0 - rows : i + s0;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (i + k < rows) {
-          const int bi = i + k + s0 >= rows ? i + k + s0 - rows : i + k + s0;
+        if (j0 + k < cols) {
+          const int bj = j0 + k + s1 >= cols ? j0 + k + s1 - cols : j0 + k + s1;
           v |= (unsigned)nbr[(size_t)bj * rows + bi] << (8 * k);
         }
     }
-    reinterpret_cast<unsigned*>(nbr_tm)[w4] = v;
+    uint8_t* out = nbr_tm + (size_t)t * MASK_STRIDE;
+    reinterpret_cast<unsigned*>(out)[a * 4 + bq] = v;
+    if (a == 0) reinterpret_cast<unsigned*>(out + TILE_WORDS)[bq] = v;
+    if (a == TI - 1) reinterpret_cast<unsigned*>(out + TILE_WORDS + 16)[bq] = v;
   }
 }
 // back to the invariant: the pages the previous launch on this stage handed out.  Block (x, q) takes the local
@@ -153,8 +153,8 @@ __global__ void __launch_bounds__(256) tsa_reset_kernel(TsaStage S, int ntile) {
   const int used = S.nalloc[q] < S.cap ? S.nalloc[q] : S.cap;
   for (int p = 1 + (int)blockIdx.x; p <= used; p += (int)gridDim.x) {
     const size_t gp = (size_t)q * S.cap + p;
-    reinterpret_cast<uint4*>(S.pages + (gp << 10))[threadIdx.x] = make_uint4(0xFFFFFF00u, 0xFFFFFF00u, 0xFFFFFF00u, 0xFFFFFF00u);
-    if (threadIdx.x < PEND_WORDS) S.ppend[gp * PEND_WORDS + threadIdx.x] = 0u;
+    reinterpret_cast<uint4*>(S.pages + (gp << 10))[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+    if (threadIdx.x < AUX_WORDS) S.paux[gp * AUX_WORDS + threadIdx.x] = 0u;
     if (threadIdx.x == 0) S.tmap[(size_t)q * ntile + S.owner[(size_t)q * (S.cap + 1) + p]] = 0u;
   }
 }
@@ -162,11 +162,10 @@ __global__ void tsa_reset_done_kernel(TsaStage S, int max_queries) {
   for (int q = threadIdx.x; q < max_queries; q += blockDim.x) S.nalloc[q] = 0;
   if (threadIdx.x == 0) *S.ticket = 0;
 }
-// fresh allocation: every page "unreached" (the zero parts are a hipMemsetAsync)
+// fresh allocation: every page "unreached"
 __global__ void tsa_fill_pages_kernel(uint4* __restrict__ p, size_t n4) {
   const size_t step = (size_t)gridDim.x * blockDim.x;
-  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < n4; w += step)
-    p[w] = make_uint4(0xFFFFFF00u, 0xFFFFFF00u, 0xFFFFFF00u, 0xFFFFFF00u);
+  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < n4; w += step) p[w] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // Launch order of a batch: longest expected search first (key = Chebyshev distance start -> goal,
@@ -219,24 +218,11 @@ __device__ unsigned long long g_tsa_stat[32];
 #define TSA_CNT(slot, v)
 #endif
 
-constexpr int TSA_SCRATCH = 2 * TW + 4;   // words behind the tile that idle lanes of a relaxation step read and rewrite
-struct alignas(16) TsaWave {
-  unsigned tile[TW * TW + TSA_SCRATCH];   // (g << 8) | job flags, halo included; index (jl+1)*TW + (il+1).  Flags: bit0 in
-                                 // the local queue, bit1 halo cell improved by this job, bit2 interior cell
-                                 // improved beyond the current bucket
-  unsigned short lq[LQ];         // local queue of LDS positions
-  unsigned char mask[TILE_WORDS];    // neighbour masks of the 32 x 32 interior cells, index jl*32 + il
-  unsigned nbpg[8];              // local pages of the eight neighbouring tiles as seen at load time (kept out of the VGPRs)
-#ifdef RNA_TSA_STATS_REEXP
-  unsigned char seen[TW * TW + TSA_SCRATCH];   // developer build: cell already expanded in this job
-#endif
-};
-
 // Per-query context of a tile job (wave-uniform).
 struct TsaCtx {
   int rows, cols, tiles_i, tiles_j;
   unsigned* pages;            // stage-wide page array
-  unsigned* ppend;            // stage-wide pending bitmaps
+  unsigned* paux;             // stage-wide edge-column copies
   unsigned* tmap;             // this query's tile -> local page table
   unsigned* owner;            // this query's local page -> tile list
   size_t page_base;           // q * cap: global page = page_base + local page (local >= 1)
@@ -244,402 +230,327 @@ struct TsaCtx {
   int* nalloc;                // LDS: local pages handed out so far
   const uint8_t* nbr_tm;
   int gi, gj;
+  int ts, sa, sb;             // start: tile, lane, row
+  int tg, ga, gb;             // goal: tile, lane, row
   __device__ __forceinline__ size_t gpage(unsigned local) const { return local ? page_base + local : 0; }
 };
 
-// Make sure tile `nt` of this query has a page; called by ONE lane per tile of a wave (lanes of a wave never ask
-// for the same tile, so a lane only ever waits for another wavefront).  Returns the local page, 0 = pool exhausted.
-__device__ __forceinline__ unsigned tsa_page_get(const TsaCtx& C, int nt, unsigned seen) {
-  unsigned v = seen;
-  if (v == 0u) {
-    const unsigned old = atomicCAS(&C.tmap[nt], 0u, TSA_BUSY);
-    if (old == 0u) {
-      const int p = atomicAdd(C.nalloc, 1) + 1;
-      if (p > C.cap) {
-        __hip_atomic_store(&C.tmap[nt], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0u;
-      }
-      C.owner[p] = (unsigned)nt;
-      __hip_atomic_store(&C.tmap[nt], (unsigned)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return (unsigned)p;
-    }
-    v = old;
-  }
-  while (v == TSA_BUSY) {
-    __builtin_amdgcn_s_sleep(1);
-    v = ld_l2(&C.tmap[nt]);
-  }
-  return v;
-}
-
-// One tile job, executed by one wavefront (lane = this wave's lane id).  `sch` supplies the
-// scheduler-specific pieces: best() / improve_best(g) (upper bound on f*), act_cur(tile) /
-// act_far(tile) (a tile received pending cells for the current / the next bucket), overflow(), pool_exhausted().
-// `pg` is the local page of tile t (a tile only becomes a job after its page exists); `role` selects which of the
-// page's two pending bitmaps is the current bucket's.  Returns the number of cell expansions.
+// One tile job, executed by one wavefront (lane = this wave's lane id = the cell's column inside the tile).
+// `sch` supplies the scheduler-specific pieces: best() / improve_best(g) (upper bound on f*), act_cur(tile) /
+// act_far(tile) (run the tile in the next round / when the next bucket opens), pool_exhausted().  `pg` is the tile's
+// local page (0: none yet -- it is all "unreached"); `first`: the tile's first job in this bucket (cells that were
+// held back by the previous bucket's bound may now pass their values on, so every row is evaluated and unchanged edge
+// cells inside the new band wake the neighbours too).  Returns the number of row evaluations.
+//
+// The 16 rows are 2 x 16 NAMED scalars (g0..g15: the field, pp0..pp15: what a cell may pass on in this bucket) and
+// every per-row step is a macro pasted 16 times: with `int g[16]` and unrolled loops the optimiser turns the rows into
+// one <16 x i32> value and copies all 16 registers at every row update (and spills them as a block).
+#define TSA_CAT_(a, b) a##b
+#define TSA_CAT(a, b) TSA_CAT_(a, b)
+#define TSA_R16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#define TSA_DEC_1 0
+#define TSA_DEC_2 1
+#define TSA_DEC_3 2
+#define TSA_DEC_4 3
+#define TSA_DEC_5 4
+#define TSA_DEC_6 5
+#define TSA_DEC_7 6
+#define TSA_DEC_8 7
+#define TSA_DEC_9 8
+#define TSA_DEC_10 9
+#define TSA_DEC_11 10
+#define TSA_DEC_12 11
+#define TSA_DEC_13 12
+#define TSA_DEC_14 13
+#define TSA_DEC_15 14
+#define TSA_INC_0 1
+#define TSA_INC_1 2
+#define TSA_INC_2 3
+#define TSA_INC_3 4
+#define TSA_INC_4 5
+#define TSA_INC_5 6
+#define TSA_INC_6 7
+#define TSA_INC_7 8
+#define TSA_INC_8 9
+#define TSA_INC_9 10
+#define TSA_INC_10 11
+#define TSA_INC_11 12
+#define TSA_INC_12 13
+#define TSA_INC_13 14
+#define TSA_INC_14 15
+#define TSA_MK_0 mk0
+#define TSA_MK_1 mk0
+#define TSA_MK_2 mk0
+#define TSA_MK_3 mk0
+#define TSA_MK_4 mk1
+#define TSA_MK_5 mk1
+#define TSA_MK_6 mk1
+#define TSA_MK_7 mk1
+#define TSA_MK_8 mk2
+#define TSA_MK_9 mk2
+#define TSA_MK_10 mk2
+#define TSA_MK_11 mk2
+#define TSA_MK_12 mk3
+#define TSA_MK_13 mk3
+#define TSA_MK_14 mk3
+#define TSA_MK_15 mk3
+#define TSA_G(b) TSA_CAT(g, b)
+#define TSA_PP(b) TSA_CAT(pp, b)
+#define TSA_MKW(b) TSA_CAT(TSA_MK_, b)   // the mask word that holds row b's byte, at bit 8 * (b & 3)
 template <class Sched>
-__device__ __forceinline__ int tsa_job(Sched& sch, TsaWave& W, const int lane, const int t, const unsigned pg, const TsaCtx& C,
-                                       const int role, const long long bucket_end TSA_ACC_PARAM) {
-  int expanded = 0;
-  const int rows = C.rows, cols = C.cols, tiles_i = C.tiles_i, tiles_j = C.tiles_j, gi = C.gi, gj = C.gj;
+__device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane_in, const int t, unsigned pg, const TsaCtx& C,
+                                       const bool first, const long long bucket_end, const int bucket_width TSA_ACC_PARAM) {
+  // an opaque copy of the lane id per job (and one more for the results phase): everything derived from it is then
+  // recomputed here instead of being hoisted out of the job loop, kept alive across the sweeps and spilled to scratch
+  int lane = lane_in;
+  asm volatile("" : "+v"(lane));
+  const int tiles_i = C.tiles_i, tiles_j = C.tiles_j, gi = C.gi, gj = C.gj;
   const int ti = t % tiles_i, tj = t / tiles_i;
-  const int i0 = ti * TS, j0 = tj * TS;
-  unsigned* ftile = C.pages + (C.gpage(pg) << 10);
-  unsigned* ptile = C.ppend + C.gpage(pg) * PEND_WORDS;
-  unsigned* pend_cur = ptile + role * TS;
-  unsigned* pend_far = ptile + (role ^ 1) * TS;
-
+  const int i0 = ti * TI, j0 = tj * TJ;
   TSA_T(t_a);
-  // 1. grab-and-clear the pending bits of this tile (lane = column jl); in the same round trip lane k < 8 looks up
-  //    the page of the neighbouring tile in direction k (0 = none yet, or outside the map)
-  unsigned seed = 0u;
-  if (lane < TS) seed = atomicExch(&pend_cur[lane], 0u);
-  unsigned nb_pg = 0u;      // lanes 0..7: local page of neighbour tile k as seen now (TSA_BUSY: being handed out)
-  int nb_t = -1;            // lanes 0..7: that tile, -1 outside the map
+  // ---- 1. page table look-up of the eight neighbouring tiles (lane k < 8: direction k; 0 = none or outside) ----
+  unsigned nb_pg = 0u;
+  int nb_t = -1;
   if (lane < 8) {
-    const int kdi = (lane == 0 || lane == 3 || lane == 5) ? -1 : ((lane == 2 || lane == 4 || lane == 7) ? 1 : 0);
-    const int kdj = lane < 3 ? -1 : (lane > 4 ? 1 : 0);
-    const int nti = ti + kdi, ntj = tj + kdj;
+    const int nti = ti + kdi_of(lane), ntj = tj + kdj_of(lane);
     if (nti >= 0 && ntj >= 0 && nti < tiles_i && ntj < tiles_j) { nb_t = ntj * tiles_i + nti; nb_pg = ld_l2(&C.tmap[nb_t]); }
   }
-  // 2. tile + halo -> LDS (after the pending bits: every grabbed bit's value is already in L2)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- 2. everything the job reads, issued before the first wait ----
+  int g0, g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15;
   {
-    // Everything a job reads from HBM is issued before the first wait: the three halo words of a lane (neighbour
-    // column, neighbour row, corner), its 16 tile words (cell r*64 + lane sits 2r rows below cell `lane`: one base
-    // address + compile-time offsets) and its 16 mask bytes -- ONE memory round trip after the pending bits.
-    // A neighbour whose page is still being handed out has nothing in it yet: read the shared "unreached" page.
-    const unsigned nb_rd = nb_pg == TSA_BUSY ? 0u : nb_pg;
-    const int h = lane & 31;
-    const bool second = lane >= 32;
-    // halo columns: tile (ti, tj-1) column 31 -> LDS jl=-1 ; tile (ti, tj+1) column 0 -> LDS jl=32
-    // halo rows:    tile (ti-1, tj) row 31 -> LDS il=-1 ; tile (ti+1, tj) row 0 -> LDS il=32 ; then the 4 corners
-    const unsigned* pcol = C.pages + (C.gpage((unsigned)__shfl((int)nb_rd, second ? 6 : 1)) << 10);
-    const unsigned* prow = C.pages + (C.gpage((unsigned)__shfl((int)nb_rd, second ? 4 : 3)) << 10);
-    const unsigned hv_col = ld_l2(&pcol[((second ? 0 : 31) << 5) + h]);
-    const unsigned hv_row = ld_l2(&prow[(h << 5) + (second ? 0 : 31)]);
-    const int cdi = (lane & 1) ? 1 : -1, cdj = (lane & 2) ? 1 : -1;
-    // corner of lane c < 4: direction (cdi, cdj) = neighbour index {0, 2, 5, 7}[c]
-    const unsigned* pcor = C.pages + (C.gpage((unsigned)__shfl((int)nb_rd, (lane & 2) ? ((lane & 1) ? 7 : 5) : ((lane & 1) ? 2 : 0))) << 10);
-    unsigned hv_cor = 0xFFFFFF00u;
-    if (lane < 4) hv_cor = ld_l2(&pcor[((cdj > 0 ? 0 : 31) << 5) + (cdi > 0 ? 0 : 31)]);
-    unsigned* tp = &W.tile[((lane >> 5) + 1) * TW + (lane & 31) + 1];
-    unsigned tv[TILE_WORDS / 64];
-#pragma unroll
-    for (int r = 0; r < TILE_WORDS / 64; ++r) tv[r] = ld_l2(&ftile[r * 64 + lane]);
-    const uint4 mv = *reinterpret_cast<const uint4*>(C.nbr_tm + ((size_t)t << 10) + lane * 16);
-    W.tile[(second ? TS + 1 : 0) * TW + h + 1] = hv_col;
-    W.tile[(h + 1) * TW + (second ? TS + 1 : 0)] = hv_row;
-    if (lane < 4) W.tile[(cdj > 0 ? TS + 1 : 0) * TW + (cdi > 0 ? TS + 1 : 0)] = hv_cor;
-#pragma unroll
-    for (int r = 0; r < TILE_WORDS / 64; ++r) tp[r * 2 * TW] = tv[r];
-    *reinterpret_cast<uint4*>(&W.mask[lane * 16]) = mv;
-    if (lane < 8) W.nbpg[lane] = nb_pg;
+    const unsigned* own = C.pages + (C.gpage(pg) << 10);
+#define TSA_LOAD(b) TSA_G(b) = (int)ld_l2(&own[(b) * TI + lane]);
+    TSA_R16(TSA_LOAD)
+#undef TSA_LOAD
   }
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-
-  TSA_T(t_b);
-  TSA_ACC(0, t_a, t_b);
-  if (lane < TSA_SCRATCH) W.tile[TW * TW + lane] = 0xFFFFFF00u;   // scratch words behind the tile (see the relaxation loop)
-#ifdef RNA_TSA_STATS_REEXP
-  for (int w = lane; w < TW * TW + TSA_SCRATCH; w += 64) W.seen[w] = 0;
-#endif
-  // 3. seed the local queue from the pending bits
-  int head = 0, tail = 0;   // wave-uniform
-  bool lq_full = false;     // a push did not fit: those cells keep their in-queue flag and are found by a rescan
+  const uint4 mv = *reinterpret_cast<const uint4*>(C.nbr_tm + (size_t)t * MASK_STRIDE + lane * 16);
+  const unsigned mk0 = mv.x, mk1 = mv.y, mk2 = mv.z, mk3 = mv.w;   // byte b of this lane = neighbour mask of cell (lane, b)
+  // X: the two halo columns and the four corners.  Lanes 0..17 hold the left one top-down (lane 0 = corner (-1,-1),
+  // lanes 1..16 = rows 0..15, lane 17 = corner (-1,16)), lanes 32..49 the right one.
+  const int xl = lane & 31;
+  const bool xr = lane >= 32, xcell = xl >= 1 && xl <= TJ;
+  int top, bot, X = 0;
+  unsigned eb = 0u;   // lanes 1..16 / 33..48: mask of the tile's own edge cell (0, xl-1) / (63, xl-1)
   {
-    unsigned bits = seed;   // lane jl holds the bits (il) of its column
-    for (;;) {
-      const bool has = bits != 0u;
-      const unsigned long long m = __ballot(has);
-      if (!m) break;
-      const int cnt = __popcll(m);
-      const bool fits = LQ >= TILE_WORDS || tail + cnt <= LQ;
-      if (has) {
-        const int il = __ffs(bits) - 1;
-        bits &= bits - 1;
-        const int p = (lane + 1) * TW + il + 1;
-        if (fits) W.lq[(tail + (int)tsa_rank(m)) & (LQ - 1)] = (unsigned short)p;
-        W.tile[p] |= 1u;
-      }
-      if (fits) tail += cnt; else lq_full = true;
-    }
+    const unsigned pgN = (unsigned)__shfl((int)nb_pg, 1), pgS = (unsigned)__shfl((int)nb_pg, 6);
+    top = (int)ld_l2(&C.pages[(C.gpage(pgN) << 10) + (TJ - 1) * TI + lane]);
+    bot = (int)ld_l2(&C.pages[(C.gpage(pgS) << 10) + lane]);
+    const int xdir = xl == 0 ? (xr ? 2 : 0) : (xl <= TJ ? (xr ? 4 : 3) : (xr ? 7 : 5));
+    const unsigned pgX = (unsigned)__shfl((int)nb_pg, xdir);
+    const int xrow = xl == 0 ? TJ - 1 : (xl <= TJ ? xl - 1 : 0);
+    if (xl <= TJ + 1) X = (int)ld_l2(&C.paux[C.gpage(pgX) * AUX_WORDS + (xr ? 0 : 16) + xrow]);   // a left tile's column 63 / a right tile's column 0
+    if (xcell) eb = C.nbr_tm[(size_t)t * MASK_STRIDE + TILE_WORDS + (xr ? 16 : 0) + xl - 1];
   }
-  __builtin_amdgcn_wave_barrier();
-
-  // 4. relax to the tile-local fixed point of the current bucket.  One lane per popped cell; the
-  //    eight directions are visited one after the other.  Within one direction all lanes target
-  //    DIFFERENT cells (target = own cell + the same offset), so the min-update of a neighbour and
-  //    the test-and-set of its in-queue flag are one plain LDS read and one plain LDS write of the
-  //    same word -- no LDS atomics (ds_min_rtn on 16 waves was the bottleneck of an earlier version)
-  //    and no divergent branches.  All f-tests (prune against the upper bound, defer to the next
-  //    bucket) happen once per POPPED cell, so the direction body is only compare / select / store.
-  //    (Tried and dropped: reading all eight neighbours at once and resolving write conflicts with
-  //    non-returning ds_min_u32 plus a returning ds_and at the pop -- four dependent LDS round trips
-  //    instead of ten, yet 27 % slower: LDS atomics cost more than the round trips they save.)
+  // ---- 3. this bucket's bound; which cells are free ----
+  // A blocked (or outside) cell keeps u = 0 for ever: every candidate is ANDed with the cell's free bit, and an
+  // "unreached" cell never passes anything on.  The heuristic of a row is recomputed where it is needed (one scalar
+  // |dj| and four vector instructions) instead of living in 16 registers: the kernel has to fit 64 VGPRs so that two
+  // workgroups share a CU.
   const int best_in = sch.best();
-  const int bend = bucket_end > (long long)INF ? INF : (int)bucket_end;
-  const int goal_p = (gi >= i0 && gi < i0 + TS && gj >= j0 && gj < j0 + TS) ? (gj - j0 + 1) * TW + (gi - i0 + 1) : -1;
-  bool ovf = false;
-  unsigned dirty_lane = 0u;   // rows (jl) of the cells this lane popped: only those rows can have changed
-  for (;;) {
-    if (tail == head) {
-      if (LQ >= TILE_WORDS || !lq_full) break;
-      // rare: the queue overflowed earlier; it is empty now, so every flagged cell is un-queued: queue them again
-      lq_full = false;
-#pragma unroll 1
-      for (int r = 0; r < TILE_WORDS / 64; ++r) {
-        const int pos = ((lane >> 5) + 1 + 2 * r) * TW + (lane & 31) + 1;
-        const unsigned long long fq = __builtin_amdgcn_ballot_w64((W.tile[pos] & 1u) != 0u);
-        const int cnt = __popcll(fq);
-        if (tail - head + cnt <= LQ) {
-          if (__builtin_amdgcn_inverse_ballot_w64(fq)) W.lq[(tail + (int)tsa_rank(fq)) & (LQ - 1)] = (unsigned short)pos;
-          tail += cnt;
-        } else if (cnt) {
-          lq_full = true;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (tail == head) break;
-    }
-    const int n = tail - head;
-    const int take = n < 64 ? n : 64;
-    const bool act = lane < take;
-    // lanes without a cell point at the scratch words behind the tile: every lane can then run the same
-    // unpredicated read-select-write per direction without ever touching a cell another lane updates
-    const int p = act ? (int)W.lq[(head + lane) & (LQ - 1)] : (TW * TW + TW + 1);
-    head += take;
-    TSA_CNT(8, 1);
-    TSA_CNT(9, take);
-    const unsigned cw = W.tile[p];
-    const int g = (int)(cw >> 8);
-    const int pil = p % TW - 1, pjl = p / TW - 1;
-    const unsigned mk = W.mask[act ? pjl * TS + pil : 0];
-    dirty_lane |= act ? 1u << pjl : 0u;
-    const unsigned ax = (unsigned)abs(i0 + pil - gi), ay = (unsigned)abs(j0 + pjl - gj);
-    const int fc = g + (int)(__umul24(ax > ay ? ax : ay, COST_S) + __umul24(ax > ay ? ay : ax, COST_D - COST_S));
-    const int sb = sch.best();
-    const int best_now = best_in < sb ? best_in : sb;
-    const bool live = act && fc <= best_now;      // else pruned: f > upper bound on f*
-    const bool later = live && fc >= bend;        // belongs to a later bucket: flag it, do not expand
-    if (act) W.tile[p] = (cw & ~1u) | (later ? 4u : 0u);   // popped: may be queued again
-    const bool ex = live && !later;               // this lane expands its cell
-#ifdef RNA_TSA_STATS_REEXP
+  const long long lim_ll = bucket_end < (long long)best_in + 1 ? bucket_end : (long long)best_in + 1;   // pass on iff f < lim
+  const int thr = KU - (int)(lim_ll > (long long)INF ? (long long)INF : lim_ll) + 1;
+  const int dxl = abs(i0 + lane - gi);
+  // (the copy of dxl is made opaque at every use: otherwise the 16 row heuristics are hoisted out of the sweeps into 16 VGPRs again)
+#define TSA_H(b) ({ int dx_ = dxl; asm volatile("" : "+v"(dx_)); const int dy_ = abs(j0 + (b) - gj); \
+                    tsa_h24(max(dx_, dy_), min(dx_, dy_)); })
+  unsigned fbits = 0u;   // bit b: this lane's cell in row b is free (and inside the map)
+#define TSA_FB(b) fbits |= (((TSA_MKW(b) >> (8 * ((b) & 3))) & 0xffu) != 0u) ? 1u << (b) : 0u;
+  TSA_R16(TSA_FB)
+#undef TSA_FB
+  // ---- 4. what the halo can contribute (once: it does not change during the job) ----
+  unsigned hz = 0u, fa = 0u, fb = 0u;   // per row: own row changed / the row above changed / the row below changed since
+  unsigned rowchg = 0u;                 // the row's last evaluation;  rows that changed at all in this job
+  unsigned long long q0 = 0ull, q15 = 0ull, qany = 0ull;   // cells of row 0 / row 15 / any row that changed and may pass their value on
+  int pp0, pp1, pp2, pp3, pp4, pp5, pp6, pp7, pp8, pp9, pp10, pp11, pp12, pp13, pp14, pp15;
+  // a row took better values in the lanes `up`: flag it and the rows next to it, remember which cells wake neighbours
+#define TSA_ROW_CHANGED(b, up)                                                                                   \
+  {                                                                                                              \
+    hz |= 1u << (b); fa |= (2u << (b)) & 0xffffu; fb |= (1u << (b)) >> 1; rowchg |= 1u << (b);                    \
+    const unsigned long long wq_ = (up) & __builtin_amdgcn_ballot_w64(TSA_PP(b) != 0);                           \
+    qany |= wq_;                                                                                                 \
+    if ((b) == 0) q0 |= wq_;                                                                                     \
+    if ((b) == TJ - 1) q15 |= wq_;                                                                               \
+  }
+  {
+    int cT, cB;
     {
-      const bool again = ex && W.seen[p] != 0;
-      TSA_CNT(14, __popcll(__builtin_amdgcn_ballot_w64(again)));
-      TSA_CNT(15, __popcll(__builtin_amdgcn_ballot_w64(ex)));
-      if (ex) W.seen[p] = 1;
+      const int pT = tsa_prop(top, TSA_H(-1), thr), pB = tsa_prop(bot, TSA_H(TJ), thr);
+      const int hX = tsa_octile(xr ? i0 + TI : i0 - 1, j0 + xl - 1, gi, gj);
+      const int pX = xl <= TJ + 1 ? tsa_prop(X, hX, thr) : 0;
+      const int sTL = __builtin_amdgcn_readlane(pX, 0), sBL = __builtin_amdgcn_readlane(pX, TJ + 1);
+      const int sTR = __builtin_amdgcn_readlane(pX, 32), sBR = __builtin_amdgcn_readlane(pX, 32 + TJ + 1);
+      // rows 0 and 15 from the rows beyond them (masks: k0 k1 k2 = (-1,-1) (0,-1) (1,-1); k5 k6 k7 = (-1,1) (0,1) (1,1));
+      // a straight step needs no mask test: a blocked source reads "unreached", a blocked target is gated by fbits
+      cT = max3i(pT - COST_S, (lane_m1(pT, sTL) - COST_D) & __builtin_amdgcn_sbfe((int)mk0, 0, 1),
+                 (lane_p1(pT, sTR) - COST_D) & __builtin_amdgcn_sbfe((int)mk0, 2, 1));
+      cB = max3i(pB - COST_S, (lane_m1(pB, sBL) - COST_D) & __builtin_amdgcn_sbfe((int)mk3, 24 + 5, 1),
+                 (lane_p1(pB, sBR) - COST_D) & __builtin_amdgcn_sbfe((int)mk3, 24 + 7, 1));
+      // columns 0 and 63 from the columns beyond them, computed where the halo column sits (lane xl = row + 1) ...
+      const int kN = xr ? 2 : 0, kS = xr ? 7 : 5;
+      int cX = max3i(pX - COST_S, (lane_m1(pX) - COST_D) & -(int)((eb >> kN) & 1u), (lane_p1(pX) - COST_D) & -(int)((eb >> kS) & 1u));
+      cX = xcell ? cX : 0;
+      // ... and turned into rows of lane 0 / lane 63 through the wave's LDS scratch (words 68.. are zero)
+      scr[lane + 3] = (unsigned)cX;
+      __builtin_amdgcn_wave_barrier();
     }
-#endif
-    expanded += ex ? 1 : 0;
-    // rare events, kept out of the straight-line path: the popped cell is the goal (tighten the bound, do not
-    // expand it), or its g is about to leave the 24-bit range
-    const bool at_goal = ex && p == goal_p;
-    const bool too_far = ex && g >= (int)G_INF - 3 * COST_D;
-    if (__builtin_amdgcn_ballot_w64(at_goal || too_far)) {
-      if (at_goal) sch.improve_best(g);
-      ovf |= too_far;
+    const uint4* rp = reinterpret_cast<const uint4*>(&scr[lane == 0 ? 4 : (lane == TI - 1 ? 36 : 68)]);
+    unsigned planted = 0u;
+    if (t == C.ts) {   // the start cell: g = 0, whatever its mask says (a blocked start still answers start == goal)
+#define TSA_PLANT(b)                                                         \
+  if ((b) == C.sb && __builtin_amdgcn_readlane(TSA_G(b), C.sa) != KU) {      \
+    TSA_G(b) = lane == C.sa ? KU : TSA_G(b);                                 \
+    planted = 1u << (b);                                                     \
+  }
+      TSA_R16(TSA_PLANT)
+#undef TSA_PLANT
     }
-    const unsigned m = (ex && !at_goal && !too_far) ? mk : 0u;
-    // candidate words of a straight / diagonal step: new g in the high bits; "| 0xff" for the test
-    // g + w < g(neighbour) on whole words; flag byte of the stored word = in-queue (interior) or
-    // halo-dirty.  Old flags need not be kept: a re-queued cell is re-tested when it is popped.
-    // All predicates are kept as 64-bit wave masks in SGPRs (ballot / inverse ballot), so the
-    // boolean algebra runs on the scalar unit and the vector unit only compares, selects and stores.
-    const unsigned gs = ((unsigned)(g + COST_S) << 8), gd = ((unsigned)(g + COST_D) << 8);
-    unsigned c_st = gs | 0xffu, c_dt = gd | 0xffu, c_si = gs | 1u, c_sh = gs | 2u, c_di = gd | 1u, c_dh = gd | 2u;
-    int pb = p - TW - 1;   // lowest neighbour: all eight offsets are non-negative immediates
-    // keep these in registers: recomputing them from g in every direction costs more than it saves
-    asm volatile("" : "+v"(pb), "+v"(c_st), "+v"(c_dt), "+v"(c_si), "+v"(c_sh), "+v"(c_di), "+v"(c_dh));
-    unsigned* const nb = &W.tile[pb];
-    const unsigned nm = ~m;
-    unsigned tail_v = (unsigned)tail;   // the queue tail as a (uniform) vector register: v_mbcnt adds it to the rank for free
-    asm volatile("" : "+v"(tail_v));
-    const unsigned long long il_lo = __builtin_amdgcn_ballot_w64(pil == 0), il_hi = __builtin_amdgcn_ballot_w64(pil == TS - 1);
-    const unsigned long long jl_lo = __builtin_amdgcn_ballot_w64(pjl == 0), jl_hi = __builtin_amdgcn_ballot_w64(pjl == TS - 1);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int di = (k == 0 || k == 3 || k == 5) ? -1 : ((k == 2 || k == 4 || k == 7) ? 1 : 0);
-      const int dj = k < 3 ? -1 : (k > 4 ? 1 : 0);
-      const int off = (di + 1) + (dj + 1) * TW;
-      const bool straight = (k == 1 || k == 3 || k == 4 || k == 6);
-      const unsigned nwv = nb[off];
-      // candidate word, all ones where direction k is not allowed (bit k of ~m set): "candidate < neighbour" is
-      // then the whole improvement test g + w < g(neighbour)
-      const unsigned cand = (straight ? c_st : c_dt) | (unsigned)__builtin_amdgcn_sbfe((int)nm, k, 1);
-      const unsigned long long improve = __builtin_amdgcn_ballot_w64(cand < nwv);
-      // flag byte: 0 idle, 1 in the queue, 2 halo-dirty, 4 deferred to the next bucket (never combined: a popped
-      // cell drops to 0 / 4, an improved one is rewritten to exactly 1 / 2)
-      const unsigned long long inq = __builtin_amdgcn_ballot_w64((nwv & 0xffu) == 1u);
-      const unsigned long long halo = (di < 0 ? il_lo : (di > 0 ? il_hi : 0ull)) | (dj < 0 ? jl_lo : (dj > 0 ? jl_hi : 0ull));
-      const unsigned word = __builtin_amdgcn_inverse_ballot_w64(halo) ? (straight ? c_sh : c_dh) : (straight ? c_si : c_di);
-      nb[off] = __builtin_amdgcn_inverse_ballot_w64(improve) ? word : nwv;   // unpredicated: rewrites the old word otherwise
-      const unsigned long long push = improve & ~halo & ~inq;
-      const int cnt = __popcll(push);
-      if (LQ >= TILE_WORDS || (int)__builtin_amdgcn_readfirstlane(tail_v) - head + cnt <= LQ) {
-        if (__builtin_amdgcn_inverse_ballot_w64(push))
-          W.lq[tsa_rank(push, tail_v) & (LQ - 1)] = (unsigned short)(pb + off);
-        tail_v += (unsigned)cnt;
-      } else {
-        lq_full = true;   // the stored words carry the in-queue flag: the rescan picks these cells up
-      }
-      // Direction k + 1 must read what direction k stored: another lane's neighbour may be the same cell.  Within
-      // one lane the eight addresses are distinct, so without this the compiler may hoist the later reads above the
-      // store (seen once the code between them became straight-line); the hardware itself executes a wavefront's
-      // LDS instructions in order.
-      asm volatile("" ::: "memory");
-    }
-    tail = (int)__builtin_amdgcn_readfirstlane(tail_v);
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+#define TSA_APPLY(b)                                                                                             \
+  {                                                                                                              \
+    if (((b) & 3) == 0) r = rp[(b) >> 2]; /* four rows per LDS read */                                           \
+    int cand = (int)(((b) & 3) == 0 ? r.x : (((b) & 3) == 1 ? r.y : (((b) & 3) == 2 ? r.z : r.w)));              \
+    if ((b) == 0) cand = max(cand, cT);                                                                          \
+    if ((b) == TJ - 1) cand = max(cand, cB);                                                                     \
+    cand &= TSA_OPEN(fbits, b);                                                                                  \
+    unsigned long long up = __builtin_amdgcn_ballot_w64(cand > TSA_G(b));                                        \
+    if (up) TSA_G(b) = __builtin_amdgcn_inverse_ballot_w64(up) ? cand : TSA_G(b);                                \
+    TSA_PP(b) = tsa_prop(TSA_G(b), TSA_H(b), thr);                                                               \
+    if ((planted >> (b)) & 1u) up |= 1ull << C.sa;                                                               \
+    if (up) TSA_ROW_CHANGED(b, up)                                                                               \
+  }
+    TSA_R16(TSA_APPLY)
+#undef TSA_APPLY
     __builtin_amdgcn_wave_barrier();
   }
-  if (ovf) sch.overflow();
-#ifdef RNA_TSA_STATS
-  {  // histogram of job sizes (expansions per job): slots 10..15 = 0, 1-15, 16-63, 64-255, 256-1023, 1024+
-    int ex = expanded;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) ex += __shfl_xor(ex, o);
-    const int b = ex == 0 ? 0 : (ex < 16 ? 1 : (ex < 64 ? 2 : (ex < 256 ? 3 : (ex < 1024 ? 4 : 5))));
-    tsa_acc[10 + b] += 1;
+  if (first) hz = fa = fb = 0xffffu;
+  TSA_T(t_b);
+  TSA_ACC(0, t_a, t_b);
+  if (!(hz | fa | fb)) { TSA_CNT(10, 1); return 0; }   // the activation that woke this tile brought nothing better
+  // ---- 5. sweeps ----
+  int evals = 0;
+  [[maybe_unused]] int hpass = 0;
+  // the (negative) step costs live in VGPRs: v_add_u32 with a DPP source cannot take a literal, and only then does the
+  // wave shift fold into the add (one instruction instead of v_mov_dpp + v_add)
+  int nS = -COST_S, nD = -COST_D;
+  asm volatile("" : "+v"(nS), "+v"(nD));
+  // one row: VERT = the best of the three candidates from the row before it in sweep direction (0 for the first row),
+  // then the two from the row's own neighbours; improved lanes take the candidate
+#define TSA_VERT(b, src, kA, kC)                                                                                                   \
+  max3i(TSA_PP(src) + nS, (lane_m1(TSA_PP(src)) + nD) & TSA_OPEN(TSA_MKW(b), 8 * ((b) & 3) + (kA)),                                \
+        (lane_p1(TSA_PP(src)) + nD) & TSA_OPEN(TSA_MKW(b), 8 * ((b) & 3) + (kC)))
+#define TSA_ROW(b, VERT)                                                                                         \
+  {                                                                                                              \
+    evals += 1;                                                                                                  \
+    int m_ = VERT;                                                                                               \
+    m_ = max3i(m_, lane_m1(TSA_PP(b)) + nS, lane_p1(TSA_PP(b)) + nS);                                            \
+    m_ &= TSA_OPEN(fbits, b);                                                                                    \
+    const unsigned long long up_ = __builtin_amdgcn_ballot_w64(m_ > TSA_G(b));                                   \
+    if (up_) {                                                                                                   \
+      const int h_ = TSA_H(b);                                                                                   \
+      TSA_G(b) = __builtin_amdgcn_inverse_ballot_w64(up_) ? m_ : TSA_G(b);                                       \
+      TSA_PP(b) = tsa_prop(TSA_G(b), h_, thr);                                                                   \
+      unsigned long long all_ = up_;                                                                             \
+      /* a row that changed runs on along itself right away (a front that moves along the lanes would otherwise   \
+         advance one cell per sweep): sim_dense2.c, 54 -> 21 row evaluations per job for 23 of these short passes */ \
+      for (int e_ = 0; e_ < RNA_TSA_HPASS; ++e_) {                                                               \
+        const int m2_ = max(lane_m1(TSA_PP(b)) + nS, lane_p1(TSA_PP(b)) + nS) & TSA_OPEN(fbits, b);              \
+        const unsigned long long up2_ = __builtin_amdgcn_ballot_w64(m2_ > TSA_G(b));                             \
+        if (!up2_) break;                                                                                        \
+        TSA_G(b) = __builtin_amdgcn_inverse_ballot_w64(up2_) ? m2_ : TSA_G(b);                                   \
+        TSA_PP(b) = tsa_prop(TSA_G(b), h_, thr);                                                                 \
+        all_ |= up2_;                                                                                            \
+        hpass += 1;                                                                                              \
+      }                                                                                                          \
+      TSA_ROW_CHANGED(b, all_)                                                                                   \
+    }                                                                                                            \
   }
-#endif
-
+#define TSA_DOWN(b) if (((fa | hz) >> (b)) & 1u) { fa &= ~(1u << (b)); hz &= ~(1u << (b)); TSA_ROW(b, TSA_VERT(b, TSA_CAT(TSA_DEC_, b), 0, 2)) }
+#define TSA_UP(b) if (((fb | hz) >> (b)) & 1u) { fb &= ~(1u << (b)); hz &= ~(1u << (b)); TSA_ROW(b, TSA_VERT(b, TSA_CAT(TSA_INC_, b), 5, 7)) }
+  for (;;) {
+    if ((fa | hz) != 0u) {
+      if ((fa | hz) & 1u) { fa &= ~1u; hz &= ~1u; TSA_ROW(0, 0) }
+      TSA_DOWN(1) TSA_DOWN(2) TSA_DOWN(3) TSA_DOWN(4) TSA_DOWN(5) TSA_DOWN(6) TSA_DOWN(7) TSA_DOWN(8)
+      TSA_DOWN(9) TSA_DOWN(10) TSA_DOWN(11) TSA_DOWN(12) TSA_DOWN(13) TSA_DOWN(14) TSA_DOWN(15)
+    }
+    if (!(hz | fa | fb)) break;
+    if ((fb | hz) != 0u) {
+      if (((fb | hz) >> 15) & 1u) { fb &= ~(1u << 15); hz &= ~(1u << 15); TSA_ROW(15, 0) }
+      TSA_UP(14) TSA_UP(13) TSA_UP(12) TSA_UP(11) TSA_UP(10) TSA_UP(9) TSA_UP(8) TSA_UP(7)
+      TSA_UP(6) TSA_UP(5) TSA_UP(4) TSA_UP(3) TSA_UP(2) TSA_UP(1) TSA_UP(0)
+    }
+    if (!(hz | fa | fb)) break;
+  }
+#undef TSA_DOWN
+#undef TSA_UP
+#undef TSA_ROW
+#undef TSA_VERT
   TSA_T(t_c);
   TSA_ACC(1, t_b, t_c);
-  // 5. write back.  Inner 30 x 30 cells are private to this tile: coalesced stores.  Edge ring:
-  //    atomicMin (a neighbouring tile's job may have improved them in HBM meanwhile).  Only rows that hold a
-  //    popped cell can differ from what was loaded (every improved interior cell is queued, hence popped).
-  const unsigned dirty = tsa_wave_or(dirty_lane);
-  // Everything after the relaxation loop derives its lane arithmetic from an opaque copy of the lane id, so that no
-  // address or index computed for the tile load stays alive across the loop: 104 -> 86 VGPRs (91 with the one-batch
-  // load above).  The register budget of this kernel decides how many wavefronts of the map-update and VFH kernels
-  // fit next to four searches per SIMD.
-  int lane_b = lane;
-  asm volatile("" : "+v"(lane_b));
-  {
-    const unsigned* tp = &W.tile[((lane_b >> 5) + 1) * TW + (lane_b & 31) + 1];
-    const int il = lane_b & 31;
-    const bool edge_col = il == 0 || il == TS - 1;
-#pragma unroll 2
-    for (int r = 0; r < TILE_WORDS / 64; ++r) {
-      if (((dirty >> (2 * r)) & 3u) == 0u) continue;            // neither row of this pair changed
-      if (!((dirty >> (2 * r + (lane_b >> 5))) & 1u)) continue;   // this lane's row did not
-      const unsigned v = tp[r * 2 * TW] & 0xFFFFFF00u;
-      const bool edge = edge_col || (r == 0 && lane_b < 32) || (r == TILE_WORDS / 64 - 1 && lane_b >= 32);
-      if (edge) {
-        if ((v >> 8) != G_INF) (void)atomicMin(&ftile[r * 64 + lane_b], v);
-      } else {
-        ftile[r * 64 + lane_b] = v;
+  TSA_CNT(8, evals);
+  TSA_CNT(11, hpass);
+  // ---- 6. results: rows that changed, the edge-column copies, the goal ----
+  asm volatile("" : "+v"(lane));
+  if (rowchg) {
+    if (pg == 0u) {   // first change of this tile: it gets a page (this job is the tile's only writer)
+      int p = 0;
+      if (lane == 0) {
+        p = atomicAdd(C.nalloc, 1) + 1;
+        if (p > C.cap) { p = 0; sch.pool_exhausted(); }
+        else { C.owner[p] = (unsigned)t; __hip_atomic_store(&C.tmap[t], (unsigned)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       }
+      pg = (unsigned)__builtin_amdgcn_readfirstlane(p);
+      if (pg == 0u) return evals;
+    }
+    unsigned* own = C.pages + (C.gpage(pg) << 10);
+    unsigned* ax = C.paux + C.gpage(pg) * AUX_WORDS + (lane ? 16 : 0);
+    const bool edge_lane = lane == 0 || lane == TI - 1;
+#define TSA_STORE(b)                             \
+  if ((rowchg >> (b)) & 1u) {                    \
+    own[(b) * TI + lane] = (unsigned)TSA_G(b);   \
+    if (edge_lane) ax[b] = (unsigned)TSA_G(b);   \
+  }
+    TSA_R16(TSA_STORE)
+#undef TSA_STORE
+    if (t == C.tg) {
+#define TSA_GOAL(b)                                                                               \
+  if ((b) == C.gb && ((rowchg >> (b)) & 1u)) {                                                    \
+    const int u = __builtin_amdgcn_readlane(TSA_G(b), C.ga); /* C.ga is wave-uniform */           \
+    if (u != 0 && lane == 0) sch.improve_best(KU - u);                                            \
+  }
+      TSA_R16(TSA_GOAL)
+#undef TSA_GOAL
     }
   }
-  //    far-bucket cells of this tile: column jl -> one pending word (bit il); deferred cells were popped too
+  // ---- 7. who has to run: neighbours whose halo got better (or may pass on now), this tile again in a later bucket ----
   {
-    bool anyfar = false;
-#pragma unroll 4
-    for (int r = 0; r < TS / 2; ++r) {
-      if (((dirty >> (2 * r)) & 3u) == 0u) continue;
-      const int jl = 2 * r + (lane_b >> 5), il = lane_b & 31;
-      const bool f = (W.tile[(jl + 1) * TW + il + 1] & 4u) != 0u;
-      const unsigned long long bm = __ballot(f);
-      const unsigned word = (unsigned)(bm >> (lane_b & 32));
-      if ((lane_b & 31) == 0 && word) { atomicOr(&pend_far[jl], word); }
-      anyfar |= bm != 0ull;
-    }
-    if (anyfar && lane_b == 0) sch.act_far(t);
+    const unsigned look = first ? 0xffffu : rowchg;
+    const long long band_ll = bucket_end - (long long)bucket_width;
+    const int thr_band = KU - (int)(band_ll > (long long)INF ? (long long)INF : band_ll);   // f >= bend - width  <=>  u - h <= thr_band
+    const int thr_best = KU - best_in;                                                         // f <= best          <=>  u - h >= thr_best
+    unsigned long long farm = 0ull;
+#define TSA_END(b)                                                                                               \
+  if ((look >> (b)) & 1u) {                                                                                      \
+    const int tb = TSA_G(b) - TSA_H(b);                                                                          \
+    if (first) { /* cells the previous bucket's bound held back */                                               \
+      const unsigned long long mq = __builtin_amdgcn_ballot_w64(TSA_PP(b) != 0 && tb <= thr_band);               \
+      qany |= mq;                                                                                                \
+      if ((b) == 0) q0 |= mq;                                                                                    \
+      if ((b) == TJ - 1) q15 |= mq;                                                                              \
+    }                                                                                                            \
+    farm |= __builtin_amdgcn_ballot_w64(TSA_G(b) != 0 && TSA_PP(b) == 0 && tb >= thr_best);                      \
   }
+    TSA_R16(TSA_END)
+#undef TSA_END
+    const unsigned am = (q0 & 1ull ? 1u : 0u) | (q0 ? 2u : 0u) | (q0 >> 63 ? 4u : 0u) | (qany & 1ull ? 8u : 0u) | (qany >> 63 ? 16u : 0u) |
+                        (q15 & 1ull ? 32u : 0u) | (q15 ? 64u : 0u) | (q15 >> 63 ? 128u : 0u);
+    if (lane < 8 && ((am >> lane) & 1u) && nb_t >= 0) sch.act_cur(nb_t);
+    if (farm && lane == 0) sch.act_far(t);
+  }
+#undef TSA_ROW_CHANGED
+#undef TSA_H
   TSA_T(t_d);
   TSA_ACC(2, t_c, t_d);
-  //    improved halo cells -> their tiles: value first, then the pending bit, then the activation.  The 136 ring
-  //    positions are three cells per lane; each stage is issued for all three before its single wait, so the
-  //    hand-over costs two memory round trips, not two per cell (plus one when a neighbour needs its first page).
-  {
-    constexpr int HK = (4 * TW + 63) / 64;
-    unsigned hv[HK];
-    unsigned hof[HK];   // (neighbour direction << 10) | word inside its page
-    int hfn[HK];
-    bool hdo[HK];
-    unsigned need = 0u;   // directions this lane hands cells to
-#pragma unroll
-    for (int k = 0; k < HK; ++k) {
-      const int hh = lane_b + 64 * k;
-      hdo[k] = false; hv[k] = 0u; hof[k] = 0u; hfn[k] = 0;
-      if (hh < 4 * TW) {
-        // ring positions: hh in [0,TW): jl=-1 row; [TW,2TW): jl=32 row; [2TW,3TW): il=-1 col; [3TW,4TW): il=32 col
-        const int side = hh / TW, u = hh % TW;
-        int pil, pjl;
-        if (side == 0) { pjl = -1; pil = u - 1; }
-        else if (side == 1) { pjl = TS; pil = u - 1; }
-        else if (side == 2) { pil = -1; pjl = u - 1; }
-        else { pil = TS; pjl = u - 1; }
-        const bool corner_dup = side >= 2 && (pjl < 0 || pjl >= TS);   // corners are covered by the row sides
-        const unsigned tw_ = W.tile[(pjl + 1) * TW + pil + 1];
-        const int ni = i0 + pil, nj = j0 + pjl;
-        if (!corner_dup && (tw_ & 2u) && ni >= 0 && nj >= 0 && ni < rows && nj < cols) {
-          const unsigned v = tw_ & 0xFFFFFF00u;
-          const int fn = (int)(v >> 8) + tsa_octile(ni, nj, gi, gj);
-          if (fn <= sch.best()) {                                // else pruned: f > upper bound on f*
-            if (ni == gi && nj == gj) sch.improve_best((int)(v >> 8));
-            const int idx = ((pjl < 0 ? 0 : (pjl >= TS ? 2 : 1)) * 3) + (pil < 0 ? 0 : (pil >= TS ? 2 : 1));   // 0..8 without 4
-            const unsigned kd = (unsigned)(idx < 4 ? idx : idx - 1);
-            hdo[k] = true; hv[k] = v; hof[k] = (kd << 10) | (unsigned)in_page(ni, nj); hfn[k] = fn;
-            need |= 1u << kd;
-          }
-        }
-      }
-    }
-    // first touch of a neighbouring tile: lane k < 8 hands out the page of direction k (other wavefronts of this
-    // workgroup may be doing the same for the same tile: tsa_page_get settles that)
-    need = tsa_wave_or(need);
-    unsigned nb_pg = 0u;
-    if (need) {
-      if (lane_b < 8) nb_pg = W.nbpg[lane_b];
-      if (lane_b < 8 && ((need >> lane_b) & 1u) && (nb_pg == 0u || nb_pg == TSA_BUSY)) {
-        const int kdi = (lane_b == 0 || lane_b == 3 || lane_b == 5) ? -1 : ((lane_b == 2 || lane_b == 4 || lane_b == 7) ? 1 : 0);
-        const int kdj = lane_b < 3 ? -1 : (lane_b > 4 ? 1 : 0);
-        nb_pg = tsa_page_get(C, (tj + kdj) * tiles_i + ti + kdi, nb_pg);
-        if (nb_pg == 0u) sch.pool_exhausted();
-      }
-    }
-    unsigned hold[HK];
-    unsigned* hpage[HK];
-    unsigned* hpend[HK];
-#pragma unroll
-    for (int k = 0; k < HK; ++k) {
-      const unsigned lp = (unsigned)__shfl((int)nb_pg, (int)(hof[k] >> 10));
-      hdo[k] = hdo[k] && lp != 0u;   // no page left: the search is being abandoned (status 5)
-      const size_t gp = C.gpage(lp);
-      hpage[k] = C.pages + (gp << 10);
-      hpend[k] = C.ppend + gp * PEND_WORDS;
-    }
-#pragma unroll
-    for (int k = 0; k < HK; ++k) hold[k] = hdo[k] ? atomicMin(&hpage[k][hof[k] & 1023u], hv[k]) : 0u;
-#pragma unroll
-    for (int k = 0; k < HK; ++k) {
-      hdo[k] = hdo[k] && hv[k] < hold[k];
-      if (hdo[k]) {
-        const unsigned l = hof[k] & 1023u;
-        atomicOr(&hpend[k][((hfn[k] >= bucket_end) ? (role ^ 1) : role) * TS + (l >> 5)], 1u << (l & 31));
-      }
-    }
-    // the values and their pending bits must be performed at L2 before the tiles can be scheduled
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < HK; ++k)
-      if (hdo[k]) {
-        const unsigned kd = hof[k] >> 10;
-        const int kdi = (kd == 0 || kd == 3 || kd == 5) ? -1 : ((kd == 2 || kd == 4 || kd == 7) ? 1 : 0);
-        const int kdj = kd < 3 ? -1 : (kd > 4 ? 1 : 0);
-        const int nt = (tj + kdj) * tiles_i + ti + kdi;
-        if (hfn[k] >= bucket_end) sch.act_far(nt); else sch.act_cur(nt);
-      }
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_wave_barrier();
-  TSA_T(t_e);
-  TSA_ACC(3, t_d, t_e);
-  return expanded;
+  return evals;
 }
 
 // scheduler state of the one-workgroup-per-query kernel lives in LDS
@@ -650,14 +561,12 @@ struct TsaLocalSched {
   unsigned* act_far_;
   __device__ __forceinline__ int best() const { return __hip_atomic_load(best_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   __device__ __forceinline__ void improve_best(int g) { atomicMin(best_, g); }
-  __device__ __forceinline__ void overflow() { *state_ = 4; }
   __device__ __forceinline__ void pool_exhausted() { *state_ = 5; }
   __device__ __forceinline__ void act_cur(int t) { atomicOr(&act_cur_[t >> 5], 1u << (t & 31)); }
   __device__ __forceinline__ void act_far(int t) { atomicOr(&act_far_[t >> 5], 1u << (t & 31)); }
 };
 
 __device__ __forceinline__ unsigned lds_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ int lds_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // Kernel arguments that are the same for every query of a launch.
 struct TsaLaunch {
@@ -674,18 +583,13 @@ struct TsaLaunch {
 constexpr int TSA_FOUND = -1000;        // provisional status between the search and the backtrace kernel
 
 // One workgroup of 16 wavefronts per query.  The kernel ends with the exact distance field in HBM and a provisional
-// result; the path is traced by tsa_backtrace_kernel (one wavefront per query, next kernel on the stream), which
-// needs none of this kernel's LDS and therefore overlaps with the searches of the other batches in flight.
-// (Several queries per workgroup -- the union of their active tiles as one job list per round -- was measured again
-// on the paged fields: wavefronts spend 83 % instead of 53 % of their life inside jobs, but four relaxing wavefronts
-// per SIMD already fill its VALU issue slots, every job gets slower by the same factor and the kernel needs 26 more
-// VGPRs, which starves the map-update kernels: 20.9 k / 18.0 k / 13.6 k cycles/s for 1 / 2 / 4 queries per workgroup.)
-__global__ void __launch_bounds__(TSA_THREADS) tsa_search_kernel(const TsaLaunch A) {
-  __shared__ TsaWave s_w[TSA_WAVES];
-  extern __shared__ unsigned s_dyn[];   // tile bitsets, sized by the launch: 2 x ((ntile + 31) / 32) words
+// result; the path is traced by tsa_backtrace_kernel (one wavefront per query, next kernel on the stream).
+__global__ void __launch_bounds__(TSA_THREADS) __attribute__((amdgpu_waves_per_eu(RNA_TSA_WAVES_PER_EU, RNA_TSA_WAVES_PER_EU))) tsa_search_kernel(const TsaLaunch A) {
+  __shared__ unsigned s_scr[TSA_WAVES][SCR_WORDS];
+  extern __shared__ unsigned s_dyn[];   // tile bitsets, sized by the launch: 3 x ((ntile + 31) / 32) words
   __shared__ unsigned short s_jobs[TSA_JOBS];
   __shared__ unsigned s_jobpg[TSA_JOBS];   // local page of each job's tile (looked up once per round by the list builders)
-  __shared__ int s_njobs, s_first_fail, s_job_next, s_best, s_state, s_bucket, s_bucket0, s_rounds, s_role, s_expanded, s_nalloc;
+  __shared__ int s_njobs, s_first_fail, s_job_next, s_best, s_state, s_bucket, s_bucket0, s_rounds, s_expanded, s_nalloc;
 
   // Workgroups take their query when they START (a ticket), not by blockIdx: the hardware deals workgroup
   // indices round-robin to the XCDs, so a fixed mapping lets one XCD with several long searches hold back
@@ -702,6 +606,7 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_search_kernel(const TsaLaunch
   const int ntile = tiles_i * tiles_j;
   const int nt_words = (ntile + 31) >> 5;
   unsigned* const s_act[2] = {s_dyn, s_dyn + nt_words};   // [0] current bucket (next round), [1] next bucket
+  unsigned* const s_first = s_dyn + 2 * nt_words;         // tiles that have not run yet in the current bucket
   rna_astar_result* const results = A.results;
 
   const bool valid = qu.start >= 0 && qu.goal >= 0 && qu.start < ncell && qu.goal < ncell;
@@ -716,7 +621,7 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_search_kernel(const TsaLaunch
 
   TsaCtx C;
   C.rows = rows; C.cols = cols; C.tiles_i = tiles_i; C.tiles_j = tiles_j;
-  C.pages = A.S.pages; C.ppend = A.S.ppend;
+  C.pages = A.S.pages; C.paux = A.S.paux;
   C.tmap = A.S.tmap + (size_t)q * ntile;
   C.owner = A.S.owner + (size_t)q * (A.S.cap + 1);
   C.page_base = (size_t)q * A.S.cap;
@@ -724,35 +629,33 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_search_kernel(const TsaLaunch
   C.nalloc = &s_nalloc;
   C.nbr_tm = A.S.nbr_tm;
   C.gi = gi; C.gj = gj;
+  C.ts = tile_of(si, sj, tiles_i); C.sa = si & (TI - 1); C.sb = sj & (TJ - 1);
+  C.tg = tile_of(gi, gj, tiles_i); C.ga = gi & (TI - 1); C.gb = gj & (TJ - 1);
 
-  for (int w = tid; w < nt_words; w += TSA_THREADS) { s_act[0][w] = 0u; s_act[1][w] = 0u; }
-  // a goal without a single traversable neighbour cannot be reached (blocked or walled in); nothing
-  // has been written yet, so no page is in use
-  if (qu.goal != qu.start && C.nbr_tm[tm_index(gi, gj, tiles_i)] == 0) {
-    if (tid == 0) results[q] = rna_astar_result{1, 0, INF, 0, 0, 0};
-    return;
+  for (int w = tid; w < 3 * nt_words; w += TSA_THREADS) s_dyn[w] = 0u;
+  if (lane >= 64 - (SCR_WORDS - 68)) s_scr[wv][68 + lane - (64 - (SCR_WORDS - 68))] = 0u;   // the zero tail of the wave's scratch
+  // a start or a goal without a single traversable neighbour: blocked or walled in; nothing has been written yet, so
+  // no page is in use
+  {
+    const unsigned ms = C.nbr_tm[(size_t)C.ts * MASK_STRIDE + C.sa * 16 + C.sb], mg = C.nbr_tm[(size_t)C.tg * MASK_STRIDE + C.ga * 16 + C.gb];
+    if (qu.goal != qu.start && (mg == 0u || ms == 0u)) {
+      if (tid == 0) results[q] = rna_astar_result{1, 0, INF, 0, 0, 0};
+      return;
+    }
   }
   if (tid == 0) {
-    s_best = INF; s_state = 0; s_rounds = 0; s_role = 0; s_expanded = 0;
+    s_best = INF; s_state = 0; s_rounds = 0; s_expanded = 0; s_nalloc = 0;
     s_bucket = tsa_octile(si, sj, gi, gj) / A.bucket_width;
     s_bucket0 = s_bucket;
-    // the start tile takes local page 1: g(start) = 0, pending in the current bucket
-    const int ts = tile_of(si, sj, tiles_i);
-    s_nalloc = 1;
-    C.owner[1] = (unsigned)ts;
-    __hip_atomic_store(&C.tmap[ts], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&C.pages[(C.gpage(1u) << 10) + in_page(si, sj)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    atomicOr(&C.ppend[C.gpage(1u) * PEND_WORDS + (sj & 31)], 1u << (si & 31));
   }
   __syncthreads();
-  if (tid == 0) {
-    const int ts = tile_of(si, sj, tiles_i);
-    s_act[0][ts >> 5] = 1u << (ts & 31);
+  if (tid == 0) {   // the start tile's first job plants g(start) = 0
+    s_act[0][C.ts >> 5] = 1u << (C.ts & 31);
+    s_first[C.ts >> 5] = 1u << (C.ts & 31);
   }
   __syncthreads();
 
-  TsaWave& W = s_w[wv];
-  int my_expanded = 0;
+  int my_evals = 0;
 #ifdef RNA_TSA_STATS
   unsigned long long tsa_acc[16] = {};
   const unsigned long long t_life0 = wall_clock64();
@@ -777,7 +680,7 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_search_kernel(const TsaLaunch
           bits &= bits - 1;
           const int t = (w << 5) + b;
           s_jobs[k] = (unsigned short)t;
-          s_jobpg[k] = ld_l2(&C.tmap[t]);   // final: a tile is activated only after its page was published
+          s_jobpg[k] = ld_l2(&C.tmap[t]);   // final for this round: only the tile's own job changes it
           ++k;
         }
       } else {
@@ -787,7 +690,7 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_search_kernel(const TsaLaunch
     __syncthreads();
     const int njobs = s_njobs < s_first_fail ? s_njobs : s_first_fail;
 #ifdef RNA_TSA_STATS
-    if (tid == 0 && njobs > 0) {   // rounds by size: slots 16..21 = 1-4, 5-8, 9-16, 17-32, 33-64, 65+ jobs; 22 = rounds
+    if (tid == 0 && njobs > 0) {   // rounds by size: slots 16..21 = 1-4, 5-8, 9-16, 17-32, 33-64, 65+ jobs
       const int b = njobs <= 4 ? 0 : (njobs <= 8 ? 1 : (njobs <= 16 ? 2 : (njobs <= 32 ? 3 : (njobs <= 64 ? 4 : 5))));
       atomicAdd(&g_tsa_stat[16 + b], 1ull);
       atomicAdd(&g_tsa_stat[24 + b], (unsigned long long)njobs);
@@ -803,25 +706,25 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_search_kernel(const TsaLaunch
       }
       __syncthreads();
       if (s_state == 1) break;
-      // advance: tiles with next-bucket pending cells become the active set
+      // advance: tiles that hold cells of the next bucket become the active set, and each of them runs as "first"
       int any = 0;
       for (int w = tid; w < nt_words; w += TSA_THREADS) {
         const unsigned b = s_act[1][w];
         s_act[0][w] = b;
+        s_first[w] = b;
         s_act[1][w] = 0u;
         any |= (b != 0u);
       }
       any = __syncthreads_or(any);
       if (tid == 0) {
         if (!any) s_state = (s_best != INF) ? 1 : 2;   // nothing left anywhere
-        else { s_state = 0; s_bucket += 1; s_role ^= 1; }
+        else { s_state = 0; s_bucket += 1; }
       }
       __syncthreads();
       if (s_state != 0) break;
       continue;
     }
 
-    const int role = s_role;
     const long long bucket_end = ((long long)s_bucket + 1) * A.bucket_width;
 
     // ---- tile jobs: one wavefront per job ----
@@ -835,16 +738,19 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_search_kernel(const TsaLaunch
       if (job >= njobs) break;
       const int t = s_jobs[job];
       const unsigned pg = s_jobpg[job];
+      const unsigned fw = lds_ld(&s_first[t >> 5]);
+      const bool first = __builtin_amdgcn_readfirstlane((int)((fw >> (t & 31)) & 1u)) != 0;
+      if (first && lane == 0) atomicAnd(&s_first[t >> 5], ~(1u << (t & 31)));
       TSA_CNT(7, 1);
-      my_expanded += tsa_job(sch, W, lane, t, pg, C, role, bucket_end TSA_ACC_ARG);
+      my_evals += tsa_job(sch, s_scr[wv], lane, t, pg, C, first, bucket_end, A.bucket_width TSA_ACC_ARG);
     }
-    // all stores / atomics of this round are performed before any wave loads tiles in the next one
+    // all stores of this round are performed before any wave loads tiles in the next one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int stop = __syncthreads_or(s_state >= 4);
     if (tid == 0) s_rounds += 1;
     if (stop) break;
   }
-  atomicAdd(&s_expanded, my_expanded);
+  if (lane == 0) atomicAdd(&s_expanded, my_evals * TI);   // dense cell updates
   __syncthreads();
 #ifdef RNA_TSA_STATS
   tsa_acc[5] = wall_clock64() - t_life0;   // wave lifetime inside the search loop
@@ -862,12 +768,13 @@ __global__ void __launch_bounds__(TSA_THREADS) tsa_search_kernel(const TsaLaunch
 }
 
 // Canonical backtrace, one wavefront per query: walk from the goal to the neighbour n with g[n] + w(n, c) == g[c],
-// lowest linear index first (lane k probes neighbour k).  The walk runs in LDS: the 32 x 32 tile of the current
+// lowest linear index first (lane k probes neighbour k).  The walk runs in LDS: the 64 x 16 tile of the current
 // cell plus its halo ring and the tile's neighbour masks are loaded once, then every step is one LDS round trip
-// until the path leaves the tile's interior -- a path of 2 000 cells is ~70 tile loads instead of 2 000 dependent
-// HBM round trips (which held a whole CU for 2-4 ms per query while the search kernel still did this itself).
+// until the path leaves the tile -- a path of 2 000 cells is ~100 tile loads instead of 2 000 dependent
+// HBM round trips.
+constexpr int BW = TI + 2;   // LDS row pitch of the backtrace image (halo included)
 __global__ void __launch_bounds__(64) tsa_backtrace_kernel(const TsaLaunch A) {
-  __shared__ unsigned s_tile[TW * TW];
+  __shared__ unsigned s_tile[BW * (TJ + 2)];
   __shared__ unsigned char s_mask[TILE_WORDS];
   const int q = blockIdx.x, lane = threadIdx.x;
   const rna_astar_result r = A.results[q];
@@ -883,71 +790,66 @@ __global__ void __launch_bounds__(64) tsa_backtrace_kernel(const TsaLaunch A) {
   int* rev = A.rev_all + (size_t)q * A.rev_cap;
   const int k = lane & 7;
   const int wk = (k == 1 || k == 3 || k == 4 || k == 6) ? COST_S : COST_D;
-  const int di = (k == 0 || k == 3 || k == 5) ? -1 : ((k == 2 || k == 4 || k == 7) ? 1 : 0);
-  const int dj = k < 3 ? -1 : (k > 4 ? 1 : 0);
-  const int off = di + dj * TW;
+  const int di = kdi_of(k), dj = kdj_of(k);
+  const int off = di + dj * BW;
   int len = 0;
   bool ok = true, done = false;
   while (ok && !done) {
     // ---- tile of the current cell + halo ring + masks -> LDS ----
-    const int ti = ci >> 5, tj = cj >> 5;
+    const int ti = ci >> 6, tj = cj >> 4;
     const int t = tj * tiles_i + ti;
     unsigned pgl = 0u;   // lane k < 8: page of the neighbouring tile in direction k; lane 8: page of this tile
     {
       const int nti = lane < 8 ? ti + di : ti, ntj = lane < 8 ? tj + dj : tj;
       if (lane < 9 && nti >= 0 && ntj >= 0 && nti < tiles_i && ntj < tiles_j) pgl = ld_l2(&tmap[ntj * tiles_i + nti]);
-      if (pgl == TSA_BUSY) pgl = 0u;
     }
-    auto page = [&](int src) -> const unsigned* {
+    auto gpage = [&](int src) -> size_t {
       const unsigned lp = (unsigned)__shfl((int)pgl, src);
-      return A.S.pages + ((lp ? page_base + lp : (size_t)0) << 10);
+      return lp ? page_base + lp : (size_t)0;
     };
     {
-      const int h = lane & 31;
-      const bool second = lane >= 32;
-      const unsigned* pcol = page(second ? 6 : 1);
-      const unsigned* prow = page(second ? 4 : 3);
-      const unsigned* pcor = page((lane & 2) ? ((lane & 1) ? 7 : 5) : ((lane & 1) ? 2 : 0));
-      const unsigned* pown = page(8);
-      const int cdi = (lane & 1) ? 1 : -1, cdj = (lane & 2) ? 1 : -1;
-      const unsigned hv_col = ld_l2(&pcol[((second ? 0 : 31) << 5) + h]);
-      const unsigned hv_row = ld_l2(&prow[(h << 5) + (second ? 0 : 31)]);
-      unsigned hv_cor = 0xFFFFFF00u;
-      if (lane < 4) hv_cor = ld_l2(&pcor[((cdj > 0 ? 0 : 31) << 5) + (cdi > 0 ? 0 : 31)]);
-      unsigned tv[TILE_WORDS / 64];
+      const int xl = lane & 31;
+      const bool xr = lane >= 32;
+      const unsigned* pown = A.S.pages + (gpage(8) << 10);
+      const unsigned top = ld_l2(&A.S.pages[(gpage(1) << 10) + (TJ - 1) * TI + lane]);
+      const unsigned bot = ld_l2(&A.S.pages[(gpage(6) << 10) + lane]);
+      const int xdir = xl == 0 ? (xr ? 2 : 0) : (xl <= TJ ? (xr ? 4 : 3) : (xr ? 7 : 5));
+      const int xrow = xl == 0 ? TJ - 1 : (xl <= TJ ? xl - 1 : 0);
+      const size_t gpx = gpage(xdir);
+      unsigned X = 0u;
+      if (xl <= TJ + 1) X = ld_l2(&A.S.paux[gpx * AUX_WORDS + (xr ? 0 : 16) + xrow]);
+      unsigned tv[TJ];
 #pragma unroll
-      for (int rr = 0; rr < TILE_WORDS / 64; ++rr) tv[rr] = ld_l2(&pown[rr * 64 + lane]);
-      const uint4 mv = *reinterpret_cast<const uint4*>(A.S.nbr_tm + ((size_t)t << 10) + lane * 16);
+      for (int b = 0; b < TJ; ++b) tv[b] = ld_l2(&pown[b * TI + lane]);
+      const uint4 mv = *reinterpret_cast<const uint4*>(A.S.nbr_tm + (size_t)t * MASK_STRIDE + lane * 16);
       __builtin_amdgcn_wave_barrier();   // the previous tile's walk has finished reading the LDS image
-      s_tile[(second ? TS + 1 : 0) * TW + h + 1] = hv_col;
-      s_tile[(h + 1) * TW + (second ? TS + 1 : 0)] = hv_row;
-      if (lane < 4) s_tile[(cdj > 0 ? TS + 1 : 0) * TW + (cdi > 0 ? TS + 1 : 0)] = hv_cor;
-      unsigned* tp = &s_tile[((lane >> 5) + 1) * TW + (lane & 31) + 1];
+      s_tile[lane + 1] = top;
+      s_tile[(TJ + 1) * BW + lane + 1] = bot;
+      if (xl <= TJ + 1) s_tile[xl * BW + (xr ? TI + 1 : 0)] = X;
 #pragma unroll
-      for (int rr = 0; rr < TILE_WORDS / 64; ++rr) tp[rr * 2 * TW] = tv[rr];
+      for (int b = 0; b < TJ; ++b) s_tile[(b + 1) * BW + lane + 1] = tv[b];
       *reinterpret_cast<uint4*>(&s_mask[lane * 16]) = mv;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     // ---- walk inside the tile ----
-    int il = ci & 31, jl = cj & 31;
-    unsigned gc = s_tile[(jl + 1) * TW + il + 1] >> 8;
+    int il = ci & (TI - 1), jl = cj & (TJ - 1);
+    unsigned uc = s_tile[(jl + 1) * BW + il + 1];
     for (;;) {
       if (lane == 0 && len < A.rev_cap) rev[len] = cj * rows + ci;
       ++len;
       if (ci == si && cj == sj) { done = true; break; }
-      if (len > ncell || gc == G_INF) { ok = false; break; }
-      const unsigned mc = s_mask[jl * TS + il];
-      const unsigned gn = s_tile[(jl + 1) * TW + il + 1 + off] >> 8;
-      const bool hit = lane < 8 && ((mc >> k) & 1u) && gn != G_INF && gn + (unsigned)wk == gc;
+      if (len > ncell || uc == 0u) { ok = false; break; }
+      const unsigned mc = s_mask[il * 16 + jl];
+      const unsigned un = s_tile[(jl + 1) * BW + il + 1 + off];
+      const bool hit = lane < 8 && ((mc >> k) & 1u) && un != 0u && un == uc + (unsigned)wk;   // g(n) + w == g(c)
       const unsigned long long m = __ballot(hit);
       if (!m) { ok = false; break; }
       const int src = __ffsll((long long)m) - 1;
-      gc = (unsigned)__shfl((int)gn, src);
-      const int sdi = (src == 0 || src == 3 || src == 5) ? -1 : ((src == 2 || src == 4 || src == 7) ? 1 : 0);
-      const int sdj = src < 3 ? -1 : (src > 4 ? 1 : 0);
+      uc = (unsigned)__shfl((int)un, src);
+      const int sdi = kdi_of(src), sdj = kdj_of(src);
       ci += sdi; cj += sdj; il += sdi; jl += sdj;
-      if (il < 0 || jl < 0 || il >= TS || jl >= TS) break;   // left the interior: load that tile
+      if (il < 0 || jl < 0 || il >= TI || jl >= TJ) break;   // left the tile: load that one
     }
   }
   if (!ok) {
@@ -981,9 +883,9 @@ __global__ void tsa_settled_kernel(int rows, int cols, int tiles_i, int tiles_j,
     for (size_t w = threadIdx.x; w < ((size_t)used << 10); w += blockDim.x) {
       const int p = 1 + (int)(w >> 10), l = (int)(w & 1023);
       const int t = (int)S.owner[(size_t)q * (S.cap + 1) + p];
-      const int i = (t % tiles_i) * TS + (l & 31), j = (t / tiles_i) * TS + (l >> 5);
-      const unsigned gv = S.pages[(((size_t)q * S.cap + p) << 10) + l] >> 8;
-      if (gv != G_INF && i < rows && j < cols && (int)gv + tsa_octile(i, j, gi, gj) <= r.cost) ++cnt;
+      const int i = (t % tiles_i) * TI + (l & (TI - 1)), j = (t / tiles_i) * TJ + (l >> 6);
+      const unsigned u = S.pages[(((size_t)q * S.cap + p) << 10) + l];
+      if (u != 0u && i < rows && j < cols && (KU - (int)u) + tsa_octile(i, j, gi, gj) <= r.cost) ++cnt;
     }
   }
   atomicAdd(&s_cnt, cnt);
@@ -993,16 +895,16 @@ __global__ void tsa_settled_kernel(int rows, int cols, int tiles_i, int tiles_j,
 
 // ---- host entry points used by astar.hip ----
 static inline int tsa_ntile(const rna_engine* e) {
-  return ((e->geom.size[0] + TS - 1) / TS) * ((e->geom.size[1] + TS - 1) / TS);
+  return ((e->geom.size[0] + TI - 1) / TI) * ((e->geom.size[1] + TJ - 1) / TJ);
 }
 bool tsa_supported(const rna_engine* e) { return (size_t)tsa_ntile(e) <= (size_t)TSA_MAX_TILE_WORDS * 32; }
 int tsa_tiles(const rna_engine* e) { return tsa_ntile(e); }
-// HBM of one pipeline stage: pages and pending bitmaps (cap per query + the shared page 0) ...
-size_t tsa_pool_bytes(int max_queries, int cap) { return ((size_t)max_queries * cap + 1) * (TILE_WORDS + PEND_WORDS) * sizeof(unsigned); }
+// HBM of one pipeline stage: pages and their edge-column copies (cap per query + the shared page 0) ...
+size_t tsa_pool_bytes(int max_queries, int cap) { return ((size_t)max_queries * cap + 1) * (TILE_WORDS + AUX_WORDS) * sizeof(unsigned); }
 // ... and one allocation that must start zeroed: ticket | nalloc | perm | mask snapshot | tmap | owner
 size_t tsa_aux_bytes(const rna_engine* e, int max_queries, int cap) {
   const size_t ntile = (size_t)tsa_ntile(e);
-  return 256 + 2 * tsa_align256((size_t)max_queries * sizeof(int)) + tsa_align256(ntile * TILE_WORDS) +
+  return 256 + 2 * tsa_align256((size_t)max_queries * sizeof(int)) + tsa_align256(ntile * MASK_STRIDE) +
          tsa_align256((size_t)max_queries * ntile * sizeof(unsigned)) + tsa_align256((size_t)max_queries * ((size_t)cap + 1) * sizeof(unsigned));
 }
 static TsaStage tsa_stage_view(const rna_engine* e, int slot) {
@@ -1012,7 +914,7 @@ static TsaStage tsa_stage_view(const rna_engine* e, int slot) {
   TsaStage S;
   S.cap = a.page_cap;
   S.pages = reinterpret_cast<unsigned*>(a.g[slot]);
-  S.ppend = S.pages + (((size_t)a.max_queries * S.cap + 1) << 10);
+  S.paux = S.pages + (((size_t)a.max_queries * S.cap + 1) << 10);
   S.ticket = reinterpret_cast<int*>(base);
   base += 256;
   S.nalloc = reinterpret_cast<int*>(base);
@@ -1020,7 +922,7 @@ static TsaStage tsa_stage_view(const rna_engine* e, int slot) {
   S.perm = reinterpret_cast<int*>(base);
   base += tsa_align256((size_t)a.max_queries * sizeof(int));
   S.nbr_tm = reinterpret_cast<uint8_t*>(base);
-  base += tsa_align256(ntile * TILE_WORDS);
+  base += tsa_align256(ntile * MASK_STRIDE);
   S.tmap = reinterpret_cast<unsigned*>(base);
   base += tsa_align256((size_t)a.max_queries * ntile * sizeof(unsigned));
   S.owner = reinterpret_cast<unsigned*>(base);
@@ -1030,8 +932,8 @@ static TsaStage tsa_stage_view(const rna_engine* e, int slot) {
 int tsa_stage_prepare(rna_engine* e, int slot) {
   const TsaStage S = tsa_stage_view(e, slot);
   const size_t pages = (size_t)e->astar.max_queries * S.cap + 1;
-  RNA_HIP(e, hipMemsetAsync(S.ppend, 0, pages * PEND_WORDS * sizeof(unsigned), e->stream));
-  hipLaunchKernelGGL(tsa_fill_pages_kernel, dim3(8192), dim3(256), 0, e->stream, reinterpret_cast<uint4*>(S.pages), pages * TILE_WORDS / 4);
+  hipLaunchKernelGGL(tsa_fill_pages_kernel, dim3(8192), dim3(256), 0, e->stream, reinterpret_cast<uint4*>(S.pages),
+                     pages * (TILE_WORDS + AUX_WORDS) / 4);
   RNA_HIP(e, hipGetLastError());
   return RNA_OK;
 }
@@ -1040,12 +942,12 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
                const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len, rna_astar_result* res_dev) {
   AstarDevice& a = e->astar;
   const int rows = e->geom.size[0], cols = e->geom.size[1];
-  const int ti = (rows + TS - 1) / TS, tj = (cols + TS - 1) / TS;
+  const int ti = (rows + TI - 1) / TI, tj = (cols + TJ - 1) / TJ;
   const TsaStage S = tsa_stage_view(e, slot);
   {
     // snapshot the neighbour masks and bring the pages the last search on this stage used back to "unreached"
     KernelTimer kt(e, RNA_K_ASTAR_INIT, init_stream);
-    hipLaunchKernelGGL(tsa_snapshot_kernel, dim3(2048), dim3(256), 0, init_stream, e->nbr, rows, cols, ti, tj, S.nbr_tm,
+    hipLaunchKernelGGL(tsa_snapshot_kernel, dim3(std::min(ti * tj, 4096)), dim3(256), 0, init_stream, e->nbr, rows, cols, ti, tj, S.nbr_tm,
                        e->geom.start[0], e->geom.start[1]);
     hipLaunchKernelGGL(tsa_reset_kernel, dim3(128, a.max_queries), dim3(256), 0, init_stream, S, ti * tj);   // ~5 pages per block at 4096^2
     hipLaunchKernelGGL(tsa_reset_done_kernel, dim3(1), dim3(256), 0, init_stream, S, a.max_queries);
@@ -1067,7 +969,7 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     A.rows = rows; A.cols = cols; A.tiles_i = ti; A.tiles_j = tj; A.s0 = e->geom.start[0]; A.s1 = e->geom.start[1];
     A.queries = q_dev; A.S = S; A.bucket_width = a.bucket_width; A.paths = paths_dev; A.max_path_len = max_len;
     A.rev_all = a.rev[slot]; A.rev_cap = a.rev_cap; A.results = res_dev;
-    hipLaunchKernelGGL(tsa_search_kernel, dim3(n), dim3(TSA_THREADS), 2 * nt_bytes, search_stream, A);
+    hipLaunchKernelGGL(tsa_search_kernel, dim3(n), dim3(TSA_THREADS), 3 * nt_bytes, search_stream, A);
     hipLaunchKernelGGL(tsa_backtrace_kernel, dim3(n), dim3(64), 0, search_stream, A);
     RNA_HIP(e, hipGetLastError());
   }
@@ -1088,18 +990,17 @@ void tsa_stats_dump() {
   }
   const double jobs = (double)st[7];
   if (jobs <= 0) return;
-  const double busy = (double)(st[0] + st[1] + st[2] + st[3]);
-  fprintf(stderr, "[tsa stats] expansions %.0f, of which repeated inside the same job %.0f (%.1f%%)\n", (double)st[15], (double)st[14], 100.0 * (double)st[14] / (double)std::max<unsigned long long>(1, st[15]));
-  fprintf(stderr, "[tsa stats, tile kernel, all launches] jobs %.0f | per job us: load %.2f relax %.2f wb %.2f handover %.2f | wave lifetime %.1f wave-ms, in jobs %.1f wave-ms (%.1f%%), in round set-up %.1f wave-ms (%.1f%%, %.2f us per round) | relax iters/job %.1f cells/iter %.1f\n",
-          jobs, st[0] * 0.01 / jobs, st[1] * 0.01 / jobs, st[2] * 0.01 / jobs, st[3] * 0.01 / jobs, st[5] * 1e-5, busy * 1e-5,
+  const double busy = (double)(st[0] + st[1] + st[2]);
+  fprintf(stderr, "[tsa stats, tile kernel, all launches] jobs %.0f (%.1f%% no-op) | per job us: load+halo %.2f sweeps %.2f results %.2f | wave lifetime %.1f wave-ms, in jobs %.1f wave-ms (%.1f%%), in round set-up %.1f wave-ms (%.1f%%, %.2f us per round) | row evaluations per job %.1f, extra horizontal passes %.1f\n",
+          jobs, 100.0 * (double)st[10] / jobs, st[0] * 0.01 / jobs, st[1] * 0.01 / jobs, st[2] * 0.01 / jobs, st[5] * 1e-5, busy * 1e-5,
           100.0 * busy / (double)st[5], st[4] * 1e-5, 100.0 * (double)st[4] / (double)st[5], st[4] * 0.01 / (double)std::max<unsigned long long>(1, st[6]),
-          st[8] / jobs, st[9] / (double)std::max<unsigned long long>(1, st[8]));
+          st[8] / jobs, st[11] / jobs);
 }
 #endif
 
 int tsa_settled(rna_engine* e, int slot, const rna_astar_query* q, const rna_astar_result* r, int n, int32_t* d_counts) {
   const int rows = e->geom.size[0], cols = e->geom.size[1];
-  const int ti = (rows + TS - 1) / TS, tj = (cols + TS - 1) / TS;
+  const int ti = (rows + TI - 1) / TI, tj = (cols + TJ - 1) / TJ;
   hipLaunchKernelGGL(tsa_settled_kernel, dim3(n), dim3(1024), 0, e->stream, rows, cols, ti, tj, q, r, tsa_stage_view(e, slot),
                      d_counts, e->geom.start[0], e->geom.start[1]);
   RNA_HIP(e, hipGetLastError());

@@ -63,7 +63,7 @@ struct AstarDevice {
   int threads = 512;               // workgroup size of the search kernel (256 / 512 / 1024)
   // Pipelined batches: `depth` independent sets of search fields + queues, each with its own HIP
   // stream, so the tail of batch k (few long queries) overlaps the head of batch k+1.
-  static constexpr int MAX_DEPTH = 8;
+  static constexpr int MAX_DEPTH = 16;
   int depth = 4;
   int32_t* g[MAX_DEPTH] = {};      // frontier kernel: [max_queries][field_stride] search fields (g << 8) | mask;
                                    // tile kernel: the stage's page pool (pages, then pending bitmaps), see astar_tile.hip
