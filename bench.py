@@ -52,9 +52,9 @@ def parse():
     ap.add_argument("--bucket-width", type=int, default=0)
     ap.add_argument("--queue-capacity", type=int, default=0)
     ap.add_argument("--max-path", type=int, default=32768)
-    ap.add_argument("--pipeline", type=int, default=6,
-                    help="A* batches in flight (rna_astar_set_pipeline_depth).  With rotating query sets the batches' tails "
-                         "differ and four stages leave CUs idle (measured 4: 17.4k, 6: 25.4k, 8: 25.0k cycles/s).  Every "
+    ap.add_argument("--pipeline", type=int, default=12,
+                    help="A* batches in flight (rna_astar_set_pipeline_depth).  Two search workgroups share a CU, so 448 queries "
+                         "run at once and the batches' tails differ (measured 8: 44.3k, 12: 49.0k, 16: 48.4k cycles/s).  Every "
                          "launch is stretched by the ones it overlaps with, and the roofline line divides by that "
                          "per-launch duration")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
@@ -361,7 +361,7 @@ def main():
                                    % (n, n, len(ray_sets[0]), nq, nq, ROTATE),
                        "cycles_per_step": nq, "rays_per_step": int(len(ray_sets[0])), "rotating_input_sets": ROTATE,
                        "astar_queries_checked": total, "astar_queries_answered": answered, "astar_paths_found": found,
-                       "astar_bucket_width": args.bucket_width or 8000, "astar_pipeline_depth": args.pipeline,
+                       "astar_bucket_width": args.bucket_width or 12000, "astar_pipeline_depth": args.pipeline,
                        "timed_seconds": t_max,
                        "parallelism": ("query-sharded x%d" % world) if layout is None else
                                       ("one map tiled %d x %d (windowed HIMM, %d-cell halo exchange, all-gather of owner "

@@ -368,16 +368,19 @@ int ensure_config(rna_engine* e) {
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         if (getenv("RNA_NO_STREAM_PRIORITY")) prio_lo = prio_hi = 0;
-        // RNA_SEARCH_CU_SKIP=n: the searches may not use the first n CUs of the queue's CU mask (ROCr deals the mask bits
-        // round-robin to the XCDs, so n = 8 is one CU per XCD), which leaves those to the engine stream
-        if (const char* m = getenv("RNA_SEARCH_CU_SKIP")) {
-          uint32_t mask[8];
-          const int skip = atoi(m);
-          for (int k = 0; k < 8; ++k) {
-            const int lo = skip - 32 * k;
-            mask[k] = lo <= 0 ? 0xffffffffu : (lo >= 32 ? 0u : (0xffffffffu << lo));
-          }
-          RNA_HIP(e, hipExtStreamCreateWithCUMask(&a.side[d], 8, mask));
+        // The search streams may not use one CU in eight (ROCr deals the bits of a queue's CU mask round-robin to the
+        // XCDs, so the first n bits are n / 8 CUs of every XCD).  A search workgroup holds its CU slot for a whole query
+        // (milliseconds) and two of them fill a CU's registers, so a stream priority cannot make room for the engine
+        // stream's short kernels (map update, VFH+, field reset) that gate the next search launch: without the reserve
+        // they take 3 ms instead of 0.3 ms each and the step rate hangs on them (22 k instead of 33 k cycles/s when this
+        // was introduced).  RNA_SEARCH_CU_SKIP=n overrides the number of reserved CUs, 0 = no mask (stream priority only).
+        int skip = e->cu_count / 8;
+        if (const char* m = getenv("RNA_SEARCH_CU_SKIP")) skip = atoi(m);
+        if (skip > 0 && skip < e->cu_count) {
+          uint32_t mask[16] = {};
+          const int words = (e->cu_count + 31) / 32 < 16 ? (e->cu_count + 31) / 32 : 16;
+          for (int c = skip; c < e->cu_count && c < 512; ++c) mask[c >> 5] |= 1u << (c & 31);
+          RNA_HIP(e, hipExtStreamCreateWithCUMask(&a.side[d], (uint32_t)words, mask));
         } else {
           RNA_HIP(e, hipStreamCreateWithPriority(&a.side[d], hipStreamNonBlocking, prio_lo));
         }

@@ -39,7 +39,7 @@ constexpr int MASK_STRIDE = TILE_WORDS + 32;  // snapshot bytes per tile: lane-m
 #define RNA_TSA_WAVES 16
 #endif
 #ifndef RNA_TSA_HPASS
-#define RNA_TSA_HPASS 4   // extra passes of a changed row along itself
+#define RNA_TSA_HPASS 8   // extra passes of a changed row along itself (2 / 4 / 8: 48.1 / 49.0 / 50.6 k cycles/s)
 #endif
 #ifndef RNA_TSA_WAVES_PER_EU
 #define RNA_TSA_WAVES_PER_EU 8   // two workgroups per CU: the kernel must fit 64 VGPRs
@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(TSA_THREADS) __attribute__((amdgpu_waves_per_e
   extern __shared__ unsigned s_dyn[];   // tile bitsets, sized by the launch: 3 x ((ntile + 31) / 32) words
   __shared__ unsigned short s_jobs[TSA_JOBS];
   __shared__ unsigned s_jobpg[TSA_JOBS];   // local page of each job's tile (looked up once per round by the list builders)
-  __shared__ int s_njobs, s_first_fail, s_job_next, s_best, s_state, s_bucket, s_bucket0, s_rounds, s_expanded, s_nalloc;
+  __shared__ int s_njobs, s_first_fail, s_job_next, s_best, s_state, s_bucket, s_bucket0, s_rounds, s_expanded, s_nalloc, s_any;
 
   // Workgroups take their query when they START (a ticket), not by blockIdx: the hardware deals workgroup
   // indices round-robin to the XCDs, so a fixed mapping lets one XCD with several long searches hold back
@@ -598,8 +598,8 @@ __global__ void __launch_bounds__(TSA_THREADS) __attribute__((amdgpu_waves_per_e
   __shared__ int s_q;
   if (threadIdx.x == 0) s_q = A.S.perm[atomicAdd(A.S.ticket, 1)];
   __syncthreads();
-  const int q = s_q;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int q = __builtin_amdgcn_readfirstlane(s_q);   // wave-uniform values belong in SGPRs: the tile jobs need every VGPR
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rows = A.rows, cols = A.cols, tiles_i = A.tiles_i, tiles_j = A.tiles_j;
   rna_astar_query qu = A.queries[q];   // buffer linear indices; the search itself runs in map space
   const int ncell = rows * cols;
@@ -664,10 +664,14 @@ __global__ void __launch_bounds__(TSA_THREADS) __attribute__((amdgpu_waves_per_e
 
   for (;;) {
     // ---- build this round's job list from the active-tile bitset ----
+    // (an opaque copy of the thread id per round: what the list builders derive from it is recomputed here instead of
+    // living -- spilled to scratch -- across the tile jobs, which need all 64 VGPRs)
+    int tid_r = threadIdx.x;
+    asm volatile("" : "+v"(tid_r));
     TSA_T(t_r0);
-    if (tid == 0) { s_njobs = 0; s_job_next = 0; s_first_fail = TSA_JOBS; }
+    if (tid_r == 0) { s_njobs = 0; s_job_next = 0; s_first_fail = TSA_JOBS; }
     __syncthreads();
-    for (int w = tid; w < nt_words; w += TSA_THREADS) {
+    for (int w = tid_r; w < nt_words; w += TSA_THREADS) {
       unsigned bits = s_act[0][w];
       if (!bits) continue;
       const int cnt = __popc(bits);
@@ -699,25 +703,27 @@ __global__ void __launch_bounds__(TSA_THREADS) __attribute__((amdgpu_waves_per_e
     if (njobs == 0) {
       // bucket k is at its fixed point: every cell with f < (k+1)*B has its exact g
       __syncthreads();
-      if (tid == 0) {
+      if (tid_r == 0) {
         const long long done_below = ((long long)s_bucket + 1) * A.bucket_width;
         if (s_best != INF && (long long)s_best < done_below) s_state = 1;
         else s_state = -1;  // try the next bucket
+        s_any = 0;
       }
       __syncthreads();
       if (s_state == 1) break;
       // advance: tiles that hold cells of the next bucket become the active set, and each of them runs as "first"
       int any = 0;
-      for (int w = tid; w < nt_words; w += TSA_THREADS) {
+      for (int w = tid_r; w < nt_words; w += TSA_THREADS) {
         const unsigned b = s_act[1][w];
         s_act[0][w] = b;
         s_first[w] = b;
         s_act[1][w] = 0u;
         any |= (b != 0u);
       }
-      any = __syncthreads_or(any);
-      if (tid == 0) {
-        if (!any) s_state = (s_best != INF) ? 1 : 2;   // nothing left anywhere
+      if (any) s_any = 1;   // (not __syncthreads_or: its library code keeps three more VGPRs alive across the tile jobs)
+      __syncthreads();
+      if (tid_r == 0) {
+        if (!s_any) s_state = (s_best != INF) ? 1 : 2;   // nothing left anywhere
         else { s_state = 0; s_bucket += 1; }
       }
       __syncthreads();
@@ -746,7 +752,8 @@ __global__ void __launch_bounds__(TSA_THREADS) __attribute__((amdgpu_waves_per_e
     }
     // all stores of this round are performed before any wave loads tiles in the next one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int stop = __syncthreads_or(s_state >= 4);
+    __syncthreads();
+    const bool stop = s_state >= 4;
     if (tid == 0) s_rounds += 1;
     if (stop) break;
   }

@@ -215,6 +215,10 @@ extern "C" int rna_create(rna_engine** out, double length_x, double length_y, do
   if (device_id < 0 || device_id >= ndev) return RNA_EINVAL;
   rna_engine* e = new rna_engine();
   e->device = device_id;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) e->cu_count = cus;
+  }
   set_geometry(e->geom, length_x, length_y, resolution, px, py);
   if (e->geom.size[0] <= 0 || e->geom.size[1] <= 0 ||
       (double)e->geom.size[0] * (double)e->geom.size[1] > 2.0e9) {

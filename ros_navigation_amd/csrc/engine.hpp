@@ -59,7 +59,7 @@ struct VfhDevice {
 struct AstarDevice {
   int max_queries = 0;
   int queue_cap = 0;
-  int bucket_width = 8000;          // f-range relaxed together (8 cells): 27.1k cycles/s against 25.4k at 16000 in the rotating bench
+  int bucket_width = 12000;         // f-range relaxed together (12 cells): 40.7 / 49.0 / 50.1 / 50.1 k cycles/s at 4000 / 8000 / 12000 / 16000
   int threads = 512;               // workgroup size of the search kernel (256 / 512 / 1024)
   // Pipelined batches: `depth` independent sets of search fields + queues, each with its own HIP
   // stream, so the tail of batch k (few long queries) overlaps the head of batch k+1.
@@ -101,6 +101,7 @@ struct ProfSlot {
 struct rna_engine {
   rna::Geom geom{};
   int device = 0;
+  int cu_count = 256;              // compute units of the device (MI355X: 256 = 8 XCDs x 32)
   hipStream_t stream = nullptr;
   size_t ncell = 0;
   float* layer[RNA_NUM_LAYERS] = {nullptr, nullptr, nullptr};

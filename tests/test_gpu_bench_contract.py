@@ -33,14 +33,14 @@ def test_bench_line_contract_on_a_small_grid():
     assert r["achieved"] > 0 and r["launches"] == 5
     assert r["traffic"] is None      # the committed PMC passes belong to the default configuration, not to this one
     rows = {x["kernel"]: x for x in d["roofline_rows"]}
-    assert set(rows) == {"himm_raster_kernel", "vfh_step_kernel"}
+    assert len(rows) == 2 and "vfh_step_kernel" in rows and any("himm_tile_raster_kernel" in k for k in rows)
     for x in rows.values():
         assert x["achieved"] > 0 and x["launches"] == 5 and abs(x["frac"] - x["achieved"] / 8000.0) < 1e-12
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     cfg = d["config"]
     # every query of every batch still in a result buffer was answered (found / no path), none failed
-    assert cfg["astar_queries_checked"] == 32 * cfg["astar_pipeline_depth"] and cfg["astar_queries_answered"] == cfg["astar_queries_checked"]
+    assert cfg["astar_queries_checked"] == 32 * min(cfg["astar_pipeline_depth"], 5 + 2) and cfg["astar_queries_answered"] == cfg["astar_queries_checked"]
     assert cfg["astar_paths_found"] > 0 and cfg["rotating_input_sets"] == 4
 
 
