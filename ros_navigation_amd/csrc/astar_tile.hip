@@ -224,6 +224,7 @@ struct TsaCtx {
   unsigned* pages;            // stage-wide page array
   unsigned* paux;             // stage-wide edge-column copies
   unsigned* tmap;             // this query's tile -> local page table
+  unsigned short* tm_lds;     // LDS copy of it (null when the map has too many tiles): a look-up costs ~100 ns instead of an L2 round trip
   unsigned* owner;            // this query's local page -> tile list
   size_t page_base;           // q * cap: global page = page_base + local page (local >= 1)
   int cap;
@@ -233,6 +234,7 @@ struct TsaCtx {
   int ts, sa, sb;             // start: tile, lane, row
   int tg, ga, gb;             // goal: tile, lane, row
   __device__ __forceinline__ size_t gpage(unsigned local) const { return local ? page_base + local : 0; }
+  __device__ __forceinline__ unsigned page_of(int t) const { return tm_lds ? (unsigned)tm_lds[t] : ld_l2(&tmap[t]); }
 };
 
 // One tile job, executed by one wavefront (lane = this wave's lane id = the cell's column inside the tile).
@@ -313,7 +315,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   int nb_t = -1;
   if (lane < 8) {
     const int nti = ti + kdi_of(lane), ntj = tj + kdj_of(lane);
-    if (nti >= 0 && ntj >= 0 && nti < tiles_i && ntj < tiles_j) { nb_t = ntj * tiles_i + nti; nb_pg = ld_l2(&C.tmap[nb_t]); }
+    if (nti >= 0 && ntj >= 0 && nti < tiles_i && ntj < tiles_j) { nb_t = ntj * tiles_i + nti; nb_pg = C.page_of(nb_t); }
   }
   // ---- 2. everything the job reads, issued before the first wait ----
   int g0, g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15;
@@ -496,7 +498,11 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       if (lane == 0) {
         p = atomicAdd(C.nalloc, 1) + 1;
         if (p > C.cap) { p = 0; sch.pool_exhausted(); }
-        else { C.owner[p] = (unsigned)t; __hip_atomic_store(&C.tmap[t], (unsigned)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else {
+          C.owner[p] = (unsigned)t;
+          __hip_atomic_store(&C.tmap[t], (unsigned)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the backtrace / reset kernels
+          if (C.tm_lds) C.tm_lds[t] = (unsigned short)p;
+        }
       }
       pg = (unsigned)__builtin_amdgcn_readfirstlane(p);
       if (pg == 0u) return evals;
@@ -574,6 +580,7 @@ struct TsaLaunch {
   const rna_astar_query* queries;
   TsaStage S;
   int bucket_width;
+  int lds_tmap;          // the launch reserved 2 * ntile bytes of LDS behind the bitsets for the page table
   int32_t* paths;
   int max_path_len;
   int32_t* rev_all;
@@ -607,6 +614,7 @@ __global__ void __launch_bounds__(TSA_THREADS) __attribute__((amdgpu_waves_per_e
   const int nt_words = (ntile + 31) >> 5;
   unsigned* const s_act[2] = {s_dyn, s_dyn + nt_words};   // [0] current bucket (next round), [1] next bucket
   unsigned* const s_first = s_dyn + 2 * nt_words;         // tiles that have not run yet in the current bucket
+  unsigned short* const s_tm = A.lds_tmap ? reinterpret_cast<unsigned short*>(s_dyn + 3 * nt_words) : nullptr;
   rna_astar_result* const results = A.results;
 
   const bool valid = qu.start >= 0 && qu.goal >= 0 && qu.start < ncell && qu.goal < ncell;
@@ -628,11 +636,12 @@ __global__ void __launch_bounds__(TSA_THREADS) __attribute__((amdgpu_waves_per_e
   C.cap = A.S.cap;
   C.nalloc = &s_nalloc;
   C.nbr_tm = A.S.nbr_tm;
+  C.tm_lds = s_tm;
   C.gi = gi; C.gj = gj;
   C.ts = tile_of(si, sj, tiles_i); C.sa = si & (TI - 1); C.sb = sj & (TJ - 1);
   C.tg = tile_of(gi, gj, tiles_i); C.ga = gi & (TI - 1); C.gb = gj & (TJ - 1);
 
-  for (int w = tid; w < 3 * nt_words; w += TSA_THREADS) s_dyn[w] = 0u;
+  for (int w = tid; w < 3 * nt_words + (A.lds_tmap ? (ntile + 1) / 2 : 0); w += TSA_THREADS) s_dyn[w] = 0u;
   if (lane >= 64 - (SCR_WORDS - 68)) s_scr[wv][68 + lane - (64 - (SCR_WORDS - 68))] = 0u;   // the zero tail of the wave's scratch
   // a start or a goal without a single traversable neighbour: blocked or walled in; nothing has been written yet, so
   // no page is in use
@@ -684,7 +693,7 @@ __global__ void __launch_bounds__(TSA_THREADS) __attribute__((amdgpu_waves_per_e
           bits &= bits - 1;
           const int t = (w << 5) + b;
           s_jobs[k] = (unsigned short)t;
-          s_jobpg[k] = ld_l2(&C.tmap[t]);   // final for this round: only the tile's own job changes it
+          s_jobpg[k] = C.page_of(t);   // final for this round: only the tile's own job changes it
           ++k;
         }
       } else {
@@ -974,9 +983,11 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     const size_t nt_bytes = (size_t)((ti * tj + 31) / 32) * sizeof(unsigned);
     TsaLaunch A;
     A.rows = rows; A.cols = cols; A.tiles_i = ti; A.tiles_j = tj; A.s0 = e->geom.start[0]; A.s1 = e->geom.start[1];
+    // the page table in LDS as long as two workgroups still fit a CU (4096^2: 32 KB each)
+    A.lds_tmap = ti * tj <= 16384 ? 1 : 0;
     A.queries = q_dev; A.S = S; A.bucket_width = a.bucket_width; A.paths = paths_dev; A.max_path_len = max_len;
     A.rev_all = a.rev[slot]; A.rev_cap = a.rev_cap; A.results = res_dev;
-    hipLaunchKernelGGL(tsa_search_kernel, dim3(n), dim3(TSA_THREADS), 3 * nt_bytes, search_stream, A);
+    hipLaunchKernelGGL(tsa_search_kernel, dim3(n), dim3(TSA_THREADS), 3 * nt_bytes + (A.lds_tmap ? (size_t)((ti * tj + 1) / 2) * 4 : 0), search_stream, A);
     hipLaunchKernelGGL(tsa_backtrace_kernel, dim3(n), dim3(64), 0, search_stream, A);
     RNA_HIP(e, hipGetLastError());
   }
