@@ -64,10 +64,22 @@ def main():
                                 "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (FETCH_SIZE doubled: gfx950 "
                                 "reports half of the bytes of 16 B/lane streaming reads, MI355X_MICROARCH.md; dword "
                                 "accesses are uncalibrated, so bench.py quotes the range from (FETCH + WRITE) * 1024)",
-                           config=dict(grid=4096, queries=256, pipeline=6, ray_poses=64, rays_per_pose=1563),
+                           config=dict(grid=4096, queries=256, pipeline=bench_pipeline(src), ray_poses=64, rays_per_pose=1563),
                            kernels=summ), f, indent=1)
     print(json.dumps({k: (v if k == "pmc" else [(short(r["name"]), r["calls"], round(r["avg_ns"] / 1e3, 1)) for r in v][:8])
                       for k, v in out.items()}, indent=1)[:3000])
+
+
+def bench_pipeline(src):
+    """pipeline depth of the profiled bench runs, from the JSON line the PMC pass printed"""
+    for name in ("pmc_fetch.log", "bench_under_rocprof.log"):
+        try:
+            for line in open(os.path.join(src, name)):
+                if line.startswith("{") and "astar_pipeline_depth" in line:
+                    return json.loads(line)["config"]["astar_pipeline_depth"]
+        except OSError:
+            pass
+    return None
 
 
 if __name__ == "__main__":
