@@ -39,7 +39,7 @@ constexpr int MASK_STRIDE = TILE_WORDS + 32;  // snapshot bytes per tile: lane-m
 #define RNA_TSA_WAVES 16
 #endif
 #ifndef RNA_TSA_HPASS
-#define RNA_TSA_HPASS 8   // extra passes of a changed row along itself (2 / 4 / 8: 48.1 / 49.0 / 50.6 k cycles/s)
+#define RNA_TSA_HPASS 16  // extra passes of a changed row along itself (2 / 4 / 8: 48.1 / 49.0 / 50.6 k cycles/s; 8 / 16: 55.8 / 56.7 k)
 #endif
 #ifndef RNA_TSA_WAVES_PER_EU
 #define RNA_TSA_WAVES_PER_EU 8   // two workgroups per CU: the kernel must fit 64 VGPRs
@@ -54,7 +54,8 @@ constexpr int TSA_JOBS = RNA_TSA_JOBS;     // tile jobs per round (more stay fla
 constexpr int COST_S = 1000, COST_D = 1414;
 constexpr int INF = 0x7fffffff;
 constexpr int KU = 0x40000000;             // field word u = KU - g; 0 = unreached
-constexpr int SCR_WORDS = 84;              // per-wave LDS scratch (column transposition): 68 + a zero tail of 16
+constexpr int SCR_WORDS = 84 + 192 + 48;   // per-wave LDS scratch: column transposition (68 + a zero tail of 16), the halo rows and
+                                           // columns as loaded (3 x 64), this tile's edge columns at the end of the job (16 + 16 + 16)
 
 __device__ __forceinline__ int tsa_octile(int i, int j, int gi, int gj) {
   const int dx = abs(i - gi), dy = abs(j - gj);
@@ -393,6 +394,9 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       cX = xcell ? cX : 0;
       // ... and turned into rows of lane 0 / lane 63 through the wave's LDS scratch (words 68.. are zero)
       scr[lane + 3] = (unsigned)cX;
+      scr[84 + lane] = (unsigned)top;        // kept for the end of the job: does a changed edge row beat what the
+      scr[84 + 64 + lane] = (unsigned)bot;   // neighbour already has?
+      scr[84 + 128 + lane] = (unsigned)X;
       __builtin_amdgcn_wave_barrier();
     }
     const uint4* rp = reinterpret_cast<const uint4*>(&scr[lane == 0 ? 4 : (lane == TI - 1 ? 36 : 68)]);
@@ -547,8 +551,47 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   }
     TSA_R16(TSA_END)
 #undef TSA_END
-    const unsigned am = (q0 & 1ull ? 1u : 0u) | (q0 ? 2u : 0u) | (q0 >> 63 ? 4u : 0u) | (qany & 1ull ? 8u : 0u) | (qany >> 63 ? 16u : 0u) |
-                        (q15 & 1ull ? 32u : 0u) | (q15 ? 64u : 0u) | (q15 >> 63 ? 128u : 0u);
+    // A changed edge cell wakes the tile beyond it only if it beats what that tile held when this job loaded its halo
+    // (its values only get better, so the test can only err towards waking): most wake-ups used to be echoes -- the
+    // front enters this tile FROM the neighbour, the cells along that edge improve, and the neighbour would be woken
+    // to find nothing new (37 % of all jobs).  Masks are ignored here (again only towards waking).
+    bool wakeN = q0 != 0ull, wakeS = q15 != 0ull;
+    if (wakeN) {
+      const int topv = (int)scr[84 + lane];
+      const int c_ = __builtin_amdgcn_inverse_ballot_w64(q0) ? g0 : 0;
+      wakeN = __builtin_amdgcn_ballot_w64(c_ + nS > topv || lane_m1(c_) + nD > topv || lane_p1(c_) + nD > topv) != 0ull;
+    }
+    if (wakeS) {
+      const int botv = (int)scr[84 + 64 + lane];
+      const int c_ = __builtin_amdgcn_inverse_ballot_w64(q15) ? g15 : 0;
+      wakeS = __builtin_amdgcn_ballot_w64(c_ + nS > botv || lane_m1(c_) + nD > botv || lane_p1(c_) + nD > botv) != 0ull;
+    }
+    // the same for the two edge columns and the four corners: lane 0 / 63 lay their 16 cells (what they may pass on)
+    // out in LDS, the lanes that hold the halo column as loaded (lane = row + 1) compare.  Unchanged cells take part
+    // too: they cannot beat a neighbour that has already seen them.
+    unsigned colw = 0u;   // bit 0 NW, 1 W, 2 SW, 3 NE, 4 E, 5 SE
+    if ((qany & 1ull) || (qany >> 63) || (q0 & 1ull) || (q0 >> 63) || (q15 & 1ull) || (q15 >> 63)) {
+      if (lane == 0 || lane == TI - 1) {
+        uint4* cp = reinterpret_cast<uint4*>(&scr[276 + (lane ? 32 : 0)]);
+        cp[0] = make_uint4((unsigned)pp0, (unsigned)pp1, (unsigned)pp2, (unsigned)pp3);
+        cp[1] = make_uint4((unsigned)pp4, (unsigned)pp5, (unsigned)pp6, (unsigned)pp7);
+        cp[2] = make_uint4((unsigned)pp8, (unsigned)pp9, (unsigned)pp10, (unsigned)pp11);
+        cp[3] = make_uint4((unsigned)pp12, (unsigned)pp13, (unsigned)pp14, (unsigned)pp15);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int xl_ = lane & 31;
+      const int v_ = (xl_ >= 1 && xl_ <= TJ) ? (int)scr[276 + (lane & 32) + xl_ - 1] : 0;
+      const int xv = (int)scr[84 + 128 + lane];
+      const bool imp = xl_ <= TJ + 1 && (v_ + nS > xv || lane_m1(v_) + nD > xv || lane_p1(v_) + nD > xv);
+      const unsigned long long im = __builtin_amdgcn_ballot_w64(imp);
+      const unsigned lo = (unsigned)im, hi = (unsigned)(im >> 32);
+      colw = ((lo & 1u) ? 1u : 0u) | ((lo & 0x1fffeu) ? 2u : 0u) | ((lo & 0x20000u) ? 4u : 0u) |
+             ((hi & 1u) ? 8u : 0u) | ((hi & 0x1fffeu) ? 16u : 0u) | ((hi & 0x20000u) ? 32u : 0u);
+      __builtin_amdgcn_wave_barrier();
+    }
+    // directions: 0 NW, 1 N, 2 NE, 3 W, 4 E, 5 SW, 6 S, 7 SE
+    const unsigned am = ((colw & 1u) ? 1u : 0u) | (wakeN ? 2u : 0u) | ((colw & 8u) ? 4u : 0u) | ((colw & 2u) ? 8u : 0u) | ((colw & 16u) ? 16u : 0u) |
+                        ((colw & 4u) ? 32u : 0u) | (wakeS ? 64u : 0u) | ((colw & 32u) ? 128u : 0u);
     if (lane < 8 && ((am >> lane) & 1u) && nb_t >= 0) sch.act_cur(nb_t);
     if (farm && lane == 0) sch.act_far(t);
   }
@@ -642,7 +685,7 @@ __global__ void __launch_bounds__(TSA_THREADS) __attribute__((amdgpu_waves_per_e
   C.tg = tile_of(gi, gj, tiles_i); C.ga = gi & (TI - 1); C.gb = gj & (TJ - 1);
 
   for (int w = tid; w < 3 * nt_words + (A.lds_tmap ? (ntile + 1) / 2 : 0); w += TSA_THREADS) s_dyn[w] = 0u;
-  if (lane >= 64 - (SCR_WORDS - 68)) s_scr[wv][68 + lane - (64 - (SCR_WORDS - 68))] = 0u;   // the zero tail of the wave's scratch
+  if (lane >= 48) s_scr[wv][68 + lane - 48] = 0u;   // the zero tail of the wave's scratch
   // a start or a goal without a single traversable neighbour: blocked or walled in; nothing has been written yet, so
   // no page is in use
   {
