@@ -1,6 +1,6 @@
 // astar_tile.hip -- tile-synchronous grid A* for gfx950 ("TSA"): the same contract and the same
 // label-correcting argument as astar.hip, but the relaxation runs in REGISTERS.  This file holds the
-// default search kernel of the engine: one workgroup (16 wavefronts) per query, rounds of tile jobs.
+// default search kernel of the engine: one workgroup (8 wavefronts) per query, rounds of tile jobs.
 //
 // The search field lives in PAGES of one 64 x 16-cell tile each (4 KiB; word = KU - g, 0 = unreached, so that a
 // fresh page is all zeros and "better" is "larger").  A wavefront owns one tile at a time: lane = column (the
@@ -36,7 +36,7 @@ constexpr int TILE_WORDS = TI * TJ;           // 1024
 constexpr int AUX_WORDS = 64;                 // per page: [0..15] copy of column 0, [16..31] copy of column 63
 constexpr int MASK_STRIDE = TILE_WORDS + 32;  // snapshot bytes per tile: lane-major masks + the two edge columns again
 #ifndef RNA_TSA_WAVES
-#define RNA_TSA_WAVES 16
+#define RNA_TSA_WAVES 8   // wavefronts per workgroup = per query; 8 wavefronts per SIMD -> four workgroups per CU (16 x 2: 60.5 k, 8 x 4: 63.5 k, 4 x 8: 42.4 k)
 #endif
 #ifndef RNA_TSA_HPASS
 #define RNA_TSA_HPASS 16  // extra passes of a changed row along itself (2 / 4 / 8: 48.1 / 49.0 / 50.6 k cycles/s; 8 / 16: 55.8 / 56.7 k)
@@ -225,7 +225,6 @@ struct TsaCtx {
   unsigned* pages;            // stage-wide page array
   unsigned* paux;             // stage-wide edge-column copies
   unsigned* tmap;             // this query's tile -> local page table
-  unsigned short* tm_lds;     // LDS copy of it (null when the map has too many tiles): a look-up costs ~100 ns instead of an L2 round trip
   unsigned* owner;            // this query's local page -> tile list
   size_t page_base;           // q * cap: global page = page_base + local page (local >= 1)
   int cap;
@@ -235,7 +234,7 @@ struct TsaCtx {
   int ts, sa, sb;             // start: tile, lane, row
   int tg, ga, gb;             // goal: tile, lane, row
   __device__ __forceinline__ size_t gpage(unsigned local) const { return local ? page_base + local : 0; }
-  __device__ __forceinline__ unsigned page_of(int t) const { return tm_lds ? (unsigned)tm_lds[t] : ld_l2(&tmap[t]); }
+  __device__ __forceinline__ unsigned page_of(int t) const { return ld_l2(&tmap[t]); }
 };
 
 // One tile job, executed by one wavefront (lane = this wave's lane id = the cell's column inside the tile).
@@ -347,8 +346,8 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   // ---- 3. this bucket's bound; which cells are free ----
   // A blocked (or outside) cell keeps u = 0 for ever: every candidate is ANDed with the cell's free bit, and an
   // "unreached" cell never passes anything on.  The heuristic of a row is recomputed where it is needed (one scalar
-  // |dj| and four vector instructions) instead of living in 16 registers: the kernel has to fit 64 VGPRs so that two
-  // workgroups share a CU.
+  // |dj| and four vector instructions) instead of living in 16 registers: the kernel has to fit 64 VGPRs so that eight
+  // wavefronts share a SIMD.
   const int best_in = sch.best();
   const long long lim_ll = bucket_end < (long long)best_in + 1 ? bucket_end : (long long)best_in + 1;   // pass on iff f < lim
   const int thr = KU - (int)(lim_ll > (long long)INF ? (long long)INF : lim_ll) + 1;
@@ -502,11 +501,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       if (lane == 0) {
         p = atomicAdd(C.nalloc, 1) + 1;
         if (p > C.cap) { p = 0; sch.pool_exhausted(); }
-        else {
-          C.owner[p] = (unsigned)t;
-          __hip_atomic_store(&C.tmap[t], (unsigned)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the backtrace / reset kernels
-          if (C.tm_lds) C.tm_lds[t] = (unsigned short)p;
-        }
+        else { C.owner[p] = (unsigned)t; __hip_atomic_store(&C.tmap[t], (unsigned)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       }
       pg = (unsigned)__builtin_amdgcn_readfirstlane(p);
       if (pg == 0u) return evals;
@@ -623,7 +618,6 @@ struct TsaLaunch {
   const rna_astar_query* queries;
   TsaStage S;
   int bucket_width;
-  int lds_tmap;          // the launch reserved 2 * ntile bytes of LDS behind the bitsets for the page table
   int32_t* paths;
   int max_path_len;
   int32_t* rev_all;
@@ -632,7 +626,7 @@ struct TsaLaunch {
 };
 constexpr int TSA_FOUND = -1000;        // provisional status between the search and the backtrace kernel
 
-// One workgroup of 16 wavefronts per query.  The kernel ends with the exact distance field in HBM and a provisional
+// One workgroup of 8 wavefronts per query, four of them per CU.  The kernel ends with the exact distance field in HBM and a provisional
 // result; the path is traced by tsa_backtrace_kernel (one wavefront per query, next kernel on the stream).
 __global__ void __launch_bounds__(TSA_THREADS) __attribute__((amdgpu_waves_per_eu(RNA_TSA_WAVES_PER_EU, RNA_TSA_WAVES_PER_EU))) tsa_search_kernel(const TsaLaunch A) {
   __shared__ unsigned s_scr[TSA_WAVES][SCR_WORDS];
@@ -657,7 +651,6 @@ __global__ void __launch_bounds__(TSA_THREADS) __attribute__((amdgpu_waves_per_e
   const int nt_words = (ntile + 31) >> 5;
   unsigned* const s_act[2] = {s_dyn, s_dyn + nt_words};   // [0] current bucket (next round), [1] next bucket
   unsigned* const s_first = s_dyn + 2 * nt_words;         // tiles that have not run yet in the current bucket
-  unsigned short* const s_tm = A.lds_tmap ? reinterpret_cast<unsigned short*>(s_dyn + 3 * nt_words) : nullptr;
   rna_astar_result* const results = A.results;
 
   const bool valid = qu.start >= 0 && qu.goal >= 0 && qu.start < ncell && qu.goal < ncell;
@@ -679,12 +672,11 @@ __global__ void __launch_bounds__(TSA_THREADS) __attribute__((amdgpu_waves_per_e
   C.cap = A.S.cap;
   C.nalloc = &s_nalloc;
   C.nbr_tm = A.S.nbr_tm;
-  C.tm_lds = s_tm;
   C.gi = gi; C.gj = gj;
   C.ts = tile_of(si, sj, tiles_i); C.sa = si & (TI - 1); C.sb = sj & (TJ - 1);
   C.tg = tile_of(gi, gj, tiles_i); C.ga = gi & (TI - 1); C.gb = gj & (TJ - 1);
 
-  for (int w = tid; w < 3 * nt_words + (A.lds_tmap ? (ntile + 1) / 2 : 0); w += TSA_THREADS) s_dyn[w] = 0u;
+  for (int w = tid; w < 3 * nt_words; w += TSA_THREADS) s_dyn[w] = 0u;
   if (lane >= 48) s_scr[wv][68 + lane - 48] = 0u;   // the zero tail of the wave's scratch
   // a start or a goal without a single traversable neighbour: blocked or walled in; nothing has been written yet, so
   // no page is in use
@@ -1026,11 +1018,9 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     const size_t nt_bytes = (size_t)((ti * tj + 31) / 32) * sizeof(unsigned);
     TsaLaunch A;
     A.rows = rows; A.cols = cols; A.tiles_i = ti; A.tiles_j = tj; A.s0 = e->geom.start[0]; A.s1 = e->geom.start[1];
-    // the page table in LDS as long as two workgroups still fit a CU (4096^2: 32 KB each)
-    A.lds_tmap = ti * tj <= 16384 ? 1 : 0;
     A.queries = q_dev; A.S = S; A.bucket_width = a.bucket_width; A.paths = paths_dev; A.max_path_len = max_len;
     A.rev_all = a.rev[slot]; A.rev_cap = a.rev_cap; A.results = res_dev;
-    hipLaunchKernelGGL(tsa_search_kernel, dim3(n), dim3(TSA_THREADS), 3 * nt_bytes + (A.lds_tmap ? (size_t)((ti * tj + 1) / 2) * 4 : 0), search_stream, A);
+    hipLaunchKernelGGL(tsa_search_kernel, dim3(n), dim3(TSA_THREADS), 3 * nt_bytes, search_stream, A);
     hipLaunchKernelGGL(tsa_backtrace_kernel, dim3(n), dim3(64), 0, search_stream, A);
     RNA_HIP(e, hipGetLastError());
   }

@@ -1,9 +1,10 @@
 """CPU-only (hipcc cross-compiles): the resource budgets of the grid-A* search kernel.  The tile job keeps a 64 x 16
-tile in registers (2 x 16 rows) and is bound by what one wavefront can issue, so throughput comes from TWO workgroups
-of 16 wavefronts per CU: the kernel has to fit 64 VGPRs (8 wavefronts per SIMD), must not spill in the tile job, and
-two workgroups' LDS has to fit a CU.  (The engine-stream kernels no longer share CUs with the searches: astar.hip keeps
-one CU in eight out of the search streams' CU mask.  Measured when the kernel needed 116 VGPRs -- one workgroup per CU:
-22 k instead of 36 k cycles/s; with the job's lane constants spilled to scratch: 33 k.)"""
+tile in registers (2 x 16 rows) and is bound by what one wavefront can issue, so throughput comes from EIGHT wavefronts
+per SIMD -- four workgroups (queries) of 8 wavefronts per CU: the kernel has to fit 64 VGPRs, must not spill in the
+tile job, and four workgroups' LDS has to fit a CU for the bench's map.  (The engine-stream kernels no longer share CUs
+with the searches: astar.hip keeps 24 CUs out of the search streams' CU mask.  Measured when the kernel needed 116
+VGPRs -- four wavefronts per SIMD: 22 k instead of 36 k cycles/s; with the job's lane constants spilled to scratch:
+33 k.)"""
 import os
 import re
 import subprocess
@@ -40,12 +41,14 @@ def alloc(vgprs):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-def test_two_search_workgroups_fit_a_cu():
+def test_eight_search_wavefronts_fit_a_simd():
     tile = resources("astar_tile.hip")
     search = next(v for k, v in tile.items() if "tsa_search_kernel" in k)
-    assert alloc(search["VGPRs"]) * 8 <= VGPRS_PER_SIMD, search      # 8 wavefronts per SIMD = 2 workgroups of 16 per CU
+    assert alloc(search["VGPRs"]) * 8 <= VGPRS_PER_SIMD, search        # 8 wavefronts per SIMD = 4 workgroups of 8 per CU
     assert search["ScratchSize"] <= 16, search                          # nothing spilled inside the tile job (one kernel-level value may be)
-    search_lds = search["LDS"] + 3 * 4 * 2048                           # + the three tile bitsets of the largest supported map (65536 tiles)
-    assert 2 * search_lds <= LDS_PER_CU, search_lds
+    bench_lds = search["LDS"] + 3 * 4 * ((64 * 256 + 31) // 32)         # + the three tile bitsets of a 4096 x 4096 map (64 x 256 tiles)
+    assert 4 * bench_lds <= LDS_PER_CU, bench_lds
+    largest_lds = search["LDS"] + 3 * 4 * 2048                          # the largest supported map (65536 tiles): at least two per CU
+    assert 2 * largest_lds <= LDS_PER_CU, largest_lds
     back = next(v for k, v in tile.items() if "tsa_backtrace_kernel" in k)
     assert back["ScratchSize"] == 0 and back["LDS"] <= 8 * 1024         # one wavefront per query, next to the searches
