@@ -43,8 +43,8 @@ PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200, help="timed steps (default: about 2 s on one MI355X)")
-    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=600, help="timed steps (default: about 2.3 s on one MI355X)")
+    ap.add_argument("--warmup", type=int, default=24, help="untimed steps: two turns of the 12-stage pipeline")
     ap.add_argument("--grid", type=int, default=4096)
     ap.add_argument("--queries", type=int, default=256, help="A* queries == VFH poses per step (cycles per step)")
     ap.add_argument("--ray-poses", type=int, default=64)
@@ -53,8 +53,8 @@ def parse():
     ap.add_argument("--queue-capacity", type=int, default=0)
     ap.add_argument("--max-path", type=int, default=32768)
     ap.add_argument("--pipeline", type=int, default=12,
-                    help="A* batches in flight (rna_astar_set_pipeline_depth).  Two search workgroups share a CU, so 448 queries "
-                         "run at once and the batches' tails differ (measured 8: 44.3k, 12: 49.0k, 16: 48.4k cycles/s).  Every "
+                    help="A* batches in flight (rna_astar_set_pipeline_depth).  Four search workgroups share a CU, so ~900 queries "
+                         "run at once and the batches' tails differ (measured 10: 56.3k, 12: 63.1k, 14: 63.2k cycles/s).  Every "
                          "launch is stretched by the ones it overlaps with, and the roofline line divides by that "
                          "per-launch duration")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
@@ -361,7 +361,7 @@ def main():
                                    % (n, n, len(ray_sets[0]), nq, nq, ROTATE),
                        "cycles_per_step": nq, "rays_per_step": int(len(ray_sets[0])), "rotating_input_sets": ROTATE,
                        "astar_queries_checked": total, "astar_queries_answered": answered, "astar_paths_found": found,
-                       "astar_bucket_width": args.bucket_width or 12000, "astar_pipeline_depth": args.pipeline,
+                       "astar_bucket_width": args.bucket_width or 24000, "astar_pipeline_depth": args.pipeline,
                        "timed_seconds": t_max,
                        "parallelism": ("query-sharded x%d" % world) if layout is None else
                                       ("one map tiled %d x %d (windowed HIMM, %d-cell halo exchange, all-gather of owner "
