@@ -162,7 +162,10 @@ def pmc_traffic(kernel, args, world):
         if (c["grid"], c["queries"], c["pipeline"], c["ray_poses"], c["rays_per_pose"]) != \
                 (args.grid, args.queries, args.pipeline, args.ray_poses, args.rays_per_pose) or world != 1 or args.tiled:
             return None, "PMC passes in profiles/ were taken on another configuration"
-        ks = [d["kernels"][name] for name in ([kernel] if isinstance(kernel, str) else kernel)]   # a slot's chain: one launch each
+        def find(name):   # template instantiations carry their arguments in the profiler's kernel name
+            hits = [v for k, v in d["kernels"].items() if k == name or k.startswith(name + "<")]
+            return max(hits, key=lambda v: v["hbm_bytes_per_launch"])
+        ks = [find(name) for name in ([kernel] if isinstance(kernel, str) else kernel)]   # a slot's chain: one launch each
         lo = sum(k["fetch_size_kb_avg"] + k["write_size_kb_avg"] for k in ks) * 1024.0
         hi = sum(2.0 * k["fetch_size_kb_avg"] + k["write_size_kb_avg"] for k in ks) * 1024.0
         return [lo, hi], "profiles/r02_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " \

@@ -45,7 +45,6 @@ constexpr int MASK_STRIDE = TILE_WORDS + 32;  // snapshot bytes per tile: lane-m
 #define RNA_TSA_WAVES_PER_EU 8   // two workgroups per CU: the kernel must fit 64 VGPRs
 #endif
 constexpr int TSA_WAVES = RNA_TSA_WAVES;
-constexpr int TSA_THREADS = TSA_WAVES * 64;
 constexpr int TSA_MAX_TILE_WORDS = 2048;   // active-tile bitset words -> up to 65536 tiles
 #ifndef RNA_TSA_JOBS
 #define RNA_TSA_JOBS 2048
@@ -628,8 +627,13 @@ constexpr int TSA_FOUND = -1000;        // provisional status between the search
 
 // One workgroup of 8 wavefronts per query, four of them per CU.  The kernel ends with the exact distance field in HBM and a provisional
 // result; the path is traced by tsa_backtrace_kernel (one wavefront per query, next kernel on the stream).
-__global__ void __launch_bounds__(TSA_THREADS) __attribute__((amdgpu_waves_per_eu(RNA_TSA_WAVES_PER_EU, RNA_TSA_WAVES_PER_EU))) tsa_search_kernel(const TsaLaunch A) {
-  __shared__ unsigned s_scr[TSA_WAVES][SCR_WORDS];
+// WAVES = wavefronts per workgroup (= per query): 8 when batches are pipelined (four queries share a CU, the throughput
+// configuration), 16 for a single batch on the engine's own stream (one workgroup per CU anyway: its latency is what
+// counts -- 256 queries on 4096^2: 32 ms instead of 46 ms).
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(RNA_TSA_WAVES_PER_EU, RNA_TSA_WAVES_PER_EU))) tsa_search_kernel(const TsaLaunch A) {
+  constexpr int TSA_THREADS = WAVES * 64;
+  __shared__ unsigned s_scr[WAVES][SCR_WORDS];
   extern __shared__ unsigned s_dyn[];   // tile bitsets, sized by the launch: 3 x ((ntile + 31) / 32) words
   __shared__ unsigned short s_jobs[TSA_JOBS];
   __shared__ unsigned s_jobpg[TSA_JOBS];   // local page of each job's tile (looked up once per round by the list builders)
@@ -1020,7 +1024,8 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     A.rows = rows; A.cols = cols; A.tiles_i = ti; A.tiles_j = tj; A.s0 = e->geom.start[0]; A.s1 = e->geom.start[1];
     A.queries = q_dev; A.S = S; A.bucket_width = a.bucket_width; A.paths = paths_dev; A.max_path_len = max_len;
     A.rev_all = a.rev[slot]; A.rev_cap = a.rev_cap; A.results = res_dev;
-    hipLaunchKernelGGL(tsa_search_kernel, dim3(n), dim3(TSA_THREADS), 3 * nt_bytes, search_stream, A);
+    if (a.depth > 1) hipLaunchKernelGGL(tsa_search_kernel<TSA_WAVES>, dim3(n), dim3(TSA_WAVES * 64), 3 * nt_bytes, search_stream, A);
+    else hipLaunchKernelGGL(tsa_search_kernel<16>, dim3(n), dim3(16 * 64), 3 * nt_bytes, search_stream, A);
     hipLaunchKernelGGL(tsa_backtrace_kernel, dim3(n), dim3(64), 0, search_stream, A);
     RNA_HIP(e, hipGetLastError());
   }
