@@ -365,6 +365,7 @@ def main():
                        "cycles_per_step": nq, "rays_per_step": int(len(ray_sets[0])), "rotating_input_sets": ROTATE,
                        "astar_queries_checked": total, "astar_queries_answered": answered, "astar_paths_found": found,
                        "astar_bucket_width": args.bucket_width or 24000, "astar_pipeline_depth": args.pipeline,
+                       "astar_allocated": dict(zip(("pipeline_depth", "pages_per_query", "max_queries"), e.astar_effective_config())),
                        "timed_seconds": t_max,
                        "parallelism": ("query-sharded x%d" % world) if layout is None else
                                       ("one map tiled %d x %d (windowed HIMM, %d-cell halo exchange, all-gather of owner "

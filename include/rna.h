@@ -240,13 +240,17 @@ int rna_astar_configure(rna_engine* e, int max_queries, int queue_capacity, int 
 /* Pipelined batches: with depth d > 1 consecutive rna_astar_batch_device calls run their searches on d
  * rotating internal streams (each with its own search fields), so the tail of one batch overlaps
  * the next batch and the next map update.  Outputs of a call are valid after rna_synchronize(); the
- * caller must give calls that may be in flight together distinct output buffers.  Default 4. */
+ * caller must give calls that may be in flight together distinct output buffers.  Default 4; up to 16. */
 int rna_astar_set_pipeline_depth(rna_engine* e, int depth);
-/* The tile kernel keeps a search's distance field in 4 KiB pages (32 x 32 cells) handed out on first touch.  By
+/* The tile kernel keeps a search's distance field in 4 KiB pages (64 x 16 cells) handed out on first touch.  By
  * default every query may take one page per tile of the map (it can never run out; HBM is only touched where a
- * search goes).  A smaller share per query makes room for more queries / pipeline stages in flight; a search that
+ * search goes; half a map's worth when the pipeline stages would not fit HBM otherwise).  A smaller share per query makes room for more queries / pipeline stages in flight; a search that
  * needs more ends with status 5.  0 = default. */
 int rna_astar_set_page_cap(rna_engine* e, int pages_per_query);
+/* What the first batch (or rna_astar_configure after a map is loaded) actually allocated: pipeline stages, pages per
+ * query and concurrent queries may have been reduced to fit 75 % of the free HBM.  Any pointer may be NULL; all three
+ * are 0 before the allocation. */
+int rna_astar_effective_config(const rna_engine* e, int* pipeline_depth, int* pages_per_query, int* max_queries);
 int rna_astar_batch(rna_engine* e, const rna_astar_query* queries_host, int n, int32_t* paths_host,
                     int max_path_len, rna_astar_result* results_host);
 int rna_astar_batch_device(rna_engine* e, const rna_astar_query* queries_device, int n, int32_t* paths_device,

@@ -32,7 +32,7 @@ SYMBOLS = [
     "rna_layers_unpack_tiles_device",
     "rna_vfh_default_params", "rna_vfh_init", "rna_vfh_reset", "rna_vfh_hist_size", "rna_vfh_step_batch",
     "rna_vfh_step_batch_device", "rna_vfh_update_batch",
-    "rna_astar_configure", "rna_astar_set_pipeline_depth", "rna_astar_set_page_cap", "rna_astar_batch", "rna_astar_batch_device", "rna_astar_settled_counts",
+    "rna_astar_configure", "rna_astar_set_pipeline_depth", "rna_astar_set_page_cap", "rna_astar_effective_config", "rna_astar_batch", "rna_astar_batch_device", "rna_astar_settled_counts",
     "rna_astar_download_nbr_mask",
     "rna_graph_astar_batch", "rna_rrt_batch", "rna_rrt_batch_device",
     "rna_to_occupancy_grid", "rna_to_occupancy_grid_device", "rna_from_occupancy_grid", "rna_vfh_hist_msg_batch",
@@ -156,6 +156,7 @@ def lib():
     L.rna_astar_configure.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.rna_astar_set_pipeline_depth.argtypes = [vp, C.c_int]
     L.rna_astar_set_page_cap.argtypes = [vp, C.c_int]
+    L.rna_astar_effective_config.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.rna_astar_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
     L.rna_astar_batch_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
     L.rna_astar_download_nbr_mask.argtypes = [vp, vp, C.c_size_t]
@@ -508,6 +509,12 @@ class Engine:
 
     def astar_pipeline_depth(self, depth):
         self._check(self._L.rna_astar_set_pipeline_depth(self.h, depth))
+
+    def astar_effective_config(self):
+        """(pipeline depth, pages per query, concurrent queries) as allocated; zeros before the first batch"""
+        d, p, q = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._check(self._L.rna_astar_effective_config(self.h, C.byref(d), C.byref(p), C.byref(q)))
+        return d.value, p.value, q.value
 
     def astar_page_cap(self, pages_per_query):
         self._check(self._L.rna_astar_set_page_cap(self.h, pages_per_query))

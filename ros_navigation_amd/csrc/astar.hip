@@ -325,7 +325,7 @@ int ensure_config(rna_engine* e) {
     a.queue_cap = (int)c;
   }
   if (e->ncell >= (1ull << 30)) return fail(e, RNA_EINVAL, "grid A*: more than 2^30 cells");
-  // fit into free HBM (25 % headroom): first fewer pipeline stages, then (tile kernel) fewer pages per query
+  // fit into free HBM (25 % headroom): (tile kernel) fewer pages per query, fewer pipeline stages, fewer pages still
   // -- a search that needs more than its share then ends with status 5 --, then fewer concurrent queries
   size_t free_b = 0, total_b = 0;
   RNA_HIP(e, hipMemGetInfo(&free_b, &total_b));
@@ -339,6 +339,9 @@ int ensure_config(rna_engine* e) {
              (double)a.rev_cap * 4.0 * a.max_queries;
     return ((double)(e->ncell + 128) * 4.0 + 3.0 * a.queue_cap * sizeof(int2)) * a.max_queries;
   };
+  // (tile kernel) half a map's worth of pages per query first -- searches touch a few per cent of the map, and twelve
+  // stages of 17.8 GB each at 4096^2 x 256 queries sit right at the budget --, then fewer stages, then fewer pages
+  if (a.mode != 0 && a.page_cap > 64 && a.page_cap > ntile / 2 && stage_bytes() * a.depth > 0.75 * (double)free_b) a.page_cap = (ntile + 1) / 2;
   while (a.depth > 1 && stage_bytes() * a.depth > 0.75 * (double)free_b) a.depth -= 1;
   while (a.mode != 0 && a.page_cap > 64 && a.page_cap > ntile / 8 && stage_bytes() * a.depth > 0.75 * (double)free_b) a.page_cap /= 2;
   while (a.max_queries > 1 && stage_bytes() * a.depth > 0.75 * (double)free_b) a.max_queries /= 2;
@@ -370,7 +373,7 @@ int ensure_config(rna_engine* e) {
         if (getenv("RNA_NO_STREAM_PRIORITY")) prio_lo = prio_hi = 0;
         // The search streams may not use three CUs in 32 (ROCr deals the bits of a queue's CU mask round-robin to the
         // XCDs, so the first n bits are n / 8 CUs of every XCD).  A search workgroup holds its CU slot for a whole query
-        // (milliseconds) and two of them fill a CU's registers, so a stream priority cannot make room for the engine
+        // (milliseconds) and four of them fill a CU's registers, so a stream priority cannot make room for the engine
         // stream's short kernels (map update, VFH+, field reset) that gate the next search launch: without the reserve
         // they take 3 ms instead of 0.3 ms each and the step rate hangs on them (22 k instead of 33 k cycles/s when this
         // was introduced; 16 / 24 / 28 / 32 / 40 reserved CUs: 46.7* / 56.3 / 55.6 / 54.6 / 50.6 k, *older kernel).
@@ -496,6 +499,16 @@ extern "C" int rna_astar_set_pipeline_depth(rna_engine* e, int depth) {
     astar_release(e);
     e->astar.depth = depth;
   }
+  return RNA_OK;
+}
+
+extern "C" int rna_astar_effective_config(const rna_engine* e, int* pipeline_depth, int* pages_per_query, int* max_queries) {
+  if (!e) return RNA_EINVAL;
+  const AstarDevice& a = e->astar;
+  const bool live = a.g[0] != nullptr;
+  if (pipeline_depth) *pipeline_depth = live ? a.depth : 0;
+  if (pages_per_query) *pages_per_query = live ? a.page_cap : 0;
+  if (max_queries) *max_queries = live ? a.max_queries : 0;
   return RNA_OK;
 }
 

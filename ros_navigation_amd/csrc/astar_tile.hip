@@ -42,7 +42,7 @@ constexpr int MASK_STRIDE = TILE_WORDS + 32;  // snapshot bytes per tile: lane-m
 #define RNA_TSA_HPASS 16  // extra passes of a changed row along itself (2 / 4 / 8: 48.1 / 49.0 / 50.6 k cycles/s; 8 / 16: 55.8 / 56.7 k)
 #endif
 #ifndef RNA_TSA_WAVES_PER_EU
-#define RNA_TSA_WAVES_PER_EU 8   // two workgroups per CU: the kernel must fit 64 VGPRs
+#define RNA_TSA_WAVES_PER_EU 8   // eight wavefronts per SIMD: the kernel must fit 64 VGPRs
 #endif
 constexpr int TSA_WAVES = RNA_TSA_WAVES;
 constexpr int TSA_MAX_TILE_WORDS = 2048;   // active-tile bitset words -> up to 65536 tiles

@@ -42,6 +42,9 @@ def test_bench_line_contract_on_a_small_grid():
     # every query of every batch still in a result buffer was answered (found / no path), none failed
     assert cfg["astar_queries_checked"] == 32 * min(cfg["astar_pipeline_depth"], 5 + 2) and cfg["astar_queries_answered"] == cfg["astar_queries_checked"]
     assert cfg["astar_paths_found"] > 0 and cfg["rotating_input_sets"] == 4
+    # what the engine really allocated (stages / pages per query / concurrent queries may shrink to fit HBM) is reported
+    alloc = cfg["astar_allocated"]
+    assert alloc["pipeline_depth"] == cfg["astar_pipeline_depth"] and alloc["pages_per_query"] > 0 and alloc["max_queries"] == 32
 
 
 def test_bench_gpus_2_spawns_two_ranks():
