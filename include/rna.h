@@ -224,7 +224,7 @@ int rna_vfh_update_batch(rna_engine* e, const double* ranges_host /* n*361*2 */,
 typedef struct { int32_t start, goal; } rna_astar_query;
 typedef struct {
   int32_t status;      /* 0 found, 1 no path, 2 invalid query, 3 path longer than max_path_len,
-                          4 path cost beyond the 24-bit g range (>= 16.7e6), 5 the query's share of search pages is
+                          4 path cost beyond the field's 30-bit g range (>= 1.07e9; frontier kernel: 24 bits), 5 the query's share of search pages is
                           used up (only after rna_astar_set_page_cap or when HBM is short), RNA_ECAPACITY queue overflow */
   int32_t path_len;    /* cells, start..goal inclusive */
   int32_t cost;        /* 1000/1414 integer cost of the path */

@@ -531,7 +531,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     const long long band_ll = bucket_end - (long long)bucket_width;
     const int thr_band = KU - (int)(band_ll > (long long)INF ? (long long)INF : band_ll);   // f >= bend - width  <=>  u - h <= thr_band
     const int thr_best = KU - best_in;                                                         // f <= best          <=>  u - h >= thr_best
-    unsigned long long farm = 0ull;
+    unsigned long long farm = 0ull, ovfm = 0ull;   // ovfm: a reached cell whose g is about to leave the 30-bit range of the field word
 #define TSA_END(b)                                                                                               \
   if ((look >> (b)) & 1u) {                                                                                      \
     const int tb = TSA_G(b) - TSA_H(b);                                                                          \
@@ -542,6 +542,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       if ((b) == TJ - 1) q15 |= mq;                                                                              \
     }                                                                                                            \
     farm |= __builtin_amdgcn_ballot_w64(TSA_G(b) != 0 && TSA_PP(b) == 0 && tb >= thr_best);                      \
+    ovfm |= __builtin_amdgcn_ballot_w64(TSA_G(b) != 0 && TSA_G(b) < 4 * COST_D);                                 \
   }
     TSA_R16(TSA_END)
 #undef TSA_END
@@ -588,6 +589,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
                         ((colw & 4u) ? 32u : 0u) | (wakeS ? 64u : 0u) | ((colw & 32u) ? 128u : 0u);
     if (lane < 8 && ((am >> lane) & 1u) && nb_t >= 0) sch.act_cur(nb_t);
     if (farm && lane == 0) sch.act_far(t);
+    if (ovfm && lane == 0) sch.overflow();   // path costs beyond 2^30 - 5656: the search is abandoned (status 4)
   }
 #undef TSA_ROW_CHANGED
 #undef TSA_H
@@ -604,6 +606,7 @@ struct TsaLocalSched {
   unsigned* act_far_;
   __device__ __forceinline__ int best() const { return __hip_atomic_load(best_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   __device__ __forceinline__ void improve_best(int g) { atomicMin(best_, g); }
+  __device__ __forceinline__ void overflow() { *state_ = 4; }
   __device__ __forceinline__ void pool_exhausted() { *state_ = 5; }
   __device__ __forceinline__ void act_cur(int t) { atomicOr(&act_cur_[t >> 5], 1u << (t & 31)); }
   __device__ __forceinline__ void act_far(int t) { atomicOr(&act_far_[t >> 5], 1u << (t & 31)); }

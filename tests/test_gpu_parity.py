@@ -359,6 +359,39 @@ def test_astar_fallback_kernel_keeps_the_contract(R, env):
                 os.environ[k] = v
 
 
+def test_astar_cost_range_of_the_field_word(R):
+    """The tile kernel's field word is 2^30 - g.  A one-cell-wide serpentine (corridors along i, joined alternately at
+    either end) makes paths of more than a million cells: a goal half way down still comes out exact (cost 5.6e8, a
+    path of 560 000 cells, reported with status 3 because it does not fit the path buffers); a goal whose cost would pass 2^30 ends with status 4 instead of a wrong answer."""
+    rows, cols = 1536, 1500
+    e = R.Engine(rows * 0.05, cols * 0.05, 0.05)
+    m = np.zeros((cols, rows), np.float32)          # m[j, i]
+    m[1::2, :] = 180.0                              # walls between the corridors j = 0, 2, 4, ...
+    for k, j in enumerate(range(1, cols, 2)):       # a gap at alternating ends
+        m[j, rows - 1 if k % 2 == 0 else 0] = 0.0
+    e.upload(R.capi.LAYER_MASTER, m.reshape(-1))
+    ncorr = (cols + 1) // 2
+
+    def cell(c, i):                                  # corridor c, position i along it
+        return (2 * c) * rows + i
+
+    def along(c, i):                                 # cells from the start to (c, i), following the serpentine
+        inside = i if c % 2 == 0 else rows - 1 - i
+        return c * (rows + 1) + inside               # every turn adds the gap cell
+    start = cell(0, 0)
+    mid_c, far_c = 365, ncorr - 1
+    q = np.zeros(2, R.capi.ASTAR_QUERY_DTYPE)
+    q["start"] = start
+    q["goal"] = [cell(mid_c, 700), cell(far_c, 5)]
+    e.astar_configure(max_queries=2)
+    res, paths = e.astar(q, 700000)
+    steps_mid = along(mid_c, 700)
+    # (status 3: longer than the path staging of a stage; cost and length are still those of the exact field)
+    assert res["status"][0] == 3 and res["cost"][0] == 1000 * steps_mid and res["path_len"][0] == steps_mid + 1
+    assert 1000 * along(far_c, 5) > 2 ** 30 and res["status"][1] == 4
+    e.close()
+
+
 def test_astar_page_pool(R):
     """The tile kernel hands search pages out on first touch.  (a) Reuse: the same engine serves batches whose
     searches cover different parts of the map, back to back and through every pipeline stage -- the lazy reset must
