@@ -306,45 +306,9 @@ __global__ void astar_settled_kernel(int rows, int cols, const rna_astar_query* 
   if (threadIdx.x == 0) counts[q] = s_cnt;
 }
 
-int ensure_config(rna_engine* e) {
+// allocation of the configuration ensure_config settled on; everything is released again on failure
+static int alloc_stages(rna_engine* e) {
   AstarDevice& a = e->astar;
-  if (a.g[0]) return RNA_OK;
-  if (a.max_queries <= 0) a.max_queries = 256;
-  if (const char* t = getenv("RNA_ASTAR_THREADS")) a.threads = atoi(t);  // tuning knob of the frontier kernel: 256 / 512 / 1024
-  a.mode = 1;
-  if (const char* k = getenv("RNA_ASTAR_KERNEL")) a.mode = (k[0] == 'f') ? 0 : 1;  // frontier | tile (default)
-  if (a.mode != 0 && !tsa_supported(e)) a.mode = 0;
-  if (a.depth < 1) a.depth = 1;
-  if (a.depth > AstarDevice::MAX_DEPTH) a.depth = AstarDevice::MAX_DEPTH;
-  if (a.queue_cap <= 0) {
-    // a bucket's queue holds the cells whose f falls into one bucket_width band of the search
-    // ellipse (plus duplicates); 64 x (rows + cols) entries is a wide margin, checked at run time
-    long long c = 64LL * (e->geom.size[0] + e->geom.size[1]);
-    if (c < 65536) c = 65536;
-    if (c > (1 << 22)) c = 1 << 22;
-    a.queue_cap = (int)c;
-  }
-  if (e->ncell >= (1ull << 30)) return fail(e, RNA_EINVAL, "grid A*: more than 2^30 cells");
-  // fit into free HBM (25 % headroom): (tile kernel) fewer pages per query, fewer pipeline stages, fewer pages still
-  // -- a search that needs more than its share then ends with status 5 --, then fewer concurrent queries
-  size_t free_b = 0, total_b = 0;
-  RNA_HIP(e, hipMemGetInfo(&free_b, &total_b));
-  const int ntile = a.mode != 0 ? tsa_tiles(e) : 0;
-  a.page_cap = ntile;
-  if (a.page_cap_request > 0 && a.page_cap_request < ntile) a.page_cap = a.page_cap_request;
-  if (const char* c = getenv("RNA_ASTAR_PAGE_CAP")) { const int v = atoi(c); if (v > 0 && v < ntile) a.page_cap = v; }
-  auto stage_bytes = [&]() -> double {
-    if (a.mode != 0)
-      return (double)tsa_pool_bytes(a.max_queries, a.page_cap) + (double)tsa_aux_bytes(e, a.max_queries, a.page_cap) +
-             (double)a.rev_cap * 4.0 * a.max_queries;
-    return ((double)(e->ncell + 128) * 4.0 + 3.0 * a.queue_cap * sizeof(int2)) * a.max_queries;
-  };
-  // (tile kernel) half a map's worth of pages per query first -- searches touch a few per cent of the map, and twelve
-  // stages of 17.8 GB each at 4096^2 x 256 queries sit right at the budget --, then fewer stages, then fewer pages
-  if (a.mode != 0 && a.page_cap > 64 && a.page_cap > ntile / 2 && stage_bytes() * a.depth > 0.75 * (double)free_b) a.page_cap = (ntile + 1) / 2;
-  while (a.depth > 1 && stage_bytes() * a.depth > 0.75 * (double)free_b) a.depth -= 1;
-  while (a.mode != 0 && a.page_cap > 64 && a.page_cap > ntile / 8 && stage_bytes() * a.depth > 0.75 * (double)free_b) a.page_cap /= 2;
-  while (a.max_queries > 1 && stage_bytes() * a.depth > 0.75 * (double)free_b) a.max_queries /= 2;
   int rc;
   // frontier kernel: each query's field is padded (the 3-cell column loads reach one word past either end) and 256-byte aligned
   a.field_stride = ((e->ncell + 64 + 63) / 64) * 64;
@@ -398,6 +362,58 @@ int ensure_config(rna_engine* e) {
   if ((rc = dev_alloc(e, &a.queries_dev, (size_t)a.max_queries)) != RNA_OK) { astar_release(e); return rc; }
   if ((rc = dev_alloc(e, &a.results_dev, (size_t)a.max_queries)) != RNA_OK) { astar_release(e); return rc; }
   return RNA_OK;
+}
+
+int ensure_config(rna_engine* e) {
+  AstarDevice& a = e->astar;
+  if (a.g[0]) return RNA_OK;
+  if (a.max_queries <= 0) a.max_queries = 256;
+  if (const char* t = getenv("RNA_ASTAR_THREADS")) a.threads = atoi(t);  // tuning knob of the frontier kernel: 256 / 512 / 1024
+  a.mode = 1;
+  if (const char* k = getenv("RNA_ASTAR_KERNEL")) a.mode = (k[0] == 'f') ? 0 : 1;  // frontier | tile (default)
+  if (a.mode != 0 && !tsa_supported(e)) a.mode = 0;
+  if (a.depth < 1) a.depth = 1;
+  if (a.depth > AstarDevice::MAX_DEPTH) a.depth = AstarDevice::MAX_DEPTH;
+  if (a.queue_cap <= 0) {
+    // a bucket's queue holds the cells whose f falls into one bucket_width band of the search
+    // ellipse (plus duplicates); 64 x (rows + cols) entries is a wide margin, checked at run time
+    long long c = 64LL * (e->geom.size[0] + e->geom.size[1]);
+    if (c < 65536) c = 65536;
+    if (c > (1 << 22)) c = 1 << 22;
+    a.queue_cap = (int)c;
+  }
+  if (e->ncell >= (1ull << 30)) return fail(e, RNA_EINVAL, "grid A*: more than 2^30 cells");
+  // fit into free HBM (25 % headroom): (tile kernel) fewer pages per query, fewer pipeline stages, fewer pages still
+  // -- a search that needs more than its share then ends with status 5 --, then fewer concurrent queries
+  size_t free_b = 0, total_b = 0;
+  RNA_HIP(e, hipMemGetInfo(&free_b, &total_b));
+  const int ntile = a.mode != 0 ? tsa_tiles(e) : 0;
+  a.page_cap = ntile;
+  if (a.page_cap_request > 0 && a.page_cap_request < ntile) a.page_cap = a.page_cap_request;
+  if (const char* c = getenv("RNA_ASTAR_PAGE_CAP")) { const int v = atoi(c); if (v > 0 && v < ntile) a.page_cap = v; }
+  auto stage_bytes = [&]() -> double {
+    if (a.mode != 0)
+      return (double)tsa_pool_bytes(a.max_queries, a.page_cap) + (double)tsa_aux_bytes(e, a.max_queries, a.page_cap) +
+             (double)a.rev_cap * 4.0 * a.max_queries;
+    return ((double)(e->ncell + 128) * 4.0 + 3.0 * a.queue_cap * sizeof(int2)) * a.max_queries;
+  };
+  // (tile kernel) half a map's worth of pages per query first -- searches touch a few per cent of the map, and twelve
+  // stages of 17.8 GB each at 4096^2 x 256 queries sit right at the budget --, then fewer stages, then fewer pages
+  if (a.mode != 0 && a.page_cap > 64 && a.page_cap > ntile / 2 && stage_bytes() * a.depth > 0.75 * (double)free_b) a.page_cap = (ntile + 1) / 2;
+  while (a.depth > 1 && stage_bytes() * a.depth > 0.75 * (double)free_b) a.depth -= 1;
+  while (a.mode != 0 && a.page_cap > 64 && a.page_cap > ntile / 8 && stage_bytes() * a.depth > 0.75 * (double)free_b) a.page_cap /= 2;
+  while (a.max_queries > 1 && stage_bytes() * a.depth > 0.75 * (double)free_b) a.max_queries /= 2;
+  // HBM may have gone to another process between hipMemGetInfo and here: step down and try again
+  for (;;) {
+    const int rc = alloc_stages(e);
+    if (rc != RNA_ENOMEM) return rc;
+    (void)hipGetLastError();   // the failed hipMalloc must not surface at the next launch check
+    if (a.mode != 0 && a.page_cap > 64 && a.page_cap > ntile / 2) a.page_cap = (ntile + 1) / 2;
+    else if (a.depth > 1) a.depth = a.depth > 2 ? a.depth * 3 / 4 : 1;
+    else if (a.mode != 0 && a.page_cap > 64 && a.page_cap > ntile / 8) a.page_cap /= 2;
+    else if (a.max_queries > 1) a.max_queries /= 2;
+    else return rc;
+  }
 }
 
 // One batch (<= max_queries): field init on the engine stream (it reads the neighbour masks, which
