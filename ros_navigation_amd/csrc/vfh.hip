@@ -83,6 +83,14 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
+#ifdef RNA_VFH_STATS
+  unsigned long long ts_[8];
+  int nts_ = 0;
+#define VFH_STAMP() ts_[nts_++] = wall_clock64()
+#else
+#define VFH_STAMP()
+#endif
+  VFH_STAMP();
   const rna_pose pose = poses[b];
 
   // ---------------- ranges (steerer.cpp:147-191) ----------------
@@ -126,6 +134,7 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
     }
   }
   __syncthreads();
+  VFH_STAMP();
 
   // ---------------- Update_VFH prologue (vfh.cpp:490-515) ----------------
   const float desired_angle = pose.goal_direction;
@@ -153,6 +162,7 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
     if (m != 0.0f) atomicOr(&nz[q >> 5], 1u << (q & 31));
   }
   __syncthreads();
+  VFH_STAMP();
   const bool emergency = s_emergency != 0;
 
   float* origin = K.origin + (size_t)b * K.H;
@@ -224,6 +234,7 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
     }
   }
   __syncthreads();
+  VFH_STAMP();
 
   // ---------------- serial tail on one lane ----------------
   if (tid == 0) {
@@ -264,10 +275,12 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
         const int sp_wide = cms < K.max_speed_wide ? cms : K.max_speed_wide;
         int left = 1, b1 = 0;
         for (int i = start; i <= (start + H); i++) {
-          const float hv = s_hist[i % H];
-          if ((hv == 0) && left) { b1 = (i % H) * SA; left = 0; }
+          const int im = i < H ? i : i - H;   // i % H for i < 2H: a runtime modulo is ~40 instructions, three of them
+                                              // per sector made this loop two thirds of the kernel's 28 us
+          const float hv = s_hist[im];
+          if ((hv == 0) && left) { b1 = im * SA; left = 0; }
           if ((hv == 1) && !left) {
-            int b2 = ((i % H) - 1) * SA;
+            int b2 = (im - 1) * SA;
             if (b2 < 0) b2 += 360;
             left = 1;
             const float angle = k_delta_angle((float)b1, (float)b2);
@@ -347,6 +360,12 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
     out[b] = o;
   }
   __syncthreads();
+  VFH_STAMP();
+#ifdef RNA_VFH_STATS
+  if (tid == 0 && b == 0)
+    printf("[vfh stats] us: ranges %.2f cells_mag %.2f histograms %.2f tail %.2f\n", (ts_[1] - ts_[0]) * 0.01, (ts_[2] - ts_[1]) * 0.01,
+           (ts_[3] - ts_[2]) * 0.01, (ts_[4] - ts_[3]) * 0.01);
+#endif
   if (tid < K.H) {
     if (origin_out) origin_out[(size_t)b * K.H + tid] = origin[tid];
     if (hist_out) hist_out[(size_t)b * K.H + tid] = hist[tid];
