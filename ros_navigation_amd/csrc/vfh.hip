@@ -32,6 +32,7 @@ constexpr int MAX_W = 64;
 constexpr int MAX_NQ = (MAX_W / 2 + 1) * MAX_W;   // 2112
 constexpr int MAX_NW = (MAX_NQ + 31) / 32;        // 66
 constexpr int MAX_H = 128;
+constexpr int VFH_OCC_CAP = 1024;
 
 struct VfhK {
   int W, H, T, CX, CY, YH, NQ, NQF, NW, max_speed, sector_angle;
@@ -79,7 +80,8 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
   __shared__ unsigned nz[MAX_NW];
   __shared__ float s_hist[MAX_H];
   __shared__ unsigned s_phi_right, s_phi_left;
-  __shared__ int s_emergency;
+  __shared__ int s_emergency, s_nocc;
+  __shared__ int occ[VFH_OCC_CAP];   // submap cells that hold an obstacle
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -92,13 +94,22 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
 #endif
   VFH_STAMP();
   const rna_pose pose = poses[b];
+  // the robot's state of the last step, needed by the serial tail only: loaded here so the round trip is long over by then
+  float st_picked = 0.0f, st_last_picked = 0.0f, st_blocked_radius = 0.0f;
+  int st_max_speed_picked = 0;
+  if (tid == 0) {
+    st_picked = K.picked[b];
+    st_last_picked = K.last_picked[b];
+    st_max_speed_picked = K.max_speed_picked[b];
+    st_blocked_radius = K.blocked_radius[b];
+  }
 
   // ---------------- ranges (steerer.cpp:147-191) ----------------
   for (int i = tid; i < 361; i += VFH_THREADS)
     rng[i] = ext_ranges ? (unsigned long long)__double_as_longlong(ext_ranges[((size_t)b * 361 + i) * 2])
                         : (unsigned long long)__double_as_longlong(5000.0);
   for (int i = tid; i < K.NW; i += VFH_THREADS) nz[i] = 0;
-  if (tid == 0) { s_phi_right = 0u; s_phi_left = __float_as_uint(180.0f); s_emergency = 0; }
+  if (tid == 0) { s_phi_right = 0u; s_phi_left = __float_as_uint(180.0f); s_emergency = 0; s_nocc = 0; }
   __syncthreads();
 
   if (!ext_ranges) {
@@ -111,26 +122,39 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
       const int sr = sm.size[0], sc = sm.size[1];
       const double offx = sm.pos[0] + (0.5 * sm.len[0] - 0.5 * g.res);
       const double offy = sm.pos[1] + (0.5 * sm.len[1] - 0.5 * g.res);
-      for (int lin = tid; lin < sr * sc; lin += VFH_THREADS) {
+      // One obstacle cell costs an f64 atan2, two fmod and a sqrt (~2 us), a free one a load and two compares, and 2 % of
+      // the cells are obstacles: they are collected first and then shared out one per lane, so the wavefronts run the
+      // trigonometry once instead of once per loop iteration that happens to hold an obstacle (6-8 us -> 3-4 us).
+      // atomicMin makes the result independent of the order.
+      auto obstacle = [&](int lin) {
         const int i = lin % sr, j = lin / sr;  // GridMapIterator order; lanes run along Index(0)
-        const int u[2] = {tl_u[0] + i, tl_u[1] + j};
-        int bi[2];
-        buffer_index(g, u, bi);
-        const float value = master[(size_t)bi[1] * g.size[0] + bi[0]];
-        if (value != value) continue;
-        if (value <= 3) continue;
         const double px = offx + g.res * (double)(-i);
         const double py = offy + g.res * (double)(-j);
         const double angle = atan2(py - pose.y, px - pose.x);
         const double deg = normalize_angle_positive(angle - pose.yaw + 3.14 / 2) * 180.0 / M_PI;
-        if (deg > 180) continue;
+        if (deg > 180) return;
         const int fl = (int)floor(deg), ce = (int)ceil(deg);
         const double dx = pose.x - px, dy = pose.y - py;
         const double distance = sqrt(dx * dx + dy * dy) * 1000.0;
         const unsigned long long bits = (unsigned long long)__double_as_longlong(distance);
         atomicMin(&rng[fl * 2], bits);
         atomicMin(&rng[ce * 2], bits);
+      };
+      for (int lin = tid; lin < sr * sc; lin += VFH_THREADS) {
+        const int i = lin % sr, j = lin / sr;
+        const int u[2] = {tl_u[0] + i, tl_u[1] + j};
+        int bi[2];
+        buffer_index(g, u, bi);
+        const float value = master[(size_t)bi[1] * g.size[0] + bi[0]];
+        if (value != value) continue;
+        if (value <= 3) continue;
+        const int k = atomicAdd(&s_nocc, 1);
+        if (k < VFH_OCC_CAP) occ[k] = lin;
+        else obstacle(lin);   // a submap with more obstacle cells than the list holds: the rest in place
       }
+      __syncthreads();
+      const int nocc = s_nocc < VFH_OCC_CAP ? s_nocc : VFH_OCC_CAP;
+      for (int k = tid; k < nocc; k += VFH_THREADS) obstacle(occ[k]);
     }
   }
   __syncthreads();
@@ -237,12 +261,20 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
   VFH_STAMP();
 
   // ---------------- serial tail on one lane ----------------
+  // the masked histogram as two 64-bit lane masks (H <= 128), so the valley search below tests bits in registers
+  // instead of making 73 dependent LDS reads
+  unsigned long long hbits_lo = 0ull, hbits_hi = 0ull;
+  if (tid < 64) {
+    hbits_lo = __ballot(tid < K.H && s_hist[tid] == 1);
+    hbits_hi = __ballot(tid + 64 < K.H && s_hist[(tid + 64) & (MAX_H - 1)] == 1);
+  }
   if (tid == 0) {
-    float picked = K.picked[b];
-    float last_picked = K.last_picked[b];
-    int max_speed_for_picked = K.max_speed_picked[b];
-    float blocked_radius = K.blocked_radius[b];
+    float picked = st_picked;
+    float last_picked = st_last_picked;
+    int max_speed_for_picked = st_max_speed_picked;
+    float blocked_radius = st_blocked_radius;
     const int H = K.H, SA = K.sector_angle;
+    auto hist_at = [&](int i) -> float { return ((i < 64 ? hbits_lo >> i : hbits_hi >> (i - 64)) & 1ull) ? 1.0f : 0.0f; };
 
     if (emergency) {
       picked = last_picked;
@@ -253,7 +285,7 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
       // ---------------- Select_Direction (vfh.cpp:755-870) ----------------
       int start = -1;
       for (int i = 0; i < H / 2; i++)
-        if (s_hist[i] == 1) { start = i; break; }
+        if (hist_at(i) == 1) { start = i; break; }
       if (start == -1) {
         picked = desired_angle;
         last_picked = picked;
@@ -277,7 +309,7 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
         for (int i = start; i <= (start + H); i++) {
           const int im = i < H ? i : i - H;   // i % H for i < 2H: a runtime modulo is ~40 instructions, three of them
                                               // per sector made this loop two thirds of the kernel's 28 us
-          const float hv = s_hist[im];
+          const float hv = hist_at(im);
           if ((hv == 0) && left) { b1 = im * SA; left = 0; }
           if ((hv == 1) && !left) {
             int b2 = (im - 1) * SA;
@@ -311,6 +343,7 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
       }
     }
 
+    VFH_STAMP();   // (developer build: lane 0's stamps 4.. subdivide the tail)
     // ---------------- speed (vfh.cpp:571-599) ----------------
     int speed_incr;
     if ((pose.dt > 0.3) || (pose.dt < 0)) speed_incr = 10;
@@ -328,6 +361,7 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
       }
       if (cant) speed_incr = -speed_incr;
     }
+    VFH_STAMP();
     int chosen_speed = last_speed + speed_incr;
     if (max_speed_for_picked < chosen_speed) chosen_speed = max_speed_for_picked;
 
@@ -363,8 +397,8 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
   VFH_STAMP();
 #ifdef RNA_VFH_STATS
   if (tid == 0 && b == 0)
-    printf("[vfh stats] us: ranges %.2f cells_mag %.2f histograms %.2f tail %.2f\n", (ts_[1] - ts_[0]) * 0.01, (ts_[2] - ts_[1]) * 0.01,
-           (ts_[3] - ts_[2]) * 0.01, (ts_[4] - ts_[3]) * 0.01);
+    printf("[vfh stats] us: ranges %.2f cells_mag %.2f histograms %.2f tail: select %.2f cant_turn %.2f rest %.2f\n", (ts_[1] - ts_[0]) * 0.01,
+           (ts_[2] - ts_[1]) * 0.01, (ts_[3] - ts_[2]) * 0.01, (ts_[4] - ts_[3]) * 0.01, (ts_[5] - ts_[4]) * 0.01, (ts_[6] - ts_[5]) * 0.01);
 #endif
   if (tid < K.H) {
     if (origin_out) origin_out[(size_t)b * K.H + tid] = origin[tid];
