@@ -97,7 +97,8 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
   // the robot's state of the last step, needed by the serial tail only: loaded here so the round trip is long over by then
   float st_picked = 0.0f, st_last_picked = 0.0f, st_blocked_radius = 0.0f;
   int st_max_speed_picked = 0;
-  if (tid == 0) {
+  const bool wave0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;   // wave-uniform: the serial tail runs as scalar control flow
+  if (wave0) {
     st_picked = K.picked[b];
     st_last_picked = K.last_picked[b];
     st_max_speed_picked = K.max_speed_picked[b];
@@ -268,7 +269,7 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
     hbits_lo = __ballot(tid < K.H && s_hist[tid] == 1);
     hbits_hi = __ballot(tid + 64 < K.H && s_hist[(tid + 64) & (MAX_H - 1)] == 1);
   }
-  if (tid == 0) {
+  if (wave0) {   // every lane of the first wavefront computes the same values; lane 0 stores them
     float picked = st_picked;
     float last_picked = st_last_picked;
     int max_speed_for_picked = st_max_speed_picked;
@@ -381,17 +382,19 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
       else if (turnrate < (-1 * maxturn)) turnrate = -1 * maxturn;
     }
 
-    K.picked[b] = picked;
-    K.last_picked[b] = last_picked;
-    K.max_speed_picked[b] = max_speed_for_picked;
-    K.blocked_radius[b] = blocked_radius;
-    K.last_chosen_speed[b] = chosen_speed;
-    rna_vfh_out o;
-    o.chosen_speed = chosen_speed;
-    o.chosen_turnrate = turnrate;
-    o.picked_angle = picked;
-    o.emergency = emergency ? 1 : 0;
-    out[b] = o;
+    if (tid == 0) {
+      K.picked[b] = picked;
+      K.last_picked[b] = last_picked;
+      K.max_speed_picked[b] = max_speed_for_picked;
+      K.blocked_radius[b] = blocked_radius;
+      K.last_chosen_speed[b] = chosen_speed;
+      rna_vfh_out o;
+      o.chosen_speed = chosen_speed;
+      o.chosen_turnrate = turnrate;
+      o.picked_angle = picked;
+      o.emergency = emergency ? 1 : 0;
+      out[b] = o;
+    }
   }
   __syncthreads();
   VFH_STAMP();
