@@ -228,7 +228,7 @@ typedef struct {
                           used up (only after rna_astar_set_page_cap or when HBM is short), RNA_ECAPACITY queue overflow */
   int32_t path_len;    /* cells, start..goal inclusive */
   int32_t cost;        /* 1000/1414 integer cost of the path */
-  int32_t expanded;    /* cell expansions the device performed (>= the oracle's settled count) */
+  int32_t expanded;    /* cell updates the device performed (tile kernel: 64 per row evaluation; >= the oracle's settled count) */
   int32_t rounds;      /* rounds of tile jobs (tile kernel), tile jobs (persistent scheduler) or frontier rounds */
   int32_t buckets;     /* f-buckets visited */
 } rna_astar_result;

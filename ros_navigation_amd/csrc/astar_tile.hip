@@ -41,6 +41,9 @@ constexpr int MASK_STRIDE = TILE_WORDS + 32;  // snapshot bytes per tile: lane-m
 #ifndef RNA_TSA_HPASS
 #define RNA_TSA_HPASS 16  // extra passes of a changed row along itself (2 / 4 / 8: 48.1 / 49.0 / 50.6 k cycles/s; 8 / 16: 55.8 / 56.7 k)
 #endif
+#ifndef RNA_TSA_REDBLACK
+#define RNA_TSA_REDBLACK 1   // rounds alternate between the two checkerboard colours of the tiles
+#endif
 #ifndef RNA_TSA_WAVES_PER_EU
 #define RNA_TSA_WAVES_PER_EU 8   // eight wavefronts per SIMD: the kernel must fit 64 VGPRs
 #endif
@@ -640,7 +643,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   extern __shared__ unsigned s_dyn[];   // tile bitsets, sized by the launch: 3 x ((ntile + 31) / 32) words
   __shared__ unsigned short s_jobs[TSA_JOBS];
   __shared__ unsigned s_jobpg[TSA_JOBS];   // local page of each job's tile (looked up once per round by the list builders)
-  __shared__ int s_njobs, s_first_fail, s_job_next, s_best, s_state, s_bucket, s_bucket0, s_rounds, s_expanded, s_nalloc, s_any;
+  __shared__ int s_njobs, s_first_fail, s_job_next, s_best, s_state, s_bucket, s_bucket0, s_rounds, s_expanded, s_nalloc, s_any, s_pending, s_phase;
 
   // Workgroups take their query when they START (a ticket), not by blockIdx: the hardware deals workgroup
   // indices round-robin to the XCDs, so a fixed mapping lets one XCD with several long searches hold back
@@ -695,7 +698,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     }
   }
   if (tid == 0) {
-    s_best = INF; s_state = 0; s_rounds = 0; s_expanded = 0; s_nalloc = 0;
+    s_best = INF; s_state = 0; s_rounds = 0; s_expanded = 0; s_nalloc = 0; s_phase = 0; s_pending = 0;
     s_bucket = tsa_octile(si, sj, gi, gj) / A.bucket_width;
     s_bucket0 = s_bucket;
   }
@@ -720,15 +723,40 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     int tid_r = threadIdx.x;
     asm volatile("" : "+v"(tid_r));
     TSA_T(t_r0);
-    if (tid_r == 0) { s_njobs = 0; s_job_next = 0; s_first_fail = TSA_JOBS; }
+    if (tid_r == 0) { s_njobs = 0; s_job_next = 0; s_first_fail = TSA_JOBS; s_pending = 0; }
     __syncthreads();
+#if RNA_TSA_REDBLACK
+    const int phase = s_phase;
+#endif
     for (int w = tid_r; w < nt_words; w += TSA_THREADS) {
       unsigned bits = s_act[0][w];
       if (!bits) continue;
+#if RNA_TSA_REDBLACK
+      // Rounds alternate between the two colours of a checkerboard over the tiles ((ti + tj) & 1): the four edge
+      // neighbours of a tile never run in the same round, so a job loads halo rows and columns that are final for the
+      // moment -- and the "does my edge beat what the neighbour holds" test of the job that wakes it is not fooled by a
+      // neighbour that advances in parallel.
+      unsigned cm;
+      if ((tiles_i & 31) == 0) {
+        cm = ((((w << 5) / tiles_i) + phase) & 1) ? 0xAAAAAAAAu : 0x55555555u;   // a word lies inside one tile row, bit parity = ti parity
+      } else {
+        cm = 0u;
+        for (unsigned rest = bits; rest; rest &= rest - 1) {
+          const int b = __ffs(rest) - 1, t = (w << 5) + b;
+          if ((((t % tiles_i) + (t / tiles_i)) & 1) == phase) cm |= 1u << b;
+        }
+      }
+      const unsigned other = bits & ~cm;
+      if (other) s_pending = 1;
+      bits &= cm;
+      if (!bits) continue;
+#else
+      const unsigned other = 0u;
+#endif
       const int cnt = __popc(bits);
       const int base = atomicAdd(&s_njobs, cnt);
       if (base + cnt <= TSA_JOBS) {
-        s_act[0][w] = 0u;
+        s_act[0][w] = other;
         int k = base;
         while (bits) {
           const int b = __ffs(bits) - 1;
@@ -749,6 +777,14 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
       const int b = njobs <= 4 ? 0 : (njobs <= 8 ? 1 : (njobs <= 16 ? 2 : (njobs <= 32 ? 3 : (njobs <= 64 ? 4 : 5))));
       atomicAdd(&g_tsa_stat[16 + b], 1ull);
       atomicAdd(&g_tsa_stat[24 + b], (unsigned long long)njobs);
+    }
+#endif
+#if RNA_TSA_REDBLACK
+    if (njobs == 0 && s_pending) {   // nothing of this colour, but the other one has work
+      __syncthreads();
+      if (tid_r == 0) s_phase ^= 1;
+      __syncthreads();
+      continue;
     }
 #endif
     if (njobs == 0) {
@@ -805,7 +841,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const bool stop = s_state >= 4;
-    if (tid == 0) s_rounds += 1;
+    if (tid == 0) { s_rounds += 1; s_phase ^= 1; }
     if (stop) break;
   }
   if (lane == 0) atomicAdd(&s_expanded, my_evals * TI);   // dense cell updates
