@@ -44,7 +44,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=600, help="timed steps (default: about 2.3 s on one MI355X)")
-    ap.add_argument("--warmup", type=int, default=24, help="untimed steps: two turns of the 12-stage pipeline")
+    ap.add_argument("--warmup", type=int, default=26, help="untimed steps: two turns of the 13-stage pipeline")
     ap.add_argument("--grid", type=int, default=4096)
     ap.add_argument("--queries", type=int, default=256, help="A* queries == VFH poses per step (cycles per step)")
     ap.add_argument("--ray-poses", type=int, default=64)
@@ -52,11 +52,12 @@ def parse():
     ap.add_argument("--bucket-width", type=int, default=0)
     ap.add_argument("--queue-capacity", type=int, default=0)
     ap.add_argument("--max-path", type=int, default=32768)
-    ap.add_argument("--pipeline", type=int, default=12,
+    ap.add_argument("--pipeline", type=int, default=13,
                     help="A* batches in flight (rna_astar_set_pipeline_depth).  Four search workgroups share a CU, so ~900 queries "
-                         "run at once and the batches' tails differ (measured 10: 56.3k, 12: 63.1k, 14: 63.2k cycles/s).  Every "
-                         "launch is stretched by the ones it overlaps with, and the roofline line divides by that "
-                         "per-launch duration")
+                         "run at once and the batches' tails differ (measured 10: 56.3k, 12: 75.9k, 13: 78.8k, 14: 80.5k cycles/s; "
+                         "from 15 on the streams outnumber the hardware queues a process gets and the rate collapses to 31k, "
+                         "so the default keeps one queue spare).  Every launch is stretched by the ones it overlaps with, and "
+                         "the roofline line divides by that per-launch duration")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--tiled-full-gather", action="store_true", help="--tiled: all-gather whole windows instead of dirty tiles")
@@ -202,7 +203,15 @@ def main():
         raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # developer switch: RNA_BENCH_FORCE_DIST=1 initialises RCCL and runs the barriers with a single rank too (how many
+    # hardware queues are left for the search streams once a communicator exists can then be measured on a one-GPU box)
+    use_dist = world > 1 or os.environ.get("RNA_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist = D.init("gloo") if share else D.init("nccl", torch.device("cuda", local_rank))
 
     n = args.grid
@@ -287,7 +296,7 @@ def main():
         return b
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def check_results(what):
@@ -334,7 +343,7 @@ def main():
         settled_sets.append(float(e.astar_settled(nq).astype(np.int64).sum()))
     settled_per_launch = float(np.mean(settled_sets))
 
-    t_max = D.max_over_ranks(elapsed, "cpu" if share else dev) if world > 1 else elapsed
+    t_max = D.max_over_ranks(elapsed, "cpu" if share else dev) if use_dist else elapsed
 
     if rank == 0:
         cycles = args.queries * world * args.steps
@@ -393,7 +402,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     e.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
