@@ -43,7 +43,7 @@ PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=600, help="timed steps (default: about 2.3 s on one MI355X)")
+    ap.add_argument("--steps", type=int, default=700, help="timed steps (default: about 2.3 s on one MI355X)")
     ap.add_argument("--warmup", type=int, default=26, help="untimed steps: two turns of the 13-stage pipeline")
     ap.add_argument("--grid", type=int, default=4096)
     ap.add_argument("--queries", type=int, default=256, help="A* queries == VFH poses per step (cycles per step)")
