@@ -335,14 +335,14 @@ static int alloc_stages(rna_engine* e) {
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         if (getenv("RNA_NO_STREAM_PRIORITY")) prio_lo = prio_hi = 0;
-        // The search streams may not use three CUs in 32 (ROCr deals the bits of a queue's CU mask round-robin to the
+        // The search streams may not use one CU in eight (ROCr deals the bits of a queue's CU mask round-robin to the
         // XCDs, so the first n bits are n / 8 CUs of every XCD).  A search workgroup holds its CU slot for a whole query
         // (milliseconds) and four of them fill a CU's registers, so a stream priority cannot make room for the engine
         // stream's short kernels (map update, VFH+, field reset) that gate the next search launch: without the reserve
         // they take 3 ms instead of 0.3 ms each and the step rate hangs on them (22 k instead of 33 k cycles/s when this
-        // was introduced; 16 / 24 / 28 / 32 / 40 reserved CUs: 46.7* / 56.3 / 55.6 / 54.6 / 50.6 k, *older kernel).
+        // was introduced; with the final kernel 16 / 24 / 32 / 40 / 48 reserved CUs: 74.6 / 78.8 / 80.5 / 78.8 / 76.7 k).
         // RNA_SEARCH_CU_SKIP=n overrides the number of reserved CUs, 0 = no mask (stream priority only).
-        int skip = e->cu_count * 3 / 32;
+        int skip = e->cu_count / 8;
         if (const char* m = getenv("RNA_SEARCH_CU_SKIP")) skip = atoi(m);
         if (skip > 0 && skip < e->cu_count) {
           uint32_t mask[16] = {};
