@@ -56,8 +56,9 @@ constexpr int TSA_JOBS = RNA_TSA_JOBS;     // tile jobs per round (more stay fla
 constexpr int COST_S = 1000, COST_D = 1414;
 constexpr int INF = 0x7fffffff;
 constexpr int KU = 0x40000000;             // field word u = KU - g; 0 = unreached
-constexpr int SCR_WORDS = 84 + 192 + 48;   // per-wave LDS scratch: column transposition (68 + a zero tail of 16), the halo rows and
-                                           // columns as loaded (3 x 64), this tile's edge columns at the end of the job (16 + 16 + 16)
+constexpr int SCR_WORDS = 84 + 192 + 48 + 64;   // per-wave LDS scratch: column transposition (68 + a zero tail of 16), the halo rows and
+                                           // columns as loaded (3 x 64), this tile's edge columns at the end of the job (16 + 16 + 16),
+                                           // the masks of the tile's edge-column cells as loaded (64)
 
 __device__ __forceinline__ int tsa_octile(int i, int j, int gi, int gj) {
   const int dx = abs(i - gi), dy = abs(j - gj);
@@ -398,6 +399,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       scr[84 + lane] = (unsigned)top;        // kept for the end of the job: does a changed edge row beat what the
       scr[84 + 64 + lane] = (unsigned)bot;   // neighbour already has?
       scr[84 + 128 + lane] = (unsigned)X;
+      scr[84 + 192 + 48 + lane] = eb;
       __builtin_amdgcn_wave_barrier();
     }
     const uint4* rp = reinterpret_cast<const uint4*>(&scr[lane == 0 ? 4 : (lane == TI - 1 ? 36 : 68)]);
@@ -552,17 +554,21 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     // A changed edge cell wakes the tile beyond it only if it beats what that tile held when this job loaded its halo
     // (its values only get better, so the test can only err towards waking): most wake-ups used to be echoes -- the
     // front enters this tile FROM the neighbour, the cells along that edge improve, and the neighbour would be woken
-    // to find nothing new (37 % of all jobs).  Masks are ignored here (again only towards waking).
+    // to find nothing new (37 % of all jobs).
+    // Each step is tested with this cell's own mask bit for it (the move, its target and -- for a diagonal -- both
+    // corner cells are free): with 30 % of the map blocked, "beats an unreached neighbour" is mostly a blocked neighbour.
     bool wakeN = q0 != 0ull, wakeS = q15 != 0ull;
     if (wakeN) {
       const int topv = (int)scr[84 + lane];
       const int c_ = __builtin_amdgcn_inverse_ballot_w64(q0) ? g0 : 0;
-      wakeN = __builtin_amdgcn_ballot_w64(c_ + nS > topv || lane_m1(c_) + nD > topv || lane_p1(c_) + nD > topv) != 0ull;
+      const int cw_ = c_ & __builtin_amdgcn_sbfe((int)mk0, 0, 1), cn_ = c_ & __builtin_amdgcn_sbfe((int)mk0, 1, 1), ce_ = c_ & __builtin_amdgcn_sbfe((int)mk0, 2, 1);
+      wakeN = __builtin_amdgcn_ballot_w64(cn_ + nS > topv || lane_m1(ce_) + nD > topv || lane_p1(cw_) + nD > topv) != 0ull;
     }
     if (wakeS) {
       const int botv = (int)scr[84 + 64 + lane];
       const int c_ = __builtin_amdgcn_inverse_ballot_w64(q15) ? g15 : 0;
-      wakeS = __builtin_amdgcn_ballot_w64(c_ + nS > botv || lane_m1(c_) + nD > botv || lane_p1(c_) + nD > botv) != 0ull;
+      const int cw_ = c_ & __builtin_amdgcn_sbfe((int)mk3, 24 + 5, 1), cs_ = c_ & __builtin_amdgcn_sbfe((int)mk3, 24 + 6, 1), ce_ = c_ & __builtin_amdgcn_sbfe((int)mk3, 24 + 7, 1);
+      wakeS = __builtin_amdgcn_ballot_w64(cs_ + nS > botv || lane_m1(ce_) + nD > botv || lane_p1(cw_) + nD > botv) != 0ull;
     }
     // the same for the two edge columns and the four corners: lane 0 / 63 lay their 16 cells (what they may pass on)
     // out in LDS, the lanes that hold the halo column as loaded (lane = row + 1) compare.  Unchanged cells take part
@@ -578,9 +584,15 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       }
       __builtin_amdgcn_wave_barrier();
       const int xl_ = lane & 31;
+      const bool xr_ = lane >= 32;
       const int v_ = (xl_ >= 1 && xl_ <= TJ) ? (int)scr[276 + (lane & 32) + xl_ - 1] : 0;
       const int xv = (int)scr[84 + 128 + lane];
-      const bool imp = xl_ <= TJ + 1 && (v_ + nS > xv || lane_m1(v_) + nD > xv || lane_p1(v_) + nD > xv);
+      const unsigned eb_ = scr[84 + 192 + 48 + lane];   // the edge cell's mask, as loaded (lanes 1..16 / 33..48)
+      // straight: k3 / k4; towards the row above: k0 / k2; towards the row below: k5 / k7
+      const int vs_ = v_ & -(int)((eb_ >> (xr_ ? 4 : 3)) & 1u), vu_ = v_ & -(int)((eb_ >> (xr_ ? 2 : 0)) & 1u), vd_ = v_ & -(int)((eb_ >> (xr_ ? 7 : 5)) & 1u);
+      // the halo cell in lane l is row l - 1 of the neighbour: it is reached straight from this lane's cell, from the
+      // cell one lane up (row l) by its "row above" step and from the one lane down (row l - 2) by its "row below" step
+      const bool imp = xl_ <= TJ + 1 && (vs_ + nS > xv || lane_p1(vu_) + nD > xv || lane_m1(vd_) + nD > xv);
       const unsigned long long im = __builtin_amdgcn_ballot_w64(imp);
       const unsigned lo = (unsigned)im, hi = (unsigned)(im >> 32);
       colw = ((lo & 1u) ? 1u : 0u) | ((lo & 0x1fffeu) ? 2u : 0u) | ((lo & 0x20000u) ? 4u : 0u) |
