@@ -513,13 +513,16 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     unsigned* own = C.pages + (C.gpage(pg) << 10);
     unsigned* ax = C.paux + C.gpage(pg) * AUX_WORDS + (lane ? 16 : 0);
     const bool edge_lane = lane == 0 || lane == TI - 1;
-#define TSA_STORE(b)                             \
-  if ((rowchg >> (b)) & 1u) {                    \
-    own[(b) * TI + lane] = (unsigned)TSA_G(b);   \
-    if (edge_lane) ax[b] = (unsigned)TSA_G(b);   \
+    unsigned long long ovfm = 0ull;   // a reached cell whose g is about to leave the 30-bit range of the field word
+#define TSA_STORE(b)                                                                              \
+  if ((rowchg >> (b)) & 1u) {                                                                     \
+    own[(b) * TI + lane] = (unsigned)TSA_G(b);                                                    \
+    if (edge_lane) ax[b] = (unsigned)TSA_G(b);                                                    \
+    ovfm |= __builtin_amdgcn_ballot_w64((unsigned)(TSA_G(b) - 1) < (unsigned)(4 * COST_D - 1));   \
   }
     TSA_R16(TSA_STORE)
 #undef TSA_STORE
+    if (ovfm && lane == 0) sch.overflow();   // path costs beyond 2^30 - 5656: the search is abandoned (status 4)
     if (t == C.tg) {
 #define TSA_GOAL(b)                                                                               \
   if ((b) == C.gb && ((rowchg >> (b)) & 1u)) {                                                    \
@@ -532,25 +535,26 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   }
   // ---- 7. who has to run: neighbours whose halo got better (or may pass on now), this tile again in a later bucket ----
   {
+    // (a) this tile again when the next bucket opens: it holds reached cells beyond this bucket's bound that may still
+    //     matter (f <= best).  Looked for in the rows that changed (all rows in a first job), and not at all once the
+    //     tile is flagged -- it runs several times per bucket.
     const unsigned look = first ? 0xffffu : rowchg;
-    const long long band_ll = bucket_end - (long long)bucket_width;
-    const int thr_band = KU - (int)(band_ll > (long long)INF ? (long long)INF : band_ll);   // f >= bend - width  <=>  u - h <= thr_band
-    const int thr_best = KU - best_in;                                                         // f <= best          <=>  u - h >= thr_best
-    unsigned long long farm = 0ull, ovfm = 0ull;   // ovfm: a reached cell whose g is about to leave the 30-bit range of the field word
+    if (look && !sch.is_far(t)) {
+      const int thr_best = KU - best_in;   // f <= best  <=>  u - h >= thr_best
+      unsigned long long farm = 0ull;
 #define TSA_END(b)                                                                                               \
-  if ((look >> (b)) & 1u) {                                                                                      \
-    const int tb = TSA_G(b) - TSA_H(b);                                                                          \
-    if (first) { /* cells the previous bucket's bound held back */                                               \
-      const unsigned long long mq = __builtin_amdgcn_ballot_w64(TSA_PP(b) != 0 && tb <= thr_band);               \
-      qany |= mq;                                                                                                \
-      if ((b) == 0) q0 |= mq;                                                                                    \
-      if ((b) == TJ - 1) q15 |= mq;                                                                              \
-    }                                                                                                            \
-    farm |= __builtin_amdgcn_ballot_w64(TSA_G(b) != 0 && TSA_PP(b) == 0 && tb >= thr_best);                      \
-    ovfm |= __builtin_amdgcn_ballot_w64(TSA_G(b) != 0 && TSA_G(b) < 4 * COST_D);                                 \
-  }
-    TSA_R16(TSA_END)
+  if ((look >> (b)) & 1u) farm |= __builtin_amdgcn_ballot_w64(TSA_G(b) != 0 && TSA_PP(b) == 0 && TSA_G(b) - TSA_H(b) >= thr_best);
+      TSA_R16(TSA_END)
 #undef TSA_END
+      if (farm && lane == 0) sch.act_far(t);
+    }
+    // (b) a first job: cells the previous bucket's bound held back may pass their values on now although they did not
+    //     change -- every edge cell that may pass on takes part in the tests below
+    if (first) {
+      q0 |= __builtin_amdgcn_ballot_w64(pp0 != 0);
+      q15 |= __builtin_amdgcn_ballot_w64(pp15 != 0);
+      qany |= (1ull << 63) | 1ull;
+    }
     // A changed edge cell wakes the tile beyond it only if it beats what that tile held when this job loaded its halo
     // (its values only get better, so the test can only err towards waking): most wake-ups used to be echoes -- the
     // front enters this tile FROM the neighbour, the cells along that edge improve, and the neighbour would be woken
@@ -603,8 +607,6 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     const unsigned am = ((colw & 1u) ? 1u : 0u) | (wakeN ? 2u : 0u) | ((colw & 8u) ? 4u : 0u) | ((colw & 2u) ? 8u : 0u) | ((colw & 16u) ? 16u : 0u) |
                         ((colw & 4u) ? 32u : 0u) | (wakeS ? 64u : 0u) | ((colw & 32u) ? 128u : 0u);
     if (lane < 8 && ((am >> lane) & 1u) && nb_t >= 0) sch.act_cur(nb_t);
-    if (farm && lane == 0) sch.act_far(t);
-    if (ovfm && lane == 0) sch.overflow();   // path costs beyond 2^30 - 5656: the search is abandoned (status 4)
   }
 #undef TSA_ROW_CHANGED
 #undef TSA_H
@@ -625,6 +627,7 @@ struct TsaLocalSched {
   __device__ __forceinline__ void pool_exhausted() { *state_ = 5; }
   __device__ __forceinline__ void act_cur(int t) { atomicOr(&act_cur_[t >> 5], 1u << (t & 31)); }
   __device__ __forceinline__ void act_far(int t) { atomicOr(&act_far_[t >> 5], 1u << (t & 31)); }
+  __device__ __forceinline__ bool is_far(int t) const { return (__hip_atomic_load(&act_far_[t >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (t & 31)) & 1u; }
 };
 
 __device__ __forceinline__ unsigned lds_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
