@@ -566,13 +566,17 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       const int topv = (int)scr[84 + lane];
       const int c_ = __builtin_amdgcn_inverse_ballot_w64(q0) ? g0 : 0;
       const int cw_ = c_ & __builtin_amdgcn_sbfe((int)mk0, 0, 1), cn_ = c_ & __builtin_amdgcn_sbfe((int)mk0, 1, 1), ce_ = c_ & __builtin_amdgcn_sbfe((int)mk0, 2, 1);
-      wakeN = __builtin_amdgcn_ballot_w64(cn_ + nS > topv || lane_m1(ce_) + nD > topv || lane_p1(cw_) + nD > topv) != 0ull;
+      // (the shifted values are formed for ALL lanes first: inside a short-circuit `||` the wave shift would run with the
+      // lanes whose first test succeeded switched off, and their neighbours would read nothing from them)
+      const int from_w_ = lane_m1(ce_) + nD, from_e_ = lane_p1(cw_) + nD;
+      wakeN = __builtin_amdgcn_ballot_w64((cn_ + nS > topv) | (from_w_ > topv) | (from_e_ > topv)) != 0ull;
     }
     if (wakeS) {
       const int botv = (int)scr[84 + 64 + lane];
       const int c_ = __builtin_amdgcn_inverse_ballot_w64(q15) ? g15 : 0;
       const int cw_ = c_ & __builtin_amdgcn_sbfe((int)mk3, 24 + 5, 1), cs_ = c_ & __builtin_amdgcn_sbfe((int)mk3, 24 + 6, 1), ce_ = c_ & __builtin_amdgcn_sbfe((int)mk3, 24 + 7, 1);
-      wakeS = __builtin_amdgcn_ballot_w64(cs_ + nS > botv || lane_m1(ce_) + nD > botv || lane_p1(cw_) + nD > botv) != 0ull;
+      const int from_w_ = lane_m1(ce_) + nD, from_e_ = lane_p1(cw_) + nD;
+      wakeS = __builtin_amdgcn_ballot_w64((cs_ + nS > botv) | (from_w_ > botv) | (from_e_ > botv)) != 0ull;
     }
     // the same for the two edge columns and the four corners: lane 0 / 63 lay their 16 cells (what they may pass on)
     // out in LDS, the lanes that hold the halo column as loaded (lane = row + 1) compare.  Unchanged cells take part
@@ -596,7 +600,8 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       const int vs_ = v_ & -(int)((eb_ >> (xr_ ? 4 : 3)) & 1u), vu_ = v_ & -(int)((eb_ >> (xr_ ? 2 : 0)) & 1u), vd_ = v_ & -(int)((eb_ >> (xr_ ? 7 : 5)) & 1u);
       // the halo cell in lane l is row l - 1 of the neighbour: it is reached straight from this lane's cell, from the
       // cell one lane up (row l) by its "row above" step and from the one lane down (row l - 2) by its "row below" step
-      const bool imp = xl_ <= TJ + 1 && (vs_ + nS > xv || lane_p1(vu_) + nD > xv || lane_m1(vd_) + nD > xv);
+      const int from_below_ = lane_p1(vu_) + nD, from_above_ = lane_m1(vd_) + nD;   // (formed for all lanes before any test, see above)
+      const bool imp = (xl_ <= TJ + 1) & ((vs_ + nS > xv) | (from_below_ > xv) | (from_above_ > xv));
       const unsigned long long im = __builtin_amdgcn_ballot_w64(imp);
       const unsigned lo = (unsigned)im, hi = (unsigned)(im >> 32);
       colw = ((lo & 1u) ? 1u : 0u) | ((lo & 0x1fffeu) ? 2u : 0u) | ((lo & 0x20000u) ? 4u : 0u) |

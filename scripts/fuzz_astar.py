@@ -100,6 +100,9 @@ while time.time() < t_end:
             if not ok:
                 print("MISMATCH (moved map)", here, "query", k, int(q["start"][k]), int(q["goal"][k]), "gpu", res[k], "oracle",
                       ores.status, ores.cost, ores.path_len, ores.settled)
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)   # everything scripts/replay_astar.py needs
+                np.savez(os.path.join(ROOT, "gpurun_out", "fuzz_astar_fail.npz"), ref=ref, rows=rows, cols=cols, start_index=np.array(g.start),
+                         pos=np.array(g.pos), q=q, bucket_width=bw, k=k)
                 sys.exit(1)
         queries += nq
     e.close()

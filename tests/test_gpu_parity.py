@@ -392,6 +392,18 @@ def test_astar_cost_range_of_the_field_word(R):
     e.close()
 
 
+def test_astar_moved_map_regression_case(R):
+    """A case scripts/fuzz_astar.py found (seed 61): 72 x 39 map after GridMap::move, bucket width 2828, 41 queries.
+    The optimal path of query 22 steps diagonally from the corner cell of one tile into the corner cell of the tile
+    diagonally below it; the wake-up test for that step ran a DPP wave shift inside a short-circuit `||`, i.e. with the
+    lanes whose straight step had already succeeded switched off, read nothing from them and left the diagonal tile
+    asleep (cost 95624 instead of 95038)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import replay_astar
+    assert replay_astar.replay(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "astar_moved_map_case2120.npz"), verbose=False) == []
+
+
 def test_astar_page_pool(R):
     """The tile kernel hands search pages out on first touch.  (a) Reuse: the same engine serves batches whose
     searches cover different parts of the map, back to back and through every pipeline stage -- the lazy reset must
