@@ -60,3 +60,19 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--gpus", "2"], capture_output=True, text=True,
                          timeout=120, cwd=ROOT, env=dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"))
     assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
+
+
+def test_default_bench_keeps_the_engine_stream_alive():
+    """The full-size loop, shortened: the search streams' CU mask has to leave the short engine-stream kernels (map
+    update, VFH+, field reset) somewhere to run -- when four search workgroups per CU took every register of every CU,
+    himm_prep took 3-6 ms instead of 0.3 ms per step and the step rate hung on the engine stream (22 k cycles/s).  Loose
+    bounds: a guard against that cliff and against the hardware-queue cliff of too many pipeline stages, not a benchmark."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "150", "--no-cpu"], capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    k = d["kernel_ms_per_step"]
+    assert k["himm_prep"] < 1.0 and k["vfh_step"] < 0.6 and k["compose_master"] < 0.6, k
+    assert sum(v for name, v in k.items() if name != "astar_search") < d["ms_per_step"], (k, d["ms_per_step"])   # the engine stream is not the bottleneck
+    assert d["value"] > 45000, d["value"]
+    assert d["config"]["astar_allocated"]["pipeline_depth"] == d["config"]["astar_pipeline_depth"]
