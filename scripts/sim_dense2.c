@@ -7,6 +7,11 @@
  *   sim_dense2 <workload.bin> bucket [nq] [variant] [TJ]
  *     variant 0: horizontal step from the row's values after this sweep's vertical step ("fresh")
  *             1: horizontal step from the row's values before this sweep touched it ("stale": one max3 chain per row)
+ *             + 10 x the number of extra passes a changed row makes along itself (the kernel: 161)
+ *   environment: SIM_REDBLACK=1  rounds alternate between the two checkerboard colours of the tiles
+ *                SIM_FILTER=1    a tile wakes a neighbour only if one of its edge cells beats, by an open step, what the
+ *                                neighbour's cell held when the job loaded its halo (astar_tile.hip, section 7)
+ *   With both set and variant 161 this is the schedule of tsa_search_kernel (tests/test_dense_model.py runs it).
  * workload.bin: see sim_dense.py
  */
 #include <stdint.h>
@@ -15,7 +20,7 @@
 #include <string.h>
 
 #define INF 0x3fffffff
-static int rows, cols, TI = 64, TJ = 16, tiles_i, tiles_j, bucket_w, variant, extra_h;
+static int rows, cols, TI = 64, TJ = 16, tiles_i, tiles_j, bucket_w, variant, extra_h, redblack, filter;
 static uint8_t* nbr;
 static int32_t* g;
 static int gi, gj;
@@ -149,17 +154,21 @@ static int job(int t, stats* st, int32_t* out, int* goal_best) {
   }
   /* results, activation */
   int far = 0, any = 0;
+  static uint8_t chg[64][64];
   for (int b = 0; b < TJ; ++b)
     for (int a = 0; a < TI; ++a) {
       const int i = i0 + a, j = j0 + b;
       const int v = cur[b][a];
       out[b * TI + a] = v;
+      chg[b][a] = 0;
       if (i >= rows || j >= cols || v >= INF) continue;
       const int ch = v < old[b][a];
+      chg[b][a] = (uint8_t)ch;
       if (ch) { any = 1; st->cells_changed++; if (i == gi && j == gj && v < *goal_best) *goal_best = v; }
       const long long f = (long long)v + octile(i, j);
       if (f > best) continue;
       if (f >= bend) { far = 1; continue; }
+      if (filter) continue;
       const int newly = first && f >= bend - bucket_w;
       if (!(ch || newly)) continue;
       const int ea = a == 0 ? -1 : (a == TI - 1 ? 1 : 0), eb = b == 0 ? -1 : (b == TJ - 1 ? 1 : 0);
@@ -167,6 +176,43 @@ static int job(int t, stats* st, int32_t* out, int* goal_best) {
       if (eb) activate(ti, tj + eb);
       if (ea && eb) activate(ti + ea, tj + eb);
     }
+  if (filter) {
+    /* the kernel's wake tests: the halo as loaded is g itself (a round's results become visible together) */
+    static const int di[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dj[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+#define PASSES(b, a) (pp[b][a] < INF)
+    /* edge rows: cells that changed and may pass on (all that may pass on in a first job); lane 0 / 63 leave their
+       outward diagonal step to the column test */
+    for (int side = 0; side < 2; ++side) {
+      const int b = side ? TJ - 1 : 0;
+      for (int a = 0; a < TI; ++a) {
+        if (!PASSES(b, a) || !(chg[b][a] || first)) continue;
+        for (int k = (side ? 5 : 0); k < (side ? 8 : 3); ++k) {
+          if (!((mk[b][a] >> k) & 1)) continue;
+          const int na = a + di[k];
+          if (na < 0 || na >= TI) continue;
+          if (pp[b][a] + ((di[k] && dj[k]) ? 1414 : 1000) < gat(i0 + na, j0 + b + dj[k])) activate(ti, tj + dj[k]);
+        }
+      }
+    }
+    /* edge columns and corners: run when a cell of lane 0 / 63 changed and may pass on (or a first job); every cell of
+       the two columns that may pass on takes part */
+    int trig = first;
+    for (int b = 0; b < TJ && !trig; ++b)
+      if ((chg[b][0] && PASSES(b, 0)) || (chg[b][TI - 1] && PASSES(b, TI - 1))) trig = 1;
+    if (trig)
+      for (int side = 0; side < 2; ++side) {
+        const int a = side ? TI - 1 : 0, da = side ? 1 : -1;
+        for (int b = 0; b < TJ; ++b) {
+          if (!PASSES(b, a)) continue;
+          for (int k = 0; k < 8; ++k) {
+            if (di[k] != da || !((mk[b][a] >> k) & 1)) continue;
+            const int nb = b + dj[k];
+            if (pp[b][a] + (dj[k] ? 1414 : 1000) < gat(i0 + a + da, j0 + nb)) activate(ti + da, tj + (nb < 0 ? -1 : (nb >= TJ ? 1 : 0)));
+          }
+        }
+      }
+#undef PASSES
+  }
   if (far) act_far[t] = 1;
   return any;
 }
@@ -184,6 +230,8 @@ int main(int argc, char** argv) {
   extra_h = argc > 4 ? atoi(argv[4]) / 10 : 0;
   if (argc > 5) TJ = atoi(argv[5]);
   if (argc > 6) TI = atoi(argv[6]);
+  redblack = getenv("SIM_REDBLACK") != NULL;
+  filter = getenv("SIM_FILTER") != NULL;
   nbr = malloc((size_t)rows * cols);
   if (fread(nbr, 1, (size_t)rows * cols, f) != (size_t)rows * cols) return 1;
   int32_t* qs = malloc(sizeof(int32_t) * 4 * hdr[2]);
@@ -212,9 +260,15 @@ int main(int argc, char** argv) {
     act_cur[(sj / TJ) * tiles_i + si / TI] = 1;
     first_f[(sj / TJ) * tiles_i + si / TI] = 1;
     st.buckets = 1;
+    int phase = 0;
     for (;;) {
-      int n = 0;
-      for (int t = 0; t < ntile; ++t) if (act_cur[t]) { list[n++] = t; act_cur[t] = 0; }
+      int n = 0, other = 0;
+      for (int t = 0; t < ntile; ++t)
+        if (act_cur[t]) {
+          if (redblack && (((t % tiles_i) + (t / tiles_i)) & 1) != phase) { other = 1; continue; }
+          list[n++] = t; act_cur[t] = 0;
+        }
+      if (n == 0 && other) { phase ^= 1; continue; }
       if (n == 0) {
         if (best != INF && best < bend) break;
         int any = 0;
@@ -237,6 +291,7 @@ int main(int argc, char** argv) {
             if (i0 + a < rows && j0 + b < cols) g[(size_t)(j0 + b) * rows + i0 + a] = outbuf[(size_t)k * TI * TJ + b * TI + a];
       }
       best = gb;
+      phase ^= 1;
     }
     long E = 0;
     for (int t = 0; t < ntile; ++t) st.tiles += touched[t];
