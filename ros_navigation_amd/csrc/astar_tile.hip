@@ -11,10 +11,16 @@
 //   2. relaxes the tile to the fixed point of the current f-bucket with alternating down / up sweeps: a row takes its
 //      three vertical candidates from the row before it (one in-lane, two through DPP wave shifts by one lane) and
 //      its two horizontal ones through the same shifts; ~16 VALU instructions per 64 cells, no LDS, no atomics, no
-//      divergence.  Rows whose sources did not change since their last evaluation are skipped (three 16-bit flag
-//      words on the scalar unit), so a job costs what its moving front costs, not 1024 cells per sweep,
-//   3. stores the rows that changed (it is the only writer of its page: plain coalesced stores), and activates the
-//      neighbouring tiles whose halo it improved.  Neighbours PULL: nothing is ever written into another tile.
+//      divergence.  A row that changed runs on along itself at once (up to 16 short passes).  Rows whose sources did
+//      not change since their last evaluation are skipped (three 16-bit flag words on the scalar unit), so a job
+//      costs what its moving front costs, not 1024 cells per sweep,
+//   3. stores the rows that changed (it is the only writer of its page: plain coalesced stores), and wakes a
+//      neighbouring tile only if one of its own edge cells beats -- by a step that cell's mask allows -- what the
+//      neighbour held when the job loaded its halo.  Neighbours PULL: nothing is ever written into another tile.
+// Rounds of jobs are separated by a workgroup barrier and alternate between the two colours of a checkerboard over the
+// tiles, so the four edge neighbours of a tile never run in the same round (the halo a job loads is final for the
+// moment, and the wake test is not fooled by a neighbour advancing in parallel); an f-bucket is finished when no tile
+// of either colour is flagged.
 // Pages are handed out by the job that first changes a tile; every query owns a contiguous run of `cap` pages and a
 // tile -> page table (tmap), so the 2-4 % of the map a search visits sits in a few MiB of HBM, and the next launch on
 // the same pipeline stage resets exactly the pages that were handed out.  Page 0 is shared, never written and always
