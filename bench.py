@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
 """bench.py -- replan cycles/sec (HIMM + VFH+ + A*) on a 4096 x 4096 grid, BASELINE.json's metric.
 
-One "step" = one pass of the hot path over one batch of synthetic input, all resident in HBM:
+One "step" = one TURN of the A* pipeline (--pipeline map updates, default 13), i.e. 13 passes of
     HIMM ray batch (64 robot origins x 1563 rays) on the laser layer + fused compose-master
-    -> VFH+ step for 256 robot poses -> grid A* for 256 (start, goal) queries.
+    -> VFH+ step for 256 robot poses -> grid A* for 256 (start, goal) queries
+all resident in HBM: 13 x 256 = 3328 replan cycles per step.  The searches of 13 consecutive passes are in
+flight at once (each on its own pipeline stage), so a single pass is not a unit whose time can be
+measured by itself: a step hands every stage one batch, and the driver's 20 steps then time 260
+passes of steady state instead of 20 passes through a pipeline that is empty at both ends.
 A "replan cycle" is one (pose -> VFH command, start/goal -> A* path) pair served against the map
-that has received its HIMM batch, so one step = 256 cycles with the ray batch amortised over them
-(SURVEY.md section 8d).  The steps rotate through ROTATE pre-generated ray batches, pose sets and
-query sets, so no step repeats its predecessor's input (HIMM clears really write, every A* batch is
+that has received its HIMM batch; the ray batch is amortised over the 256 cycles of its pass
+(SURVEY.md section 8d).  The passes rotate through ROTATE pre-generated ray batches, pose sets and
+query sets, so no pass repeats its predecessor's input (HIMM clears really write, every A* batch is
 a different one).
 
 N > 1 (`--gpus N`): one process per GPU, each with its own replicated grid and its own shard of
@@ -43,8 +47,9 @@ PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=700, help="timed steps (default: about 2.3 s on one MI355X)")
-    ap.add_argument("--warmup", type=int, default=26, help="untimed steps: two turns of the 13-stage pipeline")
+    ap.add_argument("--steps", type=int, default=54, help="timed steps; one step = one turn of the pipeline = --pipeline passes of "
+                                                           "[HIMM batch, VFH+ x queries, A* x queries] (default: 702 passes)")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed steps (turns of the pipeline)")
     ap.add_argument("--grid", type=int, default=4096)
     ap.add_argument("--queries", type=int, default=256, help="A* queries == VFH poses per step (cycles per step)")
     ap.add_argument("--ray-poses", type=int, default=64)
@@ -67,15 +72,39 @@ def parse():
     return ap.parse_args()
 
 
+def visible_gpus():
+    """GPUs this process would see, counted WITHOUT opening the HIP runtime (the parent of the ranks must never touch a
+    GPU: a process that has may not start children that exec): compute nodes of the KFD topology (`simd_count` > 0),
+    narrowed by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.  None if the topology is unreadable."""
+    import glob
+    n = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for path in nodes:
+        try:
+            with open(path) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        except (OSError, ValueError):
+            return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(args):
     """`--gpus N` without a launcher: start the N ranks as fresh child processes (this process has not touched a GPU
-    and never will) and exit with their status."""
+    and never will: it imports neither torch nor the engine) and exit with their status."""
     share = os.environ.get("RNA_BENCH_SHARE_GPU") == "1"
     if not share:
-        import torch   # device_count() does not initialise the GPU on this image
-        have = torch.cuda.device_count()
-        if have < args.gpus:
+        have = visible_gpus()
+        if have is not None and have < args.gpus:
             raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
+        # (unreadable topology: every rank checks its own device and exits non-zero without one)
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -179,7 +208,11 @@ def main():
     args = parse()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # developer switch: RNA_BENCH_FORCE_SPAWN=1 takes the spawn path (parent -> Popen -> rank -> RCCL init -> barriers ->
+    # max over ranks) with a single rank too, so that the code an N-GPU run takes can run on a one-GPU box
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("RNA_BENCH_FORCE_SPAWN") == "1"):
+        if args.gpus == 1:
+            os.environ["RNA_BENCH_FORCE_DIST"] = "1"
         spawn_ranks(args)
     import numpy as np
     import torch
@@ -275,13 +308,17 @@ def main():
     e.astar_configure(max_queries=nq, queue_capacity=args.queue_capacity, bucket_width=args.bucket_width)
     torch.cuda.synchronize()
 
+    only_astar = os.environ.get("RNA_BENCH_ONLY_ASTAR") == "1"
     step_no = [0]
     xfer = [0, 0]          # bytes received: halo strips, gathered windows
 
-    def step():
+    def one_pass():
         b = step_no[0] % args.pipeline
         k = step_no[0] % ROTATE
         step_no[0] += 1
+        if only_astar:   # developer switch RNA_BENCH_ONLY_ASTAR=1: the search capacity without the map update and VFH+ (NOT the metric)
+            e.astar_device(d_queries[k].data_ptr(), nq, d_paths[b].data_ptr(), args.max_path, d_results[b].data_ptr())
+            return b
         e.update_map_device(d_rays[k].data_ptr(), len(ray_sets[k]), compose_mode=0)
         if layout is not None and world > 1:
             xfer[0] += D.exchange_halo(e, R.capi.LAYER_MASTER, layout, rank, halo, dist, tracked=not args.tiled_full_gather)
@@ -294,6 +331,10 @@ def main():
                 e.compose_master(0)
         e.astar_device(d_queries[k].data_ptr(), nq, d_paths[b].data_ptr(), args.max_path, d_results[b].data_ptr())
         return b
+
+    def step():   # one turn of the pipeline: every stage receives one batch
+        for _ in range(args.pipeline):
+            one_pass()
 
     def barrier():
         if use_dist:
@@ -346,11 +387,13 @@ def main():
     t_max = D.max_over_ranks(elapsed, "cpu" if share else dev) if use_dist else elapsed
 
     if rank == 0:
-        cycles = args.queries * world * args.steps
+        passes = args.steps * args.pipeline
+        cycles = args.queries * world * passes
         ms_search = prof["astar_search"][0] / max(1, prof["astar_search"][1])
         alg_bytes = settled_per_launch * ASTAR_BYTES_PER_SETTLED
         achieved = alg_bytes / (ms_search * 1e-3) / 1e9 if ms_search > 0 else 0.0
         traffic, traffic_src = pmc_traffic("rna::tsa_search_kernel", args, world)
+        wall_per_pass = t_max / passes
 
         def row(kernel_key, pmc_name, alg):
             ms = prof[kernel_key][0] / max(1, prof[kernel_key][1])
@@ -363,17 +406,19 @@ def main():
         himm_alg = float(np.mean([(8.0 * np.hypot(r["ex"] - r["sx"], r["ey"] - r["sy"]) / 0.05 + 8.0 * (r["clear_end"] == 0) + 40.0).sum()
                                   for r in ray_sets]))
         out = {
-            "metric": "replan cycles/sec (HIMM+VFH++A*) on %dx%d grid" % (n, n),
+            "metric": ("replan cycles/sec (HIMM+VFH++A*) on %dx%d grid" if not only_astar else "DEVELOPER RUN, A* only, not the metric (%dx%d grid)") % (n, n),
             "value": cycles / t_max, "unit": "replan cycles/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "full replan loop on %dx%d f32 grid (res 0.05 m): %d-ray HIMM batch + fused "
-                                   "compose -> %d VFH+ poses -> %d grid-A* queries per step; 30%% rectangle "
-                                   "obstacles (seed 2); %d ray batches / pose sets / query sets in rotation"
-                                   % (n, n, len(ray_sets[0]), nq, nq, ROTATE),
-                       "cycles_per_step": nq, "rays_per_step": int(len(ray_sets[0])), "rotating_input_sets": ROTATE,
+            "config": {"workload": "full replan loop on %dx%d f32 grid (res 0.05 m); one step = one turn of the %d-stage A* "
+                                   "pipeline = %d passes of [%d-ray HIMM batch + fused compose -> %d VFH+ poses -> %d grid-A* "
+                                   "queries (one launch)]; 30%% rectangle obstacles (seed 2); %d ray batches / pose sets / "
+                                   "query sets in rotation"
+                                   % (n, n, args.pipeline, args.pipeline, len(ray_sets[0]), nq, nq, ROTATE),
+                       "cycles_per_step": nq * args.pipeline, "passes_per_step": args.pipeline, "cycles_per_pass": nq,
+                       "rays_per_pass": int(len(ray_sets[0])), "rotating_input_sets": ROTATE, "ms_per_pass": 1e3 * wall_per_pass,
                        "astar_queries_checked": total, "astar_queries_answered": answered, "astar_paths_found": found,
-                       "astar_bucket_width": args.bucket_width or 24000, "astar_pipeline_depth": args.pipeline,
+                       "astar_bucket_width": args.bucket_width or 96000, "astar_pipeline_depth": args.pipeline,
                        "astar_allocated": dict(zip(("pipeline_depth", "pages_per_query", "max_queries"), e.astar_effective_config())),
                        "timed_seconds": t_max,
                        "parallelism": ("query-sharded x%d" % world) if layout is None else
@@ -386,16 +431,17 @@ def main():
                          "avg_launch_ms": ms_search, "launches": prof["astar_search"][1],
                          # pipelined launches overlap on the GPU: each one's duration is stretched by the others, so
                          # the whole-step figure (algorithmic bytes of one launch / wall time of one step) is given too
-                         "overlapped_launches": ms_search / (1e3 * t_max / args.steps),
-                         "achieved_per_step_wall": alg_bytes / (t_max / args.steps) / 1e9},
+                         "overlapped_launches": ms_search / (1e3 * wall_per_pass),
+                         "achieved_per_pass_wall": alg_bytes / wall_per_pass / 1e9,
+                         "frac_wall": alg_bytes / wall_per_pass / 1e9 / HBM_PEAK_GBS},
             "roofline_rows": [row("himm_raster", HIMM_RASTER_CHAIN, himm_alg),
                               row("vfh_step", "vfh_step_kernel", float(nq * VFH_BYTES_PER_POSE))],
-            "kernel_ms_per_step": {k: (v[0] / args.steps) for k, v in prof.items() if v[1]},
+            "kernel_ms_per_pass": {k: (v[0] / passes) for k, v in prof.items() if v[1]},
         }
         if layout is not None:
             out["tiled"] = {"layout": [layout.ti, layout.tj], "halo_cells": halo,
-                            "halo_bytes_per_step_rank0": xfer[0] / args.steps,
-                            "gather_bytes_per_step_rank0": xfer[1] / args.steps}
+                            "halo_bytes_per_pass_rank0": xfer[0] / passes,
+                            "gather_bytes_per_pass_rank0": xfer[1] / passes}
         if not args.no_cpu and world == 1:   # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, R, master, ray_sets[0], pose_sets[0], query_sets[0], n, n, length)
         else:

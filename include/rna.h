@@ -235,7 +235,7 @@ typedef struct {
 /* max_queries: queries searched concurrently (one g-field each; larger batches are processed in
  * chunks); queue_capacity: entries of each per-query queue of the fallback frontier kernel;
  * bucket_width: the f-range (cost units, >= 2828) relaxed together before the search advances
- * (default 24000); 0 = keep/default. */
+ * (default 96000); 0 = keep/default. */
 int rna_astar_configure(rna_engine* e, int max_queries, int queue_capacity, int bucket_width);
 /* Pipelined batches: with depth d > 1 consecutive rna_astar_batch_device calls run their searches on d
  * rotating internal streams (each with its own search fields), so the tail of one batch overlaps

@@ -94,6 +94,34 @@ __device__ __forceinline__ int lane_p1(int v) { return __builtin_amdgcn_update_d
 __device__ __forceinline__ int lane_m1(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x138, 0xF, 0xF, false); }
 __device__ __forceinline__ int lane_p1(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x130, 0xF, 0xF, false); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+// Wave-wide reductions on the VALU (DPP row shifts, then the two row broadcasts): no LDS, ~8 instructions.
+// row_shr:1/2/4/8 leave the inclusive prefix of each 16-lane row in its lane 15; row_bcast:15 hands rows 0 / 2 to rows
+// 1 / 3, row_bcast:31 hands rows 0+1 to rows 2 and 3: lane 63 holds the whole wave, lane 31 the lower half.
+#define TSA_DPP_RED(op, v, ident)                                                                          \
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xF, 0xF, false));                                \
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x112, 0xF, 0xF, false));                                \
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x114, 0xF, 0xF, false));                                \
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x118, 0xF, 0xF, false));                                \
+  v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x142, 0xA, 0xF, false));
+__device__ __forceinline__ int tsa_imax(int a, int b) { return max(a, b); }
+__device__ __forceinline__ int tsa_umin(int a, int b) { return (int)min((unsigned)a, (unsigned)b); }
+// maxima of the two 32-lane halves: lane 31 / lane 63
+__device__ __forceinline__ void wave_halves_max_i32(int v, int& lo, int& hi) {
+  TSA_DPP_RED(tsa_imax, v, (int)0x80000000)
+  lo = __builtin_amdgcn_readlane(v, 31);
+  hi = __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+  TSA_DPP_RED(tsa_imax, v, (int)0x80000000)
+  v = max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x143, 0xC, 0xF, false));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned u) {
+  int v = (int)u;
+  TSA_DPP_RED(tsa_umin, v, -1)
+  v = tsa_umin(v, __builtin_amdgcn_update_dpp(-1, v, 0x143, 0xC, 0xF, false));
+  return (unsigned)__builtin_amdgcn_readlane(v, 63);
+}
 // all ones if bit `bit` of m is set, else 0.  Opaque to the optimiser on purpose: left to itself it hoists the 64 tests
 // of a tile job (16 rows x 4 diagonal moves) out of the sweeps as 64-bit lane masks, 128 SGPRs that it then spills into
 // VGPR lanes and from there into scratch.
@@ -309,8 +337,8 @@ struct TsaCtx {
 #define TSA_PP(b) TSA_CAT(pp, b)
 #define TSA_MKW(b) TSA_CAT(TSA_MK_, b)   // the mask word that holds row b's byte, at bit 8 * (b & 3)
 template <class Sched>
-__device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane_in, const int t, unsigned pg, const TsaCtx& C,
-                                       const bool first, const long long bucket_end, const int bucket_width TSA_ACC_PARAM) {
+__device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane_in, const int t, const TsaCtx& C,
+                                       const bool first, const long long bucket_end, const int key_base, const int key_shift TSA_ACC_PARAM) {
   // an opaque copy of the lane id per job (and one more for the results phase): everything derived from it is then
   // recomputed here instead of being hoisted out of the job loop, kept alive across the sweeps and spilled to scratch
   int lane = lane_in;
@@ -319,13 +347,17 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   const int ti = t % tiles_i, tj = t / tiles_i;
   const int i0 = ti * TI, j0 = tj * TJ;
   TSA_T(t_a);
-  // ---- 1. page table look-up of the eight neighbouring tiles (lane k < 8: direction k; 0 = none or outside) ----
+  // ---- 1. page table look-up of the eight neighbouring tiles (lane k < 8: direction k; 0 = none or outside) and of
+  //         the tile itself (lane 8) ----
   unsigned nb_pg = 0u;
   int nb_t = -1;
   if (lane < 8) {
     const int nti = ti + kdi_of(lane), ntj = tj + kdj_of(lane);
     if (nti >= 0 && ntj >= 0 && nti < tiles_i && ntj < tiles_j) { nb_t = ntj * tiles_i + nti; nb_pg = C.page_of(nb_t); }
+  } else if (lane == 8) {
+    nb_pg = C.page_of(t);   // final while this job runs: only the tile's own job changes it, and a tile never runs twice at once
   }
+  unsigned pg = (unsigned)__builtin_amdgcn_readlane((int)nb_pg, 8);
   // ---- 2. everything the job reads, issued before the first wait ----
   int g0, g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15;
   {
@@ -567,7 +599,12 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     // to find nothing new (37 % of all jobs).
     // Each step is tested with this cell's own mask bit for it (the move, its target and -- for a diagonal -- both
     // corner cells are free): with 30 % of the map blocked, "beats an unreached neighbour" is mostly a blocked neighbour.
+    // A wake-up carries a KEY: the lowest f = g + h among the neighbour's cells this tile improves (kept as the highest
+    // u - h; one wave reduction per side).  Free wavefronts take the queued tile with the lowest key, so tiles are
+    // relaxed roughly in the order A* would settle their cells (scripts/sim_async.c: 7 % fewer jobs than red-black
+    // rounds and no wavefront waiting at a round barrier).
     bool wakeN = q0 != 0ull, wakeS = q15 != 0ull;
+    int kfN = 0, kfS = 0, kfW = 0, kfE = 0;
     if (wakeN) {
       const int topv = (int)scr[84 + lane];
       const int c_ = __builtin_amdgcn_inverse_ballot_w64(q0) ? g0 : 0;
@@ -575,14 +612,20 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       // (the shifted values are formed for ALL lanes first: inside a short-circuit `||` the wave shift would run with the
       // lanes whose first test succeeded switched off, and their neighbours would read nothing from them)
       const int from_w_ = lane_m1(ce_) + nD, from_e_ = lane_p1(cw_) + nD;
-      wakeN = __builtin_amdgcn_ballot_w64((cn_ + nS > topv) | (from_w_ > topv) | (from_e_ > topv)) != 0ull;
+      const int un_ = max3i(cn_ + nS, from_w_, from_e_);
+      const bool imp_ = un_ > topv;
+      wakeN = __builtin_amdgcn_ballot_w64(imp_) != 0ull;
+      if (wakeN) kfN = wave_max_i32(imp_ ? un_ - TSA_H(-1) : (int)0x80000000);
     }
     if (wakeS) {
       const int botv = (int)scr[84 + 64 + lane];
       const int c_ = __builtin_amdgcn_inverse_ballot_w64(q15) ? g15 : 0;
       const int cw_ = c_ & __builtin_amdgcn_sbfe((int)mk3, 24 + 5, 1), cs_ = c_ & __builtin_amdgcn_sbfe((int)mk3, 24 + 6, 1), ce_ = c_ & __builtin_amdgcn_sbfe((int)mk3, 24 + 7, 1);
       const int from_w_ = lane_m1(ce_) + nD, from_e_ = lane_p1(cw_) + nD;
-      wakeS = __builtin_amdgcn_ballot_w64((cs_ + nS > botv) | (from_w_ > botv) | (from_e_ > botv)) != 0ull;
+      const int un_ = max3i(cs_ + nS, from_w_, from_e_);
+      const bool imp_ = un_ > botv;
+      wakeS = __builtin_amdgcn_ballot_w64(imp_) != 0ull;
+      if (wakeS) kfS = wave_max_i32(imp_ ? un_ - TSA_H(TJ) : (int)0x80000000);
     }
     // the same for the two edge columns and the four corners: lane 0 / 63 lay their 16 cells (what they may pass on)
     // out in LDS, the lanes that hold the halo column as loaded (lane = row + 1) compare.  Unchanged cells take part
@@ -607,17 +650,34 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       // the halo cell in lane l is row l - 1 of the neighbour: it is reached straight from this lane's cell, from the
       // cell one lane up (row l) by its "row above" step and from the one lane down (row l - 2) by its "row below" step
       const int from_below_ = lane_p1(vu_) + nD, from_above_ = lane_m1(vd_) + nD;   // (formed for all lanes before any test, see above)
-      const bool imp = (xl_ <= TJ + 1) & ((vs_ + nS > xv) | (from_below_ > xv) | (from_above_ > xv));
+      const int ux_ = max3i(vs_ + nS, from_below_, from_above_);
+      const bool imp = (xl_ <= TJ + 1) & (ux_ > xv);
       const unsigned long long im = __builtin_amdgcn_ballot_w64(imp);
       const unsigned lo = (unsigned)im, hi = (unsigned)(im >> 32);
       colw = ((lo & 1u) ? 1u : 0u) | ((lo & 0x1fffeu) ? 2u : 0u) | ((lo & 0x20000u) ? 4u : 0u) |
-             ((hi & 1u) ? 8u : 0u) | ((hi & 0x1fffeu) ? 16u : 0u) | ((hi & 0x20000u) ? 32u : 0u);
+             ((hi & 1u) ? 8u : 0u) | ((hi & 0x20000u) ? 32u : 0u) | ((hi & 0x1fffeu) ? 16u : 0u);
+      if (im) {   // one key per side: the corner tiles of a side share it
+        const int hX_ = tsa_octile(xr_ ? i0 + TI : i0 - 1, j0 + xl_ - 1, gi, gj);
+        wave_halves_max_i32(imp ? ux_ - hX_ : (int)0x80000000, kfW, kfE);
+      }
       __builtin_amdgcn_wave_barrier();
     }
     // directions: 0 NW, 1 N, 2 NE, 3 W, 4 E, 5 SW, 6 S, 7 SE
     const unsigned am = ((colw & 1u) ? 1u : 0u) | (wakeN ? 2u : 0u) | ((colw & 8u) ? 4u : 0u) | ((colw & 2u) ? 8u : 0u) | ((colw & 16u) ? 16u : 0u) |
                         ((colw & 4u) ? 32u : 0u) | (wakeS ? 64u : 0u) | ((colw & 32u) ? 128u : 0u);
-    if (lane < 8 && ((am >> lane) & 1u) && nb_t >= 0) sch.act_cur(nb_t);
+    unsigned wm = am & (unsigned)__builtin_amdgcn_ballot_w64(lane < 8 && nb_t >= 0);
+    if (wm) {
+      // this job's stores are in L2 before anybody is told to look at them (a woken tile's job loads with sc1 from L2)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      while (wm) {
+        const int k = __builtin_ctz(wm);
+        wm &= wm - 1u;
+        const int kf = k == 1 ? kfN : (k == 6 ? kfS : ((k == 0 || k == 3 || k == 5) ? kfW : kfE));
+        int key = (key_base - kf) >> key_shift;   // (f - f at the bucket's start), quantised
+        key = key < 0 ? 0 : (key > 0xfffe ? 0xfffe : key);
+        sch.wake(__builtin_amdgcn_readlane(nb_t, k), (unsigned)key, lane);
+      }
+    }
   }
 #undef TSA_ROW_CHANGED
 #undef TSA_H
@@ -626,22 +686,122 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   return evals;
 }
 
-// scheduler state of the one-workgroup-per-query kernel lives in LDS
+// ---- scheduler of the one-workgroup-per-query kernel: an open list of tiles in LDS ----
+// Per query (= workgroup), in LDS:
+//   st2    two bits per tile: D "a wake-up is pending" (bit 0), R "a wavefront is running the tile" (bit 1)
+//   ent    TSA_NE queue entries (key << 16 | tile), ENT_EMPTY = free.  A wake-up of a tile that is neither pending nor
+//          running appends an entry; a wake-up of a pending tile lowers the key of its entry (found by a wave-wide scan);
+//          a wake-up of a running tile only sets D -- the wavefront that runs it queues it again (key 0) when it ends.
+//   open   tiles that have to run as "first" in this f-bucket (they hold cells the last bucket's bound held back);
+//          free wavefronts drain this set before they take entries
+//   far    the same for the next bucket
+// A free wavefront takes the entry with the LOWEST key (a wave-wide minimum over the entries in use), claims its tile
+// (R, then D: an entry whose tile has nothing pending any more is stale and dropped) and runs the job.  No round
+// barriers: a bucket is at its fixed point when every wavefront of the workgroup is idle (an idle counter; a wavefront
+// only leaves the idle state when the entry counter says there is something to take, and only an idle-counted
+// wavefront looks at the counter, so "all idle" is stable and every wavefront sees it).
+// Exactness does not depend on the order: every improvement of a tile's edge that can matter to a neighbour sets the
+// neighbour's D bit after the improved words are in L2, and a bucket only ends when nothing is pending.
+#ifndef RNA_TSA_ENTRIES
+#define RNA_TSA_ENTRIES 2048
+#endif
+constexpr int TSA_NE = RNA_TSA_ENTRIES;   // (scripts/sim_async.c: at most 1065 entries at once over the bench's queries)
+constexpr unsigned ENT_EMPTY = 0xffffffffu;
+static_assert((TSA_NE & (TSA_NE - 1)) == 0 && TSA_NE % 256 == 0, "queue size: a power of two, scanned 256 entries at a time");
+
+__device__ __forceinline__ unsigned lds_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int lds_ldi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 struct TsaLocalSched {
   int* best_;
   int* state_;
-  unsigned* act_cur_;
-  unsigned* act_far_;
+  unsigned* st2_;
+  unsigned* far_;
+  unsigned* ent_;
+  int* count_;   // entries in the queue + tiles of the open set nobody has taken yet (a hint for idle wavefronts)
+  int* tail_;    // next slot to try
+  int* hi_;      // entries [0, hi) may be in use (a multiple of 256)
+  int* spill_;   // the queue was full: wake-ups were parked in `far` and this bucket runs again
   __device__ __forceinline__ int best() const { return __hip_atomic_load(best_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   __device__ __forceinline__ void improve_best(int g) { atomicMin(best_, g); }
   __device__ __forceinline__ void overflow() { *state_ = 4; }
   __device__ __forceinline__ void pool_exhausted() { *state_ = 5; }
-  __device__ __forceinline__ void act_cur(int t) { atomicOr(&act_cur_[t >> 5], 1u << (t & 31)); }
-  __device__ __forceinline__ void act_far(int t) { atomicOr(&act_far_[t >> 5], 1u << (t & 31)); }
-  __device__ __forceinline__ bool is_far(int t) const { return (__hip_atomic_load(&act_far_[t >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (t & 31)) & 1u; }
+  __device__ __forceinline__ void act_far(int t) { atomicOr(&far_[t >> 5], 1u << (t & 31)); }
+  __device__ __forceinline__ bool is_far(int t) const { return (lds_ld(&far_[t >> 5]) >> (t & 31)) & 1u; }
+  // append an entry (called by every lane of the wavefront; lane 0 acts)
+  __device__ __forceinline__ void push(unsigned e, int lane) {
+    if (lane == 0) {
+      bool ok = false;
+      for (int tries = 0; tries < 64 && !ok; ++tries) {
+        const int slot = atomicAdd(tail_, 1) & (TSA_NE - 1);
+        if (atomicCAS(&ent_[slot], ENT_EMPTY, e) == ENT_EMPTY) {
+          ok = true;
+          atomicMax(hi_, (slot | 255) + 1);
+        }
+      }
+      if (ok) {
+        atomicAdd(count_, 1);
+      } else {   // queue full: the tile (its D bit stays set) runs as a first job when this bucket is opened again
+        const int t = (int)(e & 0xffffu);
+        atomicOr(&far_[t >> 5], 1u << (t & 31));
+        *spill_ = 1;
+      }
+    }
+  }
+  // tile t has something new in its halo; key = quantised lowest f on offer (all lanes call, arguments wave-uniform)
+  __device__ __forceinline__ void wake(int t, unsigned key, int lane) {
+    const unsigned sh = 2u * ((unsigned)t & 15u);
+    unsigned old = 0u;
+    if (lane == 0) old = atomicOr(&st2_[t >> 4], 1u << sh);
+    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old) >> sh;
+    if (old & 2u) return;   // running: its wavefront sees D when it ends
+    const unsigned e = (key << 16) | (unsigned)t;
+    if (!(old & 1u)) { push(e, lane); return; }
+    // pending already: find its entry and lower the key (a failed attempt -- the entry is being appended or was just
+    // taken -- only costs order, never a wake-up: D is set)
+    const int hi = lds_ldi(hi_);
+    for (int base = 0; base < hi; base += 256) {
+      const uint4 v = *reinterpret_cast<const uint4*>(&ent_[base + lane * 4]);
+      const unsigned tt = (unsigned)t;
+      const bool m0 = (v.x & 0xffffu) == tt && v.x != ENT_EMPTY, m1 = (v.y & 0xffffu) == tt && v.y != ENT_EMPTY;
+      const bool m2 = (v.z & 0xffffu) == tt && v.z != ENT_EMPTY, m3 = (v.w & 0xffffu) == tt && v.w != ENT_EMPTY;
+      const unsigned long long found = __builtin_amdgcn_ballot_w64(m0 | m1 | m2 | m3);
+      if (found) {
+        if (lane == __builtin_ctzll(found)) {
+          const int c = m0 ? 0 : (m1 ? 1 : (m2 ? 2 : 3));
+          const unsigned cur = m0 ? v.x : (m1 ? v.y : (m2 ? v.z : v.w));
+          if (e < cur) atomicCAS(&ent_[base + lane * 4 + c], cur, e);
+        }
+        break;
+      }
+    }
+  }
+  // take the entry with the lowest key; ENT_EMPTY if the queue is empty
+  __device__ __forceinline__ unsigned pop(int lane) {
+    for (;;) {
+      const int hi = lds_ldi(hi_);
+      unsigned m = ENT_EMPTY;
+      int mb = 0;
+      for (int base = 0; base < hi; base += 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&ent_[base + lane * 4]);
+        const unsigned m4 = min(min(v.x, v.y), min(v.z, v.w));
+        mb = m4 < m ? base : mb;
+        m = min(m, m4);
+      }
+      const unsigned mm = wave_min_u32(m);
+      if (mm == ENT_EMPTY) return ENT_EMPTY;
+      const unsigned long long who = __builtin_amdgcn_ballot_w64(m == mm);
+      unsigned got = 0u;
+      if (lane == __builtin_ctzll(who)) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&ent_[mb + lane * 4]);
+        const int c = v.x == mm ? 0 : (v.y == mm ? 1 : (v.z == mm ? 2 : (v.w == mm ? 3 : -1)));
+        if (c >= 0 && atomicCAS(&ent_[mb + lane * 4 + c], mm, ENT_EMPTY) == mm) { got = 1u; atomicSub(count_, 1); }
+      }
+      if (__builtin_amdgcn_ballot_w64(got != 0u)) return mm;
+      // another wavefront took it (or lowered its key) in between: look again
+    }
+  }
 };
-
-__device__ __forceinline__ unsigned lds_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // Kernel arguments that are the same for every query of a launch.
 struct TsaLaunch {
@@ -661,15 +821,15 @@ constexpr int TSA_FOUND = -1000;        // provisional status between the search
 // result; the path is traced by tsa_backtrace_kernel (one wavefront per query, next kernel on the stream).
 // WAVES = wavefronts per workgroup (= per query): 8 when batches are pipelined (four queries share a CU, the throughput
 // configuration), 16 for a single batch on the engine's own stream (one workgroup per CU anyway: its latency is what
-// counts -- 256 queries on 4096^2: 32 ms instead of 46 ms).
+// counts).
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(RNA_TSA_WAVES_PER_EU, RNA_TSA_WAVES_PER_EU))) tsa_search_kernel(const TsaLaunch A) {
   constexpr int TSA_THREADS = WAVES * 64;
   __shared__ unsigned s_scr[WAVES][SCR_WORDS];
-  extern __shared__ unsigned s_dyn[];   // tile bitsets, sized by the launch: 3 x ((ntile + 31) / 32) words
-  __shared__ unsigned short s_jobs[TSA_JOBS];
-  __shared__ unsigned s_jobpg[TSA_JOBS];   // local page of each job's tile (looked up once per round by the list builders)
-  __shared__ int s_njobs, s_first_fail, s_job_next, s_best, s_state, s_bucket, s_bucket0, s_rounds, s_expanded, s_nalloc, s_any, s_pending, s_phase;
+  extern __shared__ unsigned s_dyn[];   // sized by the launch: st2 (2 x nt_words) | open (nt_words) | far (nt_words)
+  __shared__ __attribute__((aligned(16))) unsigned s_ent[TSA_NE];
+  __shared__ int s_best, s_state, s_bucket, s_bucket0, s_jobs_done, s_expanded, s_nalloc, s_any;
+  __shared__ int s_count, s_tail, s_hi, s_spill, s_idle, s_open_left, s_open_pos;
 
   // Workgroups take their query when they START (a ticket), not by blockIdx: the hardware deals workgroup
   // indices round-robin to the XCDs, so a fixed mapping lets one XCD with several long searches hold back
@@ -685,8 +845,9 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   const int ncell = rows * cols;
   const int ntile = tiles_i * tiles_j;
   const int nt_words = (ntile + 31) >> 5;
-  unsigned* const s_act[2] = {s_dyn, s_dyn + nt_words};   // [0] current bucket (next round), [1] next bucket
-  unsigned* const s_first = s_dyn + 2 * nt_words;         // tiles that have not run yet in the current bucket
+  unsigned* const s_st2 = s_dyn;
+  unsigned* const s_open = s_dyn + 2 * nt_words;
+  unsigned* const s_far = s_dyn + 3 * nt_words;
   rna_astar_result* const results = A.results;
 
   const bool valid = qu.start >= 0 && qu.goal >= 0 && qu.start < ncell && qu.goal < ncell;
@@ -712,7 +873,8 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   C.ts = tile_of(si, sj, tiles_i); C.sa = si & (TI - 1); C.sb = sj & (TJ - 1);
   C.tg = tile_of(gi, gj, tiles_i); C.ga = gi & (TI - 1); C.gb = gj & (TJ - 1);
 
-  for (int w = tid; w < 3 * nt_words; w += TSA_THREADS) s_dyn[w] = 0u;
+  for (int w = tid; w < 4 * nt_words; w += TSA_THREADS) s_dyn[w] = 0u;
+  for (int w = tid; w < TSA_NE; w += TSA_THREADS) s_ent[w] = ENT_EMPTY;
   if (lane >= 48) s_scr[wv][68 + lane - 48] = 0u;   // the zero tail of the wave's scratch
   // a start or a goal without a single traversable neighbour: blocked or walled in; nothing has been written yet, so
   // no page is in use
@@ -723,154 +885,162 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
       return;
     }
   }
+  // keys: (f - f at the bucket's start) >> key_shift must fit 16 bits with room for cells beyond the bucket's end
+  int key_shift = 0;
+  while (((2ll * A.bucket_width) >> key_shift) > 0xfffe) ++key_shift;
   if (tid == 0) {
-    s_best = INF; s_state = 0; s_rounds = 0; s_expanded = 0; s_nalloc = 0; s_phase = 0; s_pending = 0;
+    s_best = INF; s_state = 0; s_jobs_done = 0; s_expanded = 0; s_nalloc = 0;
     s_bucket = tsa_octile(si, sj, gi, gj) / A.bucket_width;
     s_bucket0 = s_bucket;
+    s_tail = 0; s_hi = 0; s_spill = 0; s_idle = 0; s_open_pos = 0;
+    s_count = 1; s_open_left = 1;
   }
   __syncthreads();
-  if (tid == 0) {   // the start tile's first job plants g(start) = 0
-    s_act[0][C.ts >> 5] = 1u << (C.ts & 31);
-    s_first[C.ts >> 5] = 1u << (C.ts & 31);
-  }
+  if (tid == 0) s_open[C.ts >> 5] = 1u << (C.ts & 31);   // the start tile's first job plants g(start) = 0
   __syncthreads();
 
-  int my_evals = 0;
+  int my_evals = 0, my_jobs = 0;
 #ifdef RNA_TSA_STATS
   unsigned long long tsa_acc[16] = {};
   const unsigned long long t_life0 = wall_clock64();
 #endif
-  TsaLocalSched sch{&s_best, &s_state, s_act[0], s_act[1]};
+  TsaLocalSched sch{&s_best, &s_state, s_st2, s_far, s_ent, &s_count, &s_tail, &s_hi, &s_spill};
 
-  for (;;) {
-    // ---- build this round's job list from the active-tile bitset ----
-    // (an opaque copy of the thread id per round: what the list builders derive from it is recomputed here instead of
-    // living -- spilled to scratch -- across the tile jobs, which need all 64 VGPRs)
+  for (;;) {   // one pass per f-bucket (or per re-run of a bucket whose queue overflowed)
+    const int bucket = lds_ldi(&s_bucket);
+    const long long bucket_end = ((long long)bucket + 1) * A.bucket_width;
+    const long long key_base_ll = (long long)KU - (long long)bucket * A.bucket_width;   // KU - (f at the bucket's start)
+    const int key_base = key_base_ll < -(long long)INF ? -INF : (int)key_base_ll;
+    bool idle = false;   // this wavefront is counted in s_idle
+    bool open_blocked = false;
+    for (;;) {
+      TSA_T(t_p0);
+      if (lds_ldi(&s_state) >= 4) break;
+      if (idle) {
+        if (lds_ldi(&s_idle) == WAVES) break;          // every wavefront idle: nothing queued, nothing running
+        if (lds_ldi(&s_count) <= 0) { __builtin_amdgcn_s_sleep(4); continue; }
+        if (lane == 0) atomicSub(&s_idle, 1);
+        idle = false;
+      }
+      int t = -1;
+      bool first = false;
+      // ---- 1. a tile of the open set (runs as "first") ----
+      if (!open_blocked && lds_ldi(&s_open_left) > 0) {
+        const int pos = lds_ldi(&s_open_pos);
+        const unsigned w = pos + lane < nt_words ? lds_ld(&s_open[pos + lane]) : 0u;
+        const unsigned long long nz = __builtin_amdgcn_ballot_w64(w != 0u);
+        if (!nz) {   // (wraps around: a tile that was running when it was taken is put back)
+          if (lane == 0) atomicCAS(&s_open_pos, pos, pos + 64 >= nt_words ? 0 : pos + 64);
+          continue;
+        }
+        const int l0 = __builtin_ctzll(nz);
+        const unsigned w0 = (unsigned)__builtin_amdgcn_readlane((int)w, l0);
+        const int b0 = __builtin_ctz(w0);
+        const int tt = ((pos + l0) << 5) + b0;
+        const unsigned sh = 2u * ((unsigned)tt & 15u);
+        int r = 0;   // 0: somebody else took the bit, 1: ours, 2: the tile is running right now
+        if (lane == 0) {
+          if ((atomicAnd(&s_open[pos + l0], ~(1u << b0)) >> b0) & 1u) {
+            const unsigned old = atomicOr(&s_st2[tt >> 4], 2u << sh) >> sh;
+            if (old & 2u) {   // running (as a woken tile): it has to run again as first -- bit back, D set, its wavefront queues it
+              atomicOr(&s_open[pos + l0], 1u << b0);
+              atomicOr(&s_st2[tt >> 4], 1u << sh);
+              r = 2;
+            } else {
+              atomicAnd(&s_st2[tt >> 4], ~(1u << sh));   // whatever was pending is served by this job (its entry goes stale)
+              atomicSub(&s_open_left, 1);
+              atomicSub(&s_count, 1);
+              r = 1;
+            }
+          }
+        }
+        r = __builtin_amdgcn_readfirstlane(r);
+        if (r == 0) continue;
+        if (r == 2) { open_blocked = true; continue; }   // take an entry meanwhile
+        t = tt;
+        first = true;
+      } else {
+        // ---- 2. the queued tile with the lowest key ----
+        open_blocked = false;
+        const unsigned e = sch.pop(lane);
+        if (e == ENT_EMPTY) {
+          if (lds_ldi(&s_open_left) > 0) { __builtin_amdgcn_s_sleep(2); continue; }   // (the open tile that was running)
+          if (lane == 0) atomicAdd(&s_idle, 1);
+          idle = true;
+          continue;
+        }
+        const int tt = (int)(e & 0xffffu);
+        const unsigned sh = 2u * ((unsigned)tt & 15u);
+        int r = 0;   // 0: not ours (running or stale), 1: ours, 2: ours and first
+        if (lane == 0) {
+          const unsigned old = atomicOr(&s_st2[tt >> 4], 2u << sh) >> sh;
+          if (!(old & 2u)) {
+            const unsigned old2 = atomicAnd(&s_st2[tt >> 4], ~(1u << sh)) >> sh;
+            if (old2 & 1u) {
+              r = 1;
+              if (lds_ldi(&s_open_left) > 0 && ((atomicAnd(&s_open[tt >> 5], ~(1u << (tt & 31))) >> (tt & 31)) & 1u)) {
+                atomicSub(&s_open_left, 1);
+                atomicSub(&s_count, 1);
+                r = 2;
+              }
+            } else {   // stale entry: nothing pending.  Give the tile back (a wake-up may have arrived meanwhile)
+              const unsigned old3 = atomicAnd(&s_st2[tt >> 4], ~(2u << sh)) >> sh;
+              if (old3 & 1u) r = -1;
+            }
+          }
+        }
+        r = __builtin_amdgcn_readfirstlane(r);
+        if (r == -1) { sch.push((unsigned)tt, lane); continue; }
+        if (r <= 0) continue;
+        t = tt;
+        first = r == 2;
+      }
+      TSA_T(t_p1);
+      TSA_ACC(4, t_p0, t_p1);   // taking a job
+      TSA_CNT(7, 1);
+      my_jobs += 1;
+      my_evals += tsa_job(sch, s_scr[wv], lane, t, C, first, bucket_end, key_base, key_shift TSA_ACC_ARG);
+      // the job's stores are performed before the tile can be taken again (it may have been woken while it ran)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      {
+        const unsigned sh = 2u * ((unsigned)t & 15u);
+        int again = 0;
+        if (lane == 0) again = (int)((atomicAnd(&s_st2[t >> 4], ~(2u << sh)) >> sh) & 1u);
+        if (__builtin_amdgcn_readfirstlane(again)) sch.push((unsigned)t, lane);   // key 0: as soon as possible
+      }
+    }
+    // ---- the bucket is at its fixed point (or the search is being abandoned) ----
+    __syncthreads();
+    if (s_state >= 4) break;
     int tid_r = threadIdx.x;
     asm volatile("" : "+v"(tid_r));
-    TSA_T(t_r0);
-    if (tid_r == 0) { s_njobs = 0; s_job_next = 0; s_first_fail = TSA_JOBS; s_pending = 0; }
+    const bool spilled = s_spill != 0;
     __syncthreads();
-#if RNA_TSA_REDBLACK
-    const int phase = s_phase;
-#endif
+    if (tid_r == 0) {
+      // every cell with f < (bucket + 1) * B has its exact g (unless wake-ups were parked: then this bucket runs again)
+      if (!spilled && s_best != INF && (long long)s_best < bucket_end) s_state = 1;
+      s_any = 0; s_spill = 0; s_idle = 0; s_tail = 0; s_hi = 0; s_open_pos = 0;
+    }
+    __syncthreads();
+    if (s_state == 1) break;
+    // tiles that hold cells of the next bucket (or parked wake-ups) become the open set
+    int cnt = 0;
     for (int w = tid_r; w < nt_words; w += TSA_THREADS) {
-      unsigned bits = s_act[0][w];
-      if (!bits) continue;
-#if RNA_TSA_REDBLACK
-      // Rounds alternate between the two colours of a checkerboard over the tiles ((ti + tj) & 1): the four edge
-      // neighbours of a tile never run in the same round, so a job loads halo rows and columns that are final for the
-      // moment -- and the "does my edge beat what the neighbour holds" test of the job that wakes it is not fooled by a
-      // neighbour that advances in parallel.
-      unsigned cm;
-      if ((tiles_i & 31) == 0) {
-        cm = ((((w << 5) / tiles_i) + phase) & 1) ? 0xAAAAAAAAu : 0x55555555u;   // a word lies inside one tile row, bit parity = ti parity
-      } else {
-        cm = 0u;
-        for (unsigned rest = bits; rest; rest &= rest - 1) {
-          const int b = __ffs(rest) - 1, t = (w << 5) + b;
-          if ((((t % tiles_i) + (t / tiles_i)) & 1) == phase) cm |= 1u << b;
-        }
-      }
-      const unsigned other = bits & ~cm;
-      if (other) s_pending = 1;
-      bits &= cm;
-      if (!bits) continue;
-#else
-      const unsigned other = 0u;
-#endif
-      const int cnt = __popc(bits);
-      const int base = atomicAdd(&s_njobs, cnt);
-      if (base + cnt <= TSA_JOBS) {
-        s_act[0][w] = other;
-        int k = base;
-        while (bits) {
-          const int b = __ffs(bits) - 1;
-          bits &= bits - 1;
-          const int t = (w << 5) + b;
-          s_jobs[k] = (unsigned short)t;
-          s_jobpg[k] = C.page_of(t);   // final for this round: only the tile's own job changes it
-          ++k;
-        }
-      } else {
-        atomicMin(&s_first_fail, base);   // job list full: these tiles stay flagged for the next round
-      }
+      const unsigned b = s_far[w];
+      s_open[w] = b;
+      s_far[w] = 0u;
+      cnt += __popc(b);
+    }
+    if (cnt) atomicAdd(&s_any, cnt);
+    __syncthreads();
+    if (tid_r == 0) {
+      if (!s_any) s_state = (s_best != INF) ? 1 : 2;   // nothing left anywhere
+      else { s_count = s_any; s_open_left = s_any; if (!spilled) s_bucket += 1; }
     }
     __syncthreads();
-    const int njobs = s_njobs < s_first_fail ? s_njobs : s_first_fail;
-#ifdef RNA_TSA_STATS
-    if (tid == 0 && njobs > 0) {   // rounds by size: slots 16..21 = 1-4, 5-8, 9-16, 17-32, 33-64, 65+ jobs
-      const int b = njobs <= 4 ? 0 : (njobs <= 8 ? 1 : (njobs <= 16 ? 2 : (njobs <= 32 ? 3 : (njobs <= 64 ? 4 : 5))));
-      atomicAdd(&g_tsa_stat[16 + b], 1ull);
-      atomicAdd(&g_tsa_stat[24 + b], (unsigned long long)njobs);
-    }
-#endif
-#if RNA_TSA_REDBLACK
-    if (njobs == 0 && s_pending) {   // nothing of this colour, but the other one has work
-      __syncthreads();
-      if (tid_r == 0) s_phase ^= 1;
-      __syncthreads();
-      continue;
-    }
-#endif
-    if (njobs == 0) {
-      // bucket k is at its fixed point: every cell with f < (k+1)*B has its exact g
-      __syncthreads();
-      if (tid_r == 0) {
-        const long long done_below = ((long long)s_bucket + 1) * A.bucket_width;
-        if (s_best != INF && (long long)s_best < done_below) s_state = 1;
-        else s_state = -1;  // try the next bucket
-        s_any = 0;
-      }
-      __syncthreads();
-      if (s_state == 1) break;
-      // advance: tiles that hold cells of the next bucket become the active set, and each of them runs as "first"
-      int any = 0;
-      for (int w = tid_r; w < nt_words; w += TSA_THREADS) {
-        const unsigned b = s_act[1][w];
-        s_act[0][w] = b;
-        s_first[w] = b;
-        s_act[1][w] = 0u;
-        any |= (b != 0u);
-      }
-      if (any) s_any = 1;   // (not __syncthreads_or: its library code keeps three more VGPRs alive across the tile jobs)
-      __syncthreads();
-      if (tid_r == 0) {
-        if (!s_any) s_state = (s_best != INF) ? 1 : 2;   // nothing left anywhere
-        else { s_state = 0; s_bucket += 1; }
-      }
-      __syncthreads();
-      if (s_state != 0) break;
-      continue;
-    }
-
-    const long long bucket_end = ((long long)s_bucket + 1) * A.bucket_width;
-
-    // ---- tile jobs: one wavefront per job ----
-    TSA_T(t_r1);
-    TSA_ACC(4, t_r0, t_r1);   // list build + barriers of this round
-    TSA_CNT(6, 1);            // rounds (per wave)
-    for (;;) {
-      int job = 0;
-      if (lane == 0) job = atomicAdd(&s_job_next, 1);
-      job = __builtin_amdgcn_readfirstlane(job);   // wave-uniform: the loop is a scalar branch
-      if (job >= njobs) break;
-      const int t = s_jobs[job];
-      const unsigned pg = s_jobpg[job];
-      const unsigned fw = lds_ld(&s_first[t >> 5]);
-      const bool first = __builtin_amdgcn_readfirstlane((int)((fw >> (t & 31)) & 1u)) != 0;
-      if (first && lane == 0) atomicAnd(&s_first[t >> 5], ~(1u << (t & 31)));
-      TSA_CNT(7, 1);
-      my_evals += tsa_job(sch, s_scr[wv], lane, t, pg, C, first, bucket_end, A.bucket_width TSA_ACC_ARG);
-    }
-    // all stores of this round are performed before any wave loads tiles in the next one
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const bool stop = s_state >= 4;
-    if (tid == 0) { s_rounds += 1; s_phase ^= 1; }
-    if (stop) break;
+    if (s_state != 0) break;
   }
-  if (lane == 0) atomicAdd(&s_expanded, my_evals * TI);   // dense cell updates
+  if (lane == 0) { atomicAdd(&s_expanded, my_evals * TI); atomicAdd(&s_jobs_done, my_jobs); }   // dense cell updates
   __syncthreads();
 #ifdef RNA_TSA_STATS
   tsa_acc[5] = wall_clock64() - t_life0;   // wave lifetime inside the search loop
@@ -880,10 +1050,11 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   if (tid == 0) A.S.nalloc[q] = s_nalloc < C.cap ? s_nalloc : C.cap;
 
   // provisional result: the backtrace kernel (next on the stream) finishes the found ones
+  // (`rounds` reports tile jobs per wavefront: there are no rounds any more)
   if (tid == 0) {
     const int state = s_state;
-    results[q] = rna_astar_result{state == 1 ? TSA_FOUND : (state >= 4 ? state : 1), 0, state == 1 ? s_best : INF, s_expanded, s_rounds,
-                                  s_bucket - s_bucket0 + 1};
+    results[q] = rna_astar_result{state == 1 ? TSA_FOUND : (state >= 4 ? state : 1), 0, state == 1 ? s_best : INF, s_expanded,
+                                  (s_jobs_done + WAVES - 1) / WAVES, s_bucket - s_bucket0 + 1};
   }
 }
 
@@ -1089,8 +1260,8 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     A.rows = rows; A.cols = cols; A.tiles_i = ti; A.tiles_j = tj; A.s0 = e->geom.start[0]; A.s1 = e->geom.start[1];
     A.queries = q_dev; A.S = S; A.bucket_width = a.bucket_width; A.paths = paths_dev; A.max_path_len = max_len;
     A.rev_all = a.rev[slot]; A.rev_cap = a.rev_cap; A.results = res_dev;
-    if (a.depth > 1) hipLaunchKernelGGL(tsa_search_kernel<TSA_WAVES>, dim3(n), dim3(TSA_WAVES * 64), 3 * nt_bytes, search_stream, A);
-    else hipLaunchKernelGGL(tsa_search_kernel<16>, dim3(n), dim3(16 * 64), 3 * nt_bytes, search_stream, A);
+    if (a.depth > 1) hipLaunchKernelGGL(tsa_search_kernel<TSA_WAVES>, dim3(n), dim3(TSA_WAVES * 64), 4 * nt_bytes, search_stream, A);
+    else hipLaunchKernelGGL(tsa_search_kernel<16>, dim3(n), dim3(16 * 64), 4 * nt_bytes, search_stream, A);
     hipLaunchKernelGGL(tsa_backtrace_kernel, dim3(n), dim3(64), 0, search_stream, A);
     RNA_HIP(e, hipGetLastError());
   }

@@ -59,7 +59,7 @@ struct VfhDevice {
 struct AstarDevice {
   int max_queries = 0;
   int queue_cap = 0;
-  int bucket_width = 24000;         // f-range relaxed together (24 cells): 57.6 / 63.2 / 66.9 / 67.6 / 68.1 / 67.6 / 60.3 k cycles/s at 8000 / 12000 / 16000 / 20000 / 24000 / 32000 / 48000
+  int bucket_width = 96000;         // f-range of one bucket (96 cells); inside it free wavefronts take the tile with the lowest key (astar_tile.hip)
   int threads = 512;               // workgroup size of the search kernel (256 / 512 / 1024)
   // Pipelined batches: `depth` independent sets of search fields + queues, each with its own HIP
   // stream, so the tail of batch k (few long queries) overlaps the head of batch k+1.
