@@ -25,7 +25,10 @@
 extern "C" {
 #endif
 
-#define RNA_ABI_VERSION 1
+/* 2: rna_laser_scan carries the end pose (80 bytes), rna_astar_result.expanded / .rounds changed meaning (cells written,
+ *    tile jobs per wavefront), statuses 4 / 5, profile slot astar_reset, default bucket width 96000.  A host checks
+ *    rna_abi_version() == RNA_ABI_VERSION after loading the library (capi.py and move_control_amd.hpp do). */
+#define RNA_ABI_VERSION 2
 
 typedef enum {
   RNA_OK = 0,
@@ -352,9 +355,10 @@ int rna_follow_plan(const double* plan_xy, int n, int32_t* plan_index, double x,
 /* ---- measurement ------------------------------------------------------------------------------ */
 typedef enum {
   RNA_K_HIMM_PREP = 0, RNA_K_HIMM_RASTER, RNA_K_HIMM_APPLY, RNA_K_COMPOSE, RNA_K_NBRMASK,
-  RNA_K_VFH_STEP, RNA_K_ASTAR_SEARCH, RNA_K_ASTAR_INIT, RNA_K_RRT, RNA_K_OCCUPANCY, RNA_K_COUNT
+  RNA_K_VFH_STEP, RNA_K_ASTAR_SEARCH, RNA_K_ASTAR_INIT, RNA_K_RRT, RNA_K_OCCUPANCY, RNA_K_ASTAR_RESET, RNA_K_COUNT
 } rna_kernel_id;
-/* when enabled, every launch of the kernels above is bracketed by hipEvents on the engine stream */
+/* when enabled, every launch of the kernels above is bracketed by hipEvents on the stream it runs on (the engine
+ * stream; astar_search and astar_reset: the pipeline stage's own stream) */
 int rna_profile_enable(rna_engine* e, int on);
 int rna_profile_reset(rna_engine* e);
 int rna_profile_get(rna_engine* e, int kernel_id, double* total_ms, int64_t* launches);

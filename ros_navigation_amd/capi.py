@@ -14,11 +14,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("RNA_LIB") or "librna.so")   # RNA_LIB: developer switch to an alternative build
 
 RNA_OK = 0
+ABI_VERSION = 2   # include/rna.h: RNA_ABI_VERSION
 STATUS = {0: "RNA_OK", -1: "RNA_EINVAL", -2: "RNA_ENOMEM", -3: "RNA_EHIP", -4: "RNA_ECAPACITY",
           -5: "RNA_ESTATE", -6: "RNA_ENODEVICE"}
 LAYER_MASTER, LAYER_LASER, LAYER_RANGE = 0, 1, 2
 KERNELS = ["himm_prep", "himm_raster", "himm_apply", "compose_master", "nbr_mask", "vfh_step",
-           "astar_search", "astar_init", "rrt", "to_occupancy_grid"]
+           "astar_search", "astar_init", "rrt", "to_occupancy_grid", "astar_reset"]
 
 # every symbol include/rna.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [
@@ -107,6 +108,10 @@ def lib():
     except ImportError:
         pass
     L = C.CDLL(LIB_PATH)
+    L.rna_abi_version.restype = C.c_int
+    if L.rna_abi_version() != ABI_VERSION:
+        raise RnaError("librna.so has ABI version %d, these bindings were written for %d: rebuild (make -C ros_navigation_amd/csrc)"
+                       % (L.rna_abi_version(), ABI_VERSION))
     vp = C.c_void_p
     L.rna_create.argtypes = [C.POINTER(vp), C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]
     L.rna_destroy.argtypes = [vp]

@@ -55,10 +55,6 @@ constexpr int MASK_STRIDE = TILE_WORDS + 32;  // snapshot bytes per tile: lane-m
 #endif
 constexpr int TSA_WAVES = RNA_TSA_WAVES;
 constexpr int TSA_MAX_TILE_WORDS = 2048;   // active-tile bitset words -> up to 65536 tiles
-#ifndef RNA_TSA_JOBS
-#define RNA_TSA_JOBS 2048
-#endif
-constexpr int TSA_JOBS = RNA_TSA_JOBS;     // tile jobs per round (more stay flagged for the next round)
 constexpr int COST_S = 1000, COST_D = 1414;
 constexpr int INF = 0x7fffffff;
 constexpr int KU = 0x40000000;             // field word u = KU - g; 0 = unreached
@@ -196,23 +192,21 @@ __global__ void __launch_bounds__(256) tsa_reset_kernel(TsaStage S, int ntile) {
     if (threadIdx.x == 0) S.tmap[(size_t)q * ntile + S.owner[(size_t)q * (S.cap + 1) + p]] = 0u;
   }
 }
-__global__ void tsa_reset_done_kernel(TsaStage S, int max_queries) {
+// (after the reset) page counters and the ticket back to zero; then the launch order of the batch, see below.
+// One small workgroup: it has to fit next to the search workgroups that fill every CU when batches are pipelined.
+__global__ void __launch_bounds__(256) tsa_prepare_kernel(TsaStage S, int max_queries, const rna_astar_query* __restrict__ queries, int n,
+                                                          int rows, int cols, int ranked) {
+  extern __shared__ int s_key[];
   for (int q = threadIdx.x; q < max_queries; q += blockDim.x) S.nalloc[q] = 0;
   if (threadIdx.x == 0) *S.ticket = 0;
-}
-// fresh allocation: every page "unreached"
-__global__ void tsa_fill_pages_kernel(uint4* __restrict__ p, size_t n4) {
-  const size_t step = (size_t)gridDim.x * blockDim.x;
-  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < n4; w += step) p[w] = make_uint4(0u, 0u, 0u, 0u);
-}
-
-// Launch order of a batch: longest expected search first (key = Chebyshev distance start -> goal,
-// ties by index).  Workgroups are dispatched in index order and land on the XCDs round-robin, so this
-// both starts the long queries early and deals them evenly over the eight XCDs; with the caller's
-// (arbitrary) order one XCD regularly ended up with most of the long searches (+11 % throughput).
-__global__ void __launch_bounds__(256) tsa_order_kernel(const rna_astar_query* __restrict__ queries, int n, int rows, int cols,
-                                                          int* __restrict__ perm) {
-  extern __shared__ int s_key[];
+  if (!ranked) {   // the ranking is O(n^2 / 256) per thread: large batches keep the caller's order
+    for (int i = threadIdx.x; i < n; i += blockDim.x) S.perm[i] = i;
+    return;
+  }
+  // Launch order of a batch: longest expected search first (key = Chebyshev distance start -> goal,
+  // ties by index).  Workgroups are dispatched in index order and land on the XCDs round-robin, so this
+  // both starts the long queries early and deals them evenly over the eight XCDs; with the caller's
+  // (arbitrary) order one XCD regularly ended up with most of the long searches (+11 % throughput).
   const int ncell = rows * cols;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const rna_astar_query q = queries[i];
@@ -232,12 +226,13 @@ __global__ void __launch_bounds__(256) tsa_order_kernel(const rna_astar_query* _
       const int kj = s_key[j];
       rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0;
     }
-    perm[rank] = i;
+    S.perm[rank] = i;
   }
 }
-__global__ void tsa_identity_order_kernel(int n, int* __restrict__ perm) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) perm[i] = i;
+// fresh allocation: every page "unreached"
+__global__ void tsa_fill_pages_kernel(uint4* __restrict__ p, size_t n4) {
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < n4; w += step) p[w] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 #ifdef RNA_TSA_STATS
@@ -279,7 +274,7 @@ struct TsaCtx {
 // act_far(tile) (run the tile in the next round / when the next bucket opens), pool_exhausted().  `pg` is the tile's
 // local page (0: none yet -- it is all "unreached"); `first`: the tile's first job in this bucket (cells that were
 // held back by the previous bucket's bound may now pass their values on, so every row is evaluated and unchanged edge
-// cells inside the new band wake the neighbours too).  Returns the number of row evaluations.
+// cells inside the new band wake the neighbours too).  Returns the number of rows it wrote.
 //
 // The 16 rows are 2 x 16 NAMED scalars (g0..g15: the field, pp0..pp15: what a cell may pass on in this bucket) and
 // every per-row step is a macro pasted 16 times: with `int g[16]` and unrolled loops the optimiser turns the rows into
@@ -347,6 +342,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   const int ti = t % tiles_i, tj = t / tiles_i;
   const int i0 = ti * TI, j0 = tj * TJ;
   TSA_T(t_a);
+  asm volatile("; TSA_MARK job_begin");
   // ---- 1. page table look-up of the eight neighbouring tiles (lane k < 8: direction k; 0 = none or outside) and of
   //         the tile itself (lane 8) ----
   unsigned nb_pg = 0u;
@@ -384,6 +380,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     if (xl <= TJ + 1) X = (int)ld_l2(&C.paux[C.gpage(pgX) * AUX_WORDS + (xr ? 0 : 16) + xrow]);   // a left tile's column 63 / a right tile's column 0
     if (xcell) eb = C.nbr_tm[(size_t)t * MASK_STRIDE + TILE_WORDS + (xr ? 16 : 0) + xl - 1];
   }
+  asm volatile("; TSA_MARK loads_issued");
   // ---- 3. this bucket's bound; which cells are free ----
   // A blocked (or outside) cell keeps u = 0 for ever: every candidate is ANDed with the cell's free bit, and an
   // "unreached" cell never passes anything on.  The heuristic of a row is recomputed where it is needed (one scalar
@@ -400,19 +397,23 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
 #define TSA_FB(b) fbits |= (((TSA_MKW(b) >> (8 * ((b) & 3))) & 0xffu) != 0u) ? 1u << (b) : 0u;
   TSA_R16(TSA_FB)
 #undef TSA_FB
+  asm volatile("; TSA_MARK halo_begin");
   // ---- 4. what the halo can contribute (once: it does not change during the job) ----
-  unsigned hz = 0u, fa = 0u, fb = 0u;   // per row: own row changed / the row above changed / the row below changed since
-  unsigned rowchg = 0u;                 // the row's last evaluation;  rows that changed at all in this job
-  unsigned long long q0 = 0ull, q15 = 0ull, qany = 0ull;   // cells of row 0 / row 15 / any row that changed and may pass their value on
+  // rows to evaluate in the next down / up sweep: a row is evaluated from above when the row above it changed (or it
+  // took something from the halo itself), from below when the row below it changed.  An evaluation leaves the row at
+  // the fixed point of its own horizontal steps (the passes along the row run until nothing moves, see TSA_ROW), so a
+  // row never has to be looked at again for its own sake.
+  unsigned nd = 0u, nu = 0u;
+  unsigned rowchg = 0u;                 // rows that changed at all in this job
+  unsigned long long q0 = 0ull, q15 = 0ull, qany = 0ull;   // cells of row 0 / row 15 that changed and may pass their value on; lanes that changed in any row
   int pp0, pp1, pp2, pp3, pp4, pp5, pp6, pp7, pp8, pp9, pp10, pp11, pp12, pp13, pp14, pp15;
-  // a row took better values in the lanes `up`: flag it and the rows next to it, remember which cells wake neighbours
+  // a row took better values in the lanes `up`: flag the rows next to it, remember which cells wake neighbours
 #define TSA_ROW_CHANGED(b, up)                                                                                   \
   {                                                                                                              \
-    hz |= 1u << (b); fa |= (2u << (b)) & 0xffffu; fb |= (1u << (b)) >> 1; rowchg |= 1u << (b);                    \
-    const unsigned long long wq_ = (up) & __builtin_amdgcn_ballot_w64(TSA_PP(b) != 0);                           \
-    qany |= wq_;                                                                                                 \
-    if ((b) == 0) q0 |= wq_;                                                                                     \
-    if ((b) == TJ - 1) q15 |= wq_;                                                                               \
+    nd |= (2u << (b)) & 0xffffu; nu |= (1u << (b)) >> 1; rowchg |= 1u << (b);                                     \
+    qany |= (up);                                                                                                \
+    if ((b) == 0) q0 |= (up) & __builtin_amdgcn_ballot_w64(TSA_PP(b) != 0);                                      \
+    if ((b) == TJ - 1) q15 |= (up) & __builtin_amdgcn_ballot_w64(TSA_PP(b) != 0);                                \
   }
   {
     int cT, cB;
@@ -463,78 +464,88 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     if (up) TSA_G(b) = __builtin_amdgcn_inverse_ballot_w64(up) ? cand : TSA_G(b);                                \
     TSA_PP(b) = tsa_prop(TSA_G(b), TSA_H(b), thr);                                                               \
     if ((planted >> (b)) & 1u) up |= 1ull << C.sa;                                                               \
-    if (up) TSA_ROW_CHANGED(b, up)                                                                               \
+    if (up) { nd |= 1u << (b); TSA_ROW_CHANGED(b, up) }   /* (its own horizontal steps: evaluated in the first sweep) */ \
   }
     TSA_R16(TSA_APPLY)
 #undef TSA_APPLY
     __builtin_amdgcn_wave_barrier();
   }
-  if (first) hz = fa = fb = 0xffffu;
+  asm volatile("; TSA_MARK halo_end");
+  if (first) nd = nu = 0xffffu;
   TSA_T(t_b);
   TSA_ACC(0, t_a, t_b);
-  if (!(hz | fa | fb)) { TSA_CNT(10, 1); return 0; }   // the activation that woke this tile brought nothing better
+  if (!(nd | nu)) { TSA_CNT(10, 1); return 0; }   // the wake-up brought nothing better
   // ---- 5. sweeps ----
-  int evals = 0;
-  [[maybe_unused]] int hpass = 0;
+#ifdef RNA_TSA_STATS
+  int evals = 0, hpass = 0;
+#define TSA_STAT_INC(v) v += 1
+#else
+#define TSA_STAT_INC(v)
+#endif
   // the (negative) step costs live in VGPRs: v_add_u32 with a DPP source cannot take a literal, and only then does the
   // wave shift fold into the add (one instruction instead of v_mov_dpp + v_add)
   int nS = -COST_S, nD = -COST_D;
   asm volatile("" : "+v"(nS), "+v"(nD));
   // one row: VERT = the best of the three candidates from the row before it in sweep direction (0 for the first row),
-  // then the two from the row's own neighbours; improved lanes take the candidate
+  // then the two from the row's own neighbours; improved lanes take the candidate (a plain max: the others' is not
+  // better than what they hold).  A row that changed runs on along itself until nothing moves (a front that travels
+  // along the lanes would otherwise advance one cell per sweep) -- at most RNA_TSA_HPASS passes, then the row is
+  // flagged for the next sweep (AGAIN).  The loop body is 8 vector and 3 scalar instructions per pass: the row's free
+  // mask and its pass-on threshold h + thr are formed once per evaluation.
 #define TSA_VERT(b, src, kA, kC)                                                                                                   \
   max3i(TSA_PP(src) + nS, (lane_m1(TSA_PP(src)) + nD) & TSA_OPEN(TSA_MKW(b), 8 * ((b) & 3) + (kA)),                                \
         (lane_p1(TSA_PP(src)) + nD) & TSA_OPEN(TSA_MKW(b), 8 * ((b) & 3) + (kC)))
-#define TSA_ROW(b, VERT)                                                                                         \
+#define TSA_ROW(b, VERT, AGAIN, LBL)                                                                                \
   {                                                                                                              \
-    evals += 1;                                                                                                  \
+    TSA_STAT_INC(evals);                                                                                         \
+    const int open_ = TSA_OPEN(fbits, b);                                                                        \
     int m_ = VERT;                                                                                               \
-    m_ = max3i(m_, lane_m1(TSA_PP(b)) + nS, lane_p1(TSA_PP(b)) + nS);                                            \
-    m_ &= TSA_OPEN(fbits, b);                                                                                    \
-    const unsigned long long up_ = __builtin_amdgcn_ballot_w64(m_ > TSA_G(b));                                   \
+    m_ = max3i(m_, lane_m1(TSA_PP(b)) + nS, lane_p1(TSA_PP(b)) + nS) & open_;                                    \
+    unsigned long long up_ = __builtin_amdgcn_ballot_w64(m_ > TSA_G(b));                                         \
     if (up_) {                                                                                                   \
-      const int h_ = TSA_H(b);                                                                                   \
-      TSA_G(b) = __builtin_amdgcn_inverse_ballot_w64(up_) ? m_ : TSA_G(b);                                       \
-      TSA_PP(b) = tsa_prop(TSA_G(b), h_, thr);                                                                   \
-      unsigned long long all_ = up_;                                                                             \
-      /* a row that changed runs on along itself right away (a front that moves along the lanes would otherwise   \
-         advance one cell per sweep): sim_dense2.c, 54 -> 21 row evaluations per job for 23 of these short passes */ \
-      for (int e_ = 0; e_ < RNA_TSA_HPASS; ++e_) {                                                               \
-        const int m2_ = max(lane_m1(TSA_PP(b)) + nS, lane_p1(TSA_PP(b)) + nS) & TSA_OPEN(fbits, b);              \
+      const int ht_ = TSA_H(b) + thr;   /* passes on iff u - h >= thr */                                         \
+      TSA_G(b) = max(TSA_G(b), m_);                                                                              \
+      TSA_PP(b) = TSA_G(b) >= ht_ ? TSA_G(b) : 0;                                                                \
+      int left_ = RNA_TSA_HPASS;                                                                                 \
+      for (;;) {                                                                                                 \
+        const int m2_ = (max(lane_m1(TSA_PP(b)), lane_p1(TSA_PP(b))) + nS) & open_;                              \
         const unsigned long long up2_ = __builtin_amdgcn_ballot_w64(m2_ > TSA_G(b));                             \
         if (!up2_) break;                                                                                        \
-        TSA_G(b) = __builtin_amdgcn_inverse_ballot_w64(up2_) ? m2_ : TSA_G(b);                                   \
-        TSA_PP(b) = tsa_prop(TSA_G(b), h_, thr);                                                                 \
-        all_ |= up2_;                                                                                            \
-        hpass += 1;                                                                                              \
+        TSA_STAT_INC(hpass);                                                                                     \
+        TSA_G(b) = max(TSA_G(b), m2_);                                                                           \
+        TSA_PP(b) = TSA_G(b) >= ht_ ? TSA_G(b) : 0;                                                              \
+        up_ |= up2_;                                                                                             \
+        if (--left_ == 0) { AGAIN; break; }                                                                      \
       }                                                                                                          \
-      TSA_ROW_CHANGED(b, all_)                                                                                   \
+      TSA_ROW_CHANGED(b, up_)                                                                                    \
     }                                                                                                            \
   }
-#define TSA_DOWN(b) if (((fa | hz) >> (b)) & 1u) { fa &= ~(1u << (b)); hz &= ~(1u << (b)); TSA_ROW(b, TSA_VERT(b, TSA_CAT(TSA_DEC_, b), 0, 2)) }
-#define TSA_UP(b) if (((fb | hz) >> (b)) & 1u) { fb &= ~(1u << (b)); hz &= ~(1u << (b)); TSA_ROW(b, TSA_VERT(b, TSA_CAT(TSA_INC_, b), 5, 7)) }
+#define TSA_DOWN(b) if ((nd >> (b)) & 1u) { nd &= ~(1u << (b)); TSA_ROW(b, TSA_VERT(b, TSA_CAT(TSA_DEC_, b), 0, 2), nu |= 1u << (b), d) }
+#define TSA_UP(b) if ((nu >> (b)) & 1u) { nu &= ~(1u << (b)); TSA_ROW(b, TSA_VERT(b, TSA_CAT(TSA_INC_, b), 5, 7), nd |= 1u << (b), u) }
   for (;;) {
-    if ((fa | hz) != 0u) {
-      if ((fa | hz) & 1u) { fa &= ~1u; hz &= ~1u; TSA_ROW(0, 0) }
+    if (nd != 0u) {
+      if (nd & 1u) { nd &= ~1u; TSA_ROW(0, 0, nu |= 1u, d) }
       TSA_DOWN(1) TSA_DOWN(2) TSA_DOWN(3) TSA_DOWN(4) TSA_DOWN(5) TSA_DOWN(6) TSA_DOWN(7) TSA_DOWN(8)
       TSA_DOWN(9) TSA_DOWN(10) TSA_DOWN(11) TSA_DOWN(12) TSA_DOWN(13) TSA_DOWN(14) TSA_DOWN(15)
     }
-    if (!(hz | fa | fb)) break;
-    if ((fb | hz) != 0u) {
-      if (((fb | hz) >> 15) & 1u) { fb &= ~(1u << 15); hz &= ~(1u << 15); TSA_ROW(15, 0) }
+    if (!(nd | nu)) break;
+    if (nu != 0u) {
+      if ((nu >> 15) & 1u) { nu &= ~(1u << 15); TSA_ROW(15, 0, nd |= 1u << 15, u) }
       TSA_UP(14) TSA_UP(13) TSA_UP(12) TSA_UP(11) TSA_UP(10) TSA_UP(9) TSA_UP(8) TSA_UP(7)
       TSA_UP(6) TSA_UP(5) TSA_UP(4) TSA_UP(3) TSA_UP(2) TSA_UP(1) TSA_UP(0)
     }
-    if (!(hz | fa | fb)) break;
+    if (!(nd | nu)) break;
   }
 #undef TSA_DOWN
 #undef TSA_UP
 #undef TSA_ROW
 #undef TSA_VERT
+#undef TSA_STAT_INC
   TSA_T(t_c);
   TSA_ACC(1, t_b, t_c);
   TSA_CNT(8, evals);
   TSA_CNT(11, hpass);
+  asm volatile("; TSA_MARK results_begin");
   // ---- 6. results: rows that changed, the edge-column copies, the goal ----
   asm volatile("" : "+v"(lane));
   if (rowchg) {
@@ -546,7 +557,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
         else { C.owner[p] = (unsigned)t; __hip_atomic_store(&C.tmap[t], (unsigned)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       }
       pg = (unsigned)__builtin_amdgcn_readfirstlane(p);
-      if (pg == 0u) return evals;
+      if (pg == 0u) return 0;
     }
     unsigned* own = C.pages + (C.gpage(pg) << 10);
     unsigned* ax = C.paux + C.gpage(pg) * AUX_WORDS + (lane ? 16 : 0);
@@ -571,6 +582,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
 #undef TSA_GOAL
     }
   }
+  asm volatile("; TSA_MARK wake_begin");
   // ---- 7. who has to run: neighbours whose halo got better (or may pass on now), this tile again in a later bucket ----
   {
     // (a) this tile again when the next bucket opens: it holds reached cells beyond this bucket's bound that may still
@@ -681,9 +693,10 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   }
 #undef TSA_ROW_CHANGED
 #undef TSA_H
+  asm volatile("; TSA_MARK job_end");
   TSA_T(t_d);
   TSA_ACC(2, t_c, t_d);
-  return evals;
+  return __builtin_popcount(rowchg);   // rows written
 }
 
 // ---- scheduler of the one-workgroup-per-query kernel: an open list of tiles in LDS ----
@@ -1040,7 +1053,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     __syncthreads();
     if (s_state != 0) break;
   }
-  if (lane == 0) { atomicAdd(&s_expanded, my_evals * TI); atomicAdd(&s_jobs_done, my_jobs); }   // dense cell updates
+  if (lane == 0) { atomicAdd(&s_expanded, my_evals * TI); atomicAdd(&s_jobs_done, my_jobs); }   // cells written
   __syncthreads();
 #ifdef RNA_TSA_STATS
   tsa_acc[5] = wall_clock64() - t_life0;   // wave lifetime inside the search loop
@@ -1236,22 +1249,25 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
   const int ti = (rows + TI - 1) / TI, tj = (cols + TJ - 1) / TJ;
   const TsaStage S = tsa_stage_view(e, slot);
   {
-    // snapshot the neighbour masks and bring the pages the last search on this stage used back to "unreached"
+    // snapshot of the neighbour masks: on the engine stream, before the next map update can change them
     KernelTimer kt(e, RNA_K_ASTAR_INIT, init_stream);
     hipLaunchKernelGGL(tsa_snapshot_kernel, dim3(std::min(ti * tj, 4096)), dim3(256), 0, init_stream, e->nbr, rows, cols, ti, tj, S.nbr_tm,
                        e->geom.start[0], e->geom.start[1]);
-    hipLaunchKernelGGL(tsa_reset_kernel, dim3(128, a.max_queries), dim3(256), 0, init_stream, S, ti * tj);   // ~5 pages per block at 4096^2
-    hipLaunchKernelGGL(tsa_reset_done_kernel, dim3(1), dim3(256), 0, init_stream, S, a.max_queries);
-    if (n <= 2048)   // the ranking is O(n^2 / 256) per thread: beyond this the caller order is kept
-      // one small workgroup: it has to fit next to the search workgroups that fill every CU when batches are pipelined
-      hipLaunchKernelGGL(tsa_order_kernel, dim3(1), dim3(256), (size_t)n * sizeof(int), init_stream, q_dev, n, rows, cols, S.perm);
-    else
-      hipLaunchKernelGGL(tsa_identity_order_kernel, dim3((n + 255) / 256), dim3(256), 0, init_stream, n, S.perm);
     RNA_HIP(e, hipGetLastError());
   }
   if (ev_init) {
     RNA_HIP(e, hipEventRecord(ev_init, init_stream));
     RNA_HIP(e, hipStreamWaitEvent(search_stream, ev_init, 0));
+  }
+  {
+    // the pages the last search on this stage used back to "unreached", counters, launch order: the stage's own data,
+    // on the stage's own stream (the engine stream's chain of short kernels is what gates the next batch)
+    KernelTimer kt(e, RNA_K_ASTAR_RESET, search_stream);
+    hipLaunchKernelGGL(tsa_reset_kernel, dim3(128, a.max_queries), dim3(256), 0, search_stream, S, ti * tj);   // ~5 pages per block at 4096^2
+    const int ranked = n <= 2048 ? 1 : 0;
+    hipLaunchKernelGGL(tsa_prepare_kernel, dim3(1), dim3(256), ranked ? (size_t)n * sizeof(int) : 0, search_stream, S, a.max_queries, q_dev, n,
+                       rows, cols, ranked);
+    RNA_HIP(e, hipGetLastError());
   }
   {
     KernelTimer kt(e, RNA_K_ASTAR_SEARCH, search_stream);
@@ -1260,8 +1276,10 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     A.rows = rows; A.cols = cols; A.tiles_i = ti; A.tiles_j = tj; A.s0 = e->geom.start[0]; A.s1 = e->geom.start[1];
     A.queries = q_dev; A.S = S; A.bucket_width = a.bucket_width; A.paths = paths_dev; A.max_path_len = max_len;
     A.rev_all = a.rev[slot]; A.rev_cap = a.rev_cap; A.results = res_dev;
-    if (a.depth > 1) hipLaunchKernelGGL(tsa_search_kernel<TSA_WAVES>, dim3(n), dim3(TSA_WAVES * 64), 4 * nt_bytes, search_stream, A);
-    else hipLaunchKernelGGL(tsa_search_kernel<16>, dim3(n), dim3(16 * 64), 4 * nt_bytes, search_stream, A);
+    size_t lds_dyn = 4 * nt_bytes;
+    if (const char* pad = getenv("RNA_TSA_LDS_PAD")) lds_dyn += (size_t)atoi(pad);   // developer knob: fewer search workgroups per CU
+    if (a.depth > 1) hipLaunchKernelGGL(tsa_search_kernel<TSA_WAVES>, dim3(n), dim3(TSA_WAVES * 64), lds_dyn, search_stream, A);
+    else hipLaunchKernelGGL(tsa_search_kernel<16>, dim3(n), dim3(16 * 64), lds_dyn, search_stream, A);
     hipLaunchKernelGGL(tsa_backtrace_kernel, dim3(n), dim3(64), 0, search_stream, A);
     RNA_HIP(e, hipGetLastError());
   }

@@ -201,7 +201,7 @@ extern "C" const char* rna_last_error(const rna_engine* e) { return e ? e->err.c
 
 extern "C" const char* rna_kernel_name(int id) {
   static const char* names[RNA_K_COUNT] = {"himm_prep", "himm_raster", "himm_apply", "compose_master", "nbr_mask",
-                                           "vfh_step", "astar_search", "astar_init", "rrt", "to_occupancy_grid"};
+                                           "vfh_step", "astar_search", "astar_init", "rrt", "to_occupancy_grid", "astar_reset"};
   return (id >= 0 && id < RNA_K_COUNT) ? names[id] : "?";
 }
 

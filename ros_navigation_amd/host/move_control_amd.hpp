@@ -131,6 +131,7 @@ class GridMap {
   // GridMap::setGeometry (gmc/src/GridMap.cpp:51-70)
   void setGeometry(const Length& length, double resolution, const Position& position = Position(0.0, 0.0), int device = 0) {
     if (e_) { rna_destroy(e_); e_ = nullptr; }
+    if (rna_abi_version() != RNA_ABI_VERSION) throw std::runtime_error("librna.so was built from another include/rna.h (ABI version)");
     int rc = rna_create(&e_, length[0], length[1], resolution, position[0], position[1], device);
     if (rc != RNA_OK) throw std::runtime_error("GridMap::setGeometry: rna_create failed (no MI355X / bad geometry)");
   }

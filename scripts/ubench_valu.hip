@@ -33,6 +33,15 @@
 // VALU with a scalar instruction after each (the sweeps' flag algebra): does the SALU take VALU issue slots of the same wave?
 #define VS(r) "v_max_i32 %" #r ", %" #r ", %16\ns_add_u32 s40, s40, 1\n"
 #define BODY_VS VS(0) VS(1) VS(2) VS(3) VS(4) VS(5) VS(6) VS(7) VS(8) VS(9) VS(10) VS(11) VS(12) VS(13) VS(14) VS(15)
+// scalar only: four independent chains (the scalar unit is shared by the four SIMDs of a CU)
+#define SS4 "s_add_u32 s40, s40, 1\ns_add_u32 s41, s41, 1\ns_add_u32 s42, s42, 1\ns_add_u32 s43, s43, 1\n"
+#define BODY_S SS4 SS4 SS4 SS4
+// 64-bit lane-mask algebra as in the sweeps
+#define SB4 "s_or_b64 s[40:41], s[40:41], s[44:45]\ns_and_b64 s[42:43], s[42:43], s[46:47]\ns_or_b64 s[48:49], s[48:49], s[44:45]\ns_andn2_b64 s[50:51], s[50:51], s[46:47]\n"
+#define BODY_SB SB4 SB4 SB4 SB4
+// one VALU per three SALU
+#define V3S(r) "v_max_i32 %" #r ", %" #r ", %16\ns_add_u32 s40, s40, 1\ns_add_u32 s41, s41, 1\ns_add_u32 s42, s42, 1\n"
+#define BODY_V3S V3S(0) V3S(1) V3S(2) V3S(3)
 
 #define KERNEL(name, BODY, PER_ITER)                                                                                  \
   __global__ void __launch_bounds__(256) name(int iters, int* sink, long long* cyc) {                                   \
@@ -47,7 +56,7 @@
                    : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "+v"(r8), "+v"(r9), \
                      "+v"(r10), "+v"(r11), "+v"(r12), "+v"(r13), "+v"(r14), "+v"(r15)                                   \
                    : "v"(a), "v"(b), "s"(s)                                                                             \
-                   : "vcc", "scc", "s40");                                                                                            \
+                   : "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51");                                                                                            \
     }                                                                                                                   \
     const long long t1 = __builtin_amdgcn_s_memtime();                                                                  \
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;                    \
@@ -64,6 +73,9 @@ KERNEL(k_bfe, BODY_BFE, 64)
 KERNEL(k_cmpsel, BODY_CMPSEL, 64)   // 8 x (cmp + cndmask) x 4 = 64 VALU
 KERNEL(k_mullo, BODY_MULLO, 64)
 KERNEL(k_vs, BODY_VS, 64)           // 64 VALU + 64 SALU
+KERNEL(k_s, BODY_S, 64)             // 64 SALU
+KERNEL(k_sb, BODY_SB, 64)           // 64 SALU (64-bit)
+KERNEL(k_v3s, BODY_V3S, 64)         // 16 VALU + 48 SALU
 
 template <class K>
 static void run(const char* what, K kernel, int per_iter, int waves_per_simd, int* sink, long long* cyc, double extra_salu = 0.0) {
@@ -85,7 +97,7 @@ static void run(const char* what, K kernel, int per_iter, int waves_per_simd, in
   const double med = (double)h[h.size() / 2];
   const double instr = (double)iters * per_iter;
   // s_memtime counts at a fixed 100 MHz on some parts and at the shader clock on others: report both readings
-  printf("%-34s W=%d  per wave: %.0f ticks for %.0f VALU  ->  SIMD rate %.3f VALU/tick (x W)  | wall %.3f ms -> %.3f VALU/ns/SIMD%s\n", what,
+  printf("%-34s W=%d  per wave: %.0f ticks for %.0f instr  ->  SIMD rate %.3f instr/tick (x W)  | wall %.3f ms -> %.3f instr/ns/SIMD%s\n", what,
          waves_per_simd, med, instr, waves_per_simd * instr / med, ms, (double)blocks * 4 * instr / (ms * 1e6) / (256.0 * 4.0),
          extra_salu > 0 ? "  (+ as many SALU)" : "");
   hipEventDestroy(e0);
@@ -108,7 +120,10 @@ int main() {
     run("v_bfe_i32", k_bfe, k_bfe_per_iter, w, sink, cyc);
     run("v_cmp + v_cndmask", k_cmpsel, k_cmpsel_per_iter, w, sink, cyc);
     run("v_mul_lo_u32", k_mullo, k_mullo_per_iter, w, sink, cyc);
-    run("v_max_i32 ; s_add_u32 alternating", k_vs, k_vs_per_iter, w, sink, cyc, 1.0);
+    run("v_max_i32 ; s_add_u32 alternating (instr = 64 VALU + 64 SALU)", k_vs, k_vs_per_iter, w, sink, cyc, 1.0);
+    run("s_add_u32 only (instr = SALU)", k_s, k_s_per_iter, w, sink, cyc);
+    run("s_or/and_b64 only (instr = SALU)", k_sb, k_sb_per_iter, w, sink, cyc);
+    run("1 v_max : 3 s_add (instr = all 64)", k_v3s, k_v3s_per_iter, w, sink, cyc);
   }
   return 0;
 }

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(capi):
     for s in syms:
         assert hasattr(L, s), "librna.so does not export %s" % s
     assert sorted(capi.SYMBOLS) == syms
-    assert L.rna_abi_version() == 1
+    assert L.rna_abi_version() == capi.ABI_VERSION == int(re.search(r"#define RNA_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "rna.h")).read()).group(1))
 
 
 def test_struct_layouts_match_header(capi):
