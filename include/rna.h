@@ -359,6 +359,8 @@ typedef enum {
 } rna_kernel_id;
 /* when enabled, every launch of the kernels above is bracketed by hipEvents on the stream it runs on (the engine
  * stream; astar_search and astar_reset: the pipeline stage's own stream) */
+/* on: 0 off, 1 every slot, 2 only astar_search / astar_reset (an event record is a packet of its own on the stream:
+ * bracketing the ten slots of the engine stream costs its chain of short kernels about 1 ms per replan pass) */
 int rna_profile_enable(rna_engine* e, int on);
 int rna_profile_reset(rna_engine* e);
 int rna_profile_get(rna_engine* e, int kernel_id, double* total_ms, int64_t* launches);

@@ -611,7 +611,8 @@ class Engine:
         return x, y, yb, (int(th[0]), int(th[1]))
 
     def profile(self, on=True):
-        self._check(self._L.rna_profile_enable(self.h, 1 if on else 0))
+        """True / 1: every kernel slot, 2: only the slots on the A* stages' own streams, False / 0: off"""
+        self._check(self._L.rna_profile_enable(self.h, int(on)))
 
     def profile_reset(self):
         self._check(self._L.rna_profile_reset(self.h))

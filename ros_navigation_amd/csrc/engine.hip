@@ -235,7 +235,18 @@ extern "C" int rna_create(rna_engine** out, double length_x, double length_y, do
     int prio_lo = 0, prio_hi = 0;   // numerically lower = higher priority
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (getenv("RNA_NO_STREAM_PRIORITY")) prio_lo = prio_hi = 0;
-    if (hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return bail(RNA_EHIP);
+    // developer knob RNA_ENGINE_CU_MASK=n: the engine stream may only use the first n CUs of the mask order (the CUs
+    // the pipelined search streams leave free, astar.hip) -- its short kernels then never land next to search
+    // workgroups on a CU whose issue slots they fill
+    int only = 0;
+    if (const char* m = getenv("RNA_ENGINE_CU_MASK")) only = atoi(m);
+    hipDeviceProp_t prop;
+    if (only > 0 && hipGetDeviceProperties(&prop, device_id) == hipSuccess && only < prop.multiProcessorCount) {
+      uint32_t mask[16] = {};
+      for (int c = 0; c < only && c < 512; ++c) mask[c >> 5] |= 1u << (c & 31);
+      const int words = (prop.multiProcessorCount + 31) / 32 < 16 ? (prop.multiProcessorCount + 31) / 32 : 16;
+      if (hipExtStreamCreateWithCUMask(&e->stream, (uint32_t)words, mask) != hipSuccess) return bail(RNA_EHIP);
+    } else if (hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return bail(RNA_EHIP);
   }
   for (int l = 0; l < RNA_NUM_LAYERS; ++l) {
     if ((rc = dev_alloc(e, &e->layer[l], e->ncell)) != RNA_OK) return bail(rc);
@@ -735,7 +746,7 @@ extern "C" int rna_move(rna_engine* e, double nx, double ny, int* moved) {
 
 extern "C" int rna_profile_enable(rna_engine* e, int on) {
   if (!e) return RNA_EINVAL;
-  e->profiling = on != 0;
+  e->profiling = on < 0 ? 0 : (on > 2 ? 1 : on);
   return RNA_OK;
 }
 

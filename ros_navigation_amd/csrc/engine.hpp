@@ -117,7 +117,7 @@ struct rna_engine {
   rna::HimmScratch himm;
   rna::VfhDevice vfh;
   rna::AstarDevice astar;
-  bool profiling = false;
+  int profiling = 0;                // 0 off, 1 every kernel slot, 2 only the slots of the A* pipeline stages' own streams
   rna::ProfSlot prof[RNA_K_COUNT];
   std::vector<hipEvent_t> free_events;   // recycled hipEvents of the profiler
   size_t pending_events = 0;
@@ -155,14 +155,17 @@ struct KernelTimer {
   }
   hipStream_t st;
   KernelTimer(rna_engine* eng, int kid, hipStream_t stream = nullptr) : e(eng), id(kid), st(stream ? stream : eng->stream) {
-    if (!e->profiling) return;
+    if (!wanted()) return;
     if (e->pending_events > 16384) (void)profile_flush(e);
     a = take(e);
     b = take(e);
     if (a) (void)hipEventRecord(a, st);
   }
+  // mode 2: only what runs on a pipeline stage's own stream.  An event record is a barrier packet of its own: on the
+  // engine stream, whose chain of short kernels gates the next batch, the brackets of ten kernel slots cost ~1 ms per pass
+  bool wanted() const { return e->profiling == 1 || (e->profiling == 2 && (id == RNA_K_ASTAR_SEARCH || id == RNA_K_ASTAR_RESET)); }
   ~KernelTimer() {
-    if (!e->profiling || !a || !b) return;
+    if (!wanted() || !a || !b) return;
     (void)hipEventRecord(b, st);
     e->prof[id].pending.emplace_back(a, b);
     e->pending_events += 2;
