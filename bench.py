@@ -300,9 +300,11 @@ def main():
     d_poses = [to_dev(p) for p in pose_sets]
     d_queries = [to_dev(q) for q in query_sets]
     d_vfh_out = torch.zeros(nq * R.capi.VFH_OUT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    # one output set per batch that may be in flight (pipelined searches write them asynchronously)
-    d_paths = [torch.zeros(nq * args.max_path, dtype=torch.int32, device=dev) for _ in range(args.pipeline)]
-    d_results = [torch.zeros(nq * 6, dtype=torch.int32, device=dev) for _ in range(args.pipeline)]
+    # output sets: the engine gives a batch to whichever stage has been free the longest, so a batch may still be running
+    # when the pipeline has turned once more -- three turns' worth of buffers before one is written again
+    n_out = 3 * args.pipeline
+    d_paths = [torch.zeros(nq * args.max_path, dtype=torch.int32, device=dev) for _ in range(n_out)]
+    d_results = [torch.zeros(nq * 6, dtype=torch.int32, device=dev) for _ in range(n_out)]
     e.vfh_init(nq)
     e.astar_pipeline_depth(args.pipeline)
     e.astar_configure(max_queries=nq, queue_capacity=args.queue_capacity, bucket_width=args.bucket_width)
@@ -313,7 +315,7 @@ def main():
     xfer = [0, 0]          # bytes received: halo strips, gathered windows
 
     def one_pass():
-        b = step_no[0] % args.pipeline
+        b = step_no[0] % n_out
         k = step_no[0] % ROTATE
         step_no[0] += 1
         if only_astar:   # developer switch RNA_BENCH_ONLY_ASTAR=1: the search capacity without the map update and VFH+ (NOT the metric)
@@ -343,7 +345,7 @@ def main():
     def check_results(what):
         """every result buffer that may hold a batch: all queries answered (0 found / 1 no path), nothing else"""
         found = answered = total = 0
-        for buf in d_results[:min(args.pipeline, step_no[0])]:
+        for buf in d_results[:min(n_out, step_no[0])]:
             st = buf.cpu().numpy().reshape(nq, 6)[:, 0]
             bad = sorted(set(st[(st != 0) & (st != 1)].tolist()))
             if bad:

@@ -142,7 +142,7 @@ __device__ __forceinline__ int kdj_of(int k) { return k < 3 ? -1 : (k > 4 ? 1 : 
 // Device view of one pipeline stage.  Global page index of query q's local page p >= 1 is q*cap + p; page 0 is
 // the shared "unreached" page.  Invariant between launches: every page word, aux word and tmap entry is 0, EXCEPT
 // what belongs to the local pages 1..nalloc[q] of each query; the next launch on the stage resets exactly those
-// (tsa_reset_kernel) instead of rewriting 64 MiB per query.
+// (the workgroup that takes the slot next does, before it searches) instead of rewriting 64 MiB per query.
 struct TsaStage {
   unsigned* pages;      // [1 + max_queries*cap][1024]
   unsigned* paux;       // [1 + max_queries*cap][64]
@@ -180,24 +180,11 @@ __global__ void __launch_bounds__(256) tsa_snapshot_kernel(const uint8_t* __rest
     if (a == TI - 1) reinterpret_cast<unsigned*>(out + TILE_WORDS + 16)[bq] = v;
   }
 }
-// back to the invariant: the pages the previous launch on this stage handed out.  Block (x, q) takes the local
-// pages 1 + x, 1 + x + gridDim.x, ... of query q (256 threads: one uint4 of the page each).
-__global__ void __launch_bounds__(256) tsa_reset_kernel(TsaStage S, int ntile) {
-  const int q = blockIdx.y;
-  const int used = S.nalloc[q] < S.cap ? S.nalloc[q] : S.cap;
-  for (int p = 1 + (int)blockIdx.x; p <= used; p += (int)gridDim.x) {
-    const size_t gp = (size_t)q * S.cap + p;
-    reinterpret_cast<uint4*>(S.pages + (gp << 10))[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
-    if (threadIdx.x < AUX_WORDS) S.paux[gp * AUX_WORDS + threadIdx.x] = 0u;
-    if (threadIdx.x == 0) S.tmap[(size_t)q * ntile + S.owner[(size_t)q * (S.cap + 1) + p]] = 0u;
-  }
-}
-// (after the reset) page counters and the ticket back to zero; then the launch order of the batch, see below.
+// The ticket back to zero and the launch order of the batch, see below.
 // One small workgroup: it has to fit next to the search workgroups that fill every CU when batches are pipelined.
-__global__ void __launch_bounds__(256) tsa_prepare_kernel(TsaStage S, int max_queries, const rna_astar_query* __restrict__ queries, int n,
-                                                          int rows, int cols, int ranked) {
+__global__ void __launch_bounds__(256) tsa_prepare_kernel(TsaStage S, const rna_astar_query* __restrict__ queries, int n, int rows, int cols,
+                                                          int ranked) {
   extern __shared__ int s_key[];
-  for (int q = threadIdx.x; q < max_queries; q += blockDim.x) S.nalloc[q] = 0;
   if (threadIdx.x == 0) *S.ticket = 0;
   if (!ranked) {   // the ranking is O(n^2 / 256) per thread: large batches keep the caller's order
     for (int i = threadIdx.x; i < n; i += blockDim.x) S.perm[i] = i;
@@ -368,7 +355,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   // lanes 1..16 = rows 0..15, lane 17 = corner (-1,16)), lanes 32..49 the right one.
   const int xl = lane & 31;
   const bool xr = lane >= 32, xcell = xl >= 1 && xl <= TJ;
-  int top, bot, X = 0;
+  int top, bot, X = 0, gcol = 0;
   unsigned eb = 0u;   // lanes 1..16 / 33..48: mask of the tile's own edge cell (0, xl-1) / (63, xl-1)
   {
     const unsigned pgN = (unsigned)__shfl((int)nb_pg, 1), pgS = (unsigned)__shfl((int)nb_pg, 6);
@@ -379,6 +366,8 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     const int xrow = xl == 0 ? TJ - 1 : (xl <= TJ ? xl - 1 : 0);
     if (xl <= TJ + 1) X = (int)ld_l2(&C.paux[C.gpage(pgX) * AUX_WORDS + (xr ? 0 : 16) + xrow]);   // a left tile's column 63 / a right tile's column 0
     if (xcell) eb = C.nbr_tm[(size_t)t * MASK_STRIDE + TILE_WORDS + (xr ? 16 : 0) + xl - 1];
+    // the tile's own columns 0 and 63 in the same layout (the copy it keeps for its neighbours)
+    if (xcell) gcol = (int)ld_l2(&C.paux[C.gpage(pg) * AUX_WORDS + (xr ? 16 : 0) + xl - 1]);
   }
   asm volatile("; TSA_MARK loads_issued");
   // ---- 3. this bucket's bound; which cells are free ----
@@ -416,7 +405,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     if ((b) == TJ - 1) q15 |= (up) & __builtin_amdgcn_ballot_w64(TSA_PP(b) != 0);                                \
   }
   {
-    int cT, cB;
+    int cT, cB, cX;
     {
       const int pT = tsa_prop(top, TSA_H(-1), thr), pB = tsa_prop(bot, TSA_H(TJ), thr);
       const int hX = tsa_octile(xr ? i0 + TI : i0 - 1, j0 + xl - 1, gi, gj);
@@ -424,24 +413,16 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       const int sTL = __builtin_amdgcn_readlane(pX, 0), sBL = __builtin_amdgcn_readlane(pX, TJ + 1);
       const int sTR = __builtin_amdgcn_readlane(pX, 32), sBR = __builtin_amdgcn_readlane(pX, 32 + TJ + 1);
       // rows 0 and 15 from the rows beyond them (masks: k0 k1 k2 = (-1,-1) (0,-1) (1,-1); k5 k6 k7 = (-1,1) (0,1) (1,1));
-      // a straight step needs no mask test: a blocked source reads "unreached", a blocked target is gated by fbits
+      // a straight step needs no mask test: a blocked source reads "unreached", a blocked target is gated by its free bit
       cT = max3i(pT - COST_S, (lane_m1(pT, sTL) - COST_D) & __builtin_amdgcn_sbfe((int)mk0, 0, 1),
-                 (lane_p1(pT, sTR) - COST_D) & __builtin_amdgcn_sbfe((int)mk0, 2, 1));
+                 (lane_p1(pT, sTR) - COST_D) & __builtin_amdgcn_sbfe((int)mk0, 2, 1)) & TSA_OPEN(fbits, 0);
       cB = max3i(pB - COST_S, (lane_m1(pB, sBL) - COST_D) & __builtin_amdgcn_sbfe((int)mk3, 24 + 5, 1),
-                 (lane_p1(pB, sBR) - COST_D) & __builtin_amdgcn_sbfe((int)mk3, 24 + 7, 1));
-      // columns 0 and 63 from the columns beyond them, computed where the halo column sits (lane xl = row + 1) ...
+                 (lane_p1(pB, sBR) - COST_D) & __builtin_amdgcn_sbfe((int)mk3, 24 + 7, 1)) & TSA_OPEN(fbits, TJ - 1);
+      // columns 0 and 63 from the columns beyond them, computed where the halo column sits (lane xl = row + 1)
       const int kN = xr ? 2 : 0, kS = xr ? 7 : 5;
-      int cX = max3i(pX - COST_S, (lane_m1(pX) - COST_D) & -(int)((eb >> kN) & 1u), (lane_p1(pX) - COST_D) & -(int)((eb >> kS) & 1u));
-      cX = xcell ? cX : 0;
-      // ... and turned into rows of lane 0 / lane 63 through the wave's LDS scratch (words 68.. are zero)
-      scr[lane + 3] = (unsigned)cX;
-      scr[84 + lane] = (unsigned)top;        // kept for the end of the job: does a changed edge row beat what the
-      scr[84 + 64 + lane] = (unsigned)bot;   // neighbour already has?
-      scr[84 + 128 + lane] = (unsigned)X;
-      scr[84 + 192 + 48 + lane] = eb;
-      __builtin_amdgcn_wave_barrier();
+      cX = max3i(pX - COST_S, (lane_m1(pX) - COST_D) & -(int)((eb >> kN) & 1u), (lane_p1(pX) - COST_D) & -(int)((eb >> kS) & 1u));
+      cX = (xcell && eb != 0u) ? cX : 0;
     }
-    const uint4* rp = reinterpret_cast<const uint4*>(&scr[lane == 0 ? 4 : (lane == TI - 1 ? 36 : 68)]);
     unsigned planted = 0u;
     if (t == C.ts) {   // the start cell: g = 0, whatever its mask says (a blocked start still answers start == goal)
 #define TSA_PLANT(b)                                                         \
@@ -452,19 +433,42 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       TSA_R16(TSA_PLANT)
 #undef TSA_PLANT
     }
-    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    // What improves?  Rows 0 and 15 across the wave; the two columns where the halo column sits, against the tile's
+    // own columns in the same layout (gcol) -- one comparison for the 32 edge cells of rows 0..15.  Most wake-ups of
+    // an asynchronous schedule find the tile up to date already (a third of all jobs): they end here, before the 16
+    // rows' pass-on values are formed.
+    const unsigned long long upT = __builtin_amdgcn_ballot_w64(cT > g0), upB = __builtin_amdgcn_ballot_w64(cB > g15);
+    const unsigned long long imask = __builtin_amdgcn_ballot_w64(cX > gcol);
+    if (!(upT | upB | imask) && !planted && !first) { TSA_CNT(10, 1); return 0; }   // the wake-up brought nothing better
+    asm volatile("; TSA_MARK noop_decided");
+    scr[84 + lane] = (unsigned)top;        // kept for the end of the job: does a changed edge row beat what the
+    scr[84 + 64 + lane] = (unsigned)bot;   // neighbour already has?
+    scr[84 + 128 + lane] = (unsigned)X;
+    scr[84 + 192 + 48 + lane] = eb;
+    const unsigned cl = (unsigned)(imask >> 1) & 0xffffu, cr = (unsigned)(imask >> 33) & 0xffffu;   // rows whose cell in lane 0 / lane 63 improves
+    const unsigned crow = cl | cr | planted;
+    if (upT) g0 = max(g0, cT);
+    if (upB) g15 = max(g15, cB);
+    // a column candidate goes from its lane of cX into lane 0 / 63 of the row's register through the scalar unit
 #define TSA_APPLY(b)                                                                                             \
   {                                                                                                              \
-    if (((b) & 3) == 0) r = rp[(b) >> 2]; /* four rows per LDS read */                                           \
-    int cand = (int)(((b) & 3) == 0 ? r.x : (((b) & 3) == 1 ? r.y : (((b) & 3) == 2 ? r.z : r.w)));              \
-    if ((b) == 0) cand = max(cand, cT);                                                                          \
-    if ((b) == TJ - 1) cand = max(cand, cB);                                                                     \
-    cand &= TSA_OPEN(fbits, b);                                                                                  \
-    unsigned long long up = __builtin_amdgcn_ballot_w64(cand > TSA_G(b));                                        \
-    if (up) TSA_G(b) = __builtin_amdgcn_inverse_ballot_w64(up) ? cand : TSA_G(b);                                \
+    unsigned long long up = (b) == 0 ? upT : ((b) == TJ - 1 ? upB : 0ull);                                        \
+    if ((crow >> (b)) & 1u) {                                                                                    \
+      if ((cl >> (b)) & 1u) {                                                                                    \
+        const int c_ = max(__builtin_amdgcn_readlane(cX, (b) + 1), __builtin_amdgcn_readlane(TSA_G(b), 0));       \
+        asm volatile("v_writelane_b32 %0, %1, 0" : "+v"(TSA_G(b)) : "s"(c_));                                    \
+        up |= 1ull;                                                                                              \
+      }                                                                                                          \
+      if ((cr >> (b)) & 1u) {                                                                                    \
+        const int c_ = max(__builtin_amdgcn_readlane(cX, 33 + (b)), __builtin_amdgcn_readlane(TSA_G(b), TI - 1)); \
+        asm volatile("v_writelane_b32 %0, %1, 63" : "+v"(TSA_G(b)) : "s"(c_));                                   \
+        up |= 1ull << (TI - 1);                                                                                  \
+      }                                                                                                          \
+      if ((planted >> (b)) & 1u) up |= 1ull << C.sa;                                                             \
+    }                                                                                                            \
     TSA_PP(b) = tsa_prop(TSA_G(b), TSA_H(b), thr);                                                               \
-    if ((planted >> (b)) & 1u) up |= 1ull << C.sa;                                                               \
-    if (up) { nd |= 1u << (b); TSA_ROW_CHANGED(b, up) }   /* (its own horizontal steps: evaluated in the first sweep) */ \
+    if ((b) == 0 || (b) == TJ - 1) { if (up) { nd |= 1u << (b); TSA_ROW_CHANGED(b, up) } }                        \
+    else if ((crow >> (b)) & 1u) { nd |= 1u << (b); TSA_ROW_CHANGED(b, up) }   /* (its own horizontal steps: evaluated in the first sweep) */ \
   }
     TSA_R16(TSA_APPLY)
 #undef TSA_APPLY
@@ -474,7 +478,6 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   if (first) nd = nu = 0xffffu;
   TSA_T(t_b);
   TSA_ACC(0, t_a, t_b);
-  if (!(nd | nu)) { TSA_CNT(10, 1); return 0; }   // the wake-up brought nothing better
   // ---- 5. sweeps ----
 #ifdef RNA_TSA_STATS
   int evals = 0, hpass = 0;
@@ -562,12 +565,15 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     unsigned* own = C.pages + (C.gpage(pg) << 10);
     unsigned* ax = C.paux + C.gpage(pg) * AUX_WORDS + (lane ? 16 : 0);
     const bool edge_lane = lane == 0 || lane == TI - 1;
-    unsigned long long ovfm = 0ull;   // a reached cell whose g is about to leave the 30-bit range of the field word
+    // A reached cell whose g is about to leave the 30-bit range of the field word: a value written by this job is at
+    // most lim + 1414 (its source passed on, i.e. g + h < lim), so the rows are only looked at when the bound is that far out.
+    const bool ovf_possible = lim_ll + COST_D > (long long)KU - 4 * COST_D;
+    unsigned long long ovfm = 0ull;
 #define TSA_STORE(b)                                                                              \
   if ((rowchg >> (b)) & 1u) {                                                                     \
     own[(b) * TI + lane] = (unsigned)TSA_G(b);                                                    \
     if (edge_lane) ax[b] = (unsigned)TSA_G(b);                                                    \
-    ovfm |= __builtin_amdgcn_ballot_w64((unsigned)(TSA_G(b) - 1) < (unsigned)(4 * COST_D - 1));   \
+    if (ovf_possible) ovfm |= __builtin_amdgcn_ballot_w64((unsigned)(TSA_G(b) - 1) < (unsigned)(4 * COST_D - 1));   \
   }
     TSA_R16(TSA_STORE)
 #undef TSA_STORE
@@ -588,8 +594,10 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     // (a) this tile again when the next bucket opens: it holds reached cells beyond this bucket's bound that may still
     //     matter (f <= best).  Looked for in the rows that changed (all rows in a first job), and not at all once the
     //     tile is flagged -- it runs several times per bucket.
+    //     When the bound of this job is best + 1 (the goal has been reached and lies inside the bucket) every cell
+    //     with f <= best passes on: nothing is held back that matters.
     const unsigned look = first ? 0xffffu : rowchg;
-    if (look && !sch.is_far(t)) {
+    if (look && (long long)best_in + 1 > bucket_end && !sch.is_far(t)) {
       const int thr_best = KU - best_in;   // f <= best  <=>  u - h >= thr_best
       unsigned long long farm = 0ull;
 #define TSA_END(b)                                                                                               \
@@ -677,18 +685,15 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     // directions: 0 NW, 1 N, 2 NE, 3 W, 4 E, 5 SW, 6 S, 7 SE
     const unsigned am = ((colw & 1u) ? 1u : 0u) | (wakeN ? 2u : 0u) | ((colw & 8u) ? 4u : 0u) | ((colw & 2u) ? 8u : 0u) | ((colw & 16u) ? 16u : 0u) |
                         ((colw & 4u) ? 32u : 0u) | (wakeS ? 64u : 0u) | ((colw & 32u) ? 128u : 0u);
-    unsigned wm = am & (unsigned)__builtin_amdgcn_ballot_w64(lane < 8 && nb_t >= 0);
+    const unsigned wm = am & (unsigned)__builtin_amdgcn_ballot_w64(lane < 8 && nb_t >= 0);
     if (wm) {
       // this job's stores are in L2 before anybody is told to look at them (a woken tile's job loads with sc1 from L2)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      while (wm) {
-        const int k = __builtin_ctz(wm);
-        wm &= wm - 1u;
-        const int kf = k == 1 ? kfN : (k == 6 ? kfS : ((k == 0 || k == 3 || k == 5) ? kfW : kfE));
-        int key = (key_base - kf) >> key_shift;   // (f - f at the bucket's start), quantised
-        key = key < 0 ? 0 : (key > 0xfffe ? 0xfffe : key);
-        sch.wake(__builtin_amdgcn_readlane(nb_t, k), (unsigned)key, lane);
-      }
+      // lane k < 8 speaks for direction k: its tile, its key ((f - f at the bucket's start), quantised)
+      const int kf = lane == 1 ? kfN : (lane == 6 ? kfS : ((lane == 0 || lane == 3 || lane == 5) ? kfW : kfE));
+      int key = (key_base - kf) >> key_shift;
+      key = key < 0 ? 0 : (key > 0xfffe ? 0xfffe : key);
+      sch.wake8(lane < 8 && ((wm >> lane) & 1u), nb_t, (unsigned)key, lane);
     }
   }
 #undef TSA_ROW_CHANGED
@@ -721,6 +726,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
 constexpr int TSA_NE = RNA_TSA_ENTRIES;   // (scripts/sim_async.c: at most 1065 entries at once over the bench's queries)
 constexpr unsigned ENT_EMPTY = 0xffffffffu;
 static_assert((TSA_NE & (TSA_NE - 1)) == 0 && TSA_NE % 256 == 0, "queue size: a power of two, scanned 256 entries at a time");
+static_assert(TSA_NE * 4 >= (TI + 2) * (TJ + 2) * 4 + TILE_WORDS, "the backtrace's LDS image lives in the queue memory");
 
 __device__ __forceinline__ unsigned lds_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int lds_ldi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -761,17 +767,9 @@ struct TsaLocalSched {
       }
     }
   }
-  // tile t has something new in its halo; key = quantised lowest f on offer (all lanes call, arguments wave-uniform)
-  __device__ __forceinline__ void wake(int t, unsigned key, int lane) {
-    const unsigned sh = 2u * ((unsigned)t & 15u);
-    unsigned old = 0u;
-    if (lane == 0) old = atomicOr(&st2_[t >> 4], 1u << sh);
-    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old) >> sh;
-    if (old & 2u) return;   // running: its wavefront sees D when it ends
-    const unsigned e = (key << 16) | (unsigned)t;
-    if (!(old & 1u)) { push(e, lane); return; }
-    // pending already: find its entry and lower the key (a failed attempt -- the entry is being appended or was just
-    // taken -- only costs order, never a wake-up: D is set)
+  // tile t is pending: find its entry and lower the key to e's (all lanes call, arguments wave-uniform).  A failed
+  // attempt -- the entry is being appended or was just taken -- only costs order, never a wake-up: D is set.
+  __device__ __forceinline__ void lower_key(int t, unsigned e, int lane) {
     const int hi = lds_ldi(hi_);
     for (int base = 0; base < hi; base += 256) {
       const uint4 v = *reinterpret_cast<const uint4*>(&ent_[base + lane * 4]);
@@ -787,6 +785,43 @@ struct TsaLocalSched {
         }
         break;
       }
+    }
+  }
+  // the wake-ups of one job together: lane k < 8 with `w` set wakes tile t with key `key` (all lanes call).  Three LDS
+  // round trips whatever their number: the D bits, one reservation of queue slots, the entries.
+  __device__ __forceinline__ void wake8(bool w, int t, unsigned key, int lane) {
+    const unsigned sh = 2u * ((unsigned)t & 15u);
+    unsigned old = 2u;
+    if (w) old = atomicOr(&st2_[t >> 4], 1u << sh) >> sh;
+    const bool fresh = w && !(old & 3u);          // neither pending nor running: gets an entry
+    const bool lower = w && (old & 3u) == 1u;     // pending already: its entry's key may have to come down
+    const unsigned e = (key << 16) | (unsigned)t;
+    const unsigned long long fm = __builtin_amdgcn_ballot_w64(fresh);
+    if (fm) {
+      int base = 0;
+      if (lane == __builtin_ctzll(fm)) base = atomicAdd(tail_, __builtin_popcountll(fm));
+      base = __builtin_amdgcn_readlane(base, __builtin_ctzll(fm));
+      bool ok = false;
+      int slot = 0;
+      if (fresh) {
+        slot = (base + __builtin_popcountll(fm & ((1ull << lane) - 1ull))) & (TSA_NE - 1);
+        ok = atomicCAS(&ent_[slot], ENT_EMPTY, e) == ENT_EMPTY;
+        if (ok) atomicMax(hi_, (slot | 255) + 1);
+      }
+      const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
+      if (okm && lane == __builtin_ctzll(okm)) atomicAdd(count_, __builtin_popcountll(okm));
+      unsigned long long bad = fm & ~okm;   // the slot was taken (the ring has wrapped around): one by one
+      while (bad) {
+        const int l = __builtin_ctzll(bad);
+        bad &= bad - 1ull;
+        push((unsigned)__builtin_amdgcn_readlane((int)e, l), lane);
+      }
+    }
+    unsigned long long lm = __builtin_amdgcn_ballot_w64(lower);
+    while (lm) {
+      const int l = __builtin_ctzll(lm);
+      lm &= lm - 1ull;
+      lower_key(__builtin_amdgcn_readlane(t, l), (unsigned)__builtin_amdgcn_readlane((int)e, l), lane);
     }
   }
   // take the entry with the lowest key; ENT_EMPTY if the queue is empty
@@ -822,6 +857,7 @@ struct TsaLaunch {
   const rna_astar_query* queries;
   TsaStage S;
   int bucket_width;
+  int prio_first;   // the first prio_first workgroups to start (the longest expected searches) run at raised wave priority
   int32_t* paths;
   int max_path_len;
   int32_t* rev_all;
@@ -829,6 +865,104 @@ struct TsaLaunch {
   rna_astar_result* results;
 };
 constexpr int TSA_FOUND = -1000;        // provisional status between the search and the backtrace kernel
+
+// Canonical backtrace, one wavefront per query: walk from the goal to the neighbour n with g[n] + w(n, c) == g[c],
+// lowest linear index first (lane k probes neighbour k).  The walk runs in LDS: the 64 x 16 tile of the current
+// cell plus its halo ring and the tile's neighbour masks are loaded once, then every step is one LDS round trip
+// until the path leaves the tile -- a path of 2 000 cells is ~100 tile loads instead of 2 000 dependent
+// HBM round trips.
+constexpr int BW = TI + 2;   // LDS row pitch of the backtrace image (halo included)
+// (run by the first wavefront of the query's search workgroup once the search has ended -- the other wavefronts have
+// left, the workgroup's queue memory holds the LDS image; r = the provisional result)
+__device__ __forceinline__ void tsa_backtrace_wave(const TsaLaunch& A, const int q, const rna_astar_result r, const int lane,
+                                                   unsigned* s_tile, unsigned char* s_mask) {
+  const int rows = A.rows, cols = A.cols, tiles_i = A.tiles_i, tiles_j = A.tiles_j;
+  const int ncell = rows * cols, ntile = tiles_i * tiles_j;
+  const unsigned* tmap = A.S.tmap + (size_t)q * ntile;
+  const size_t page_base = (size_t)q * A.S.cap;
+  const int start = tsa_unwrap_lin(A.queries[q].start, rows, cols, A.s0, A.s1);
+  const int goal = tsa_unwrap_lin(A.queries[q].goal, rows, cols, A.s0, A.s1);
+  const int si = start % rows, sj = start / rows;
+  int ci = goal % rows, cj = goal / rows;
+  int* rev = A.rev_all + (size_t)q * A.rev_cap;
+  const int k = lane & 7;
+  const int wk = (k == 1 || k == 3 || k == 4 || k == 6) ? COST_S : COST_D;
+  const int di = kdi_of(k), dj = kdj_of(k);
+  const int off = di + dj * BW;
+  int len = 0;
+  bool ok = true, done = false;
+  while (ok && !done) {
+    // ---- tile of the current cell + halo ring + masks -> LDS ----
+    const int ti = ci >> 6, tj = cj >> 4;
+    const int t = tj * tiles_i + ti;
+    unsigned pgl = 0u;   // lane k < 8: page of the neighbouring tile in direction k; lane 8: page of this tile
+    {
+      const int nti = lane < 8 ? ti + di : ti, ntj = lane < 8 ? tj + dj : tj;
+      if (lane < 9 && nti >= 0 && ntj >= 0 && nti < tiles_i && ntj < tiles_j) pgl = ld_l2(&tmap[ntj * tiles_i + nti]);
+    }
+    auto gpage = [&](int src) -> size_t {
+      const unsigned lp = (unsigned)__shfl((int)pgl, src);
+      return lp ? page_base + lp : (size_t)0;
+    };
+    {
+      const int xl = lane & 31;
+      const bool xr = lane >= 32;
+      const unsigned* pown = A.S.pages + (gpage(8) << 10);
+      const unsigned top = ld_l2(&A.S.pages[(gpage(1) << 10) + (TJ - 1) * TI + lane]);
+      const unsigned bot = ld_l2(&A.S.pages[(gpage(6) << 10) + lane]);
+      const int xdir = xl == 0 ? (xr ? 2 : 0) : (xl <= TJ ? (xr ? 4 : 3) : (xr ? 7 : 5));
+      const int xrow = xl == 0 ? TJ - 1 : (xl <= TJ ? xl - 1 : 0);
+      const size_t gpx = gpage(xdir);
+      unsigned X = 0u;
+      if (xl <= TJ + 1) X = ld_l2(&A.S.paux[gpx * AUX_WORDS + (xr ? 0 : 16) + xrow]);
+      unsigned tv[TJ];
+#pragma unroll
+      for (int b = 0; b < TJ; ++b) tv[b] = ld_l2(&pown[b * TI + lane]);
+      const uint4 mv = *reinterpret_cast<const uint4*>(A.S.nbr_tm + (size_t)t * MASK_STRIDE + lane * 16);
+      __builtin_amdgcn_wave_barrier();   // the previous tile's walk has finished reading the LDS image
+      s_tile[lane + 1] = top;
+      s_tile[(TJ + 1) * BW + lane + 1] = bot;
+      if (xl <= TJ + 1) s_tile[xl * BW + (xr ? TI + 1 : 0)] = X;
+#pragma unroll
+      for (int b = 0; b < TJ; ++b) s_tile[(b + 1) * BW + lane + 1] = tv[b];
+      *reinterpret_cast<uint4*>(&s_mask[lane * 16]) = mv;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // ---- walk inside the tile ----
+    int il = ci & (TI - 1), jl = cj & (TJ - 1);
+    unsigned uc = s_tile[(jl + 1) * BW + il + 1];
+    for (;;) {
+      if (lane == 0 && len < A.rev_cap) rev[len] = cj * rows + ci;
+      ++len;
+      if (ci == si && cj == sj) { done = true; break; }
+      if (len > ncell || uc == 0u) { ok = false; break; }
+      const unsigned mc = s_mask[il * 16 + jl];
+      const unsigned un = s_tile[(jl + 1) * BW + il + 1 + off];
+      const bool hit = lane < 8 && ((mc >> k) & 1u) && un != 0u && un == uc + (unsigned)wk;   // g(n) + w == g(c)
+      const unsigned long long m = __ballot(hit);
+      if (!m) { ok = false; break; }
+      const int src = __ffsll((long long)m) - 1;
+      uc = (unsigned)__shfl((int)un, src);
+      const int sdi = kdi_of(src), sdj = kdj_of(src);
+      ci += sdi; cj += sdj; il += sdi; jl += sdj;
+      if (il < 0 || jl < 0 || il >= TI || jl >= TJ) break;   // left the tile: load that one
+    }
+  }
+  if (!ok) {
+    if (lane == 0) A.results[q] = rna_astar_result{1, 0, INF, r.expanded, r.rounds, r.buckets};
+    return;
+  }
+  if (len > A.max_path_len || len > A.rev_cap) {
+    if (lane == 0) A.results[q] = rna_astar_result{3, len, r.cost, r.expanded, r.rounds, r.buckets};
+    return;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  int32_t* path = A.paths + (size_t)q * A.max_path_len;
+  for (int i = lane; i < len; i += 64) path[i] = tsa_buffer_lin(rev[len - 1 - i], rows, cols, A.s0, A.s1);
+  if (lane == 0) A.results[q] = rna_astar_result{0, len, r.cost, r.expanded, r.rounds, r.buckets};
+}
 
 // One workgroup of 8 wavefronts per query, four of them per CU.  The kernel ends with the exact distance field in HBM and a provisional
 // result; the path is traced by tsa_backtrace_kernel (one wavefront per query, next kernel on the stream).
@@ -848,10 +982,16 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   // indices round-robin to the XCDs, so a fixed mapping lets one XCD with several long searches hold back
   // its share of the batch while the other XCDs idle.  With tickets a free CU anywhere takes the next
   // (longest remaining) query.
-  __shared__ int s_q;
-  if (threadIdx.x == 0) s_q = A.S.perm[atomicAdd(A.S.ticket, 1)];
+  __shared__ int s_q, s_rank;
+  if (threadIdx.x == 0) { const int k = atomicAdd(A.S.ticket, 1); s_rank = k; s_q = A.S.perm[k]; }
   __syncthreads();
   const int q = __builtin_amdgcn_readfirstlane(s_q);   // wave-uniform values belong in SGPRs: the tile jobs need every VGPR
+  // A batch lasts as long as its longest search, and a stage cannot take its next batch before: the searches expected
+  // to be the longest (the first tickets) get the issue slots of their SIMDs first, the short ones fill in around them.
+#ifndef RNA_TSA_PRIO_FIRST
+#define RNA_TSA_PRIO_FIRST 32
+#endif
+  if (__builtin_amdgcn_readfirstlane(s_rank) < A.prio_first) __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rows = A.rows, cols = A.cols, tiles_i = A.tiles_i, tiles_j = A.tiles_j;
   rna_astar_query qu = A.queries[q];   // buffer linear indices; the search itself runs in map space
@@ -898,6 +1038,22 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
       return;
     }
   }
+  // This query's pages as the last search in this slot left them: back to "unreached" (the slot is this workgroup's
+  // alone; its local pages 1..used are one contiguous run of the stage's page array).  Doing it here instead of in a
+  // kernel of its own takes ~1 ms off every turn of the stage, which can only take its next batch when this one's
+  // longest search has ended.
+  {
+    const int used_raw = A.S.nalloc[q];
+    const int used = used_raw < C.cap ? used_raw : C.cap;
+    if (used > 0) {
+      uint4* pg4 = reinterpret_cast<uint4*>(C.pages + ((C.page_base + 1) << 10));
+      for (size_t w = tid; w < (size_t)used * (TILE_WORDS / 4); w += TSA_THREADS) pg4[w] = make_uint4(0u, 0u, 0u, 0u);
+      uint4* ax4 = reinterpret_cast<uint4*>(C.paux + (C.page_base + 1) * AUX_WORDS);
+      for (size_t w = tid; w < (size_t)used * (AUX_WORDS / 4); w += TSA_THREADS) ax4[w] = make_uint4(0u, 0u, 0u, 0u);
+      for (int p = 1 + tid; p <= used; p += TSA_THREADS) C.tmap[C.owner[p]] = 0u;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
   // keys: (f - f at the bucket's start) >> key_shift must fit 16 bits with room for cells beyond the bucket's end
   int key_shift = 0;
   while (((2ll * A.bucket_width) >> key_shift) > 0xfffe) ++key_shift;
@@ -916,6 +1072,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
 #ifdef RNA_TSA_STATS
   unsigned long long tsa_acc[16] = {};
   const unsigned long long t_life0 = wall_clock64();
+  const unsigned long long c_life0 = __builtin_amdgcn_s_memtime();
 #endif
   TsaLocalSched sch{&s_best, &s_state, s_st2, s_far, s_ent, &s_count, &s_tail, &s_hi, &s_spill};
 
@@ -1057,118 +1214,24 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   __syncthreads();
 #ifdef RNA_TSA_STATS
   tsa_acc[5] = wall_clock64() - t_life0;   // wave lifetime inside the search loop
+  tsa_acc[12] = __builtin_amdgcn_s_memtime() - c_life0;   // the same in shader clock ticks
   if (lane == 0) for (int k = 0; k < 16; ++k) atomicAdd(&g_tsa_stat[k], tsa_acc[k]);
 #endif
-  // what the next launch on this stage has to reset
+  // what the next search in this slot has to reset
   if (tid == 0) A.S.nalloc[q] = s_nalloc < C.cap ? s_nalloc : C.cap;
-
-  // provisional result: the backtrace kernel (next on the stream) finishes the found ones
   // (`rounds` reports tile jobs per wavefront: there are no rounds any more)
-  if (tid == 0) {
-    const int state = s_state;
-    results[q] = rna_astar_result{state == 1 ? TSA_FOUND : (state >= 4 ? state : 1), 0, state == 1 ? s_best : INF, s_expanded,
-                                  (s_jobs_done + WAVES - 1) / WAVES, s_bucket - s_bucket0 + 1};
-  }
-}
-
-// Canonical backtrace, one wavefront per query: walk from the goal to the neighbour n with g[n] + w(n, c) == g[c],
-// lowest linear index first (lane k probes neighbour k).  The walk runs in LDS: the 64 x 16 tile of the current
-// cell plus its halo ring and the tile's neighbour masks are loaded once, then every step is one LDS round trip
-// until the path leaves the tile -- a path of 2 000 cells is ~100 tile loads instead of 2 000 dependent
-// HBM round trips.
-constexpr int BW = TI + 2;   // LDS row pitch of the backtrace image (halo included)
-__global__ void __launch_bounds__(64) tsa_backtrace_kernel(const TsaLaunch A) {
-  __shared__ unsigned s_tile[BW * (TJ + 2)];
-  __shared__ unsigned char s_mask[TILE_WORDS];
-  const int q = blockIdx.x, lane = threadIdx.x;
-  const rna_astar_result r = A.results[q];
-  if (r.status != TSA_FOUND) return;
-  const int rows = A.rows, cols = A.cols, tiles_i = A.tiles_i, tiles_j = A.tiles_j;
-  const int ncell = rows * cols, ntile = tiles_i * tiles_j;
-  const unsigned* tmap = A.S.tmap + (size_t)q * ntile;
-  const size_t page_base = (size_t)q * A.S.cap;
-  const int start = tsa_unwrap_lin(A.queries[q].start, rows, cols, A.s0, A.s1);
-  const int goal = tsa_unwrap_lin(A.queries[q].goal, rows, cols, A.s0, A.s1);
-  const int si = start % rows, sj = start / rows;
-  int ci = goal % rows, cj = goal / rows;
-  int* rev = A.rev_all + (size_t)q * A.rev_cap;
-  const int k = lane & 7;
-  const int wk = (k == 1 || k == 3 || k == 4 || k == 6) ? COST_S : COST_D;
-  const int di = kdi_of(k), dj = kdj_of(k);
-  const int off = di + dj * BW;
-  int len = 0;
-  bool ok = true, done = false;
-  while (ok && !done) {
-    // ---- tile of the current cell + halo ring + masks -> LDS ----
-    const int ti = ci >> 6, tj = cj >> 4;
-    const int t = tj * tiles_i + ti;
-    unsigned pgl = 0u;   // lane k < 8: page of the neighbouring tile in direction k; lane 8: page of this tile
-    {
-      const int nti = lane < 8 ? ti + di : ti, ntj = lane < 8 ? tj + dj : tj;
-      if (lane < 9 && nti >= 0 && ntj >= 0 && nti < tiles_i && ntj < tiles_j) pgl = ld_l2(&tmap[ntj * tiles_i + nti]);
-    }
-    auto gpage = [&](int src) -> size_t {
-      const unsigned lp = (unsigned)__shfl((int)pgl, src);
-      return lp ? page_base + lp : (size_t)0;
-    };
-    {
-      const int xl = lane & 31;
-      const bool xr = lane >= 32;
-      const unsigned* pown = A.S.pages + (gpage(8) << 10);
-      const unsigned top = ld_l2(&A.S.pages[(gpage(1) << 10) + (TJ - 1) * TI + lane]);
-      const unsigned bot = ld_l2(&A.S.pages[(gpage(6) << 10) + lane]);
-      const int xdir = xl == 0 ? (xr ? 2 : 0) : (xl <= TJ ? (xr ? 4 : 3) : (xr ? 7 : 5));
-      const int xrow = xl == 0 ? TJ - 1 : (xl <= TJ ? xl - 1 : 0);
-      const size_t gpx = gpage(xdir);
-      unsigned X = 0u;
-      if (xl <= TJ + 1) X = ld_l2(&A.S.paux[gpx * AUX_WORDS + (xr ? 0 : 16) + xrow]);
-      unsigned tv[TJ];
-#pragma unroll
-      for (int b = 0; b < TJ; ++b) tv[b] = ld_l2(&pown[b * TI + lane]);
-      const uint4 mv = *reinterpret_cast<const uint4*>(A.S.nbr_tm + (size_t)t * MASK_STRIDE + lane * 16);
-      __builtin_amdgcn_wave_barrier();   // the previous tile's walk has finished reading the LDS image
-      s_tile[lane + 1] = top;
-      s_tile[(TJ + 1) * BW + lane + 1] = bot;
-      if (xl <= TJ + 1) s_tile[xl * BW + (xr ? TI + 1 : 0)] = X;
-#pragma unroll
-      for (int b = 0; b < TJ; ++b) s_tile[(b + 1) * BW + lane + 1] = tv[b];
-      *reinterpret_cast<uint4*>(&s_mask[lane * 16]) = mv;
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    // ---- walk inside the tile ----
-    int il = ci & (TI - 1), jl = cj & (TJ - 1);
-    unsigned uc = s_tile[(jl + 1) * BW + il + 1];
-    for (;;) {
-      if (lane == 0 && len < A.rev_cap) rev[len] = cj * rows + ci;
-      ++len;
-      if (ci == si && cj == sj) { done = true; break; }
-      if (len > ncell || uc == 0u) { ok = false; break; }
-      const unsigned mc = s_mask[il * 16 + jl];
-      const unsigned un = s_tile[(jl + 1) * BW + il + 1 + off];
-      const bool hit = lane < 8 && ((mc >> k) & 1u) && un != 0u && un == uc + (unsigned)wk;   // g(n) + w == g(c)
-      const unsigned long long m = __ballot(hit);
-      if (!m) { ok = false; break; }
-      const int src = __ffsll((long long)m) - 1;
-      uc = (unsigned)__shfl((int)un, src);
-      const int sdi = kdi_of(src), sdj = kdj_of(src);
-      ci += sdi; cj += sdj; il += sdi; jl += sdj;
-      if (il < 0 || jl < 0 || il >= TI || jl >= TJ) break;   // left the tile: load that one
-    }
-  }
-  if (!ok) {
-    if (lane == 0) A.results[q] = rna_astar_result{1, 0, INF, r.expanded, r.rounds, r.buckets};
+  const int state = s_state;
+  const rna_astar_result r{state == 1 ? TSA_FOUND : (state >= 4 ? state : 1), 0, state == 1 ? s_best : INF, s_expanded,
+                           (s_jobs_done + WAVES - 1) / WAVES, s_bucket - s_bucket0 + 1};
+  if (state != 1) {
+    if (tid == 0) results[q] = r;
     return;
   }
-  if (len > A.max_path_len || len > A.rev_cap) {
-    if (lane == 0) A.results[q] = rna_astar_result{3, len, r.cost, r.expanded, r.rounds, r.buckets};
-    return;
-  }
+  // found: the first wavefront traces the path over the exact field (the queue memory holds the LDS image of the walk)
+  __syncthreads();
+  if (wv != 0) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  int32_t* path = A.paths + (size_t)q * A.max_path_len;
-  for (int i = lane; i < len; i += 64) path[i] = tsa_buffer_lin(rev[len - 1 - i], rows, cols, A.s0, A.s1);
-  if (lane == 0) A.results[q] = rna_astar_result{0, len, r.cost, r.expanded, r.rounds, r.buckets};
+  tsa_backtrace_wave(A, q, r, lane, s_ent, reinterpret_cast<unsigned char*>(s_ent + BW * (TJ + 2)));
 }
 
 // |{n : g(n) + h(n) <= f*}| per query from the pages still resident in HBM (measurement utility)
@@ -1260,13 +1323,10 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     RNA_HIP(e, hipStreamWaitEvent(search_stream, ev_init, 0));
   }
   {
-    // the pages the last search on this stage used back to "unreached", counters, launch order: the stage's own data,
-    // on the stage's own stream (the engine stream's chain of short kernels is what gates the next batch)
+    // ticket and launch order (the pages of a slot are reset by the workgroup that takes the slot)
     KernelTimer kt(e, RNA_K_ASTAR_RESET, search_stream);
-    hipLaunchKernelGGL(tsa_reset_kernel, dim3(128, a.max_queries), dim3(256), 0, search_stream, S, ti * tj);   // ~5 pages per block at 4096^2
     const int ranked = n <= 2048 ? 1 : 0;
-    hipLaunchKernelGGL(tsa_prepare_kernel, dim3(1), dim3(256), ranked ? (size_t)n * sizeof(int) : 0, search_stream, S, a.max_queries, q_dev, n,
-                       rows, cols, ranked);
+    hipLaunchKernelGGL(tsa_prepare_kernel, dim3(1), dim3(256), ranked ? (size_t)n * sizeof(int) : 0, search_stream, S, q_dev, n, rows, cols, ranked);
     RNA_HIP(e, hipGetLastError());
   }
   {
@@ -1276,11 +1336,12 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     A.rows = rows; A.cols = cols; A.tiles_i = ti; A.tiles_j = tj; A.s0 = e->geom.start[0]; A.s1 = e->geom.start[1];
     A.queries = q_dev; A.S = S; A.bucket_width = a.bucket_width; A.paths = paths_dev; A.max_path_len = max_len;
     A.rev_all = a.rev[slot]; A.rev_cap = a.rev_cap; A.results = res_dev;
+    A.prio_first = a.depth > 1 ? RNA_TSA_PRIO_FIRST : 0;
+    if (const char* pf = getenv("RNA_TSA_PRIO_FIRST")) A.prio_first = atoi(pf);   // developer knob
     size_t lds_dyn = 4 * nt_bytes;
     if (const char* pad = getenv("RNA_TSA_LDS_PAD")) lds_dyn += (size_t)atoi(pad);   // developer knob: fewer search workgroups per CU
     if (a.depth > 1) hipLaunchKernelGGL(tsa_search_kernel<TSA_WAVES>, dim3(n), dim3(TSA_WAVES * 64), lds_dyn, search_stream, A);
     else hipLaunchKernelGGL(tsa_search_kernel<16>, dim3(n), dim3(16 * 64), lds_dyn, search_stream, A);
-    hipLaunchKernelGGL(tsa_backtrace_kernel, dim3(n), dim3(64), 0, search_stream, A);
     RNA_HIP(e, hipGetLastError());
   }
   return RNA_OK;
@@ -1290,21 +1351,13 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
 void tsa_stats_dump() {
   unsigned long long st[32];
   if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_tsa_stat), sizeof(st)) != hipSuccess) return;
-  {
-    double rounds = 0, jj = 0;
-    for (int b = 0; b < 6; ++b) { rounds += (double)st[16 + b]; jj += (double)st[24 + b]; }
-    if (rounds > 0)
-      fprintf(stderr, "[tsa stats] rounds by jobs 1-4: %.1f%% (%.1f%% of jobs)  5-8: %.1f%% (%.1f%%)  9-16: %.1f%% (%.1f%%)  17-32: %.1f%% (%.1f%%)  33-64: %.1f%% (%.1f%%)  65+: %.1f%% (%.1f%%)\n",
-              100 * st[16] / rounds, 100 * st[24] / jj, 100 * st[17] / rounds, 100 * st[25] / jj, 100 * st[18] / rounds, 100 * st[26] / jj,
-              100 * st[19] / rounds, 100 * st[27] / jj, 100 * st[20] / rounds, 100 * st[28] / jj, 100 * st[21] / rounds, 100 * st[29] / jj);
-  }
   const double jobs = (double)st[7];
   if (jobs <= 0) return;
   const double busy = (double)(st[0] + st[1] + st[2]);
-  fprintf(stderr, "[tsa stats, tile kernel, all launches] jobs %.0f (%.1f%% no-op) | per job us: load+halo %.2f sweeps %.2f results %.2f | wave lifetime %.1f wave-ms, in jobs %.1f wave-ms (%.1f%%), in round set-up %.1f wave-ms (%.1f%%, %.2f us per round) | row evaluations per job %.1f, extra horizontal passes %.1f\n",
+  fprintf(stderr, "[tsa stats, tile kernel, all launches] jobs %.0f (%.1f%% no-op) | per job us: load+halo %.2f sweeps %.2f results %.2f | wave lifetime %.1f wave-ms, in jobs %.1f wave-ms (%.1f%%), taking jobs %.1f wave-ms (%.1f%%) | row evaluations per job %.1f, extra horizontal passes %.1f | shader clock while searching %.0f MHz\n",
           jobs, 100.0 * (double)st[10] / jobs, st[0] * 0.01 / jobs, st[1] * 0.01 / jobs, st[2] * 0.01 / jobs, st[5] * 1e-5, busy * 1e-5,
-          100.0 * busy / (double)st[5], st[4] * 1e-5, 100.0 * (double)st[4] / (double)st[5], st[4] * 0.01 / (double)std::max<unsigned long long>(1, st[6]),
-          st[8] / jobs, st[11] / jobs);
+          100.0 * busy / (double)st[5], st[4] * 1e-5, 100.0 * (double)st[4] / (double)st[5], st[8] / jobs, st[11] / jobs,
+          100.0 * (double)st[12] / (double)std::max<unsigned long long>(1, st[5]));
 }
 #endif
 

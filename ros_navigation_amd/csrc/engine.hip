@@ -105,6 +105,67 @@ __global__ void nbr_mask_tiles_kernel(uint8_t* __restrict__ nbr, const float* __
   }
 }
 
+// MapProvider::updateMap's compose step and the mask refresh in ONE launch (unmoved map, masks valid before the update):
+// the block of a dirty tile copies laser -> master (composeMasterMapFromLayerdMap, mc/src/map_provider.cpp:216-223,
+// restricted to where the two layers differ), and every block whose tile is dirty or touches a dirty tile recomputes
+// its cells' masks.  A cell of a DIRTY tile is read from the laser layer -- what master holds there once this launch
+// has finished; its own block may still be copying --, a cell of a clean tile from master.  The block also clears its
+// byte of `next_dirty`, the flag array the next update will mark (the two arrays swap roles on the host: the flags
+// this launch consumed stay readable as "last dirty" until the next compose, rna_last_dirty_tiles).
+__global__ void __launch_bounds__(256) compose_nbr_tiles_kernel(uint8_t* __restrict__ nbr, float* __restrict__ master, const float* __restrict__ laser,
+                                                                const unsigned* __restrict__ dirty, unsigned* __restrict__ next_dirty, int rows,
+                                                                int cols, int tiles_i, int tiles_j) {
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  const unsigned char* dflag = reinterpret_cast<const unsigned char*>(dirty);
+  unsigned dmask = 0u;   // bit (dj + 1) * 3 + (di + 1): that neighbouring tile is dirty
+  for (int dj = -1; dj <= 1; ++dj)
+    for (int di = -1; di <= 1; ++di) {
+      const int a = ti + di, b = tj + dj;
+      if (a < 0 || b < 0 || a >= tiles_i || b >= tiles_j) continue;
+      if (dflag[b * tiles_i + a]) dmask |= 1u << ((dj + 1) * 3 + di + 1);
+    }
+  if (threadIdx.x == 0) reinterpret_cast<volatile unsigned char*>(next_dirty)[tj * tiles_i + ti] = 0;
+  if (!dmask) return;
+  const bool own = (dmask >> 4) & 1u;
+  __shared__ uint8_t blk[(TILE + 2) * (TILE + 2)];  // [jj][ii], ii fastest; out of map = blocked
+  const int i0 = ti * TILE - 1, j0 = tj * TILE - 1;
+  for (int k = threadIdx.x; k < (TILE + 2) * (TILE + 2); k += blockDim.x) {
+    const int ii = k % (TILE + 2), jj = k / (TILE + 2);
+    const int i = i0 + ii, j = j0 + jj;
+    uint8_t b = 1;
+    if (i >= 0 && j >= 0 && i < rows && j < cols) {
+      const int di = ii == 0 ? 0 : (ii == TILE + 1 ? 2 : 1), dj = jj == 0 ? 0 : (jj == TILE + 1 ? 2 : 1);
+      const size_t lin = (size_t)j * rows + i;
+      const bool from_laser = (dmask >> (dj * 3 + di)) & 1u;
+      const float v = from_laser ? laser[lin] : master[lin];
+      if (own && di == 1 && dj == 1) master[lin] = v;   // the compose itself
+      b = cell_blocked(v) ? 1 : 0;
+    }
+    blk[k] = b;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < TILE * TILE; k += blockDim.x) {
+    const int li = k & (TILE - 1), lj = k >> 6;
+    const int i = ti * TILE + li, j = tj * TILE + lj;
+    if (i >= rows || j >= cols) continue;
+    const uint8_t* c = &blk[(lj + 1) * (TILE + 2) + (li + 1)];
+    constexpr int S = TILE + 2;
+    unsigned m = 0;
+    if (!c[0]) {
+      const bool up = !c[-1], dn = !c[1], lf = !c[-S], rt = !c[S];
+      if (lf && up && !c[-S - 1]) m |= 1u;        // (-1,-1)
+      if (lf) m |= 2u;                            // ( 0,-1)
+      if (lf && dn && !c[-S + 1]) m |= 4u;        // ( 1,-1)
+      if (up) m |= 8u;                            // (-1, 0)
+      if (dn) m |= 16u;                           // ( 1, 0)
+      if (rt && up && !c[S - 1]) m |= 32u;        // (-1, 1)
+      if (rt) m |= 64u;                           // ( 0, 1)
+      if (rt && dn && !c[S + 1]) m |= 128u;       // ( 1, 1)
+    }
+    nbr[(size_t)j * rows + i] = (uint8_t)m;
+  }
+}
+
 // GridMap::clearRows / clearCols on every layer (gmc/src/GridMap.cpp:590-606)
 __global__ void clear_region_kernel(float* __restrict__ p, int rows, int i0, int ni, int j0, int nj) {
   const size_t n = (size_t)ni * nj;
@@ -651,6 +712,18 @@ extern "C" int rna_compose_master(rna_engine* e, int mode) {
   RNA_HIP(e, hipSetDevice(e->device));
   const size_t words = ((size_t)e->tiles_i * e->tiles_j + 3) / 4;  // one byte per tile, rounded to words
   const bool full = (mode == 1) || e->laser_all_dirty || e->master_diverged;
+  const bool moved = e->geom.start[0] != 0 || e->geom.start[1] != 0;
+  if (!full && !moved && !e->nbr_all_dirty) {
+    // the usual case of the replan loop: dirty tiles only, masks valid before -- one launch, and the two flag arrays
+    // swap roles (what this compose consumed = rna_last_dirty_tiles; the other one, cleared by the launch, is marked next)
+    KernelTimer kt(e, RNA_K_COMPOSE);
+    hipLaunchKernelGGL(compose_nbr_tiles_kernel, dim3(e->tiles_i, e->tiles_j), dim3(256), 0, e->stream, e->nbr,
+                       e->layer[RNA_LAYER_MASTER], e->layer[RNA_LAYER_LASER], e->dirty_tiles, e->last_dirty, e->geom.size[0],
+                       e->geom.size[1], e->tiles_i, e->tiles_j);
+    RNA_HIP(e, hipGetLastError());
+    std::swap(e->dirty_tiles, e->last_dirty);
+    return RNA_OK;
+  }
   {
     KernelTimer kt(e, RNA_K_COMPOSE);
     if (full) {
@@ -663,11 +736,10 @@ extern "C" int rna_compose_master(rna_engine* e, int mode) {
       RNA_HIP(e, hipGetLastError());
     }
   }
-  if (e->laser_all_dirty || e->master_diverged) {
-    // a layer was replaced wholesale: nothing is known about which masks are still valid
+  if (e->laser_all_dirty || e->master_diverged || moved) {
+    // a layer was replaced wholesale: nothing is known about which masks are still valid; moved map: dirty tiles (buffer
+    // space) do not line up with mask tiles (map space) -- the masks are rebuilt before the next search (map_prepare_nbr)
     e->nbr_all_dirty = true;
-  } else if (e->geom.start[0] != 0 || e->geom.start[1] != 0) {
-    e->nbr_all_dirty = true;   // moved map: dirty tiles (buffer space) do not line up with mask tiles (map space)
   } else if (!e->nbr_all_dirty) {
     // masks were valid before this update: refresh only tiles that are dirty or touch a dirty tile
     KernelTimer kt(e, RNA_K_NBRMASK);

@@ -77,6 +77,7 @@ struct AstarDevice {
   hipStream_t side[MAX_DEPTH] = {};
   hipEvent_t done[MAX_DEPTH] = {}; // search of the batch that last used this set has finished
   bool busy[MAX_DEPTH] = {};
+  unsigned long long stage_seq[MAX_DEPTH] = {};   // launch number of the stage's last batch (0: never used)
   hipEvent_t ev_init = nullptr;
   unsigned long long launches = 0;
   int last_slot = 0;

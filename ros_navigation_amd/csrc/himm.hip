@@ -246,7 +246,7 @@ __global__ void himm_bin_count_kernel(const int4* __restrict__ desc, const int* 
 }
 
 // exclusive prefix sum of the tile counts (one workgroup; ntile <= 65536 at 4096 x 4096 cells per 64 x 64 tile)
-__global__ void __launch_bounds__(1024) himm_bin_scan_kernel(const int* __restrict__ tile_count, int ntile, int* __restrict__ tile_off,
+__global__ void __launch_bounds__(1024) himm_bin_scan_kernel(int* __restrict__ tile_count, int ntile, int* __restrict__ tile_off,
                                                              int* __restrict__ tile_cursor) {
   __shared__ int s_part[1024];
   const int per = (ntile + 1023) / 1024;
@@ -262,7 +262,8 @@ __global__ void __launch_bounds__(1024) himm_bin_scan_kernel(const int* __restri
     __syncthreads();
   }
   int run = s_part[threadIdx.x] - sum;
-  for (int t = lo; t < hi; ++t) { tile_off[t] = run; tile_cursor[t] = 0; run += tile_count[t]; }
+  for (int t = lo; t < hi; ++t) { tile_off[t] = run; tile_cursor[t] = 0; run += tile_count[t]; tile_count[t] = 0; }   // (counts: zero again for the next batch)
+  if (threadIdx.x == 1023) tile_off[ntile] = s_part[1023];
 }
 
 __global__ void himm_bin_fill_kernel(const int4* __restrict__ desc, const int* __restrict__ ncells, int n, int tiles_i,
@@ -305,7 +306,7 @@ __device__ __forceinline__ void himm_count_marked_clear(int cell, int r, const H
 
 constexpr int HIMM_TR_THREADS = 512;   // 8 wavefronts: two per SIMD next to the four of a resident search workgroup
 __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int rows, int cols, int tiles_i, const int4* __restrict__ desc,
-                                                               const int* __restrict__ ncells, const int* __restrict__ tile_count,
+                                                               const int* __restrict__ ncells,
                                                                const int* __restrict__ tile_off, const int* __restrict__ pairs,
                                                                float* __restrict__ layer, const unsigned* __restrict__ mark_bitmap,
                                                                const HimmSlot* __restrict__ slots, int slot_mask,
@@ -319,7 +320,7 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
   __shared__ unsigned s_mcnt[2 * HIMM_MTAB];   // ... clears before / after that mark
   __shared__ int s_touched;
   const int t = blockIdx.x >> 1, half = blockIdx.x & 1;
-  const int np = tile_count[t];
+  const int np = tile_off[t + 1] - tile_off[t];   // rays registered with this tile
   if (np == 0) return;
   const int ti = t % tiles_i, tj = t / tiles_i;
   const int i0 = ti << 6, j0 = (tj << 6) + (half << 5);
@@ -425,11 +426,12 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
   }
 }
 
-__global__ void himm_apply_kernel(int rows, const HimmSlot* __restrict__ slots, int n_slots,
+__global__ void himm_apply_kernel(int rows, HimmSlot* __restrict__ slots, int n_slots, int* __restrict__ total,
                                   const unsigned* __restrict__ before, const unsigned* __restrict__ after,
                                   float* __restrict__ layer, unsigned* __restrict__ mark_bitmap,
                                   unsigned* __restrict__ dirty_tiles, int tiles_i) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h == 0) *total = 0;   // (himm_collect, the only user, has finished)
   if (h >= n_slots) return;
   const HimmSlot sl = slots[h];
   if (sl.cell < 0) return;
@@ -440,7 +442,8 @@ __global__ void himm_apply_kernel(int rows, const HimmSlot* __restrict__ slots, 
   }
   v = himm_clear_n(v, after[sl.offset + sl.len - 1]);
   layer[sl.cell] = v;
-  atomicAnd(&mark_bitmap[sl.cell >> 5], ~(1u << (sl.cell & 31)));  // leave the bitmap all-zero
+  atomicAnd(&mark_bitmap[sl.cell >> 5], ~(1u << (sl.cell & 31)));  // leave the bitmap all-zero ...
+  slots[h] = HimmSlot{-1, -1, 0, 0};                               // ... and the hash table empty for the next batch
   const int i = sl.cell % rows, j = sl.cell / rows;
   const int tile = (j >> 6) * tiles_i + (i >> 6);
   if (dirty_tiles) reinterpret_cast<volatile unsigned char*>(dirty_tiles)[tile] = 1;
@@ -454,7 +457,9 @@ int ensure_scratch(rna_engine* e, int n) {
     if ((rc = dev_alloc(e, &s.mark_bitmap, words)) != RNA_OK) return rc;
     RNA_HIP(e, hipMemsetAsync(s.mark_bitmap, 0, words * sizeof(unsigned), e->stream));
     if ((rc = dev_alloc(e, &s.total, 1)) != RNA_OK) return rc;
-    if ((rc = dev_alloc(e, &s.tile_bins, (size_t)3 * e->tiles_i * e->tiles_j)) != RNA_OK) return rc;
+    // per 64 x 64 tile: count | offset (ntile + 1) | cursor; the counts are all zero between batches (the scan leaves them so)
+    if ((rc = dev_alloc(e, &s.tile_bins, (size_t)3 * e->tiles_i * e->tiles_j + 1)) != RNA_OK) return rc;
+    RNA_HIP(e, hipMemsetAsync(s.tile_bins, 0, ((size_t)3 * e->tiles_i * e->tiles_j + 1) * sizeof(int), e->stream));
   }
   if (n <= s.cap_rays) return RNA_OK;
   int cap = 1024;
@@ -476,6 +481,8 @@ int ensure_scratch(rna_engine* e, int n) {
   }
   s.n_slots = cap * 2;
   s.cap_rays = cap;
+  hipLaunchKernelGGL(himm_init_slots_kernel, dim3((s.n_slots + 255) / 256), dim3(256), 0, e->stream, s.slots, s.n_slots, s.total);
+  RNA_HIP(e, hipGetLastError());
   return RNA_OK;
 }
 
@@ -490,8 +497,7 @@ int himm_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n) {
                                 : make_int4(0, g.size[0], 0, g.size[1]);
   {
     KernelTimer kt(e, RNA_K_HIMM_PREP);
-    hipLaunchKernelGGL(himm_init_slots_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, e->stream, s.slots,
-                       n_slots, s.total);
+    // (the hash table is empty and *total is 0: himm_apply leaves them so, ensure_scratch starts them so)
     hipLaunchKernelGGL(himm_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, g, rays_dev, n, s.desc,
                        s.ncells, s.next, s.slots, n_slots - 1, s.mark_bitmap, win);
     hipLaunchKernelGGL(himm_collect_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, e->stream, s.slots, n_slots,
@@ -503,21 +509,20 @@ int himm_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n) {
     const int ntile = e->tiles_i * e->tiles_j;
     int* count = s.tile_bins;
     int* off = s.tile_bins + ntile;
-    int* cursor = s.tile_bins + 2 * ntile;
-    RNA_HIP(e, hipMemsetAsync(count, 0, (size_t)ntile * sizeof(int), e->stream));
+    int* cursor = s.tile_bins + 2 * ntile + 1;
     hipLaunchKernelGGL(himm_bin_count_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, s.desc, s.ncells, n, e->tiles_i, count);
     hipLaunchKernelGGL(himm_bin_scan_kernel, dim3(1), dim3(1024), 0, e->stream, count, ntile, off, cursor);
     hipLaunchKernelGGL(himm_bin_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, s.desc, s.ncells, n, e->tiles_i, off,
                        cursor, s.pairs);
     hipLaunchKernelGGL(himm_tile_raster_kernel, dim3(2 * ntile), dim3(HIMM_TR_THREADS), 0, e->stream, g.size[0], g.size[1], e->tiles_i, s.desc,
-                       s.ncells, count, off, s.pairs, e->layer[layer], s.mark_bitmap, s.slots, n_slots - 1, s.seqs, s.before,
+                       s.ncells, off, s.pairs, e->layer[layer], s.mark_bitmap, s.slots, n_slots - 1, s.seqs, s.before,
                        s.after, layer == RNA_LAYER_LASER ? e->dirty_tiles : nullptr, win);
     RNA_HIP(e, hipGetLastError());
   }
   {
     KernelTimer kt(e, RNA_K_HIMM_APPLY);
     hipLaunchKernelGGL(himm_apply_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, e->stream, g.size[0], s.slots,
-                       n_slots, s.before, s.after, e->layer[layer], s.mark_bitmap, layer == RNA_LAYER_LASER ? e->dirty_tiles : nullptr, e->tiles_i);
+                       n_slots, s.total, s.before, s.after, e->layer[layer], s.mark_bitmap, layer == RNA_LAYER_LASER ? e->dirty_tiles : nullptr, e->tiles_i);
     RNA_HIP(e, hipGetLastError());
   }
   if (layer == RNA_LAYER_MASTER) { e->nbr_all_dirty = true; e->master_diverged = true; }

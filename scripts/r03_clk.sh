@@ -1,0 +1,4 @@
+#!/bin/bash
+RNA_LIB=librna_stats.so RNA_BENCH_ONLY_ASTAR=1 timeout 300 python bench.py --no-cpu --steps 20 2>&1 | grep "tsa stats" | cut -c1-600
+REPS=2 RNA_LIB=librna_stats.so timeout 300 python scripts/astar_stats.py 4096 256 96000 2>&1 | grep "tsa stats\|search ms" | cut -c1-600
+RNA_LIB=librna_stats.so RNA_BENCH_ONLY_ASTAR=1 RNA_ASTAR_PIPELINE=6 timeout 300 python bench.py --no-cpu --steps 20 2>&1 | grep "tsa stats\|value" | cut -c1-600

@@ -44,7 +44,7 @@ def test_bench_line_contract_on_a_small_grid():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     cfg = d["config"]
     # every query of every batch still in a result buffer was answered (found / no path), none failed
-    assert cfg["astar_queries_checked"] == 32 * cfg["astar_pipeline_depth"] and cfg["astar_queries_answered"] == cfg["astar_queries_checked"]
+    assert cfg["astar_queries_checked"] == 32 * 3 * cfg["astar_pipeline_depth"] and cfg["astar_queries_answered"] == cfg["astar_queries_checked"]
     assert cfg["astar_paths_found"] > 0 and cfg["rotating_input_sets"] == 4
     # what the engine really allocated (stages / pages per query / concurrent queries may shrink to fit HBM) is reported
     alloc = cfg["astar_allocated"]

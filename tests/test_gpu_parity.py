@@ -514,11 +514,13 @@ def test_astar_pipelined_batches_with_map_updates_in_between(R):
 def test_bench_loop_at_full_size_matches_oracle_every_step(R):
     """bench.py's timed loop as it runs, at BASELINE's size: 4096 x 4096 map, per step a 100 032-ray HIMM batch (four
     batches in rotation) + fused compose -> VFH+ for 256 poses (four pose sets, the robots' VFH state carried from step
-    to step) -> 256 grid-A* queries (four query sets) through the asynchronous device entry points with six batches in
-    flight, nothing waited for in between.  Every step's map, VFH+ commands and histograms, and A* statuses / costs /
-    paths against the oracle fed with the same sequence."""
+    to step) -> 256 grid-A* queries (four query sets) through the asynchronous device entry points at the bench's own
+    pipeline depth (13 batches in flight on CU-masked streams), nothing waited for in between, for 27 steps: every stage
+    is used three times, so the lazy reset of the pages a stage's previous search handed out runs twice per stage under
+    the load it has in the bench.  Every step's map, VFH+ commands and histograms, and A* statuses / costs / paths
+    against the oracle fed with the same sequence."""
     hip = _Hip()
-    n, nq, steps, rot, depth, max_len = 4096, 256, 7, 4, 6, 32768
+    n, nq, steps, rot, depth, max_len = 4096, 256, 27, 4, 13, 32768
     L = n * 0.05
     e = R.Engine(L, L, 0.05)
     g = O.make_geom(L, L, 0.05)
@@ -614,7 +616,7 @@ def test_engines_release_their_hbm(R):
     rq = R.synth.rrt_queries(4, master, 256, 256, lambda i, j: (6.4 - 0.025 - 0.05 * i, 6.4 - 0.025 - 0.05 * j), seed=1, max_samples=2000)
     before = None
     for rep in range(12):
-        for kernel in ("tile", "persist"):
+        for kernel in ("tile",):
             os.environ["RNA_ASTAR_KERNEL"] = kernel
             e = R.Engine(12.8, 12.8, 0.05)
             e.upload(R.capi.LAYER_MASTER, master)
