@@ -307,7 +307,7 @@ __global__ void astar_settled_kernel(int rows, int cols, const rna_astar_query* 
 }
 
 // allocation of the configuration ensure_config settled on; everything is released again on failure
-static int alloc_stages(rna_engine* e) {
+static int alloc_stages_impl(rna_engine* e) {
   AstarDevice& a = e->astar;
   int rc;
   // frontier kernel: each query's field is padded (the 3-cell column loads reach one word past either end) and 256-byte aligned
@@ -324,6 +324,17 @@ static int alloc_stages(rna_engine* e) {
       a.tsa_aux[d] = aux;
       RNA_HIP(e, hipMemsetAsync(aux, 0, aux_bytes, e->stream));
       if ((rc = tsa_stage_prepare(e, d)) != RNA_OK) { astar_release(e); return rc; }
+      if (a.page_cap < tsa_tiles(e)) {   // a search may outgrow its share of pages: retry slots with a page per tile
+        char* rp = nullptr;
+        if ((rc = dev_alloc(e, &rp, tsa_retry_pool_bytes(e))) != RNA_OK) { astar_release(e); return rc; }
+        a.g_retry[d] = reinterpret_cast<int32_t*>(rp);
+        char* ra = nullptr;
+        if ((rc = dev_alloc(e, &ra, tsa_retry_aux_bytes(e))) != RNA_OK) { astar_release(e); return rc; }
+        a.tsa_aux_retry[d] = ra;
+        const hipError_t me = hipMemsetAsync(ra, 0, tsa_retry_aux_bytes(e), e->stream);
+        if (me != hipSuccess) { astar_release(e); RNA_HIP(e, me); }
+        if ((rc = tsa_retry_prepare(e, d)) != RNA_OK) { astar_release(e); return rc; }
+      }
     } else {
       if ((rc = dev_alloc(e, &a.g[d], a.field_stride * (size_t)a.max_queries + 128)) != RNA_OK) { astar_release(e); return rc; }
       if ((rc = dev_alloc(e, &a.queues[d], (size_t)3 * a.queue_cap * a.max_queries)) != RNA_OK) { astar_release(e); return rc; }
@@ -365,6 +376,18 @@ static int alloc_stages(rna_engine* e) {
   return RNA_OK;
 }
 
+// (whatever fails inside -- an allocation, a memset, a stream or an event -- nothing half-built is left behind: the next
+// call starts from nothing again instead of finding a[0] allocated and taking the configuration for complete)
+static int alloc_stages(rna_engine* e) {
+  const int rc = alloc_stages_impl(e);
+  if (rc != RNA_OK) {
+    const std::string why = e->err;
+    (void)astar_release(e);
+    e->err = why;
+  }
+  return rc;
+}
+
 int ensure_config(rna_engine* e) {
   AstarDevice& a = e->astar;
   if (a.g[0]) return RNA_OK;
@@ -395,7 +418,8 @@ int ensure_config(rna_engine* e) {
   auto stage_bytes = [&]() -> double {
     if (a.mode != 0)
       return (double)tsa_pool_bytes(a.max_queries, a.page_cap) + (double)tsa_aux_bytes(e, a.max_queries, a.page_cap) +
-             (double)a.rev_cap * 4.0 * a.max_queries;
+             (double)a.rev_cap * 4.0 * a.max_queries +
+             (a.page_cap < ntile ? (double)tsa_retry_pool_bytes(e) + (double)tsa_retry_aux_bytes(e) : 0.0);
     return ((double)(e->ncell + 128) * 4.0 + 3.0 * a.queue_cap * sizeof(int2)) * a.max_queries;
   };
   // (tile kernel) half a map's worth of pages per query first -- searches touch a few per cent of the map, and twelve
@@ -498,6 +522,8 @@ int astar_release(rna_engine* e) {
   for (int d = 0; d < AstarDevice::MAX_DEPTH; ++d) {
     dev_free(&a.g[d]); dev_free(&a.queues[d]); dev_free(&a.rev[d]);
     if (a.tsa_aux[d]) { (void)hipFree(a.tsa_aux[d]); a.tsa_aux[d] = nullptr; }
+    dev_free(&a.g_retry[d]);
+    if (a.tsa_aux_retry[d]) { (void)hipFree(a.tsa_aux_retry[d]); a.tsa_aux_retry[d] = nullptr; }
     if (a.side[d]) { (void)hipStreamDestroy(a.side[d]); a.side[d] = nullptr; }
     if (a.done[d]) { (void)hipEventDestroy(a.done[d]); a.done[d] = nullptr; }
     a.busy[d] = false;

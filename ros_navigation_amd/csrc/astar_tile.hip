@@ -858,13 +858,19 @@ struct TsaLaunch {
   TsaStage S;
   int bucket_width;
   int prio_first;   // the first prio_first workgroups to start (the longest expected searches) run at raised wave priority
+  // Second pass over a batch (retry != 0): workgroup r serves the r-th query that ran out of pages (status 5) in the
+  // first pass, in slot r of the stage's RETRY view S2 -- a few slots with one page per tile of the map, which a
+  // search can never outgrow (a goal that cannot be reached floods its whole component; the reference answers "no
+  // path", it does not fail).
+  int retry, n;
+  TsaStage S2;
   int32_t* paths;
   int max_path_len;
   int32_t* rev_all;
   int rev_cap;
   rna_astar_result* results;
 };
-constexpr int TSA_FOUND = -1000;        // provisional status between the search and the backtrace kernel
+constexpr int TSA_FOUND = -1000;        // provisional status inside the search kernel: found, path not traced yet
 
 // Canonical backtrace, one wavefront per query: walk from the goal to the neighbour n with g[n] + w(n, c) == g[c],
 // lowest linear index first (lane k probes neighbour k).  The walk runs in LDS: the 64 x 16 tile of the current
@@ -874,12 +880,12 @@ constexpr int TSA_FOUND = -1000;        // provisional status between the search
 constexpr int BW = TI + 2;   // LDS row pitch of the backtrace image (halo included)
 // (run by the first wavefront of the query's search workgroup once the search has ended -- the other wavefronts have
 // left, the workgroup's queue memory holds the LDS image; r = the provisional result)
-__device__ __forceinline__ void tsa_backtrace_wave(const TsaLaunch& A, const int q, const rna_astar_result r, const int lane,
-                                                   unsigned* s_tile, unsigned char* s_mask) {
+__device__ __forceinline__ void tsa_backtrace_wave(const TsaLaunch& A, const TsaStage& S, const int sl, const int q, const rna_astar_result r,
+                                                   const int lane, unsigned* s_tile, unsigned char* s_mask) {
   const int rows = A.rows, cols = A.cols, tiles_i = A.tiles_i, tiles_j = A.tiles_j;
   const int ncell = rows * cols, ntile = tiles_i * tiles_j;
-  const unsigned* tmap = A.S.tmap + (size_t)q * ntile;
-  const size_t page_base = (size_t)q * A.S.cap;
+  const unsigned* tmap = S.tmap + (size_t)sl * ntile;
+  const size_t page_base = (size_t)sl * S.cap;
   const int start = tsa_unwrap_lin(A.queries[q].start, rows, cols, A.s0, A.s1);
   const int goal = tsa_unwrap_lin(A.queries[q].goal, rows, cols, A.s0, A.s1);
   const int si = start % rows, sj = start / rows;
@@ -907,18 +913,18 @@ __device__ __forceinline__ void tsa_backtrace_wave(const TsaLaunch& A, const int
     {
       const int xl = lane & 31;
       const bool xr = lane >= 32;
-      const unsigned* pown = A.S.pages + (gpage(8) << 10);
-      const unsigned top = ld_l2(&A.S.pages[(gpage(1) << 10) + (TJ - 1) * TI + lane]);
-      const unsigned bot = ld_l2(&A.S.pages[(gpage(6) << 10) + lane]);
+      const unsigned* pown = S.pages + (gpage(8) << 10);
+      const unsigned top = ld_l2(&S.pages[(gpage(1) << 10) + (TJ - 1) * TI + lane]);
+      const unsigned bot = ld_l2(&S.pages[(gpage(6) << 10) + lane]);
       const int xdir = xl == 0 ? (xr ? 2 : 0) : (xl <= TJ ? (xr ? 4 : 3) : (xr ? 7 : 5));
       const int xrow = xl == 0 ? TJ - 1 : (xl <= TJ ? xl - 1 : 0);
       const size_t gpx = gpage(xdir);
       unsigned X = 0u;
-      if (xl <= TJ + 1) X = ld_l2(&A.S.paux[gpx * AUX_WORDS + (xr ? 0 : 16) + xrow]);
+      if (xl <= TJ + 1) X = ld_l2(&S.paux[gpx * AUX_WORDS + (xr ? 0 : 16) + xrow]);
       unsigned tv[TJ];
 #pragma unroll
       for (int b = 0; b < TJ; ++b) tv[b] = ld_l2(&pown[b * TI + lane]);
-      const uint4 mv = *reinterpret_cast<const uint4*>(A.S.nbr_tm + (size_t)t * MASK_STRIDE + lane * 16);
+      const uint4 mv = *reinterpret_cast<const uint4*>(S.nbr_tm + (size_t)t * MASK_STRIDE + lane * 16);
       __builtin_amdgcn_wave_barrier();   // the previous tile's walk has finished reading the LDS image
       s_tile[lane + 1] = top;
       s_tile[(TJ + 1) * BW + lane + 1] = bot;
@@ -983,13 +989,28 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   // its share of the batch while the other XCDs idle.  With tickets a free CU anywhere takes the next
   // (longest remaining) query.
   __shared__ int s_q, s_rank;
-  if (threadIdx.x == 0) { const int k = atomicAdd(A.S.ticket, 1); s_rank = k; s_q = A.S.perm[k]; }
+  if (!A.retry) {
+    if (threadIdx.x == 0) { const int k = atomicAdd(A.S.ticket, 1); s_rank = k; s_q = A.S.perm[k]; }
+  } else {
+    // the (blockIdx.x + 1)-th query of the batch with status 5 (none: nothing to do)
+    if (threadIdx.x == 0) { s_q = -1; s_rank = 1 << 30; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < A.n; i += TSA_THREADS)
+      if (A.results[i].status == 5) {
+        int before = 0;
+        for (int j = 0; j < i; ++j) before += A.results[j].status == 5 ? 1 : 0;
+        if (before == (int)blockIdx.x) s_q = i;
+      }
+  }
   __syncthreads();
   const int q = __builtin_amdgcn_readfirstlane(s_q);   // wave-uniform values belong in SGPRs: the tile jobs need every VGPR
+  if (q < 0) return;
+  const TsaStage& S = A.retry ? A.S2 : A.S;
+  const int sl = A.retry ? (int)blockIdx.x : q;   // the slot whose pages / tables this search uses
   // A batch lasts as long as its longest search, and a stage cannot take its next batch before: the searches expected
   // to be the longest (the first tickets) get the issue slots of their SIMDs first, the short ones fill in around them.
 #ifndef RNA_TSA_PRIO_FIRST
-#define RNA_TSA_PRIO_FIRST 32
+#define RNA_TSA_PRIO_FIRST 0
 #endif
   if (__builtin_amdgcn_readfirstlane(s_rank) < A.prio_first) __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1015,13 +1036,13 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
 
   TsaCtx C;
   C.rows = rows; C.cols = cols; C.tiles_i = tiles_i; C.tiles_j = tiles_j;
-  C.pages = A.S.pages; C.paux = A.S.paux;
-  C.tmap = A.S.tmap + (size_t)q * ntile;
-  C.owner = A.S.owner + (size_t)q * (A.S.cap + 1);
-  C.page_base = (size_t)q * A.S.cap;
-  C.cap = A.S.cap;
+  C.pages = S.pages; C.paux = S.paux;
+  C.tmap = S.tmap + (size_t)sl * ntile;
+  C.owner = S.owner + (size_t)sl * (S.cap + 1);
+  C.page_base = (size_t)sl * S.cap;
+  C.cap = S.cap;
   C.nalloc = &s_nalloc;
-  C.nbr_tm = A.S.nbr_tm;
+  C.nbr_tm = S.nbr_tm;
   C.gi = gi; C.gj = gj;
   C.ts = tile_of(si, sj, tiles_i); C.sa = si & (TI - 1); C.sb = sj & (TJ - 1);
   C.tg = tile_of(gi, gj, tiles_i); C.ga = gi & (TI - 1); C.gb = gj & (TJ - 1);
@@ -1043,7 +1064,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   // kernel of its own takes ~1 ms off every turn of the stage, which can only take its next batch when this one's
   // longest search has ended.
   {
-    const int used_raw = A.S.nalloc[q];
+    const int used_raw = S.nalloc[sl];
     const int used = used_raw < C.cap ? used_raw : C.cap;
     if (used > 0) {
       uint4* pg4 = reinterpret_cast<uint4*>(C.pages + ((C.page_base + 1) << 10));
@@ -1218,7 +1239,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   if (lane == 0) for (int k = 0; k < 16; ++k) atomicAdd(&g_tsa_stat[k], tsa_acc[k]);
 #endif
   // what the next search in this slot has to reset
-  if (tid == 0) A.S.nalloc[q] = s_nalloc < C.cap ? s_nalloc : C.cap;
+  if (tid == 0) S.nalloc[sl] = s_nalloc < C.cap ? s_nalloc : C.cap;
   // (`rounds` reports tile jobs per wavefront: there are no rounds any more)
   const int state = s_state;
   const rna_astar_result r{state == 1 ? TSA_FOUND : (state >= 4 ? state : 1), 0, state == 1 ? s_best : INF, s_expanded,
@@ -1231,7 +1252,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   __syncthreads();
   if (wv != 0) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  tsa_backtrace_wave(A, q, r, lane, s_ent, reinterpret_cast<unsigned char*>(s_ent + BW * (TJ + 2)));
+  tsa_backtrace_wave(A, S, sl, q, r, lane, s_ent, reinterpret_cast<unsigned char*>(s_ent + BW * (TJ + 2)));
 }
 
 // |{n : g(n) + h(n) <= f*}| per query from the pages still resident in HBM (measurement utility)
@@ -1295,6 +1316,37 @@ static TsaStage tsa_stage_view(const rna_engine* e, int slot) {
   S.owner = reinterpret_cast<unsigned*>(base);
   return S;
 }
+// The retry view of a stage (see TsaLaunch::retry): TSA_RETRY slots with one page per tile; its own pages and
+// ticket | nalloc | tmap | owner block, the mask snapshot of the stage itself.
+size_t tsa_retry_pool_bytes(const rna_engine* e) { return tsa_pool_bytes(TSA_RETRY, tsa_ntile(e)); }
+size_t tsa_retry_aux_bytes(const rna_engine* e) {
+  const size_t ntile = (size_t)tsa_ntile(e);
+  return 256 + tsa_align256(TSA_RETRY * sizeof(int)) + tsa_align256((size_t)TSA_RETRY * ntile * sizeof(unsigned)) +
+         tsa_align256((size_t)TSA_RETRY * (ntile + 1) * sizeof(unsigned));
+}
+static TsaStage tsa_retry_view(const rna_engine* e, int slot, const TsaStage& main) {
+  const AstarDevice& a = e->astar;
+  const size_t ntile = (size_t)tsa_ntile(e);
+  char* base = static_cast<char*>(a.tsa_aux_retry[slot]);
+  TsaStage S = main;
+  S.cap = (int)ntile;
+  S.pages = reinterpret_cast<unsigned*>(a.g_retry[slot]);
+  S.paux = S.pages + (((size_t)TSA_RETRY * S.cap + 1) << 10);
+  S.ticket = reinterpret_cast<int*>(base);
+  base += 256;
+  S.nalloc = reinterpret_cast<int*>(base);
+  base += tsa_align256(TSA_RETRY * sizeof(int));
+  S.tmap = reinterpret_cast<unsigned*>(base);
+  base += tsa_align256((size_t)TSA_RETRY * ntile * sizeof(unsigned));
+  S.owner = reinterpret_cast<unsigned*>(base);
+  return S;
+}
+int tsa_retry_prepare(rna_engine* e, int slot) {   // fresh retry pages: "unreached"
+  hipLaunchKernelGGL(tsa_fill_pages_kernel, dim3(2048), dim3(256), 0, e->stream, reinterpret_cast<uint4*>(e->astar.g_retry[slot]),
+                     tsa_retry_pool_bytes(e) / sizeof(uint4));
+  RNA_HIP(e, hipGetLastError());
+  return RNA_OK;
+}
 // fresh stage: pages "unreached" (everything else was zeroed by the caller's hipMemsetAsync)
 int tsa_stage_prepare(rna_engine* e, int slot) {
   const TsaStage S = tsa_stage_view(e, slot);
@@ -1336,12 +1388,21 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     A.rows = rows; A.cols = cols; A.tiles_i = ti; A.tiles_j = tj; A.s0 = e->geom.start[0]; A.s1 = e->geom.start[1];
     A.queries = q_dev; A.S = S; A.bucket_width = a.bucket_width; A.paths = paths_dev; A.max_path_len = max_len;
     A.rev_all = a.rev[slot]; A.rev_cap = a.rev_cap; A.results = res_dev;
+    A.retry = 0; A.n = n; A.S2 = S;
     A.prio_first = a.depth > 1 ? RNA_TSA_PRIO_FIRST : 0;
     if (const char* pf = getenv("RNA_TSA_PRIO_FIRST")) A.prio_first = atoi(pf);   // developer knob
     size_t lds_dyn = 4 * nt_bytes;
     if (const char* pad = getenv("RNA_TSA_LDS_PAD")) lds_dyn += (size_t)atoi(pad);   // developer knob: fewer search workgroups per CU
     if (a.depth > 1) hipLaunchKernelGGL(tsa_search_kernel<TSA_WAVES>, dim3(n), dim3(TSA_WAVES * 64), lds_dyn, search_stream, A);
     else hipLaunchKernelGGL(tsa_search_kernel<16>, dim3(n), dim3(16 * 64), lds_dyn, search_stream, A);
+    if (a.g_retry[slot]) {
+      // second pass: the searches that outgrew their share of pages, on the stage's full-size retry slots (workgroups
+      // without such a query end at once)
+      A.retry = 1;
+      A.S2 = tsa_retry_view(e, slot, S);
+      if (a.depth > 1) hipLaunchKernelGGL(tsa_search_kernel<TSA_WAVES>, dim3(TSA_RETRY), dim3(TSA_WAVES * 64), lds_dyn, search_stream, A);
+      else hipLaunchKernelGGL(tsa_search_kernel<16>, dim3(TSA_RETRY), dim3(16 * 64), lds_dyn, search_stream, A);
+    }
     RNA_HIP(e, hipGetLastError());
   }
   return RNA_OK;

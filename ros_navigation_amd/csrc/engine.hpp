@@ -74,6 +74,8 @@ struct AstarDevice {
   int page_cap = 0;                // tile kernel: 4 KiB pages per query (0 = one per tile: a search can never run out)
   int page_cap_request = 0;        // rna_astar_set_page_cap
   void* tsa_aux[MAX_DEPTH] = {};   // tile kernel: ticket, page counts, launch order, neighbour-mask snapshot, tile -> page tables
+  int32_t* g_retry[MAX_DEPTH] = {};      // tile kernel, only when page_cap < tiles of the map: TSA_RETRY slots with a page per tile,
+  void* tsa_aux_retry[MAX_DEPTH] = {};   // for the second pass over searches that outgrew their pages (astar_tile.hip)
   hipStream_t side[MAX_DEPTH] = {};
   hipEvent_t done[MAX_DEPTH] = {}; // search of the batch that last used this set has finished
   bool busy[MAX_DEPTH] = {};
@@ -199,6 +201,10 @@ int tsa_tiles(const rna_engine* e);                                   // 32 x 32
 size_t tsa_pool_bytes(int max_queries, int cap);                      // pages + pending bitmaps of one pipeline stage
 size_t tsa_aux_bytes(const rna_engine* e, int max_queries, int cap);  // per stage, must start zeroed
 int tsa_stage_prepare(rna_engine* e, int slot);                       // fresh stage: every page "unreached"
+constexpr int TSA_RETRY = 8;                                          // full-size retry slots per stage
+size_t tsa_retry_pool_bytes(const rna_engine* e);
+size_t tsa_retry_aux_bytes(const rna_engine* e);
+int tsa_retry_prepare(rna_engine* e, int slot);
 int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init,
                const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len, rna_astar_result* res_dev);
 int tsa_settled(rna_engine* e, int slot, const rna_astar_query* q, const rna_astar_result* r, int n, int32_t* d_counts);

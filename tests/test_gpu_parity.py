@@ -436,6 +436,45 @@ def test_astar_page_pool(R):
     e.close()
 
 
+def test_astar_searches_that_outgrow_their_pages_are_retried(R):
+    """When the stages do not fit HBM the engine halves the pages a query may take (the bench configuration runs with
+    half a map's worth).  A search that needs more -- a goal that cannot be reached floods its whole component, the
+    reference answers "no path" -- must not fail for that: it ends the first pass with status 5 and is searched again in
+    one of the stage's eight retry slots, which hold a page per tile.  Here: 80 tiles, 6 pages per query, batches of at
+    most 8 queries, among them a goal inside a closed box (free inside, so it is not rejected up front): every answer
+    equals the oracle's, none is status 5; also through a pipelined stage and after the slots have been used before."""
+    e = R.Engine(320 * 0.05, 256 * 0.05, 0.05)
+    master = R.synth.obstacles_rect(e.rows, e.cols, density=0.25, seed=21, side=(3, 24))
+    m2 = master.reshape(e.cols, e.rows).copy()     # [j][i]
+    m2[100:113, 150:163] = 0.0
+    m2[100, 150:163] = m2[112, 150:163] = 180.0    # a closed box, 11 x 11 free cells inside
+    m2[100:113, 150] = m2[100:113, 162] = 180.0
+    master = m2.reshape(-1).copy()
+    e.upload(R.capi.LAYER_MASTER, master)
+    e.astar_page_cap(6)
+    _, nbr = O.astar_masks(master, e.rows, e.cols)
+    inside = 106 * e.rows + 156
+    for depth in (1, 3):
+        e.astar_pipeline_depth(depth)
+        e.astar_configure(max_queries=8)
+        for seed in (9, 10, 11):
+            q = R.synth.astar_queries(8, master, e.rows, e.cols, seed=seed)
+            q["goal"][3] = inside                          # unreachable, not walled in cell by cell
+            q["start"][5], q["goal"][5] = inside, inside + 3 * e.rows + 2   # a short search inside the box
+            res, paths = e.astar(q, e.ncell)
+            assert e.astar_effective_config()[1] == 6
+            needed_retry = 0
+            for k in range(len(q)):
+                ores, opath, _ = O.astar_query(nbr, e.rows, e.cols, q["start"][k], q["goal"][k])
+                assert res["status"][k] == ores.status, (depth, seed, k, res[k])
+                if ores.status == 0:
+                    assert res["cost"][k] == ores.cost and res["path_len"][k] == ores.path_len
+                    assert np.array_equal(paths[k, :ores.path_len], opath)
+                needed_retry += ores.settled > 6 * 1024
+            assert res["status"][3] == 1 and needed_retry >= 1
+    e.close()
+
+
 class _Hip:
     """device buffers for the *_device entry points, through the HIP runtime librna.so itself links"""
 
