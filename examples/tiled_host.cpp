@@ -109,6 +109,7 @@ int main(int argc, char** argv) {
   }
   std::printf("tiled_host rank %d/%d OK: window (%d+%d, %d+%d), halo %d cells, %zu halo bytes, %zu gathered bytes, %d paths\n", rank, world,
               w[0], w[1], w[2], w[3], halo, halo_bytes, gather_bytes, found);
+  rna_rccl_release();   // the exchange's staging buffers
   rna_destroy(e);
   ncclCommDestroy(comm);
   return 0;

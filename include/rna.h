@@ -227,18 +227,21 @@ int rna_vfh_update_batch(rna_engine* e, const double* ranges_host /* n*361*2 */,
 typedef struct { int32_t start, goal; } rna_astar_query;
 typedef struct {
   int32_t status;      /* 0 found, 1 no path, 2 invalid query, 3 path longer than max_path_len,
-                          4 path cost beyond the field's 30-bit g range (>= 1.07e9; frontier kernel: 24 bits), 5 the query's share of search pages is
-                          used up (only after rna_astar_set_page_cap or when HBM is short), RNA_ECAPACITY queue overflow */
+                          4 path cost beyond the field's 30-bit g range (>= 1.07e9), 5 the query's share of search pages was
+                          used up AND the batch's eight full-size retry slots were taken by other such queries (pages are
+                          only limited after rna_astar_set_page_cap or when HBM is short; a goal that cannot be reached
+                          floods its component -- it is searched again on a retry slot and answers 1, not 5) */
   int32_t path_len;    /* cells, start..goal inclusive */
   int32_t cost;        /* 1000/1414 integer cost of the path */
-  int32_t expanded;    /* cell updates the device performed (tile kernel: 64 per row evaluation; >= the oracle's settled count) */
-  int32_t rounds;      /* rounds of tile jobs (tile kernel), tile jobs (persistent scheduler) or frontier rounds */
+  int32_t expanded;    /* cells the device wrote (64 per row of a tile a job changed; >= the oracle's settled count) */
+  int32_t rounds;      /* tile jobs per wavefront of the query's workgroup (rounds 1-2: barrier-separated rounds of jobs) */
   int32_t buckets;     /* f-buckets visited */
 } rna_astar_result;
 /* max_queries: queries searched concurrently (one g-field each; larger batches are processed in
- * chunks); queue_capacity: entries of each per-query queue of the fallback frontier kernel;
- * bucket_width: the f-range (cost units, >= 2828) relaxed together before the search advances
- * (default 96000); 0 = keep/default. */
+ * chunks); queue_capacity: ignored (the cell queues of the frontier kernel removed in round 3; the tile kernel's open
+ * list has a fixed size in LDS and parks what does not fit); bucket_width: the f-range (cost units, >= 2828) inside
+ * which free wavefronts take tiles by key before the search advances (default 96000); 0 = keep/default.
+ * Maps of more than 65 536 tiles of 64 x 16 cells (8192 x 8192 cells) are refused with RNA_EINVAL. */
 int rna_astar_configure(rna_engine* e, int max_queries, int queue_capacity, int bucket_width);
 /* Pipelined batches: with depth d > 1 consecutive rna_astar_batch_device calls run their searches on d
  * rotating internal streams (each with its own search fields), so the tail of one batch overlaps

@@ -39,6 +39,8 @@ int rna_rccl_exchange_halo(rna_engine* e, void* comm, const rna_tile_layout* lay
 int rna_rccl_gather_dirty(rna_engine* e, void* comm, const rna_tile_layout* layout, int rank, int layer_a, int layer_b,
                           size_t* bytes_received);
 int rna_rccl_gather_layer(rna_engine* e, void* comm, const rna_tile_layout* layout, int rank, int layer, size_t* bytes_received);
+/* The staging buffers the three calls above grow on demand (per calling thread) go back to the device allocator. */
+int rna_rccl_release(void);
 
 #ifdef __cplusplus
 }

@@ -150,6 +150,9 @@ def lib():
     L.rna_last_dirty_tiles.argtypes = [vp, vp, C.c_size_t]
     L.rna_layer_pack_tiles.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.rna_layers_unpack_tiles.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.rna_last_dirty_tiles_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.rna_layer_pack_tiles_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.rna_layers_unpack_tiles_device.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.rna_vfh_default_params.argtypes = [C.POINTER(VfhParams)]
     L.rna_vfh_default_params.restype = None
     L.rna_vfh_init.argtypes = [vp, C.POINTER(VfhParams), C.c_int]
@@ -456,6 +459,23 @@ class Engine:
         la, lb = (layers[0], layers[1]) if len(layers) > 1 else (layers[0], -1)
         i0, ni, j0, nj = window
         self._check(self._L.rna_layers_unpack_tiles(self.h, la, lb, _ptr(tiles), len(tiles), i0, ni, j0, nj, t.data_ptr()))
+
+    def last_dirty_tiles_device(self, window, list_ptr, count_ptr):
+        """the flagged tiles that intersect window = (i0, ni, j0, nj), compacted into a device list (room for every tile
+        of the map) and their number into a device int; asynchronous on the engine's stream"""
+        i0, ni, j0, nj = window
+        self._check(self._L.rna_last_dirty_tiles_device(self.h, i0, ni, j0, nj, list_ptr, count_ptr))
+
+    def pack_tiles_device(self, layer, list_ptr, n, window, dense_ptr):
+        i0, ni, j0, nj = window
+        if n:
+            self._check(self._L.rna_layer_pack_tiles_device(self.h, layer, list_ptr, n, i0, ni, j0, nj, dense_ptr))
+
+    def unpack_tiles_device(self, layers, list_ptr, n, window, dense_ptr):
+        la, lb = (layers[0], layers[1]) if len(layers) > 1 else (layers[0], -1)
+        i0, ni, j0, nj = window
+        if n:
+            self._check(self._L.rna_layers_unpack_tiles_device(self.h, la, lb, list_ptr, n, i0, ni, j0, nj, dense_ptr))
 
     def _torch_device(self):
         import torch

@@ -25,7 +25,7 @@ void shard_bounds(int n, int rank, int world, int& lo, int& hi) {   // dist.shar
 }
 int rank_of(const rna_tile_layout* L, int a, int b) { return (a >= 0 && a < L->ti && b >= 0 && b < L->tj) ? a * L->tj + b : -1; }
 
-struct DevBuf {   // grows on demand, freed when the process ends or the next larger request arrives
+struct DevBuf {   // grows on demand; freed by rna_rccl_release (or when the next larger request arrives)
   void* p = nullptr;
   size_t cap = 0;
   int ensure(size_t bytes) {
@@ -36,6 +36,7 @@ struct DevBuf {   // grows on demand, freed when the process ends or the next la
     cap = bytes;
     return RNA_OK;
   }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 thread_local DevBuf t_send[2], t_recv[2], t_list, t_lists, t_counts, t_data, t_all;
 
@@ -191,5 +192,13 @@ extern "C" int rna_rccl_gather_dirty(rna_engine* e, void* comm_, const rna_tile_
     got += (size_t)counts[r] * TILE * TILE * sizeof(float);
   }
   if (bytes_received) *bytes_received = got;
+  return RNA_OK;
+}
+
+// the calling thread's staging buffers (strips, tile lists, gathered tiles) back to the device allocator: a host calls
+// it when it stops exchanging (before ncclCommDestroy), every thread that drove an exchange for itself
+extern "C" int rna_rccl_release(void) {
+  for (int k = 0; k < 2; ++k) { t_send[k].release(); t_recv[k].release(); }
+  t_list.release(); t_lists.release(); t_counts.release(); t_data.release(); t_all.release();
   return RNA_OK;
 }

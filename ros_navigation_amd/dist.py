@@ -207,6 +207,45 @@ def gather_layer(grid, layer, layout, rank, dist):
     return got
 
 
+def _gather_dirty_device(grid, layers, layout, rank, dist, tile):
+    """gather_dirty with the tile lists resident on the GPU (RCCL backend): the flags are compacted into a device list
+    (rna_last_dirty_tiles_device), lists and tile data are all-gathered as device tensors and unpacked from device lists;
+    only the `world` counters visit the host, to size the collectives -- the same sequence as rna_rccl_gather_dirty
+    (csrc/rccl_tiled.hip) runs for a C++ host."""
+    import torch
+    dev = grid._torch_device()
+    tiles_i, tiles_j = grid.tile_grid()
+    win = layout.window(rank)
+    lst_all = torch.empty(tiles_i * tiles_j, dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    grid.last_dirty_tiles_device(win, lst_all.data_ptr(), count.data_ptr())
+    grid.synchronize()                                   # the engine stream wrote list and count; torch's stream reads them
+    counts_t = [torch.zeros_like(count) for _ in range(layout.world)]
+    dist.all_gather(counts_t, count)
+    counts = [int(c.item()) for c in counts_t]           # 4 * world bytes: the one host visit
+    cap = max(counts)
+    if cap == 0:
+        return 0
+    lst = lst_all[:cap].contiguous()
+    lists = [torch.empty_like(lst) for _ in range(layout.world)]
+    dist.all_gather(lists, lst)
+    pad = torch.zeros(cap * tile * tile, dtype=torch.float32, device=dev)
+    torch.cuda.current_stream(dev).synchronize()
+    grid.pack_tiles_device(layers[0], lst.data_ptr(), counts[rank], win, pad.data_ptr())
+    grid.synchronize()
+    parts = [torch.empty_like(pad) for _ in range(layout.world)]
+    dist.all_gather(parts, pad)
+    torch.cuda.current_stream(dev).synchronize()
+    got = 0
+    for r in range(layout.world):
+        if r == rank or counts[r] == 0:
+            continue
+        grid.unpack_tiles_device(layers, lists[r].data_ptr(), counts[r], layout.window(r), parts[r].data_ptr())
+        got += counts[r] * tile * tile * 4
+    grid.synchronize()                                   # lists / parts may be freed by torch after this call returns
+    return got
+
+
 def gather_dirty(grid, layers, layout, rank, dist, tile=64):
     """Incremental form of gather_layer: every rank hands on only the 64 x 64 tiles its last map update changed
     (grid.last_dirty_tiles(), clipped to its window), and the receivers write them into `layers` (laser and master, so
@@ -217,6 +256,8 @@ def gather_dirty(grid, layers, layout, rank, dist, tile=64):
     import torch
     if layout.world == 1:
         return 0
+    if dist.get_backend() == "nccl":
+        return _gather_dirty_device(grid, layers, layout, rank, dist, tile)
     tiles_i = (layout.rows + tile - 1) // tile
     flags = grid.last_dirty_tiles()
     win = layout.window(rank)

@@ -16,6 +16,7 @@ from ros_navigation_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIM = "/tmp/rna_sim_dense2"
+SIM_ASYNC = "/tmp/rna_sim_async"
 
 
 @pytest.fixture(scope="module")
@@ -50,3 +51,28 @@ def test_tile_schedule_model_matches_the_oracle(sim, tmp_path, rows, cols, densi
             for variant in ("0", "161"):
                 out = subprocess.run([sim, wl, str(bucket), "24", variant], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
                 assert out.returncode == 0 and "mismatches 0" in out.stdout, (bucket, env, variant, out.stdout[-400:], out.stderr[-400:])
+
+
+@pytest.fixture(scope="module")
+def sim_async():
+    subprocess.check_call(["gcc", "-O2", "-o", SIM_ASYNC, os.path.join(ROOT, "scripts", "sim_async.c")])
+    return SIM_ASYNC
+
+
+@pytest.mark.parametrize("rows,cols,density,side", [(200, 150, 0.30, (2, 20)), (333, 97, 0.45, (1, 6))])
+def test_open_list_schedule_model_matches_the_oracle(sim_async, tmp_path, rows, cols, density, side):
+    """scripts/sim_async.c: the asynchronous schedule of tsa_search_kernel as a discrete-event model -- W wavefronts take
+    the queued tile with the lowest key, a job reads the field as it is when it starts and publishes when it ends, a tile
+    woken while it runs is queued again by its own wavefront (policy 4 is the kernel's protocol: pending / running bits,
+    stale entries dropped; policies 1-3 are the alternatives it was chosen from, policy 0 the round-2 red-black rounds).
+    Every policy, wavefront count and bucket width must reproduce the oracle's cost and settled count E exactly: the
+    exactness argument (any order, as long as no wake-up is lost) executed without a GPU."""
+    wl = str(tmp_path / "wl.bin")
+    rec = workload(wl, rows, cols, 16, seed=rows + cols, density=density, side=side)
+    assert (rec[:, 2] < 0x7fffffff).sum() >= 8
+    for policy in ("0", "1", "2", "3", "4"):
+        for bucket, waves in ((2828, 3), (24000, 8), (96000, 8), (400000, 16)):
+            for env in ({}, {"SIM_KSHIFT": "2"}, {"SIM_DIRTYKEY": "2", "SIM_KSHIFT": "10"}):
+                out = subprocess.run([sim_async, wl, str(bucket), "16", policy, str(waves)], capture_output=True, text=True,
+                                     env=dict(os.environ, **env), timeout=300)
+                assert out.returncode == 0 and "mismatches 0" in out.stdout, (policy, bucket, waves, env, out.stdout[-400:], out.stderr[-400:])

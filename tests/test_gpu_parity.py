@@ -335,28 +335,18 @@ def test_astar_paths_bit_identical(R, rows, cols, density, seed):
     e.close()
 
 
-@pytest.mark.parametrize("env", [{"RNA_ASTAR_KERNEL": "frontier"}])
-def test_astar_fallback_kernel_keeps_the_contract(R, env):
-    """The default is the tile-synchronous kernel; the frontier kernel (the fallback for maps beyond 65 536 tiles) is
-    selected by an environment variable read when an engine first plans.  It must reproduce the oracle's paths, costs
-    and settled counts, also when the same engine is reused for a second, different batch."""
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        e = R.Engine(200 * 0.05, 120 * 0.05, 0.05)
-        master = R.synth.obstacles_rect(e.rows, e.cols, density=0.3, seed=12)
-        e.upload(R.capi.LAYER_MASTER, master)
-        for seed in (1, 2):
-            q = R.synth.astar_queries(40, master, e.rows, e.cols, seed=seed)
-            q["goal"][0] = q["start"][0]
-            check_astar(R, e, master, q, e.ncell, max_queries=64, bucket_width=4000)
-        e.close()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+def test_astar_refuses_maps_beyond_65536_tiles(R):
+    """Tile numbers are 16 bits in the search's queue entries: a map of more than 65 536 tiles of 64 x 16 cells
+    (8192 x 8192 cells) is refused loudly (RNA_EINVAL), the engine stays usable for everything else.  (The cell-granular
+    frontier kernel that served such maps in rounds 1-2 did not handle moved maps and was removed.)"""
+    e = R.Engine(8256 * 0.05, 8192 * 0.05, 0.05)          # 129 x 512 tiles
+    q = np.zeros(1, R.capi.ASTAR_QUERY_DTYPE)
+    q["goal"][0] = 5
+    with pytest.raises(R.capi.RnaError) as err:
+        e.astar(q, 64)
+    assert "65 536 tiles" in str(err.value)
+    assert e.get_index(0.0, 0.0) is not None
+    e.close()
 
 
 def test_astar_cost_range_of_the_field_word(R):

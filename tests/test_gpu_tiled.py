@@ -261,3 +261,74 @@ def test_config5_full_size_windowed_himm_union_is_the_whole_map_update():
     assert same_f32(union, A)
     assert touched_windows == 8 and int(changed.sum()) > 100000
     e.close()
+
+
+def test_gather_dirty_with_device_side_tile_lists():
+    """dist.gather_dirty's RCCL path keeps the tile lists on the GPU (rna_last_dirty_tiles_device -> all-gather of device
+    tensors -> rna_layers_unpack_tiles_device; only the counters visit the host).  RCCL needs one device per rank, so on
+    the one-GPU test box the two ranks are two threads with an engine each and an in-process all-gather that hands the
+    device tensors over -- the data path between the collectives is the one two GPUs take.  After the exchange both
+    replicas hold the oracle's whole-map update in both layers."""
+    import threading
+    import torch
+    import ros_navigation_amd as R
+    from ros_navigation_amd import dist as D
+    rows, cols, world = 300, 260, 2
+    L = D.TileLayout.for_world(rows, cols, world)
+    g = O.make_geom(rows * 0.05, cols * 0.05, 0.05)
+    rng = np.random.default_rng(5)
+    before = rng.choice(np.array([np.nan, 0, 10, 50, 150, 180], np.float32), rows * cols)
+    rays = R.synth.rays(6, 700, rows * 0.05, cols * 0.05, seed=3, lmin=0.2, lmax=5.0, margin=0.5)
+    after = before.copy()
+    O.himm_update(g, after, rays.view(O.RAY_DTYPE))
+
+    class ThreadDist:
+        """all_gather between the threads of this process (tensors stay on the device)"""
+        def __init__(self, n):
+            self.n, self.slots, self.bar = n, [None] * n, threading.Barrier(n)
+            self.local = threading.local()
+
+        def get_backend(self):
+            return "nccl"
+
+        def all_gather(self, outs, t):
+            torch.cuda.current_stream(t.device).synchronize()
+            self.slots[self.local.rank] = t
+            self.bar.wait()
+            for k in range(self.n):
+                outs[k].copy_(self.slots[k])
+            torch.cuda.current_stream(t.device).synchronize()
+            self.bar.wait()
+
+    fake = ThreadDist(world)
+    engines, errors, got_bytes = [None] * world, [], [0] * world
+
+    def run(rank):
+        try:
+            fake.local.rank = rank
+            e = R.Engine(rows * 0.05, cols * 0.05, 0.05)
+            engines[rank] = e
+            e.upload(R.capi.LAYER_LASER, before)
+            e.compose_master(1)
+            i0, ni, j0, nj = L.window(rank)
+            e.himm_set_window(i0, j0, ni, nj)
+            e.update_map(rays, compose_mode=0)
+            got_bytes[rank] = D.gather_dirty(e, (R.capi.LAYER_LASER, R.capi.LAYER_MASTER), L, rank, fake)
+            e.compose_master(0)
+            e.synchronize()
+        except Exception as ex:   # noqa: BLE001
+            errors.append((rank, repr(ex)))
+            fake.bar.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    assert all(b > 0 and b % (64 * 64 * 4) == 0 for b in got_bytes), got_bytes
+    for rank in range(world):
+        e = engines[rank]
+        assert same_f32(e.download(R.capi.LAYER_LASER), after), rank
+        assert same_f32(e.download(R.capi.LAYER_MASTER), after), rank
+        e.close()

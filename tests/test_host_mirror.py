@@ -9,6 +9,10 @@ SRC = os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp")
 EXE = "/tmp/rna_host_mirror_test"
 NODE_SRC = os.path.join(ROOT, "tests", "cpp", "nav_graph_node_shaped.cpp")
 NODE_EXE = "/tmp/rna_nav_graph_node_shaped"
+NAV_SRC = os.path.join(ROOT, "tests", "cpp", "nav_node_shaped.cpp")
+NAV_EXE = "/tmp/rna_nav_node_shaped"
+RATE_SRC = os.path.join(ROOT, "tests", "cpp", "rate_loop_test.cpp")
+RATE_EXE = "/tmp/rna_rate_loop_test"
 
 
 def build(src=SRC, exe=EXE):
@@ -29,6 +33,46 @@ def test_node_main_with_the_reference_signatures_compiles():
     """nav_graph_node.cpp's members, constructor initialiser list and goalCb, verbatim, against move_control_api.hpp"""
     build(NODE_SRC, NODE_EXE)
     assert os.path.exists(NODE_EXE)
+
+
+def test_nav_node_main_with_the_reference_signatures_compiles():
+    """nav_node.cpp's members, constructor and makePlan / taileredPlan / ifGoalAchieved (the RRT flow), against move_control_api.hpp"""
+    build(NAV_SRC, NAV_EXE)
+    assert os.path.exists(NAV_EXE)
+
+
+def test_ros_seams_rate_keeping_without_ros():
+    """ros/rate_loop.hpp -- what ros/ros_seams.cpp runs the reference's three loops on -- with a simulated clock: 5 / 2 / 5 Hz
+    kept the way ros::Rate keeps them, overruns counted, latest-message cache, 0.2 s scan rate limit"""
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-pthread", RATE_SRC, "-o", RATE_EXE])
+    out = subprocess.run([RATE_EXE], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "rate loop ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_ros_sources_are_guarded_and_name_the_reference_topics():
+    """The ROS nodes cannot be built here (no ROS in this image): what can be checked is that every ROS source compiles to
+    nothing without <ros/ros.h> (seams) or refuses loudly (node mains), and that topics, frames and rates are the reference's."""
+    ros_dir = os.path.join(ROOT, "ros")
+    seams = open(os.path.join(ros_dir, "ros_seams.cpp")).read()
+    for topic in ("/left_range", "/right_range", "/front_left_range", "/front_right_range", "/front_range", "/laser_scan", "/odom",
+                  "global_map", "local_map", "/mobile_base/commands/velocity", '"hist"', '"odom"', '"base_link"'):
+        assert topic in seams, topic
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "ros_navigation_amd", "host"), os.path.join(ros_dir, "ros_seams.cpp")])
+    for node in ("nav_graph_node_amd.cpp", "nav_node_amd.cpp", "nav_only_vfh_node_amd.cpp"):
+        out = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", os.path.join(ros_dir, node)], capture_output=True, text=True)
+        assert out.returncode != 0 and "catkin workspace" in out.stderr
+    cm = open(os.path.join(ROOT, "CMakeLists.txt")).read()
+    for name in ("mapTest_graph", "mapTest_vfh", "OUTPUT_NAME mapTest)", "ros/ros_seams.cpp"):
+        assert name in cm, name
+
+
+@pytest.mark.gpu
+def test_nav_node_rrt_flow_through_the_reference_signatures_on_gpu():
+    """mapTest's planning flow (10 m window -> RrtPlanner -> taileredPlan -> Steerer) on the default 600 x 600 map, against the oracle"""
+    build(NAV_SRC, NAV_EXE)
+    out = subprocess.run([NAV_EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "nav_node-shaped main OK" in out.stdout, out.stdout + out.stderr
 
 
 @pytest.mark.gpu

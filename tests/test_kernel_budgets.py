@@ -1,10 +1,11 @@
 """CPU-only (hipcc cross-compiles): the resource budgets of the grid-A* search kernel.  The tile job keeps a 64 x 16
 tile in registers (2 x 16 rows) and is bound by what one wavefront can issue, so throughput comes from EIGHT wavefronts
 per SIMD -- four workgroups (queries) of 8 wavefronts per CU: the kernel has to fit 64 VGPRs, must not spill in the
-tile job, and four workgroups' LDS has to fit a CU for the bench's map.  (The engine-stream kernels no longer share CUs
-with the searches: astar.hip keeps 24 CUs out of the search streams' CU mask.  Measured when the kernel needed 116
-VGPRs -- four wavefronts per SIMD: 22 k instead of 36 k cycles/s; with the job's lane constants spilled to scratch:
-33 k.)"""
+tile job, and four workgroups' LDS (scratch per wavefront, the 2048-entry open list, four tile bit sets) has to fit a CU
+for the bench's map.  (astar.hip keeps 32 of the 256 CUs out of the search streams' CU mask for the engine stream's
+short kernels.  Measured when the kernel needed 116 VGPRs -- four wavefronts per SIMD: 22 k instead of 36 k cycles/s;
+with the job's lane constants spilled to scratch: 33 k.)  The path backtrace runs inside the search kernel since round 3
+(first wavefront, in the open list's LDS): its budget is the search kernel's."""
 import os
 import re
 import subprocess
@@ -48,9 +49,8 @@ def test_eight_search_wavefronts_fit_a_simd():
     assert alloc(single["VGPRs"]) * 8 <= VGPRS_PER_SIMD and single["ScratchSize"] <= 16, single
     assert alloc(search["VGPRs"]) * 8 <= VGPRS_PER_SIMD, search        # 8 wavefronts per SIMD = 4 workgroups of 8 per CU
     assert search["ScratchSize"] <= 16, search                          # nothing spilled inside the tile job (one kernel-level value may be)
-    bench_lds = search["LDS"] + 3 * 4 * ((64 * 256 + 31) // 32)         # + the three tile bitsets of a 4096 x 4096 map (64 x 256 tiles)
+    bench_lds = search["LDS"] + 4 * 4 * ((64 * 256 + 31) // 32)         # + the tile bit sets (pending / running pairs, open, far) of a 4096 x 4096 map (64 x 256 tiles)
     assert 4 * bench_lds <= LDS_PER_CU, bench_lds
-    largest_lds = search["LDS"] + 3 * 4 * 2048                          # the largest supported map (65536 tiles): at least two per CU
+    largest_lds = search["LDS"] + 4 * 4 * 2048                          # the largest supported map (65536 tiles): at least two per CU
     assert 2 * largest_lds <= LDS_PER_CU, largest_lds
-    back = next(v for k, v in tile.items() if "tsa_backtrace_kernel" in k)
-    assert back["ScratchSize"] == 0 and back["LDS"] <= 8 * 1024         # one wavefront per query, next to the searches
+    assert not any("tsa_backtrace_kernel" in k or "tsa_reset_kernel" in k for k in tile)   # both live inside the search kernel now
