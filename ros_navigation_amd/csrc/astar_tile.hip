@@ -40,7 +40,7 @@ namespace rna {
 constexpr int TI = 64, TJ = 16;               // tile: 64 cells along i (lanes) x 16 along j (registers)
 constexpr int TILE_WORDS = TI * TJ;           // 1024
 constexpr int AUX_WORDS = 64;                 // per page: [0..15] copy of column 0, [16..31] copy of column 63
-constexpr int MASK_STRIDE = TILE_WORDS + 32;  // snapshot bytes per tile: lane-major masks + the two edge columns again
+constexpr int MASK_STRIDE = TILE_WORDS + 32 + 128;  // snapshot bytes per tile: lane-major masks + the two edge columns again + 16 "free" bits per lane
 #ifndef RNA_TSA_WAVES
 #define RNA_TSA_WAVES 8   // wavefronts per workgroup = per query; 8 wavefronts per SIMD -> four workgroups per CU (16 x 2: 60.5 k, 8 x 4: 63.5 k, 4 x 8: 42.4 k)
 #endif
@@ -161,6 +161,7 @@ __host__ __device__ inline size_t tsa_align256(size_t x) { return (x + 255) & ~(
 // 16-byte load --, then the 16 masks of column 0 and the 16 of column 63 once more for the halo step.
 __global__ void __launch_bounds__(256) tsa_snapshot_kernel(const uint8_t* __restrict__ nbr, int rows, int cols, int tiles_i, int tiles_j,
                                                              uint8_t* __restrict__ nbr_tm, int s0, int s1) {
+  __shared__ unsigned s_free[256];
   const int a = threadIdx.x & 63, bq = threadIdx.x >> 6;
   for (int t = blockIdx.x; t < tiles_i * tiles_j; t += gridDim.x) {
     const int i = (t % tiles_i) * TI + a, j0 = (t / tiles_i) * TJ + bq * 4;
@@ -178,6 +179,15 @@ __global__ void __launch_bounds__(256) tsa_snapshot_kernel(const uint8_t* __rest
     reinterpret_cast<unsigned*>(out)[a * 4 + bq] = v;
     if (a == 0) reinterpret_cast<unsigned*>(out + TILE_WORDS)[bq] = v;
     if (a == TI - 1) reinterpret_cast<unsigned*>(out + TILE_WORDS + 16)[bq] = v;
+    // bit b of a lane's "free" word: the cell in row b has at least one traversable neighbour, i.e. is free and inside
+    // the map (a job would otherwise derive the 16 bits from the mask bytes every time: ~50 vector instructions)
+    s_free[threadIdx.x] = (((v & 0xffu) != 0u) ? 1u : 0u) | (((v & 0xff00u) != 0u) ? 2u : 0u) | (((v & 0xff0000u) != 0u) ? 4u : 0u) |
+                          (((v & 0xff000000u) != 0u) ? 8u : 0u);
+    __syncthreads();
+    if (bq == 0)
+      reinterpret_cast<unsigned short*>(out + TILE_WORDS + 32)[a] =
+          (unsigned short)(s_free[a] | (s_free[64 + a] << 4) | (s_free[128 + a] << 8) | (s_free[192 + a] << 12));
+    __syncthreads();
   }
 }
 // The ticket back to zero and the launch order of the batch, see below.
@@ -351,6 +361,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   }
   const uint4 mv = *reinterpret_cast<const uint4*>(C.nbr_tm + (size_t)t * MASK_STRIDE + lane * 16);
   const unsigned mk0 = mv.x, mk1 = mv.y, mk2 = mv.z, mk3 = mv.w;   // byte b of this lane = neighbour mask of cell (lane, b)
+  const unsigned fbits_ld = reinterpret_cast<const unsigned short*>(C.nbr_tm + (size_t)t * MASK_STRIDE + TILE_WORDS + 32)[lane];
   // X: the two halo columns and the four corners.  Lanes 0..17 hold the left one top-down (lane 0 = corner (-1,-1),
   // lanes 1..16 = rows 0..15, lane 17 = corner (-1,16)), lanes 32..49 the right one.
   const int xl = lane & 31;
@@ -382,10 +393,8 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   // (the copy of dxl is made opaque at every use: otherwise the 16 row heuristics are hoisted out of the sweeps into 16 VGPRs again)
 #define TSA_H(b) ({ int dx_ = dxl; asm volatile("" : "+v"(dx_)); const int dy_ = abs(j0 + (b) - gj); \
                     tsa_h24(max(dx_, dy_), min(dx_, dy_)); })
-  unsigned fbits = 0u;   // bit b: this lane's cell in row b is free (and inside the map)
-#define TSA_FB(b) fbits |= (((TSA_MKW(b) >> (8 * ((b) & 3))) & 0xffu) != 0u) ? 1u << (b) : 0u;
-  TSA_R16(TSA_FB)
-#undef TSA_FB
+  // bit b: this lane's cell in row b is free (and inside the map) -- from the snapshot, loaded with the masks
+  const unsigned fbits = fbits_ld;
   asm volatile("; TSA_MARK halo_begin");
   // ---- 4. what the halo can contribute (once: it does not change during the job) ----
   // rows to evaluate in the next down / up sweep: a row is evaluated from above when the row above it changed (or it
@@ -482,8 +491,10 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
 #ifdef RNA_TSA_STATS
   int evals = 0, hpass = 0;
 #define TSA_STAT_INC(v) v += 1
+#define TSA_STAT_HP(left) hpass += (left) ? RNA_TSA_HPASS - 1 - (31 - __builtin_clz(left)) : RNA_TSA_HPASS   /* passes that moved something */
 #else
 #define TSA_STAT_INC(v)
+#define TSA_STAT_HP(left)
 #endif
   // the (negative) step costs live in VGPRs: v_add_u32 with a DPP source cannot take a literal, and only then does the
   // wave shift fold into the add (one instruction instead of v_mov_dpp + v_add)
@@ -498,7 +509,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
 #define TSA_VERT(b, src, kA, kC)                                                                                                   \
   max3i(TSA_PP(src) + nS, (lane_m1(TSA_PP(src)) + nD) & TSA_OPEN(TSA_MKW(b), 8 * ((b) & 3) + (kA)),                                \
         (lane_p1(TSA_PP(src)) + nD) & TSA_OPEN(TSA_MKW(b), 8 * ((b) & 3) + (kC)))
-#define TSA_ROW(b, VERT, AGAIN, LBL)                                                                                \
+#define TSA_ROW(b, VERT, AGVAR)                                                                                     \
   {                                                                                                              \
     TSA_STAT_INC(evals);                                                                                         \
     const int open_ = TSA_OPEN(fbits, b);                                                                        \
@@ -509,31 +520,50 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       const int ht_ = TSA_H(b) + thr;   /* passes on iff u - h >= thr */                                         \
       TSA_G(b) = max(TSA_G(b), m_);                                                                              \
       TSA_PP(b) = TSA_G(b) >= ht_ ? TSA_G(b) : 0;                                                                \
-      int left_ = RNA_TSA_HPASS;                                                                                 \
-      for (;;) {                                                                                                 \
-        const int m2_ = (max(lane_m1(TSA_PP(b)), lane_p1(TSA_PP(b))) + nS) & open_;                              \
-        const unsigned long long up2_ = __builtin_amdgcn_ballot_w64(m2_ > TSA_G(b));                             \
-        if (!up2_) break;                                                                                        \
-        TSA_STAT_INC(hpass);                                                                                     \
-        TSA_G(b) = max(TSA_G(b), m2_);                                                                           \
-        TSA_PP(b) = TSA_G(b) >= ht_ ? TSA_G(b) : 0;                                                              \
-        up_ |= up2_;                                                                                             \
-        if (--left_ == 0) { AGAIN; break; }                                                                      \
+      /* the passes along the row, hand-scheduled: 8 vector + 4 scalar instructions per pass that moves something, 5 + 1 \
+         for the last one (the compiler's version of this loop spent 7 scalar instructions and two s_nop per pass on the    \
+         loop control).  `left_` holds one bit per pass still allowed. */                                                \
+      unsigned left_ = 1u << (RNA_TSA_HPASS - 1);                                                                  \
+      {                                                                                                          \
+        int t1_, t2_;                                                                                            \
+        asm volatile(                                                                                            \
+            "s_nop 1\n"   /* pp was written by the instruction before: two wait states before a DPP read */      \
+            ".Lhp_top%=:\n\t"                                                                                     \
+            "v_add_u32_dpp %[t1], %[pp], %[nS] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
+            "v_add_u32_dpp %[t2], %[pp], %[nS] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"             \
+            "v_max_i32 %[t1], %[t1], %[t2]\n\t"                                                                   \
+            "v_and_b32 %[t1], %[t1], %[open]\n\t"                                                                 \
+            "v_cmp_gt_i32 vcc, %[t1], %[g]\n\t"                                                                   \
+            "s_cbranch_vccz .Lhp_done%=\n\t"                                                                      \
+            "v_max_i32 %[g], %[g], %[t1]\n\t"                                                                     \
+            "s_or_b64 %[all], %[all], vcc\n\t"                                                                    \
+            "v_cmp_ge_i32 vcc, %[g], %[ht]\n\t"                                                                   \
+            "s_nop 1\n\t"                                                                                         \
+            "v_cndmask_b32 %[pp], 0, %[g], vcc\n\t"                                                               \
+            "s_lshr_b32 %[left], %[left], 1\n\t"                                                                  \
+            "s_cbranch_scc1 .Lhp_top%=\n\t"                                                                       \
+            "s_bitset1_b32 %[ag], %[bit]\n"   /* out of passes: the row is looked at again in the next sweep */  \
+            ".Lhp_done%=:"                                                                                        \
+            : [g] "+v"(TSA_G(b)), [pp] "+v"(TSA_PP(b)), [all] "+s"(up_), [left] "+s"(left_), [ag] "+s"(AGVAR),    \
+              [t1] "=&v"(t1_), [t2] "=&v"(t2_)                                                                   \
+            : [nS] "v"(nS), [open] "v"(open_), [ht] "v"(ht_), [bit] "n"(b)                                       \
+            : "vcc", "scc");                                                                                     \
       }                                                                                                          \
+      TSA_STAT_HP(left_);                                                                                        \
       TSA_ROW_CHANGED(b, up_)                                                                                    \
     }                                                                                                            \
   }
-#define TSA_DOWN(b) if ((nd >> (b)) & 1u) { nd &= ~(1u << (b)); TSA_ROW(b, TSA_VERT(b, TSA_CAT(TSA_DEC_, b), 0, 2), nu |= 1u << (b), d) }
-#define TSA_UP(b) if ((nu >> (b)) & 1u) { nu &= ~(1u << (b)); TSA_ROW(b, TSA_VERT(b, TSA_CAT(TSA_INC_, b), 5, 7), nd |= 1u << (b), u) }
+#define TSA_DOWN(b) if ((nd >> (b)) & 1u) { nd &= ~(1u << (b)); TSA_ROW(b, TSA_VERT(b, TSA_CAT(TSA_DEC_, b), 0, 2), nu) }
+#define TSA_UP(b) if ((nu >> (b)) & 1u) { nu &= ~(1u << (b)); TSA_ROW(b, TSA_VERT(b, TSA_CAT(TSA_INC_, b), 5, 7), nd) }
   for (;;) {
     if (nd != 0u) {
-      if (nd & 1u) { nd &= ~1u; TSA_ROW(0, 0, nu |= 1u, d) }
+      if (nd & 1u) { nd &= ~1u; TSA_ROW(0, 0, nu) }
       TSA_DOWN(1) TSA_DOWN(2) TSA_DOWN(3) TSA_DOWN(4) TSA_DOWN(5) TSA_DOWN(6) TSA_DOWN(7) TSA_DOWN(8)
       TSA_DOWN(9) TSA_DOWN(10) TSA_DOWN(11) TSA_DOWN(12) TSA_DOWN(13) TSA_DOWN(14) TSA_DOWN(15)
     }
     if (!(nd | nu)) break;
     if (nu != 0u) {
-      if ((nu >> 15) & 1u) { nu &= ~(1u << 15); TSA_ROW(15, 0, nd |= 1u << 15, u) }
+      if ((nu >> 15) & 1u) { nu &= ~(1u << 15); TSA_ROW(15, 0, nd) }
       TSA_UP(14) TSA_UP(13) TSA_UP(12) TSA_UP(11) TSA_UP(10) TSA_UP(9) TSA_UP(8) TSA_UP(7)
       TSA_UP(6) TSA_UP(5) TSA_UP(4) TSA_UP(3) TSA_UP(2) TSA_UP(1) TSA_UP(0)
     }
@@ -544,6 +574,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
 #undef TSA_ROW
 #undef TSA_VERT
 #undef TSA_STAT_INC
+#undef TSA_STAT_HP
   TSA_T(t_c);
   TSA_ACC(1, t_b, t_c);
   TSA_CNT(8, evals);
