@@ -79,7 +79,9 @@ static int alloc_stages_impl(rna_engine* e) {
         }
       }
       RNA_HIP(e, hipEventCreateWithFlags(&a.done[d], hipEventDisableTiming));
+      RNA_HIP(e, hipEventCreateWithFlags(&a.snap_done[d], hipEventDisableTiming));
     }
+    a.snap_pending[d] = false;
     a.busy[d] = false;
     a.stage_seq[d] = 0;
   }
@@ -204,6 +206,8 @@ int astar_release(rna_engine* e) {
     if (a.tsa_aux_retry[d]) { (void)hipFree(a.tsa_aux_retry[d]); a.tsa_aux_retry[d] = nullptr; }
     if (a.side[d]) { (void)hipStreamDestroy(a.side[d]); a.side[d] = nullptr; }
     if (a.done[d]) { (void)hipEventDestroy(a.done[d]); a.done[d] = nullptr; }
+    if (a.snap_done[d]) { (void)hipEventDestroy(a.snap_done[d]); a.snap_done[d] = nullptr; }
+    a.snap_pending[d] = false;
     a.busy[d] = false;
   }
   if (a.ev_init) { (void)hipEventDestroy(a.ev_init); a.ev_init = nullptr; }
@@ -217,7 +221,7 @@ int astar_release(rna_engine* e) {
 extern "C" int rna_astar_configure(rna_engine* e, int max_queries, int queue_capacity, int bucket_width) {
   if (!e || max_queries < 0 || queue_capacity < 0 || bucket_width < 0) return RNA_EINVAL;
   if (bucket_width != 0 && bucket_width < 2 * COST_D) return fail(e, RNA_EINVAL, "bucket_width must be >= 2828");
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   RNA_HIP(e, hipStreamSynchronize(e->stream));
   AstarDevice& a = e->astar;
   if (max_queries || queue_capacity) astar_release(e);
@@ -233,7 +237,7 @@ extern "C" int rna_astar_configure(rna_engine* e, int max_queries, int queue_cap
 
 extern "C" int rna_astar_set_pipeline_depth(rna_engine* e, int depth) {
   if (!e || depth < 1 || depth > AstarDevice::MAX_DEPTH) return RNA_EINVAL;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   if (depth != e->astar.depth) {
     astar_release(e);
     e->astar.depth = depth;
@@ -253,7 +257,7 @@ extern "C" int rna_astar_effective_config(const rna_engine* e, int* pipeline_dep
 
 extern "C" int rna_astar_set_page_cap(rna_engine* e, int pages_per_query) {
   if (!e || pages_per_query < 0) return RNA_EINVAL;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   if (pages_per_query != e->astar.page_cap_request) {
     astar_release(e);
     e->astar.page_cap_request = pages_per_query;
@@ -265,7 +269,7 @@ extern "C" int rna_astar_batch_device(rna_engine* e, const rna_astar_query* quer
                                       int max_path_len, rna_astar_result* results) {
   if (!e || n < 0 || max_path_len <= 0 || (n > 0 && (!queries || !paths || !results))) return RNA_EINVAL;
   if (n == 0) return RNA_OK;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER_NOJOIN(e);   // (reads the neighbour masks only; map_prepare_nbr joins if it has to rebuild them)
   int rc = ensure_config(e);
   if (rc != RNA_OK) return rc;
   if ((rc = map_prepare_nbr(e)) != RNA_OK) return rc;
@@ -282,7 +286,7 @@ extern "C" int rna_astar_batch(rna_engine* e, const rna_astar_query* queries_hos
                                int max_path_len, rna_astar_result* results_host) {
   if (!e || n < 0 || max_path_len <= 0 || (n > 0 && (!queries_host || !paths_host || !results_host))) return RNA_EINVAL;
   if (n == 0) return RNA_OK;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   int rc = ensure_config(e);
   if (rc != RNA_OK) return rc;
   if ((rc = map_prepare_nbr(e)) != RNA_OK) return rc;
@@ -313,7 +317,7 @@ extern "C" int rna_astar_batch(rna_engine* e, const rna_astar_query* queries_hos
 
 extern "C" int rna_astar_download_nbr_mask(rna_engine* e, uint8_t* host, size_t n) {
   if (!e || !host || n != e->ncell) return RNA_EINVAL;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   int rc = map_prepare_nbr(e);
   if (rc != RNA_OK) return rc;
   RNA_HIP(e, hipMemcpyAsync(host, e->nbr, n, hipMemcpyDeviceToHost, e->stream));
@@ -325,7 +329,7 @@ extern "C" int rna_astar_settled_counts(rna_engine* e, int32_t* counts_host, int
   if (!e || !counts_host || n <= 0) return RNA_EINVAL;
   AstarDevice& a = e->astar;
   if (!a.g[0] || !a.last_queries || n != a.last_n) return fail(e, RNA_ESTATE, "no resident A* batch of that size");
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   int32_t* d_counts = nullptr;
   int rc = sync_all(e);
   if (rc != RNA_OK) return rc;

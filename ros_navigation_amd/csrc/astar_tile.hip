@@ -1394,16 +1394,23 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
   const int rows = e->geom.size[0], cols = e->geom.size[1];
   const int ti = (rows + TI - 1) / TI, tj = (cols + TJ - 1) / TJ;
   const TsaStage S = tsa_stage_view(e, slot);
+  // Snapshot of the neighbour masks as they are NOW (a later map update must not disturb a search in flight).  Pipelined:
+  // on the stage's own stream, behind an event of the engine stream (whatever changes the masks next waits for the
+  // snapshot, side_join) -- the engine stream's chain of map-update kernels is what gates the next batch, the stage has
+  // time.  Single stream: in place.
+  if (ev_init) {
+    RNA_HIP(e, hipEventRecord(ev_init, init_stream));
+    RNA_HIP(e, hipStreamWaitEvent(search_stream, ev_init, 0));
+  }
   {
-    // snapshot of the neighbour masks: on the engine stream, before the next map update can change them
-    KernelTimer kt(e, RNA_K_ASTAR_INIT, init_stream);
-    hipLaunchKernelGGL(tsa_snapshot_kernel, dim3(std::min(ti * tj, 4096)), dim3(256), 0, init_stream, e->nbr, rows, cols, ti, tj, S.nbr_tm,
+    KernelTimer kt(e, RNA_K_ASTAR_INIT, search_stream);
+    hipLaunchKernelGGL(tsa_snapshot_kernel, dim3(std::min(ti * tj, 4096)), dim3(256), 0, search_stream, e->nbr, rows, cols, ti, tj, S.nbr_tm,
                        e->geom.start[0], e->geom.start[1]);
     RNA_HIP(e, hipGetLastError());
   }
   if (ev_init) {
-    RNA_HIP(e, hipEventRecord(ev_init, init_stream));
-    RNA_HIP(e, hipStreamWaitEvent(search_stream, ev_init, 0));
+    RNA_HIP(e, hipEventRecord(a.snap_done[slot], search_stream));
+    a.snap_pending[slot] = true;
   }
   {
     // ticket and launch order (the pages of a slot are reset by the workgroup that takes the slot)

@@ -341,6 +341,9 @@ extern "C" void rna_destroy(rna_engine* e) {
   (void)profile_flush(e);
   for (hipEvent_t ev : e->free_events) (void)hipEventDestroy(ev);
   e->free_events.clear();
+  if (e->vfh_stream) (void)hipStreamDestroy(e->vfh_stream);
+  if (e->ev_vfh_go) (void)hipEventDestroy(e->ev_vfh_go);
+  if (e->ev_vfh_done) (void)hipEventDestroy(e->ev_vfh_done);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -366,7 +369,7 @@ static void layer_changed(rna_engine* e, int layer) {
 
 extern "C" int rna_layer_upload(rna_engine* e, int layer, const float* host, size_t n) {
   if (!e || !host || layer < 0 || layer >= RNA_NUM_LAYERS || n != e->ncell) return RNA_EINVAL;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   RNA_HIP(e, hipMemcpyAsync(e->layer[layer], host, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
   RNA_HIP(e, hipStreamSynchronize(e->stream));
   layer_changed(e, layer);
@@ -375,7 +378,7 @@ extern "C" int rna_layer_upload(rna_engine* e, int layer, const float* host, siz
 
 extern "C" int rna_layer_download(rna_engine* e, int layer, float* host, size_t n) {
   if (!e || !host || layer < 0 || layer >= RNA_NUM_LAYERS || n != e->ncell) return RNA_EINVAL;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   RNA_HIP(e, hipMemcpyAsync(host, e->layer[layer], n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   RNA_HIP(e, hipStreamSynchronize(e->stream));
   return RNA_OK;
@@ -383,7 +386,7 @@ extern "C" int rna_layer_download(rna_engine* e, int layer, float* host, size_t 
 
 extern "C" int rna_layer_fill(rna_engine* e, int layer, float value) {
   if (!e || layer < 0 || layer >= RNA_NUM_LAYERS) return RNA_EINVAL;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   int rc = fill_layer(e, e->layer[layer], value);
   layer_changed(e, layer);
   return rc;
@@ -403,7 +406,7 @@ static int region_copy(rna_engine* e, int layer, int i0, int ni, int j0, int nj,
   if (ni <= 0 || nj <= 0) return RNA_OK;
   if (i0 < 0 || j0 < 0 || i0 + ni > e->geom.size[0] || j0 + nj > e->geom.size[1])
     return rna::fail(e, RNA_EINVAL, "region outside the map");
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   float* blk = e->layer[layer] + (size_t)j0 * e->geom.size[0] + i0;
   const size_t lpitch = (size_t)e->geom.size[0] * sizeof(float), dpitch = (size_t)ni * sizeof(float);
   if (pack) {
@@ -451,7 +454,7 @@ static int get_submap(rna_engine* e, int layer, double px, double py, double lx,
   if (si.size[0] <= 0 || si.size[1] <= 0 || si.size[0] > e->geom.size[0] || si.size[1] > e->geom.size[1]) return 0;
   const size_t n = (size_t)si.size[0] * si.size[1];
   if (n > cap) return rna::fail(e, RNA_ECAPACITY, "rna_get_submap: output buffer smaller than the submap");
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   float* dst = out;
   float* staging = nullptr;
   if (to_host) {
@@ -471,7 +474,7 @@ static int get_submap(rna_engine* e, int layer, double px, double py, double lx,
 
 extern "C" int rna_last_dirty_tiles(rna_engine* e, uint8_t* flags_host, size_t n_tiles) {
   if (!e || !flags_host || n_tiles != (size_t)e->tiles_i * e->tiles_j) return RNA_EINVAL;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   RNA_HIP(e, hipMemcpyAsync(flags_host, e->last_dirty, n_tiles, hipMemcpyDeviceToHost, e->stream));
   RNA_HIP(e, hipStreamSynchronize(e->stream));
   return RNA_OK;
@@ -501,7 +504,7 @@ extern "C" int rna_layer_pack_tiles(rna_engine* e, int layer, const int32_t* til
   if (!e || layer < 0 || layer >= RNA_NUM_LAYERS || n < 0 || (n > 0 && (!tiles_host || !dense_device))) return RNA_EINVAL;
   if (n == 0) return RNA_OK;
   if (!window_ok(e, i0, ni, j0, nj)) return rna::fail(e, RNA_EINVAL, "window outside the map");
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   int rc = stage_tile_list(e, tiles_host, n);
   if (rc != RNA_OK) return rc;
   hipLaunchKernelGGL(pack_tiles_kernel, dim3(n), dim3(256), 0, e->stream, e->layer[layer], e->geom.size[0], e->tiles_i,
@@ -518,7 +521,7 @@ extern "C" int rna_layers_unpack_tiles(rna_engine* e, int layer_a, int layer_b, 
     return RNA_EINVAL;
   if (n == 0) return RNA_OK;
   if (!window_ok(e, i0, ni, j0, nj)) return rna::fail(e, RNA_EINVAL, "window outside the map");
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   int rc = stage_tile_list(e, tiles_host, n);
   if (rc != RNA_OK) return rc;
   hipLaunchKernelGGL(unpack_tiles_kernel, dim3(n), dim3(256), 0, e->stream, e->layer[layer_a],
@@ -534,7 +537,7 @@ extern "C" int rna_layers_unpack_tiles(rna_engine* e, int layer_a, int layer_b, 
 extern "C" int rna_last_dirty_tiles_device(rna_engine* e, int i0, int ni, int j0, int nj, int32_t* list_device, int* count_device) {
   if (!e || !list_device || !count_device) return RNA_EINVAL;
   if (!window_ok(e, i0, ni, j0, nj)) return rna::fail(e, RNA_EINVAL, "window outside the map");
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   const int ntile = e->tiles_i * e->tiles_j;
   RNA_HIP(e, hipMemsetAsync(count_device, 0, sizeof(int), e->stream));
   hipLaunchKernelGGL(dirty_list_kernel, dim3((ntile + 255) / 256), dim3(256), 0, e->stream, e->last_dirty, e->tiles_i, ntile, i0,
@@ -548,7 +551,7 @@ extern "C" int rna_layer_pack_tiles_device(rna_engine* e, int layer, const int32
   if (!e || layer < 0 || layer >= RNA_NUM_LAYERS || n < 0 || (n > 0 && (!tiles_device || !dense_device))) return RNA_EINVAL;
   if (n == 0) return RNA_OK;
   if (!window_ok(e, i0, ni, j0, nj)) return rna::fail(e, RNA_EINVAL, "window outside the map");
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   hipLaunchKernelGGL(pack_tiles_kernel, dim3(n), dim3(256), 0, e->stream, e->layer[layer], e->geom.size[0], e->tiles_i,
                      tiles_device, i0, i0 + ni, j0, j0 + nj, dense_device);
   RNA_HIP(e, hipGetLastError());
@@ -562,7 +565,7 @@ extern "C" int rna_layers_unpack_tiles_device(rna_engine* e, int layer_a, int la
     return RNA_EINVAL;
   if (n == 0) return RNA_OK;
   if (!window_ok(e, i0, ni, j0, nj)) return rna::fail(e, RNA_EINVAL, "window outside the map");
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   hipLaunchKernelGGL(unpack_tiles_kernel, dim3(n), dim3(256), 0, e->stream, e->layer[layer_a],
                      layer_b >= 0 ? e->layer[layer_b] : (float*)nullptr, e->geom.size[0], e->tiles_i, tiles_device, i0,
                      i0 + ni, j0, j0 + nj, dense_device, e->dirty_tiles);
@@ -646,7 +649,7 @@ extern "C" void* rna_stream(rna_engine* e) { return e ? (void*)e->stream : nullp
 
 extern "C" int rna_synchronize(rna_engine* e) {
   if (!e) return RNA_EINVAL;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   return sync_all(e);
 }
 
@@ -669,8 +672,23 @@ extern "C" int rna_get_position(const rna_engine* e, int32_t i, int32_t j, doubl
 
 namespace rna {
 
+int side_join(rna_engine* e) {
+  if (e->vfh_pending) {
+    RNA_HIP(e, hipStreamWaitEvent(e->stream, e->ev_vfh_done, 0));
+    e->vfh_pending = false;
+  }
+  AstarDevice& a = e->astar;
+  for (int d = 0; d < AstarDevice::MAX_DEPTH; ++d)
+    if (a.snap_pending[d]) {
+      RNA_HIP(e, hipStreamWaitEvent(e->stream, a.snap_done[d], 0));
+      a.snap_pending[d] = false;
+    }
+  return RNA_OK;
+}
+
 int sync_all(rna_engine* e) {
   RNA_HIP(e, hipStreamSynchronize(e->stream));
+  if (e->vfh_stream) RNA_HIP(e, hipStreamSynchronize(e->vfh_stream));
   for (int d = 0; d < AstarDevice::MAX_DEPTH; ++d)
     if (e->astar.side[d]) RNA_HIP(e, hipStreamSynchronize(e->astar.side[d]));
   return RNA_OK;
@@ -696,6 +714,7 @@ int profile_flush(rna_engine* e) {
 // Recompute A* neighbour masks where the master layer changed.
 int map_prepare_nbr(rna_engine* e) {
   if (!e->nbr_all_dirty) return RNA_OK;
+  { const int rc = side_join(e); if (rc != RNA_OK) return rc; }   // snapshots in flight read the masks this rebuilds
   KernelTimer kt(e, RNA_K_NBRMASK);
   hipLaunchKernelGGL(nbr_mask_tiles_kernel, dim3(e->tiles_i, e->tiles_j), dim3(256), 0, e->stream, e->nbr,
                      e->layer[RNA_LAYER_MASTER], e->dirty_tiles, 1, e->geom.size[0], e->geom.size[1], e->tiles_i,
@@ -709,7 +728,7 @@ int map_prepare_nbr(rna_engine* e) {
 
 extern "C" int rna_compose_master(rna_engine* e, int mode) {
   if (!e || (mode != 0 && mode != 1)) return RNA_EINVAL;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   const size_t words = ((size_t)e->tiles_i * e->tiles_j + 3) / 4;  // one byte per tile, rounded to words
   const bool full = (mode == 1) || e->laser_all_dirty || e->master_diverged;
   const bool moved = e->geom.start[0] != 0 || e->geom.start[1] != 0;
@@ -764,7 +783,7 @@ extern "C" int rna_compose_master(rna_engine* e, int mode) {
 // rows/cols of every layer, keep position_ aligned to the grid.
 extern "C" int rna_move(rna_engine* e, double nx, double ny, int* moved) {
   if (!e) return RNA_EINVAL;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   Geom& g = e->geom;
   const double pshift[2] = {nx - g.pos[0], ny - g.pos[1]};
   int ishift[2];
@@ -824,7 +843,7 @@ extern "C" int rna_profile_enable(rna_engine* e, int on) {
 
 extern "C" int rna_profile_reset(rna_engine* e) {
   if (!e) return RNA_EINVAL;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   int rc = profile_flush(e);
   if (rc != RNA_OK) return rc;
   for (auto& p : e->prof) { p.total_ms = 0; p.launches = 0; }
@@ -833,7 +852,7 @@ extern "C" int rna_profile_reset(rna_engine* e) {
 
 extern "C" int rna_profile_get(rna_engine* e, int id, double* total_ms, int64_t* launches) {
   if (!e || id < 0 || id >= RNA_K_COUNT) return RNA_EINVAL;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   int rc = profile_flush(e);
   if (rc != RNA_OK) return rc;
   if (total_ms) *total_ms = e->prof[id].total_ms;

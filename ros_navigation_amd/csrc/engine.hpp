@@ -78,6 +78,8 @@ struct AstarDevice {
   void* tsa_aux_retry[MAX_DEPTH] = {};   // for the second pass over searches that outgrew their pages (astar_tile.hip)
   hipStream_t side[MAX_DEPTH] = {};
   hipEvent_t done[MAX_DEPTH] = {}; // search of the batch that last used this set has finished
+  hipEvent_t snap_done[MAX_DEPTH] = {};   // the stage's mask snapshot (taken on the stage's stream) has been taken
+  bool snap_pending[MAX_DEPTH] = {};
   bool busy[MAX_DEPTH] = {};
   unsigned long long stage_seq[MAX_DEPTH] = {};   // launch number of the stage's last batch (0: never used)
   hipEvent_t ev_init = nullptr;
@@ -106,6 +108,12 @@ struct rna_engine {
   int device = 0;
   int cu_count = 256;              // compute units of the device (MI355X: 256 = 8 XCDs x 32)
   hipStream_t stream = nullptr;
+  // Side work: the pipelined replan loop runs the VFH+ step on a stream of its own and the mask snapshot of a search
+  // launch on the stage's stream, so that neither sits in the engine stream's chain of map-update kernels.  Both only
+  // READ the map (master layer / neighbour masks); whatever may WRITE what they read joins them first (RNA_ENTER).
+  hipStream_t vfh_stream = nullptr;
+  hipEvent_t ev_vfh_go = nullptr, ev_vfh_done = nullptr;
+  bool vfh_pending = false;
   size_t ncell = 0;
   float* layer[RNA_NUM_LAYERS] = {nullptr, nullptr, nullptr};
   int tiles_i = 0, tiles_j = 0;
@@ -188,6 +196,18 @@ template <typename T>
 inline void dev_free(T** p) {
   if (*p) { (void)hipFree(*p); *p = nullptr; }
 }
+
+// the engine stream waits for the side work in flight (see rna_engine::vfh_stream); cheap when there is none
+int side_join(rna_engine* e);
+// entry of a C-ABI call that enqueues on the engine stream: select the device, join the side work.  Calls that cannot
+// disturb it (the ray batch of the laser layer, the searches, the VFH+ step itself, getters) use RNA_ENTER_NOJOIN.
+#define RNA_ENTER(e)                                        \
+  do {                                                      \
+    RNA_HIP(e, hipSetDevice((e)->device));                  \
+    const int rc_join_ = rna::side_join(e);                 \
+    if (rc_join_ != RNA_OK) return rc_join_;                \
+  } while (0)
+#define RNA_ENTER_NOJOIN(e) RNA_HIP(e, hipSetDevice((e)->device))
 
 // module entry points used across translation units
 int himm_release(rna_engine* e);

@@ -558,7 +558,9 @@ extern "C" int rna_himm_set_window(rna_engine* e, int i0, int j0, int ni, int nj
 extern "C" int rna_himm_update_device(rna_engine* e, int layer, const rna_ray* rays_device, int n) {
   if (!e || layer < 0 || layer >= RNA_NUM_LAYERS || n < 0 || (n > 0 && !rays_device)) return RNA_EINVAL;
   if (n == 0) return RNA_OK;
-  RNA_HIP(e, hipSetDevice(e->device));
+  // the ray batch of the laser (or range) layer touches nothing the side work reads (VFH+: master, snapshots: the masks)
+  if (layer == RNA_LAYER_MASTER) RNA_ENTER(e);
+  else RNA_ENTER_NOJOIN(e);
   int rc = ensure_scratch(e, n);
   if (rc != RNA_OK) return rc;
   return himm_launch(e, layer, rays_device, n);
@@ -567,7 +569,7 @@ extern "C" int rna_himm_update_device(rna_engine* e, int layer, const rna_ray* r
 extern "C" int rna_himm_update(rna_engine* e, int layer, const rna_ray* rays_host, int n) {
   if (!e || layer < 0 || layer >= RNA_NUM_LAYERS || n < 0 || (n > 0 && !rays_host)) return RNA_EINVAL;
   if (n == 0) return RNA_OK;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   int rc = ensure_scratch(e, n);
   if (rc != RNA_OK) return rc;
   RNA_HIP(e, hipMemcpyAsync(e->himm.rays_dev, rays_host, (size_t)n * sizeof(rna_ray), hipMemcpyHostToDevice,

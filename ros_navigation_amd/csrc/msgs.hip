@@ -62,7 +62,7 @@ int grid_for(size_t n, int block) {
 
 extern "C" int rna_to_occupancy_grid_device(rna_engine* e, int layer, float data_min, float data_max, int8_t* out_dev) {
   if (!e || !out_dev || layer < 0 || layer >= RNA_NUM_LAYERS) return RNA_EINVAL;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   KernelTimer kt(e, RNA_K_OCCUPANCY);
   hipLaunchKernelGGL(to_occupancy_kernel, dim3(grid_for(e->ncell, 256)), dim3(256), 0, e->stream, e->geom, e->layer[layer],
                      data_min, data_max, out_dev);
@@ -72,7 +72,7 @@ extern "C" int rna_to_occupancy_grid_device(rna_engine* e, int layer, float data
 
 extern "C" int rna_to_occupancy_grid(rna_engine* e, int layer, float data_min, float data_max, int8_t* out_host) {
   if (!e || !out_host) return RNA_EINVAL;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   int8_t* d = nullptr;
   int rc = dev_alloc(e, &d, e->ncell);
   if (rc != RNA_OK) return rc;
@@ -90,7 +90,7 @@ extern "C" int rna_from_occupancy_grid(rna_engine* e, int layer, const int8_t* d
   if (!e || !data_host || layer < 0 || layer >= RNA_NUM_LAYERS) return RNA_EINVAL;
   if (e->geom.start[0] != 0 || e->geom.start[1] != 0)   // the reference resets the geometry in that case (:230-236)
     return fail(e, RNA_ESTATE, "rna_from_occupancy_grid: map has been moved (start index != 0)");
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   int8_t* d = nullptr;
   int rc = dev_alloc(e, &d, e->ncell);
   if (rc != RNA_OK) return rc;
@@ -118,7 +118,7 @@ extern "C" int rna_vfh_hist_msg_batch(rna_engine* e, int n, uint16_t* x_data_hos
   thresholds[1] = (uint16_t)(unsigned)(4000000.0 / 1000.0);   // HIGH_OBSTACLE_THRESHOLD, steerer.cpp:14,208
   for (int i = 0; i < bins; ++i) x_data_host[i] = (uint16_t)(i * e->vfh.p.sector_angle);
   if (n == 0) return RNA_OK;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   uint16_t* d = nullptr;
   const size_t cnt = (size_t)n * bins;
   int rc = dev_alloc(e, &d, 2 * cnt);

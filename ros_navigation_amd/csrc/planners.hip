@@ -594,7 +594,7 @@ extern "C" int rna_graph_astar_batch(rna_engine* e, int nv, const double* vertex
   if (n == 0) return RNA_OK;
   for (int k = 0; k < 2 * ne; ++k)
     if (edge_uv[k] < 0 || edge_uv[k] >= nv) return RNA_EINVAL;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   // out-edge lists in add_edge order: add_edge(u,v) appends to u's list and to v's list
   std::vector<int> off(nv + 1, 0), fill(nv, 0), adj_v(2 * ne + 1);
   std::vector<float> adj_w(2 * ne + 1);
@@ -673,7 +673,7 @@ extern "C" int rna_rrt_batch_device(rna_engine* e, const rna_rrt_query* queries,
                                     int max_path_len, rna_rrt_result* results) {
   if (!e || n < 0 || max_path_len <= 0 || (n > 0 && (!queries || !paths_xy || !results))) return RNA_EINVAL;
   if (n == 0) return RNA_OK;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   double *tx = nullptr, *ty = nullptr;
   int* tp = nullptr;
   int rc = rrt_launch(e, queries, n, paths_xy, max_path_len, results, &tx, &ty, &tp);
@@ -687,7 +687,7 @@ extern "C" int rna_rrt_batch(rna_engine* e, const rna_rrt_query* queries_host, i
   if (!e || n < 0 || max_path_len <= 0 || (n > 0 && (!queries_host || !paths_xy_host || !results_host)))
     return RNA_EINVAL;
   if (n == 0) return RNA_OK;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   rna_rrt_query* dq = nullptr;
   rna_rrt_result* dr = nullptr;
   double *dp = nullptr, *tx = nullptr, *ty = nullptr;

@@ -140,7 +140,7 @@ extern "C" int rna_scan_to_rays_device(rna_engine* e, const rna_laser_scan* scan
   if (!e || n_scans < 0 || max_rays < 0 || max_beams_per_scan <= 0 || !n_rays_device) return RNA_EINVAL;
   if (n_scans > 0 && (!scans_device || !ranges_device || !rays_device)) return RNA_EINVAL;
   if (max_beams_per_scan > SCAN_MAX_BEAMS) return fail(e, RNA_EINVAL, "rna_scan_to_rays: more than 8192 beams per scan");
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   if (n_scans == 0) {
     RNA_HIP(e, hipMemsetAsync(n_rays_device, 0, sizeof(int), e->stream));
     return RNA_OK;
@@ -179,7 +179,7 @@ extern "C" int rna_scan_to_rays(rna_engine* e, const rna_laser_scan* scans_host,
     if (sc.n_ranges > max_beams) max_beams = sc.n_ranges;
   }
   if (max_beams > SCAN_MAX_BEAMS) return fail(e, RNA_EINVAL, "rna_scan_to_rays: more than 8192 beams per scan");
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   rna_laser_scan* d_scans = nullptr;
   float* d_ranges = nullptr;
   rna_ray* d_rays = nullptr;

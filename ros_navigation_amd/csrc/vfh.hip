@@ -583,12 +583,33 @@ int ensure_staging(rna_engine* e, bool ranges) {
   return RNA_OK;
 }
 
+// `side`: on the engine's VFH+ stream, behind an event of the engine stream (rna_engine::vfh_stream); the map update that
+// follows only joins it where it writes the master layer
 int launch_step(rna_engine* e, const rna_pose* poses_dev, const double* ranges_dev, int n, rna_vfh_out* out_dev,
-                float* origin_dev, float* hist_dev) {
-  KernelTimer kt(e, RNA_K_VFH_STEP);
-  hipLaunchKernelGGL(vfh_step_kernel, dim3(n), dim3(VFH_THREADS), 0, e->stream, make_k(e), e->geom,
-                     e->layer[RNA_LAYER_MASTER], poses_dev, ranges_dev, out_dev, origin_dev, hist_dev);
-  RNA_HIP(e, hipGetLastError());
+                float* origin_dev, float* hist_dev, bool side = false) {
+  hipStream_t st = e->stream;
+  if (side) {
+    if (!e->vfh_stream) {
+      int prio_lo = 0, prio_hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+      RNA_HIP(e, hipStreamCreateWithPriority(&e->vfh_stream, hipStreamNonBlocking, prio_hi));
+      RNA_HIP(e, hipEventCreateWithFlags(&e->ev_vfh_go, hipEventDisableTiming));
+      RNA_HIP(e, hipEventCreateWithFlags(&e->ev_vfh_done, hipEventDisableTiming));
+    }
+    RNA_HIP(e, hipEventRecord(e->ev_vfh_go, e->stream));
+    RNA_HIP(e, hipStreamWaitEvent(e->vfh_stream, e->ev_vfh_go, 0));
+    st = e->vfh_stream;
+  }
+  {
+    KernelTimer kt(e, RNA_K_VFH_STEP, st);
+    hipLaunchKernelGGL(vfh_step_kernel, dim3(n), dim3(VFH_THREADS), 0, st, make_k(e), e->geom,
+                       e->layer[RNA_LAYER_MASTER], poses_dev, ranges_dev, out_dev, origin_dev, hist_dev);
+    RNA_HIP(e, hipGetLastError());
+  }
+  if (side) {
+    RNA_HIP(e, hipEventRecord(e->ev_vfh_done, e->vfh_stream));
+    e->vfh_pending = true;
+  }
   return RNA_OK;
 }
 
@@ -622,7 +643,7 @@ extern "C" void rna_vfh_default_params(rna_vfh_params* p) {  // Steerer::initVfh
 
 extern "C" int rna_vfh_init(rna_engine* e, const rna_vfh_params* p, int n_robots) {
   if (!e || !p || n_robots <= 0) return RNA_EINVAL;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   HostTables t;
   if (!build_tables(*p, t)) return fail(e, RNA_EINVAL, "rna_vfh_init: unsupported VFH parameters");
   RNA_HIP(e, hipStreamSynchronize(e->stream));
@@ -660,7 +681,7 @@ extern "C" int rna_vfh_init(rna_engine* e, const rna_vfh_params* p, int n_robots
 extern "C" int rna_vfh_reset(rna_engine* e) {
   if (!e) return RNA_EINVAL;
   if (!e->vfh.ready) return fail(e, RNA_ESTATE, "rna_vfh_reset before rna_vfh_init");
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   const int n = e->vfh.n_robots;
   const int threads = n * e->vfh.H;
   hipLaunchKernelGGL(vfh_reset_kernel, dim3((threads + 255) / 256), dim3(256), 0, e->stream, make_k(e), n);
@@ -677,8 +698,9 @@ extern "C" int rna_vfh_step_batch_device(rna_engine* e, const rna_pose* poses, i
   if (!e->vfh.ready) return fail(e, RNA_ESTATE, "rna_vfh_step_batch before rna_vfh_init");
   if (n > e->vfh.n_robots) return fail(e, RNA_EINVAL, "more poses than VFH instances");
   if (n == 0) return RNA_OK;
-  RNA_HIP(e, hipSetDevice(e->device));
-  return launch_step(e, poses, nullptr, n, out, origin_hist, hist);
+  RNA_ENTER_NOJOIN(e);   // (steps on the VFH+ stream follow one another there)
+  // next to pipelined searches the step runs on its own stream: it only reads the master layer and the robots' state
+  return launch_step(e, poses, nullptr, n, out, origin_hist, hist, e->astar.depth > 1 && !getenv("RNA_VFH_INLINE"));
 }
 
 static int step_host(rna_engine* e, const double* ranges_host, const rna_pose* poses_host, int n,
@@ -688,7 +710,7 @@ static int step_host(rna_engine* e, const double* ranges_host, const rna_pose* p
   VfhDevice& v = e->vfh;
   if (n > v.n_robots) return fail(e, RNA_EINVAL, "more poses than VFH instances");
   if (n == 0) return RNA_OK;
-  RNA_HIP(e, hipSetDevice(e->device));
+  RNA_ENTER(e);
   int rc = ensure_staging(e, ranges_host != nullptr);
   if (rc != RNA_OK) return rc;
   RNA_HIP(e, hipMemcpyAsync(v.poses_dev, poses_host, (size_t)n * sizeof(rna_pose), hipMemcpyHostToDevice, e->stream));
