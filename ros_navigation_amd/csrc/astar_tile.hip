@@ -330,7 +330,7 @@ struct TsaCtx {
 #define TSA_MKW(b) TSA_CAT(TSA_MK_, b)   // the mask word that holds row b's byte, at bit 8 * (b & 3)
 template <class Sched>
 __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane_in, const int t, const TsaCtx& C,
-                                       const bool first, const long long bucket_end, const int key_base, const int key_shift TSA_ACC_PARAM) {
+                                       const bool first, const long long bucket_end, const int key_base, const int key_shift, int* freed_slot TSA_ACC_PARAM) {
   // an opaque copy of the lane id per job (and one more for the results phase): everything derived from it is then
   // recomputed here instead of being hoisted out of the job loop, kept alive across the sweeps and spilled to scratch
   int lane = lane_in;
@@ -603,11 +603,16 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
 #define TSA_STORE(b)                                                                              \
   if ((rowchg >> (b)) & 1u) {                                                                     \
     own[(b) * TI + lane] = (unsigned)TSA_G(b);                                                    \
-    if (edge_lane) ax[b] = (unsigned)TSA_G(b);                                                    \
     if (ovf_possible) ovfm |= __builtin_amdgcn_ballot_w64((unsigned)(TSA_G(b) - 1) < (unsigned)(4 * COST_D - 1));   \
   }
     TSA_R16(TSA_STORE)
 #undef TSA_STORE
+    // the copies of columns 0 and 63 for the neighbours: lanes 0 and 63 only, one change of the exec mask for all rows
+    if (edge_lane) {
+#define TSA_STORE_EDGE(b) if ((rowchg >> (b)) & 1u) ax[b] = (unsigned)TSA_G(b);
+      TSA_R16(TSA_STORE_EDGE)
+#undef TSA_STORE_EDGE
+    }
     if (ovfm && lane == 0) sch.overflow();   // path costs beyond 2^30 - 5656: the search is abandoned (status 4)
     if (t == C.tg) {
 #define TSA_GOAL(b)                                                                               \
@@ -724,7 +729,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       const int kf = lane == 1 ? kfN : (lane == 6 ? kfS : ((lane == 0 || lane == 3 || lane == 5) ? kfW : kfE));
       int key = (key_base - kf) >> key_shift;
       key = key < 0 ? 0 : (key > 0xfffe ? 0xfffe : key);
-      sch.wake8(lane < 8 && ((wm >> lane) & 1u), nb_t, (unsigned)key, lane);
+      sch.wake8(lane < 8 && ((wm >> lane) & 1u), nb_t, (unsigned)key, lane, freed_slot);
     }
   }
 #undef TSA_ROW_CHANGED
@@ -820,7 +825,7 @@ struct TsaLocalSched {
   }
   // the wake-ups of one job together: lane k < 8 with `w` set wakes tile t with key `key` (all lanes call).  Three LDS
   // round trips whatever their number: the D bits, one reservation of queue slots, the entries.
-  __device__ __forceinline__ void wake8(bool w, int t, unsigned key, int lane) {
+  __device__ __forceinline__ void wake8(bool w, int t, unsigned key, int lane, int* freed) {
     const unsigned sh = 2u * ((unsigned)t & 15u);
     unsigned old = 2u;
     if (w) old = atomicOr(&st2_[t >> 4], 1u << sh) >> sh;
@@ -829,13 +834,20 @@ struct TsaLocalSched {
     const unsigned e = (key << 16) | (unsigned)t;
     const unsigned long long fm = __builtin_amdgcn_ballot_w64(fresh);
     if (fm) {
+      // the slot this wavefront emptied when it took its job goes to the first entry, the others get fresh ones
+      const int reuse = *freed;
+      *freed = -1;
+      const int first_lane = __builtin_ctzll(fm);
+      const unsigned long long need = reuse >= 0 ? fm & (fm - 1ull) : fm;
       int base = 0;
-      if (lane == __builtin_ctzll(fm)) base = atomicAdd(tail_, __builtin_popcountll(fm));
-      base = __builtin_amdgcn_readlane(base, __builtin_ctzll(fm));
+      if (need) {
+        if (lane == __builtin_ctzll(need)) base = atomicAdd(tail_, __builtin_popcountll(need));
+        base = __builtin_amdgcn_readlane(base, __builtin_ctzll(need));
+      }
       bool ok = false;
       int slot = 0;
       if (fresh) {
-        slot = (base + __builtin_popcountll(fm & ((1ull << lane) - 1ull))) & (TSA_NE - 1);
+        slot = (reuse >= 0 && lane == first_lane) ? reuse : ((base + __builtin_popcountll(need & ((1ull << lane) - 1ull))) & (TSA_NE - 1));
         ok = atomicCAS(&ent_[slot], ENT_EMPTY, e) == ENT_EMPTY;
         if (ok) atomicMax(hi_, (slot | 255) + 1);
       }
@@ -855,8 +867,9 @@ struct TsaLocalSched {
       lower_key(__builtin_amdgcn_readlane(t, l), (unsigned)__builtin_amdgcn_readlane((int)e, l), lane);
     }
   }
-  // take the entry with the lowest key; ENT_EMPTY if the queue is empty
-  __device__ __forceinline__ unsigned pop(int lane) {
+  // take the entry with the lowest key; ENT_EMPTY if the queue is empty.  *freed = the slot it sat in (a wavefront's
+  // next wake-up goes there: the entries in use stay packed at the low end, and the scans over them short)
+  __device__ __forceinline__ unsigned pop(int lane, int* freed) {
     for (;;) {
       const int hi = lds_ldi(hi_);
       unsigned m = ENT_EMPTY;
@@ -870,13 +883,14 @@ struct TsaLocalSched {
       const unsigned mm = wave_min_u32(m);
       if (mm == ENT_EMPTY) return ENT_EMPTY;
       const unsigned long long who = __builtin_amdgcn_ballot_w64(m == mm);
-      unsigned got = 0u;
+      int got = -1;
       if (lane == __builtin_ctzll(who)) {
         const uint4 v = *reinterpret_cast<const uint4*>(&ent_[mb + lane * 4]);
         const int c = v.x == mm ? 0 : (v.y == mm ? 1 : (v.z == mm ? 2 : (v.w == mm ? 3 : -1)));
-        if (c >= 0 && atomicCAS(&ent_[mb + lane * 4 + c], mm, ENT_EMPTY) == mm) { got = 1u; atomicSub(count_, 1); }
+        if (c >= 0 && atomicCAS(&ent_[mb + lane * 4 + c], mm, ENT_EMPTY) == mm) { got = mb + lane * 4 + c; atomicSub(count_, 1); }
       }
-      if (__builtin_amdgcn_ballot_w64(got != 0u)) return mm;
+      got = __builtin_amdgcn_readlane(got, __builtin_ctzll(who));
+      if (got >= 0) { *freed = got; return mm; }
       // another wavefront took it (or lowered its key) in between: look again
     }
   }
@@ -1146,6 +1160,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
       }
       int t = -1;
       bool first = false;
+      int freed_slot = -1;   // the queue slot this wavefront emptied when it took the job (wake8 fills it again)
       // ---- 1. a tile of the open set (runs as "first") ----
       if (!open_blocked && lds_ldi(&s_open_left) > 0) {
         const int pos = lds_ldi(&s_open_pos);
@@ -1184,7 +1199,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
       } else {
         // ---- 2. the queued tile with the lowest key ----
         open_blocked = false;
-        const unsigned e = sch.pop(lane);
+        const unsigned e = sch.pop(lane, &freed_slot);
         if (e == ENT_EMPTY) {
           if (lds_ldi(&s_open_left) > 0) { __builtin_amdgcn_s_sleep(2); continue; }   // (the open tile that was running)
           if (lane == 0) atomicAdd(&s_idle, 1);
@@ -1221,7 +1236,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
       TSA_ACC(4, t_p0, t_p1);   // taking a job
       TSA_CNT(7, 1);
       my_jobs += 1;
-      my_evals += tsa_job(sch, s_scr[wv], lane, t, C, first, bucket_end, key_base, key_shift TSA_ACC_ARG);
+      my_evals += tsa_job(sch, s_scr[wv], lane, t, C, first, bucket_end, key_base, key_shift, &freed_slot TSA_ACC_ARG);
       // the job's stores are performed before the tile can be taken again (it may have been woken while it ran)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       {
