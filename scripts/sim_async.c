@@ -28,7 +28,7 @@ static int rows, cols, TI = 64, TJ = 16, tiles_i, tiles_j, bucket_w, extra_h = 1
 static uint8_t* nbr;
 static int32_t* g;
 static int gi, gj;
-static int excl8 = 0, keymode = 1, kshift = -1, nodec = 0, dirtykey = 0, maxlive = 0;
+static int excl4 = 0, excl8 = 0, keymode = 1, kshift = -1, nodec = 0, dirtykey = 0, maxlive = 0;
 static long long* popkey;
 static double C_LOAD = 3.8, C_ROW = 0.2, C_HP = 0.065, C_RES = 2.6, C_ROUND = 2.4, C_POP = 0.3;
 
@@ -55,6 +55,9 @@ typedef struct {
   long long wkey[8];    /* lowest f the waker offers that neighbour */
   int far, any, goal_best, rowsn, hp, noop;
   double cost;
+  int32_t ppv[64 * 16];     /* what each cell may pass on (INF: nothing) */
+  uint8_t chgv[64 * 16];    /* the cell changed in this job */
+  int first;
 } jobres;
 
 /* one job on the CURRENT g; nothing is written: the caller applies `r` when the job ends */
@@ -158,6 +161,9 @@ static void job(int t, int first, jobres* r) {
     dir ^= 1;
   }
   static uint8_t chg[16][64];
+  r->first = first;
+  for (int b = 0; b < TJ; ++b)
+    for (int a = 0; a < TI; ++a) { r->ppv[b * TI + a] = pp[b][a]; r->chgv[b * TI + a] = 0; }
   for (int b = 0; b < TJ; ++b)
     for (int a = 0; a < TI; ++a) {
       const int i = i0 + a, j = j0 + b;
@@ -167,6 +173,7 @@ static void job(int t, int first, jobres* r) {
       if (i >= rows || j >= cols || v >= INF) continue;
       const int ch = v < old[b][a];
       chg[b][a] = (uint8_t)ch;
+      r->chgv[b * TI + a] = (uint8_t)ch;
       if (ch) { r->any = 1; if (i == gi && j == gj && v < r->goal_best) r->goal_best = v; }
       const long long f = (long long)v + octile(i, j);
       if (f > best) continue;
@@ -218,6 +225,39 @@ static void job(int t, int first, jobres* r) {
     for (int k = 0; k < 8; ++k) r->wkey[k] = m;
   }
   r->cost = C_LOAD + C_ROW * r->rowsn + C_HP * r->hp + C_RES;
+}
+
+/* SIM_FRESH: the wake tests of a job evaluated when it ENDS against what the neighbours hold THEN (the kernel would
+   re-read their edge rows / columns after its stores), instead of against the halo it loaded when it started */
+static int fresh = 0;
+static void wake_fresh(jobres* r) {
+  static const int di[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dj[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+  const int t = r->t, ti = t % tiles_i, tj = t / tiles_i, i0 = ti * TI, j0 = tj * TJ;
+  for (int k = 0; k < 8; ++k) { r->wake[k] = -1; r->wkey[k] = (long long)1 << 60; }
+  if (r->noop) return;
+  for (int b = 0; b < TJ; ++b)
+    for (int a = 0; a < TI; ++a) {
+      if (a != 0 && a != TI - 1 && b != 0 && b != TJ - 1) continue;
+      const int i = i0 + a, j = j0 + b;
+      if (i >= rows || j >= cols) continue;
+      const int p = r->ppv[b * TI + a];
+      if (p >= INF) continue;
+      const uint8_t m = nbr[(size_t)j * rows + i];
+      for (int k = 0; k < 8; ++k) {
+        if (!((m >> k) & 1)) continue;
+        const int na = a + di[k], nb = b + dj[k];
+        if (na >= 0 && na < TI && nb >= 0 && nb < TJ) continue;
+        const int c = p + ((di[k] && dj[k]) ? 1414 : 1000);
+        if (c < gat(i0 + na, j0 + nb)) {
+          const int wi = ti + (na < 0 ? -1 : (na >= TI ? 1 : 0)), wj = tj + (nb < 0 ? -1 : (nb >= TJ ? 1 : 0));
+          if (wi < 0 || wj < 0 || wi >= tiles_i || wj >= tiles_j) continue;
+          const int kk = (wj - tj + 1) * 3 + (wi - ti + 1), k8 = kk < 4 ? kk : kk - 1;
+          const long long f = (long long)c + octile(i0 + na, j0 + nb);
+          r->wake[k8] = wj * tiles_i + wi;
+          if (f < r->wkey[k8]) r->wkey[k8] = f;
+        }
+      }
+    }
 }
 
 static void apply(const jobres* r) {
@@ -273,8 +313,12 @@ static int pop4(int* spent) {
   *spent = 0;
   for (;;) {
     if (nent == 0) return -1;
-    int bi = 0;
-    for (int k = 1; k < nent; ++k) if (ents[k].key < ents[bi].key || (ents[k].key == ents[bi].key && ents[k].t < ents[bi].t)) bi = k;
+    int bi = -1;
+    for (int k = 0; k < nent; ++k) {
+      if (excl4 && nb_running(ents[k].t)) continue;
+      if (bi < 0 || ents[k].key < ents[bi].key || (ents[k].key == ents[bi].key && ents[k].t < ents[bi].t)) bi = k;
+    }
+    if (bi < 0) return -1;   /* everything queued sits next to a running tile */
     const int t = ents[bi].t;
     ents[bi] = ents[--nent];
     if (running[t]) { (*spent)++; stale_pops++; continue; }   /* its runner sees D when it ends */
@@ -327,6 +371,8 @@ int main(int argc, char** argv) {
   const int subbins = argc > 6 ? atoi(argv[6]) : 0;
   if (getenv("SIM_HPASS")) extra_h = atoi(getenv("SIM_HPASS"));
   if (getenv("SIM_EXCL8")) excl8 = 1;
+  if (getenv("SIM_FRESH")) fresh = 1;
+  if (getenv("SIM_EXCL")) excl4 = 1;   /* policy 4: a tile does not start while one of its four edge neighbours runs */
   if (getenv("SIM_NODEC")) nodec = 1;                            /* a queued tile keeps the key of its first wake-up */
   if (getenv("SIM_DIRTYKEY")) dirtykey = atoi(getenv("SIM_DIRTYKEY"));   /* key of a tile woken while it ran: 0 the waker's, 1 the key it was taken with, 2 lowest, 3 highest */
   if (getenv("SIM_KEY")) keymode = atoi(getenv("SIM_KEY"));     /* 1: lowest f offered to that neighbour; 2: lowest f offered to any neighbour by this job */
@@ -461,8 +507,9 @@ int main(int argc, char** argv) {
         for (int w = 0; w < W; ++w) if (busy[w] && (wd < 0 || tend[w] < tend[wd])) wd = w;
         now = tend[wd];
         busy[wd] = 0; nrun--;
-        const jobres* r = &slot[wd];
+        jobres* r = &slot[wd];
         apply(r);
+        if (fresh) wake_fresh(r);
         running[r->t] = 0;
         if (r->far) farflag[r->t] = 1;
         if (policy == 4) {
