@@ -245,25 +245,37 @@ __global__ void himm_bin_count_kernel(const int4* __restrict__ desc, const int* 
   w.for_each_tile_lockstep(tiles_i, [&](bool act, int t) { (void)wave_tile_add(tile_count, act, t); });
 }
 
-// exclusive prefix sum of the tile counts (one workgroup; ntile <= 65536 at 4096 x 4096 cells per 64 x 64 tile)
+// exclusive prefix sum of the tile counts (one workgroup; ntile <= 65536 at 4096 x 4096 cells per 64 x 64 tile), and the
+// list of the tiles that hold at least one ray: the rasteriser's workgroups take (tile, half) jobs from that list with a
+// ticket instead of one workgroup per half tile of the map -- of the 8192 half tiles of a 4096^2 map a 100 k-ray batch
+// touches ~1500, and next to the search workgroups that fill every CU each EMPTY workgroup still had to wait for a slot.
 __global__ void __launch_bounds__(1024) himm_bin_scan_kernel(int* __restrict__ tile_count, int ntile, int* __restrict__ tile_off,
-                                                             int* __restrict__ tile_cursor) {
+                                                             int* __restrict__ tile_cursor, int* __restrict__ active,
+                                                             int* __restrict__ n_active, int* __restrict__ ticket) {
   __shared__ int s_part[1024];
+  __shared__ int s_act[1024];
   const int per = (ntile + 1023) / 1024;
   const int lo = threadIdx.x * per, hi = min(ntile, lo + per);
-  int sum = 0;
-  for (int t = lo; t < hi; ++t) sum += tile_count[t];
+  int sum = 0, nact = 0;
+  for (int t = lo; t < hi; ++t) { const int c = tile_count[t]; sum += c; nact += c > 0; }
   s_part[threadIdx.x] = sum;
+  s_act[threadIdx.x] = nact;
   __syncthreads();
   for (int o = 1; o < 1024; o <<= 1) {
-    const int v = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+    const int v = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0, a = threadIdx.x >= o ? s_act[threadIdx.x - o] : 0;
     __syncthreads();
     s_part[threadIdx.x] += v;
+    s_act[threadIdx.x] += a;
     __syncthreads();
   }
-  int run = s_part[threadIdx.x] - sum;
-  for (int t = lo; t < hi; ++t) { tile_off[t] = run; tile_cursor[t] = 0; run += tile_count[t]; tile_count[t] = 0; }   // (counts: zero again for the next batch)
-  if (threadIdx.x == 1023) tile_off[ntile] = s_part[1023];
+  int run = s_part[threadIdx.x] - sum, arun = s_act[threadIdx.x] - nact;
+  for (int t = lo; t < hi; ++t) {
+    const int c = tile_count[t];
+    tile_off[t] = run; tile_cursor[t] = 0; run += c;
+    if (c > 0) active[arun++] = t;
+    tile_count[t] = 0;   // (counts: zero again for the next batch)
+  }
+  if (threadIdx.x == 1023) { tile_off[ntile] = s_part[1023]; *n_active = s_act[1023]; *ticket = 0; }
 }
 
 __global__ void himm_bin_fill_kernel(const int4* __restrict__ desc, const int* __restrict__ ncells, int n, int tiles_i,
@@ -304,10 +316,12 @@ __device__ __forceinline__ void himm_count_marked_clear(int cell, int r, const H
   else atomicAdd(&after[off + len - 1], 1u);
 }
 
-constexpr int HIMM_TR_THREADS = 512;   // 8 wavefronts: two per SIMD next to the four of a resident search workgroup
+constexpr int HIMM_TR_THREADS = 512;   // (a power of two: the lane -> ray permutation of the rasteriser relies on it) // 8 wavefronts: two per SIMD next to the four of a resident search workgroup
 __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int rows, int cols, int tiles_i, const int4* __restrict__ desc,
                                                                const int* __restrict__ ncells,
                                                                const int* __restrict__ tile_off, const int* __restrict__ pairs,
+                                                               const int* __restrict__ active, const int* __restrict__ n_active,
+                                                               int* __restrict__ ticket,
                                                                float* __restrict__ layer, const unsigned* __restrict__ mark_bitmap,
                                                                const HimmSlot* __restrict__ slots, int slot_mask,
                                                                const int* __restrict__ seqs, unsigned* __restrict__ before,
@@ -318,10 +332,16 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
   __shared__ int s_moff[HIMM_MTAB];     // per marked cell (by rank): offset of its marks in seqs / before / after, -1: not a single-mark cell
   __shared__ int s_mseq[HIMM_MTAB];     // ... the ray sequence number of its one mark
   __shared__ unsigned s_mcnt[2 * HIMM_MTAB];   // ... clears before / after that mark
-  __shared__ int s_touched;
-  const int t = blockIdx.x >> 1, half = blockIdx.x & 1;
-  const int np = tile_off[t + 1] - tile_off[t];   // rays registered with this tile
-  if (np == 0) return;
+  __shared__ int s_touched, s_job;
+  const int njobs = 2 * *n_active;
+  for (;;) {   // (tile, half) jobs by ticket
+  __syncthreads();   // the previous job's LDS has been read
+  if (threadIdx.x == 0) s_job = atomicAdd(ticket, 1);
+  __syncthreads();
+  const int job = s_job;
+  if (job >= njobs) break;
+  const int t = active[job >> 1], half = job & 1;
+  const int np = tile_off[t + 1] - tile_off[t];   // rays registered with this tile (> 0)
   const int ti = t % tiles_i, tj = t / tiles_i;
   const int i0 = ti << 6, j0 = (tj << 6) + (half << 5);
   for (int c = threadIdx.x; c < 32 * 64; c += HIMM_TR_THREADS) s_cnt[c] = 0u;
@@ -363,8 +383,12 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
   const int* mine = pairs + tile_off[t];
   bool touched = false;
   for (int base = 0; base < np; base += HIMM_TR_THREADS) {
-    const int p = base + (int)threadIdx.x;
-    if (p >= np) break;
+    // The rays of a scan are consecutive in the list and leave their origin a quarter of a degree apart: taken lane by
+    // lane, the 64 lanes of a wavefront would walk the same few cells for dozens of steps and their LDS adds would
+    // serialise on the address.  The lanes take every 33rd ray instead (x -> 33 x mod 512 is a bijection): neighbouring
+    // lanes are 7.6 degrees apart and part after a few cells.
+    const int p = base + (int)((threadIdx.x * 33u) & (unsigned)(HIMM_TR_THREADS - 1));
+    if (p >= np) continue;
     const int r = mine[p];
     const RayWalk w(desc[r], ncells[r]);
     // the ray's cells whose major coordinate lies in this tile
@@ -407,7 +431,7 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
   }
   if (touched) s_touched = 1;
   __syncthreads();
-  if (!s_touched) return;
+  if (!s_touched) continue;
   // flags exist for the laser layer only ("laser differs from master here")
   if (threadIdx.x == 0 && dirty_tiles) reinterpret_cast<volatile unsigned char*>(dirty_tiles)[t] = 1;
   if (threadIdx.x < HIMM_MTAB && s_moff[threadIdx.x] >= 0) {
@@ -424,6 +448,7 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
     const float v = *p, nv = himm_clear_n(v, k);
     if (__float_as_int(nv) != __float_as_int(v)) *p = nv;
   }
+  }   // next job
 }
 
 __global__ void himm_apply_kernel(int rows, HimmSlot* __restrict__ slots, int n_slots, int* __restrict__ total,
@@ -457,9 +482,10 @@ int ensure_scratch(rna_engine* e, int n) {
     if ((rc = dev_alloc(e, &s.mark_bitmap, words)) != RNA_OK) return rc;
     RNA_HIP(e, hipMemsetAsync(s.mark_bitmap, 0, words * sizeof(unsigned), e->stream));
     if ((rc = dev_alloc(e, &s.total, 1)) != RNA_OK) return rc;
-    // per 64 x 64 tile: count | offset (ntile + 1) | cursor; the counts are all zero between batches (the scan leaves them so)
-    if ((rc = dev_alloc(e, &s.tile_bins, (size_t)3 * e->tiles_i * e->tiles_j + 1)) != RNA_OK) return rc;
-    RNA_HIP(e, hipMemsetAsync(s.tile_bins, 0, ((size_t)3 * e->tiles_i * e->tiles_j + 1) * sizeof(int), e->stream));
+    // per 64 x 64 tile: count | offset (ntile + 1) | cursor | list of the tiles with rays, then their number and the
+    // rasteriser's ticket; the counts are all zero between batches (the scan leaves them so)
+    if ((rc = dev_alloc(e, &s.tile_bins, (size_t)4 * e->tiles_i * e->tiles_j + 3)) != RNA_OK) return rc;
+    RNA_HIP(e, hipMemsetAsync(s.tile_bins, 0, ((size_t)4 * e->tiles_i * e->tiles_j + 3) * sizeof(int), e->stream));
   }
   if (n <= s.cap_rays) return RNA_OK;
   int cap = 1024;
@@ -510,12 +536,17 @@ int himm_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n) {
     int* count = s.tile_bins;
     int* off = s.tile_bins + ntile;
     int* cursor = s.tile_bins + 2 * ntile + 1;
+    int* active = s.tile_bins + 3 * ntile + 1;
+    int* n_active = s.tile_bins + 4 * ntile + 1;
+    int* ticket = s.tile_bins + 4 * ntile + 2;
     hipLaunchKernelGGL(himm_bin_count_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, s.desc, s.ncells, n, e->tiles_i, count);
-    hipLaunchKernelGGL(himm_bin_scan_kernel, dim3(1), dim3(1024), 0, e->stream, count, ntile, off, cursor);
+    hipLaunchKernelGGL(himm_bin_scan_kernel, dim3(1), dim3(1024), 0, e->stream, count, ntile, off, cursor, active, n_active, ticket);
     hipLaunchKernelGGL(himm_bin_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, s.desc, s.ncells, n, e->tiles_i, off,
                        cursor, s.pairs);
-    hipLaunchKernelGGL(himm_tile_raster_kernel, dim3(2 * ntile), dim3(HIMM_TR_THREADS), 0, e->stream, g.size[0], g.size[1], e->tiles_i, s.desc,
-                       s.ncells, off, s.pairs, e->layer[layer], s.mark_bitmap, s.slots, n_slots - 1, s.seqs, s.before,
+    // (tile, half) jobs are taken by ticket: as many workgroups as can be resident and useful, not one per half tile
+    const int raster_wgs = std::min(2 * ntile, std::max(256, 4 * e->cu_count));
+    hipLaunchKernelGGL(himm_tile_raster_kernel, dim3(raster_wgs), dim3(HIMM_TR_THREADS), 0, e->stream, g.size[0], g.size[1], e->tiles_i, s.desc,
+                       s.ncells, off, s.pairs, active, n_active, ticket, e->layer[layer], s.mark_bitmap, s.slots, n_slots - 1, s.seqs, s.before,
                        s.after, layer == RNA_LAYER_LASER ? e->dirty_tiles : nullptr, win);
     RNA_HIP(e, hipGetLastError());
   }
