@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/
 ASTAR_BYTES_PER_SETTLED = 44   # 8 neighbour occupancy reads x 4 B + 12 B g/parent/flag RMW
 VFH_BYTES_PER_POSE = 4 * 31 * 31 + 2 * 72 * 4 + 32
 ROTATE = int(os.environ.get("RNA_BENCH_ROTATE", "4"))   # distinct ray batches / pose sets / query sets the steps cycle through (developer override)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
 
 
 def parse():
@@ -198,7 +198,7 @@ def pmc_traffic(kernel, args, world):
         ks = [find(name) for name in ([kernel] if isinstance(kernel, str) else kernel)]   # a slot's chain: one launch each
         lo = sum(k["fetch_size_kb_avg"] + k["write_size_kb_avg"] for k in ks) * 1024.0
         hi = sum(2.0 * k["fetch_size_kb_avg"] + k["write_size_kb_avg"] for k in ks) * 1024.0
-        return [lo, hi], "profiles/r02_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " \
+        return [lo, hi], "profiles/r03_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " \
                          "[(FETCH+WRITE), (2*FETCH+WRITE)] x 1024 B per launch"
     except Exception:
         return None, "no PMC summary committed for this kernel"

@@ -903,7 +903,7 @@ struct TsaLaunch {
   TsaStage S;
   int bucket_width;
   int prio_first;   // the first prio_first workgroups to start (the longest expected searches) run at raised wave priority
-  // Second pass over a batch (retry != 0): workgroup r serves the r-th query that ran out of pages (status 5) in the
+  // Second pass over a batch (the RETRY instantiation of the kernel, a launch of its own; `retry` is informational): workgroup r serves the r-th query that ran out of pages (status 5) in the
   // first pass, in slot r of the stage's RETRY view S2 -- a few slots with one page per tile of the map, which a
   // search can never outgrow (a goal that cannot be reached floods its whole component; the reference answers "no
   // path", it does not fail).
@@ -1020,7 +1020,7 @@ __device__ __forceinline__ void tsa_backtrace_wave(const TsaLaunch& A, const Tsa
 // WAVES = wavefronts per workgroup (= per query): 8 when batches are pipelined (four queries share a CU, the throughput
 // configuration), 16 for a single batch on the engine's own stream (one workgroup per CU anyway: its latency is what
 // counts).
-template <int WAVES>
+template <int WAVES, bool RETRY>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(RNA_TSA_WAVES_PER_EU, RNA_TSA_WAVES_PER_EU))) tsa_search_kernel(const TsaLaunch A) {
   constexpr int TSA_THREADS = WAVES * 64;
   __shared__ unsigned s_scr[WAVES][SCR_WORDS];
@@ -1034,7 +1034,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   // its share of the batch while the other XCDs idle.  With tickets a free CU anywhere takes the next
   // (longest remaining) query.
   __shared__ int s_q, s_rank;
-  if (!A.retry) {
+  if (!RETRY) {
     if (threadIdx.x == 0) { const int k = atomicAdd(A.S.ticket, 1); s_rank = k; s_q = A.S.perm[k]; }
   } else {
     // the (blockIdx.x + 1)-th query of the batch with status 5 (none: nothing to do)
@@ -1050,8 +1050,8 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   __syncthreads();
   const int q = __builtin_amdgcn_readfirstlane(s_q);   // wave-uniform values belong in SGPRs: the tile jobs need every VGPR
   if (q < 0) return;
-  const TsaStage& S = A.retry ? A.S2 : A.S;
-  const int sl = A.retry ? (int)blockIdx.x : q;   // the slot whose pages / tables this search uses
+  const TsaStage& S = RETRY ? A.S2 : A.S;
+  const int sl = RETRY ? (int)blockIdx.x : q;   // the slot whose pages / tables this search uses
   // A batch lasts as long as its longest search, and a stage cannot take its next batch before: the searches expected
   // to be the longest (the first tickets) get the issue slots of their SIMDs first, the short ones fill in around them.
 #ifndef RNA_TSA_PRIO_FIRST
@@ -1446,15 +1446,15 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     if (const char* pf = getenv("RNA_TSA_PRIO_FIRST")) A.prio_first = atoi(pf);   // developer knob
     size_t lds_dyn = 4 * nt_bytes;
     if (const char* pad = getenv("RNA_TSA_LDS_PAD")) lds_dyn += (size_t)atoi(pad);   // developer knob: fewer search workgroups per CU
-    if (a.depth > 1) hipLaunchKernelGGL(tsa_search_kernel<TSA_WAVES>, dim3(n), dim3(TSA_WAVES * 64), lds_dyn, search_stream, A);
-    else hipLaunchKernelGGL(tsa_search_kernel<16>, dim3(n), dim3(16 * 64), lds_dyn, search_stream, A);
+    if (a.depth > 1) hipLaunchKernelGGL((tsa_search_kernel<TSA_WAVES, false>), dim3(n), dim3(TSA_WAVES * 64), lds_dyn, search_stream, A);
+    else hipLaunchKernelGGL((tsa_search_kernel<16, false>), dim3(n), dim3(16 * 64), lds_dyn, search_stream, A);
     if (a.g_retry[slot]) {
       // second pass: the searches that outgrew their share of pages, on the stage's full-size retry slots (workgroups
       // without such a query end at once)
       A.retry = 1;
       A.S2 = tsa_retry_view(e, slot, S);
-      if (a.depth > 1) hipLaunchKernelGGL(tsa_search_kernel<TSA_WAVES>, dim3(TSA_RETRY), dim3(TSA_WAVES * 64), lds_dyn, search_stream, A);
-      else hipLaunchKernelGGL(tsa_search_kernel<16>, dim3(TSA_RETRY), dim3(16 * 64), lds_dyn, search_stream, A);
+      if (a.depth > 1) hipLaunchKernelGGL((tsa_search_kernel<TSA_WAVES, true>), dim3(TSA_RETRY), dim3(TSA_WAVES * 64), lds_dyn, search_stream, A);
+      else hipLaunchKernelGGL((tsa_search_kernel<16, true>), dim3(TSA_RETRY), dim3(16 * 64), lds_dyn, search_stream, A);
     }
     RNA_HIP(e, hipGetLastError());
   }

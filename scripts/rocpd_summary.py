@@ -60,7 +60,7 @@ def main():
         out["pmc"] = summ
         with open(os.path.join(dst, "%s_pmc_summary.json" % tag), "w") as f:
             json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py "
-                                "--steps 8 --warmup 4 --no-cpu` (the default configuration below); per launch: "
+                                "--steps 2 --warmup 1 --no-cpu` (r02: --steps 8 --warmup 4; the default configuration below); per launch: "
                                 "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (FETCH_SIZE doubled: gfx950 "
                                 "reports half of the bytes of 16 B/lane streaming reads, MI355X_MICROARCH.md; dword "
                                 "accesses are uncalibrated, so bench.py quotes the range from (FETCH + WRITE) * 1024)",

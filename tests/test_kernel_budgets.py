@@ -44,8 +44,8 @@ def alloc(vgprs):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_eight_search_wavefronts_fit_a_simd():
     tile = resources("astar_tile.hip")
-    search = next(v for k, v in tile.items() if "tsa_search_kernelILi8E" in k)     # the pipelined instantiation: 8 wavefronts per workgroup
-    single = next(v for k, v in tile.items() if "tsa_search_kernelILi16E" in k)    # one batch at a time: 16
+    search = next(v for k, v in tile.items() if "tsa_search_kernelILi8ELb0E" in k)     # the pipelined instantiation: 8 wavefronts per workgroup
+    single = next(v for k, v in tile.items() if "tsa_search_kernelILi16ELb0E" in k)    # one batch at a time: 16
     assert alloc(single["VGPRs"]) * 8 <= VGPRS_PER_SIMD and single["ScratchSize"] <= 16, single
     assert alloc(search["VGPRs"]) * 8 <= VGPRS_PER_SIMD, search        # 8 wavefronts per SIMD = 4 workgroups of 8 per CU
     assert search["ScratchSize"] <= 16, search                          # nothing spilled inside the tile job (one kernel-level value may be)
