@@ -17,6 +17,8 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 using namespace rna;
@@ -85,7 +87,22 @@ static int alloc_stages_impl(rna_engine* e) {
     a.busy[d] = false;
     a.stage_seq[d] = 0;
   }
-  if (a.depth > 1) RNA_HIP(e, hipEventCreateWithFlags(&a.ev_init, hipEventDisableTiming));
+  if (a.depth > 1) {
+    RNA_HIP(e, hipEventCreateWithFlags(&a.ev_init, hipEventDisableTiming));
+    RNA_HIP(e, hipEventCreateWithFlags(&a.ev_prep, hipEventDisableTiming));
+    a.ring_n = 2 * a.depth;
+    a.ring_stride = tsa_ring_bytes(e, a.max_queries);
+    if ((rc = dev_alloc(e, &a.ring_mem, a.ring_stride * (size_t)a.ring_n)) != RNA_OK) return rc;
+    RNA_HIP(e, hipMemsetAsync(a.ring_mem, 0, a.ring_stride * (size_t)a.ring_n, e->stream));
+    for (int r = 0; r < a.ring_n; ++r) {
+      RNA_HIP(e, hipEventCreateWithFlags(&a.ring_free[r], hipEventDisableTiming));
+      a.ring_used[r] = false;
+    }
+    if (a.g_retry[0]) {
+      RNA_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&a.retry_flag), AstarDevice::MAX_DEPTH * sizeof(int), hipHostMallocCoherent));
+      for (int d = 0; d < AstarDevice::MAX_DEPTH; ++d) a.retry_flag[d] = 0;
+    }
+  }
   a.launches = 0;
   if ((rc = dev_alloc(e, &a.queries_dev, (size_t)a.max_queries)) != RNA_OK) { astar_release(e); return rc; }
   if ((rc = dev_alloc(e, &a.results_dev, (size_t)a.max_queries)) != RNA_OK) { astar_release(e); return rc; }
@@ -144,31 +161,71 @@ int ensure_config(rna_engine* e) {
   }
 }
 
-// One batch (<= max_queries): field init on the engine stream (it reads the neighbour masks, which
-// the next map update may overwrite), then the search on this pipeline stage's own stream.
+// The stage's search has finished (its `done` event is complete): if searches of that batch ran out of pages, their
+// second pass goes out now and the stage stays busy (returns true).
+static bool stage_settled(rna_engine* e, int d, int* rc) {
+  AstarDevice& a = e->astar;
+  *rc = RNA_OK;
+  if (!a.retry_armed[d]) return true;
+  a.retry_armed[d] = false;
+  if (!a.retry_flag || a.retry_flag[d] == 0) return true;
+  a.retry_flag[d] = 0;
+  hipStream_t st = a.depth > 1 ? a.side[d] : e->stream;
+  *rc = tsa_retry_launch(e, d, st);
+  if (*rc != RNA_OK) return true;
+  if (a.depth > 1 && hipEventRecord(a.done[d], st) != hipSuccess) { *rc = fail(e, RNA_EHIP, "hipEventRecord"); return true; }
+  return false;
+}
+
+// One batch (<= max_queries): mask snapshot + launch order on the side stream (it reads the neighbour masks, which the
+// next map update may overwrite), then the search on a pipeline stage's own stream.
 int launch_chunk(rna_engine* e, const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len,
                  rna_astar_result* res_dev, int* slot_out) {
   AstarDevice& a = e->astar;
-  // Which stage: the one that has been free the longest -- not simply the next in turn.  A batch lasts as long as its
-  // longest search; taking the stages strictly in turn, the engine stream waits for the one slow batch while the stages
-  // behind it have long finished (they sat idle 40 % of the time at thirteen stages).  If none is free, the oldest.
+  // Which stage: one that IS free, the one that has been free the longest -- not simply the next in turn.  A batch lasts
+  // as long as its longest search; taking the stages strictly in turn, a new batch waits for the one slow batch while
+  // the stages behind it have long finished (they sat idle 40 % of the time at thirteen stages).  If none is free the
+  // HOST waits for one (a few hundred microseconds at the bench's load): what the batch needs from the engine stream
+  // is enqueued before the wait, so the search starts the moment a stage frees up -- enqueued blindly behind "the
+  // oldest", as in round 2, a stage's stream sat idle 7 ms between two searches of 23 ms.
   int slot = 0;
   if (a.depth > 1) {
-    int best = -1, oldest = 0;
-    for (int d = 0; d < a.depth; ++d) {
-      if (a.stage_seq[d] < a.stage_seq[oldest]) oldest = d;
-      bool free_now = !a.busy[d];
-      if (!free_now) {
-        const hipError_t q = hipEventQuery(a.done[d]);
-        if (q == hipSuccess) { a.busy[d] = false; free_now = true; }
-        else (void)hipGetLastError();   // hipErrorNotReady is not an error
+    static const bool nowait = getenv("RNA_ASTAR_NOWAIT") != nullptr;   // developer knob: the round-2 behaviour
+    for (int spin = 0;; ++spin) {
+      int best = -1, oldest = 0;
+      for (int d = 0; d < a.depth; ++d) {
+        if (a.stage_seq[d] < a.stage_seq[oldest]) oldest = d;
+        bool free_now = !a.busy[d];
+        if (!free_now) {
+          const hipError_t q = hipEventQuery(a.done[d]);
+          if (q == hipSuccess) {
+            int rc = RNA_OK;
+            if (stage_settled(e, d, &rc)) { a.busy[d] = false; free_now = true; }
+            if (rc != RNA_OK) return rc;
+          } else {
+            (void)hipGetLastError();   // hipErrorNotReady is not an error
+          }
+        }
+        if (free_now && (best < 0 || a.stage_seq[d] < a.stage_seq[best])) best = d;
       }
-      if (free_now && (best < 0 || a.stage_seq[d] < a.stage_seq[best])) best = d;
+      if (best >= 0) { slot = best; break; }
+      if (nowait) { slot = oldest; break; }
+      if (spin > 64) std::this_thread::sleep_for(std::chrono::microseconds(20));
+      else std::this_thread::yield();
     }
-    slot = best >= 0 ? best : oldest;
+    // the ring entry this launch writes: the batch that read it 2 x depth launches ago is over and settled
+    const unsigned long long prev = a.launches + 1 >= (unsigned long long)a.ring_n ? a.launches + 1 - (unsigned long long)a.ring_n : 0;
+    if (prev > 0)
+      for (int d = 0; d < a.depth; ++d)
+        if (a.busy[d] && a.stage_seq[d] == prev) {
+          int rc = RNA_OK;
+          do { RNA_HIP(e, hipEventSynchronize(a.done[d])); } while (!stage_settled(e, d, &rc) && rc == RNA_OK);
+          if (rc != RNA_OK) return rc;
+          a.busy[d] = false;
+        }
   }
   hipStream_t search_stream = a.depth > 1 ? a.side[slot] : e->stream;
-  if (a.depth > 1 && a.busy[slot]) RNA_HIP(e, hipStreamWaitEvent(e->stream, a.done[slot], 0));  // wait until the stage is free again
+  if (a.depth > 1 && a.busy[slot]) RNA_HIP(e, hipStreamWaitEvent(search_stream, a.done[slot], 0));   // (RNA_ASTAR_NOWAIT only; the same stream anyway)
   {
     int rc = tsa_launch(e, slot, e->stream, search_stream, a.depth > 1 ? a.ev_init : nullptr, q_dev, n, paths_dev, max_len, res_dev);
     if (rc != RNA_OK) return rc;
@@ -193,6 +250,18 @@ namespace rna {
 #ifdef RNA_TSA_STATS
 void tsa_stats_dump();
 #endif
+// every stream is idle (sync_all): second passes that are due go out and are waited for
+int astar_settle(rna_engine* e) {
+  AstarDevice& a = e->astar;
+  for (int d = 0; d < a.depth && d < AstarDevice::MAX_DEPTH; ++d) {
+    if (!a.busy[d]) continue;
+    int rc = RNA_OK;
+    while (!stage_settled(e, d, &rc) && rc == RNA_OK) RNA_HIP(e, hipStreamSynchronize(a.side[d]));
+    if (rc != RNA_OK) return rc;
+    a.busy[d] = false;
+  }
+  return RNA_OK;
+}
 int astar_release(rna_engine* e) {
   AstarDevice& a = e->astar;
   (void)sync_all(e);
@@ -211,6 +280,15 @@ int astar_release(rna_engine* e) {
     a.busy[d] = false;
   }
   if (a.ev_init) { (void)hipEventDestroy(a.ev_init); a.ev_init = nullptr; }
+  if (a.ev_prep) { (void)hipEventDestroy(a.ev_prep); a.ev_prep = nullptr; }
+  for (int r = 0; r < AstarDevice::MAX_RING; ++r) {
+    if (a.ring_free[r]) { (void)hipEventDestroy(a.ring_free[r]); a.ring_free[r] = nullptr; }
+    a.ring_used[r] = false;
+  }
+  dev_free(&a.ring_mem);
+  a.ring_n = 0;
+  if (a.retry_flag) { (void)hipHostFree(a.retry_flag); a.retry_flag = nullptr; }
+  for (int d = 0; d < AstarDevice::MAX_DEPTH; ++d) a.retry_armed[d] = false;
   dev_free(&a.queries_dev); dev_free(&a.results_dev); dev_free(&a.paths_dev);
   a.paths_cap = 0;
   a.last_queries = nullptr; a.last_results = nullptr; a.last_n = 0;
@@ -305,7 +383,12 @@ extern "C" int rna_astar_batch(rna_engine* e, const rna_astar_query* queries_hos
     int slot = 0;
     rc = launch_chunk(e, a.queries_dev, m, a.paths_dev, max_path_len, a.results_dev, &slot);
     if (rc != RNA_OK) return rc;
-    if (a.depth > 1) RNA_HIP(e, hipStreamWaitEvent(e->stream, a.done[slot], 0));
+    if (a.depth > 1) {
+      int src = RNA_OK;
+      do { RNA_HIP(e, hipEventSynchronize(a.done[slot])); } while (!stage_settled(e, slot, &src) && src == RNA_OK);
+      if (src != RNA_OK) return src;
+      a.busy[slot] = false;
+    }
     RNA_HIP(e, hipMemcpyAsync(results_host + o, a.results_dev, (size_t)m * sizeof(rna_astar_result),
                               hipMemcpyDeviceToHost, e->stream));
     RNA_HIP(e, hipMemcpyAsync(paths_host + (size_t)o * max_path_len, a.paths_dev,

@@ -31,6 +31,7 @@
 // The round-1/2 worklist-in-LDS kernel this replaces, and the measurements behind the switch: DESIGN.md 5.
 #include "engine.hpp"
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 using namespace rna;
@@ -232,6 +233,8 @@ __global__ void tsa_fill_pages_kernel(uint4* __restrict__ p, size_t n4) {
   for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < n4; w += step) p[w] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+constexpr int TSA_NCLS = 256;   // key classes of the open list (four per lane in a pop), see TsaLocalSched
+
 #ifdef RNA_TSA_STATS
 // developer build: phase timers (100 MHz wall clock ticks summed over all jobs), printed by the host
 __device__ unsigned long long g_tsa_stat[32];
@@ -330,7 +333,7 @@ struct TsaCtx {
 #define TSA_MKW(b) TSA_CAT(TSA_MK_, b)   // the mask word that holds row b's byte, at bit 8 * (b & 3)
 template <class Sched>
 __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane_in, const int t, const TsaCtx& C,
-                                       const bool first, const long long bucket_end, const int key_base, const int key_shift, int* freed_slot TSA_ACC_PARAM) {
+                                       const bool first, const long long bucket_end, const int key_base, const int key_shift, int* spare TSA_ACC_PARAM) {
   // an opaque copy of the lane id per job (and one more for the results phase): everything derived from it is then
   // recomputed here instead of being hoisted out of the job loop, kept alive across the sweeps and spilled to scratch
   int lane = lane_in;
@@ -395,6 +398,8 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
                     tsa_h24(max(dx_, dy_), min(dx_, dy_)); })
   // bit b: this lane's cell in row b is free (and inside the map) -- from the snapshot, loaded with the masks
   const unsigned fbits = fbits_ld;
+  TSA_T(t_h0);
+  TSA_ACC(9, t_a, t_h0);   // issuing the loads + waiting for them
   asm volatile("; TSA_MARK halo_begin");
   // ---- 4. what the halo can contribute (once: it does not change during the job) ----
   // rows to evaluate in the next down / up sweep: a row is evaluated from above when the row above it changed (or it
@@ -448,7 +453,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     // rows' pass-on values are formed.
     const unsigned long long upT = __builtin_amdgcn_ballot_w64(cT > g0), upB = __builtin_amdgcn_ballot_w64(cB > g15);
     const unsigned long long imask = __builtin_amdgcn_ballot_w64(cX > gcol);
-    if (!(upT | upB | imask) && !planted && !first) { TSA_CNT(10, 1); return 0; }   // the wake-up brought nothing better
+    if (!(upT | upB | imask) && !planted && !first) { TSA_CNT(10, 1); TSA_T(t_n); TSA_ACC(15, t_a, t_n); return 0; }   // the wake-up brought nothing better
     asm volatile("; TSA_MARK noop_decided");
     scr[84 + lane] = (unsigned)top;        // kept for the end of the job: does a changed edge row beat what the
     scr[84 + 64 + lane] = (unsigned)bot;   // neighbour already has?
@@ -608,15 +613,21 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     TSA_R16(TSA_STORE)
 #undef TSA_STORE
     // the copies of columns 0 and 63 for the neighbours: lanes 0 and 63 only, one change of the exec mask for all rows
+    // (an opaque copy of the row set for every loop over it: the compiler otherwise keeps the sixteen conditions of the
+    // first loop as sixteen lane masks -- 32 scalar registers, spilled to a VGPR's lanes and read back one by one)
+    unsigned rowchg_e = rowchg;
+    asm volatile("" : "+s"(rowchg_e));
     if (edge_lane) {
-#define TSA_STORE_EDGE(b) if ((rowchg >> (b)) & 1u) ax[b] = (unsigned)TSA_G(b);
+#define TSA_STORE_EDGE(b) if ((rowchg_e >> (b)) & 1u) ax[b] = (unsigned)TSA_G(b);
       TSA_R16(TSA_STORE_EDGE)
 #undef TSA_STORE_EDGE
     }
     if (ovfm && lane == 0) sch.overflow();   // path costs beyond 2^30 - 5656: the search is abandoned (status 4)
     if (t == C.tg) {
+      unsigned rowchg_g = rowchg;
+      asm volatile("" : "+s"(rowchg_g));
 #define TSA_GOAL(b)                                                                               \
-  if ((b) == C.gb && ((rowchg >> (b)) & 1u)) {                                                    \
+  if ((b) == C.gb && ((rowchg_g >> (b)) & 1u)) {                                                    \
     const int u = __builtin_amdgcn_readlane(TSA_G(b), C.ga); /* C.ga is wave-uniform */           \
     if (u != 0 && lane == 0) sch.improve_best(KU - u);                                            \
   }
@@ -624,6 +635,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
 #undef TSA_GOAL
     }
   }
+  TSA_T(t_w0);
   asm volatile("; TSA_MARK wake_begin");
   // ---- 7. who has to run: neighbours whose halo got better (or may pass on now), this tile again in a later bucket ----
   {
@@ -632,7 +644,8 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     //     tile is flagged -- it runs several times per bucket.
     //     When the bound of this job is best + 1 (the goal has been reached and lies inside the bucket) every cell
     //     with f <= best passes on: nothing is held back that matters.
-    const unsigned look = first ? 0xffffu : rowchg;
+    unsigned look = first ? 0xffffu : rowchg;
+    asm volatile("" : "+s"(look));
     if (look && (long long)best_in + 1 > bucket_end && !sch.is_far(t)) {
       const int thr_best = KU - best_in;   // f <= best  <=>  u - h >= thr_best
       unsigned long long farm = 0ull;
@@ -728,8 +741,12 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       // lane k < 8 speaks for direction k: its tile, its key ((f - f at the bucket's start), quantised)
       const int kf = lane == 1 ? kfN : (lane == 6 ? kfS : ((lane == 0 || lane == 3 || lane == 5) ? kfW : kfE));
       int key = (key_base - kf) >> key_shift;
-      key = key < 0 ? 0 : (key > 0xfffe ? 0xfffe : key);
-      sch.wake8(lane < 8 && ((wm >> lane) & 1u), nb_t, (unsigned)key, lane, freed_slot);
+      key = key < 0 ? 0 : (key > TSA_NCLS - 1 ? TSA_NCLS - 1 : key);
+      TSA_T(t_w1);
+      sch.wake8(lane < 8 && ((wm >> lane) & 1u), nb_t, (unsigned)key, lane, spare);
+      TSA_T(t_w2);
+      TSA_ACC(3, t_w1, t_w2);   // queueing the wake-ups
+      TSA_CNT(13, 1);
     }
   }
 #undef TSA_ROW_CHANGED
@@ -737,32 +754,42 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   asm volatile("; TSA_MARK job_end");
   TSA_T(t_d);
   TSA_ACC(2, t_c, t_d);
+  TSA_ACC(6, t_w0, t_d);   // wake tests + queueing
   return __builtin_popcount(rowchg);   // rows written
 }
 
 // ---- scheduler of the one-workgroup-per-query kernel: an open list of tiles in LDS ----
 // Per query (= workgroup), in LDS:
 //   st2    two bits per tile: D "a wake-up is pending" (bit 0), R "a wavefront is running the tile" (bit 1)
-//   ent    TSA_NE queue entries (key << 16 | tile), ENT_EMPTY = free.  A wake-up of a tile that is neither pending nor
-//          running appends an entry; a wake-up of a pending tile lowers the key of its entry (found by a wave-wide scan);
-//          a wake-up of a running tile only sets D -- the wavefront that runs it queues it again (key 0) when it ends.
+//   head   TSA_NCLS stacks of queue nodes, one per key class (key = the lowest f the waker offers the tile, counted
+//          from the bucket's start and quantised): tag << 16 | index of the top node (0xffff: empty)
+//   node   TSA_NP queue nodes: next << 16 | tile
+//   bm     one bit per node: free
+//   qc     tile -> key class of the newest entry pushed for it (direct-mapped, TSA_QC lines; a hint)
 //   open   tiles that have to run as "first" in this f-bucket (they hold cells the last bucket's bound held back);
 //          free wavefronts drain this set before they take entries
 //   far    the same for the next bucket
-// A free wavefront takes the entry with the LOWEST key (a wave-wide minimum over the entries in use), claims its tile
-// (R, then D: an entry whose tile has nothing pending any more is stale and dropped) and runs the job.  No round
-// barriers: a bucket is at its fixed point when every wavefront of the workgroup is idle (an idle counter; a wavefront
-// only leaves the idle state when the entry counter says there is something to take, and only an idle-counted
-// wavefront looks at the counter, so "all idle" is stable and every wavefront sees it).
+// A wake-up of a tile that is not running pushes a node on the stack of its key class -- also when the tile is pending
+// already (its older entry goes stale: an entry whose tile has nothing pending when it is taken is dropped); a wake-up
+// of a running tile only sets D -- the wavefront that runs it queues it again (class 0) when it ends.  A free wavefront
+// takes the top node of the lowest class that has one, claims its tile (R, then D) and runs the job.  Every queue
+// operation is a handful of LDS round trips whatever the queue holds (round 2's array of (key, tile) entries was scanned
+// for its minimum by every pop and for the tile's entry by every wake-up of a pending tile: 2.8 us of wavefront time per
+// job, a sixth of the kernel; scripts/sim_async.c: last-in-first-out inside a class costs no more jobs than the exact
+// minimum did).  No round barriers: a bucket is at its fixed point when every wavefront of the workgroup is idle (an
+// idle counter; a wavefront only leaves the idle state when the entry counter says there is something to take, and
+// only an idle-counted wavefront looks at the counter, so "all idle" is stable and every wavefront sees it).
 // Exactness does not depend on the order: every improvement of a tile's edge that can matter to a neighbour sets the
 // neighbour's D bit after the improved words are in L2, and a bucket only ends when nothing is pending.
-#ifndef RNA_TSA_ENTRIES
-#define RNA_TSA_ENTRIES 2048
+#ifndef RNA_TSA_NODES
+#define RNA_TSA_NODES 3072
 #endif
-constexpr int TSA_NE = RNA_TSA_ENTRIES;   // (scripts/sim_async.c: at most 1065 entries at once over the bench's queries)
-constexpr unsigned ENT_EMPTY = 0xffffffffu;
-static_assert((TSA_NE & (TSA_NE - 1)) == 0 && TSA_NE % 256 == 0, "queue size: a power of two, scanned 256 entries at a time");
-static_assert(TSA_NE * 4 >= (TI + 2) * (TJ + 2) * 4 + TILE_WORDS, "the backtrace's LDS image lives in the queue memory");
+constexpr int TSA_NP = RNA_TSA_NODES;   // (scripts/sim_async.c: ~3 400 entries at once in the worst of the bench's queries, stale ones included; more: see `spill`)
+constexpr int TSA_BMW = TSA_NP / 32;
+constexpr int TSA_QC = 1024;            // lines of the tile -> queued class table
+constexpr unsigned POP_EMPTY = 0xffffffffu;
+static_assert(TSA_NP % 32 == 0 && TSA_NP < 0xffff, "node indices are 16 bits, 0xffff = none");
+static_assert(TSA_NP * 4 >= (TI + 2) * (TJ + 2) * 4 + TILE_WORDS, "the backtrace's LDS image lives in the queue memory");
 
 __device__ __forceinline__ unsigned lds_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int lds_ldi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -772,126 +799,122 @@ struct TsaLocalSched {
   int* state_;
   unsigned* st2_;
   unsigned* far_;
-  unsigned* ent_;
+  unsigned* node_;
+  unsigned* head_;
+  unsigned* bm_;
+  unsigned* qc_;
   int* count_;   // entries in the queue + tiles of the open set nobody has taken yet (a hint for idle wavefronts)
-  int* tail_;    // next slot to try
-  int* hi_;      // entries [0, hi) may be in use (a multiple of 256)
-  int* spill_;   // the queue was full: wake-ups were parked in `far` and this bucket runs again
+  int* spill_;   // no free node: wake-ups were parked in `far` and this bucket runs again
   __device__ __forceinline__ int best() const { return __hip_atomic_load(best_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   __device__ __forceinline__ void improve_best(int g) { atomicMin(best_, g); }
   __device__ __forceinline__ void overflow() { *state_ = 4; }
   __device__ __forceinline__ void pool_exhausted() { *state_ = 5; }
   __device__ __forceinline__ void act_far(int t) { atomicOr(&far_[t >> 5], 1u << (t & 31)); }
   __device__ __forceinline__ bool is_far(int t) const { return (lds_ld(&far_[t >> 5]) >> (t & 31)) & 1u; }
-  // append an entry (called by every lane of the wavefront; lane 0 acts)
-  __device__ __forceinline__ void push(unsigned e, int lane) {
-    if (lane == 0) {
-      bool ok = false;
-      for (int tries = 0; tries < 64 && !ok; ++tries) {
-        const int slot = atomicAdd(tail_, 1) & (TSA_NE - 1);
-        if (atomicCAS(&ent_[slot], ENT_EMPTY, e) == ENT_EMPTY) {
-          ok = true;
-          atomicMax(hi_, (slot | 255) + 1);
-        }
+  // a free node (-1: none found).  Every lane that needs one probes on its own, from a start of its own.
+  __device__ __forceinline__ int node_alloc(unsigned seed) {
+    unsigned w = ((seed & 0xffffu) * (unsigned)TSA_BMW) >> 16;
+    for (int tries = 0; tries < 32; ++tries) {
+      const unsigned v = lds_ld(&bm_[w]);
+      if (v) {
+        const unsigned b = v & (0u - v);
+        if (atomicAnd(&bm_[w], ~b) & b) return (int)(w * 32u) + __builtin_ctz(b);
+      } else {
+        w = w + 1u == (unsigned)TSA_BMW ? 0u : w + 1u;
       }
-      if (ok) {
+    }
+    return -1;
+  }
+  __device__ __forceinline__ void node_free(int idx) { atomicOr(&bm_[idx >> 5], 1u << (idx & 31)); }
+  // node idx (owned by the caller) on top of class cls
+  __device__ __forceinline__ void link(int idx, unsigned t, unsigned cls) {
+    for (;;) {
+      const unsigned hv = lds_ld(&head_[cls]);
+      __hip_atomic_store(&node_[idx], (hv << 16) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" ::: "memory");   // (a wavefront's LDS operations are performed in the order they were issued)
+      if (atomicCAS(&head_[cls], hv, ((hv + 0x10000u) & 0xffff0000u) | (unsigned)idx) == hv) break;
+    }
+  }
+  // tile t gets an entry of class cls (called by every lane of the wavefront with uniform arguments; lane 0 acts)
+  __device__ __forceinline__ void push(unsigned t, unsigned cls, int lane, int* spare) {
+    if (lane == 0) {
+      const int idx = *spare >= 0 ? *spare : node_alloc(t * 29u);
+      if (idx >= 0) {
+        link(idx, t, cls);
         atomicAdd(count_, 1);
-      } else {   // queue full: the tile (its D bit stays set) runs as a first job when this bucket is opened again
-        const int t = (int)(e & 0xffffu);
+        __hip_atomic_store(&qc_[t & (unsigned)(TSA_QC - 1)], (t << 8) | cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {   // no node: the tile (its D bit stays set) runs as a first job when this bucket is opened again
         atomicOr(&far_[t >> 5], 1u << (t & 31));
         *spill_ = 1;
       }
     }
+    *spare = -1;
   }
-  // tile t is pending: find its entry and lower the key to e's (all lanes call, arguments wave-uniform).  A failed
-  // attempt -- the entry is being appended or was just taken -- only costs order, never a wake-up: D is set.
-  __device__ __forceinline__ void lower_key(int t, unsigned e, int lane) {
-    const int hi = lds_ldi(hi_);
-    for (int base = 0; base < hi; base += 256) {
-      const uint4 v = *reinterpret_cast<const uint4*>(&ent_[base + lane * 4]);
-      const unsigned tt = (unsigned)t;
-      const bool m0 = (v.x & 0xffffu) == tt && v.x != ENT_EMPTY, m1 = (v.y & 0xffffu) == tt && v.y != ENT_EMPTY;
-      const bool m2 = (v.z & 0xffffu) == tt && v.z != ENT_EMPTY, m3 = (v.w & 0xffffu) == tt && v.w != ENT_EMPTY;
-      const unsigned long long found = __builtin_amdgcn_ballot_w64(m0 | m1 | m2 | m3);
-      if (found) {
-        if (lane == __builtin_ctzll(found)) {
-          const int c = m0 ? 0 : (m1 ? 1 : (m2 ? 2 : 3));
-          const unsigned cur = m0 ? v.x : (m1 ? v.y : (m2 ? v.z : v.w));
-          if (e < cur) atomicCAS(&ent_[base + lane * 4 + c], cur, e);
-        }
-        break;
-      }
-    }
-  }
-  // the wake-ups of one job together: lane k < 8 with `w` set wakes tile t with key `key` (all lanes call).  Three LDS
-  // round trips whatever their number: the D bits, one reservation of queue slots, the entries.
-  __device__ __forceinline__ void wake8(bool w, int t, unsigned key, int lane, int* freed) {
+  // the wake-ups of one job together: lane k < 8 with `w` set wakes tile t with key class `cls` (all lanes call)
+  __device__ __forceinline__ void wake8(bool w, int t, unsigned cls, int lane, int* spare) {
     const unsigned sh = 2u * ((unsigned)t & 15u);
     unsigned old = 2u;
     if (w) old = atomicOr(&st2_[t >> 4], 1u << sh) >> sh;
-    const bool fresh = w && !(old & 3u);          // neither pending nor running: gets an entry
-    const bool lower = w && (old & 3u) == 1u;     // pending already: its entry's key may have to come down
-    const unsigned e = (key << 16) | (unsigned)t;
-    const unsigned long long fm = __builtin_amdgcn_ballot_w64(fresh);
-    if (fm) {
-      // the slot this wavefront emptied when it took its job goes to the first entry, the others get fresh ones
-      const int reuse = *freed;
-      *freed = -1;
-      const int first_lane = __builtin_ctzll(fm);
-      const unsigned long long need = reuse >= 0 ? fm & (fm - 1ull) : fm;
-      int base = 0;
-      if (need) {
-        if (lane == __builtin_ctzll(need)) base = atomicAdd(tail_, __builtin_popcountll(need));
-        base = __builtin_amdgcn_readlane(base, __builtin_ctzll(need));
-      }
-      bool ok = false;
-      int slot = 0;
-      if (fresh) {
-        slot = (reuse >= 0 && lane == first_lane) ? reuse : ((base + __builtin_popcountll(need & ((1ull << lane) - 1ull))) & (TSA_NE - 1));
-        ok = atomicCAS(&ent_[slot], ENT_EMPTY, e) == ENT_EMPTY;
-        if (ok) atomicMax(hi_, (slot | 255) + 1);
-      }
-      const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
-      if (okm && lane == __builtin_ctzll(okm)) atomicAdd(count_, __builtin_popcountll(okm));
-      unsigned long long bad = fm & ~okm;   // the slot was taken (the ring has wrapped around): one by one
-      while (bad) {
-        const int l = __builtin_ctzll(bad);
-        bad &= bad - 1ull;
-        push((unsigned)__builtin_amdgcn_readlane((int)e, l), lane);
+    bool q = w && !(old & 2u);   // not running: an entry
+    // ... unless the tile is pending with an entry of this class or a lower one already (`qc`, a direct-mapped table
+    // tile -> class of its newest entry; a hint: another tile's line or a stale one only costs a duplicate or order)
+    const unsigned qi = (unsigned)t & (unsigned)(TSA_QC - 1);
+    if (q && (old & 1u)) {
+      const unsigned c = lds_ld(&qc_[qi]);
+      if ((c >> 8) == (unsigned)t && (c & 0xffu) <= cls) q = false;
+    }
+    if (q) __hip_atomic_store(&qc_[qi], ((unsigned)t << 8) | cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned long long qm = __builtin_amdgcn_ballot_w64(q);
+    if (!qm) return;
+    // the node this wavefront took off the queue with its job goes to the first entry
+    const int reuse = *spare;
+    *spare = -1;
+    int idx = -1;
+    if (q) {
+      idx = (reuse >= 0 && lane == __builtin_ctzll(qm)) ? reuse : node_alloc((unsigned)t * 29u + (unsigned)lane * 8191u);
+      if (idx >= 0) {
+        link(idx, (unsigned)t, cls);
+      } else {
+        atomicOr(&far_[t >> 5], 1u << (t & 31));
+        *spill_ = 1;
       }
     }
-    unsigned long long lm = __builtin_amdgcn_ballot_w64(lower);
-    while (lm) {
-      const int l = __builtin_ctzll(lm);
-      lm &= lm - 1ull;
-      lower_key(__builtin_amdgcn_readlane(t, l), (unsigned)__builtin_amdgcn_readlane((int)e, l), lane);
-    }
+    const unsigned long long okm = __builtin_amdgcn_ballot_w64(idx >= 0);
+    if (okm && lane == __builtin_ctzll(okm)) atomicAdd(count_, __builtin_popcountll(okm));
   }
-  // take the entry with the lowest key; ENT_EMPTY if the queue is empty.  *freed = the slot it sat in (a wavefront's
-  // next wake-up goes there: the entries in use stay packed at the low end, and the scans over them short)
-  __device__ __forceinline__ unsigned pop(int lane, int* freed) {
+  // take the top entry of the lowest class that has one: its tile, POP_EMPTY if the queue is empty.  The node becomes
+  // the wavefront's spare one (*spare; the one it held goes back to the pool).
+  __device__ __forceinline__ unsigned pop(int lane, int* spare) {
     for (;;) {
-      const int hi = lds_ldi(hi_);
-      unsigned m = ENT_EMPTY;
-      int mb = 0;
-      for (int base = 0; base < hi; base += 256) {
-        const uint4 v = *reinterpret_cast<const uint4*>(&ent_[base + lane * 4]);
-        const unsigned m4 = min(min(v.x, v.y), min(v.z, v.w));
-        mb = m4 < m ? base : mb;
-        m = min(m, m4);
+      asm volatile("" ::: "memory");
+      uint4 h;   // classes 4 lane .. 4 lane + 3
+      {
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        const v4u hv4 = *reinterpret_cast<const volatile v4u*>(&head_[4 * lane]);
+        h = make_uint4(hv4.x, hv4.y, hv4.z, hv4.w);
       }
-      const unsigned mm = wave_min_u32(m);
-      if (mm == ENT_EMPTY) return ENT_EMPTY;
-      const unsigned long long who = __builtin_amdgcn_ballot_w64(m == mm);
-      int got = -1;
-      if (lane == __builtin_ctzll(who)) {
-        const uint4 v = *reinterpret_cast<const uint4*>(&ent_[mb + lane * 4]);
-        const int c = v.x == mm ? 0 : (v.y == mm ? 1 : (v.z == mm ? 2 : (v.w == mm ? 3 : -1)));
-        if (c >= 0 && atomicCAS(&ent_[mb + lane * 4 + c], mm, ENT_EMPTY) == mm) { got = mb + lane * 4 + c; atomicSub(count_, 1); }
+      const bool e0 = (h.x & 0xffffu) != 0xffffu, e1 = (h.y & 0xffffu) != 0xffffu, e2 = (h.z & 0xffffu) != 0xffffu, e3 = (h.w & 0xffffu) != 0xffffu;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(e0 | e1 | e2 | e3);
+      if (!m) return POP_EMPTY;
+      const int f = __builtin_ctzll(m);
+      unsigned got = POP_EMPTY;
+      if (lane == f) {
+        const int c = e0 ? 0 : (e1 ? 1 : (e2 ? 2 : 3));
+        const unsigned hv = e0 ? h.x : (e1 ? h.y : (e2 ? h.z : h.w));
+        const unsigned idx = hv & 0xffffu;
+        const unsigned nd = lds_ld(&node_[idx]);
+        if (atomicCAS(&head_[4 * lane + c], hv, ((hv + 0x10000u) & 0xffff0000u) | (nd >> 16)) == hv) {
+          got = (idx << 16) | (nd & 0xffffu);
+          atomicSub(count_, 1);
+        }
       }
-      got = __builtin_amdgcn_readlane(got, __builtin_ctzll(who));
-      if (got >= 0) { *freed = got; return mm; }
-      // another wavefront took it (or lowered its key) in between: look again
+      got = (unsigned)__builtin_amdgcn_readlane((int)got, f);
+      if (got != POP_EMPTY) {
+        if (*spare >= 0 && lane == 0) node_free(*spare);
+        *spare = (int)(got >> 16);
+        return got & 0xffffu;
+      }
+      // another wavefront changed that stack in between: look again
     }
   }
 };
@@ -908,6 +931,7 @@ struct TsaLaunch {
   // search can never outgrow (a goal that cannot be reached floods its whole component; the reference answers "no
   // path", it does not fail).
   int retry, n;
+  int* retry_count;   // (host memory, may be null) searches of this launch that ended with status 5
   TsaStage S2;
   int32_t* paths;
   int max_path_len;
@@ -1025,9 +1049,12 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   constexpr int TSA_THREADS = WAVES * 64;
   __shared__ unsigned s_scr[WAVES][SCR_WORDS];
   extern __shared__ unsigned s_dyn[];   // sized by the launch: st2 (2 x nt_words) | open (nt_words) | far (nt_words)
-  __shared__ __attribute__((aligned(16))) unsigned s_ent[TSA_NE];
+  __shared__ __attribute__((aligned(16))) unsigned s_node[TSA_NP];
+  __shared__ __attribute__((aligned(16))) unsigned s_head[TSA_NCLS];
+  __shared__ unsigned s_bm[TSA_BMW];
+  __shared__ unsigned s_qc[TSA_QC];
   __shared__ int s_best, s_state, s_bucket, s_bucket0, s_jobs_done, s_expanded, s_nalloc, s_any;
-  __shared__ int s_count, s_tail, s_hi, s_spill, s_idle, s_open_left, s_open_pos;
+  __shared__ int s_count, s_spill, s_idle, s_open_left, s_open_pos;
 
   // Workgroups take their query when they START (a ticket), not by blockIdx: the hardware deals workgroup
   // indices round-robin to the XCDs, so a fixed mapping lets one XCD with several long searches hold back
@@ -1093,7 +1120,9 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   C.tg = tile_of(gi, gj, tiles_i); C.ga = gi & (TI - 1); C.gb = gj & (TJ - 1);
 
   for (int w = tid; w < 4 * nt_words; w += TSA_THREADS) s_dyn[w] = 0u;
-  for (int w = tid; w < TSA_NE; w += TSA_THREADS) s_ent[w] = ENT_EMPTY;
+  for (int w = tid; w < TSA_NCLS; w += TSA_THREADS) s_head[w] = 0xffffu;
+  for (int w = tid; w < TSA_BMW; w += TSA_THREADS) s_bm[w] = 0xffffffffu;
+  for (int w = tid; w < TSA_QC; w += TSA_THREADS) s_qc[w] = 0xffffffffu;
   if (lane >= 48) s_scr[wv][68 + lane - 48] = 0u;   // the zero tail of the wave's scratch
   // a start or a goal without a single traversable neighbour: blocked or walled in; nothing has been written yet, so
   // no page is in use
@@ -1120,14 +1149,14 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
-  // keys: (f - f at the bucket's start) >> key_shift must fit 16 bits with room for cells beyond the bucket's end
+  // key classes: (f - f at the bucket's start) >> key_shift, the last class takes everything beyond
   int key_shift = 0;
-  while (((2ll * A.bucket_width) >> key_shift) > 0xfffe) ++key_shift;
+  while (((long long)A.bucket_width >> key_shift) > TSA_NCLS - 1) ++key_shift;
   if (tid == 0) {
     s_best = INF; s_state = 0; s_jobs_done = 0; s_expanded = 0; s_nalloc = 0;
     s_bucket = tsa_octile(si, sj, gi, gj) / A.bucket_width;
     s_bucket0 = s_bucket;
-    s_tail = 0; s_hi = 0; s_spill = 0; s_idle = 0; s_open_pos = 0;
+    s_spill = 0; s_idle = 0; s_open_pos = 0;
     s_count = 1; s_open_left = 1;
   }
   __syncthreads();
@@ -1140,7 +1169,8 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   const unsigned long long t_life0 = wall_clock64();
   const unsigned long long c_life0 = __builtin_amdgcn_s_memtime();
 #endif
-  TsaLocalSched sch{&s_best, &s_state, s_st2, s_far, s_ent, &s_count, &s_tail, &s_hi, &s_spill};
+  TsaLocalSched sch{&s_best, &s_state, s_st2, s_far, s_node, s_head, s_bm, s_qc, &s_count, &s_spill};
+  int spare = -1;   // a queue node this wavefront owns (the one its last job's entry sat in): its next wake-up uses it
 
   for (;;) {   // one pass per f-bucket (or per re-run of a bucket whose queue overflowed)
     const int bucket = lds_ldi(&s_bucket);
@@ -1160,7 +1190,6 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
       }
       int t = -1;
       bool first = false;
-      int freed_slot = -1;   // the queue slot this wavefront emptied when it took the job (wake8 fills it again)
       // ---- 1. a tile of the open set (runs as "first") ----
       if (!open_blocked && lds_ldi(&s_open_left) > 0) {
         const int pos = lds_ldi(&s_open_pos);
@@ -1199,8 +1228,8 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
       } else {
         // ---- 2. the queued tile with the lowest key ----
         open_blocked = false;
-        const unsigned e = sch.pop(lane, &freed_slot);
-        if (e == ENT_EMPTY) {
+        const unsigned e = sch.pop(lane, &spare);
+        if (e == POP_EMPTY) {
           if (lds_ldi(&s_open_left) > 0) { __builtin_amdgcn_s_sleep(2); continue; }   // (the open tile that was running)
           if (lane == 0) atomicAdd(&s_idle, 1);
           idle = true;
@@ -1209,7 +1238,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
         const int tt = (int)(e & 0xffffu);
         const unsigned sh = 2u * ((unsigned)tt & 15u);
         int r = 0;   // 0: not ours (running or stale), 1: ours, 2: ours and first
-        if (lane == 0) {
+        if (lane == 0 && ((lds_ld(&s_st2[tt >> 4]) >> sh) & 3u) == 1u) {   // (a look first: most entries that are not ours are stale or their tile is running)
           const unsigned old = atomicOr(&s_st2[tt >> 4], 2u << sh) >> sh;
           if (!(old & 2u)) {
             const unsigned old2 = atomicAnd(&s_st2[tt >> 4], ~(1u << sh)) >> sh;
@@ -1227,7 +1256,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
           }
         }
         r = __builtin_amdgcn_readfirstlane(r);
-        if (r == -1) { sch.push((unsigned)tt, lane); continue; }
+        if (r == -1) { sch.push((unsigned)tt, 0u, lane, &spare); continue; }
         if (r <= 0) continue;
         t = tt;
         first = r == 2;
@@ -1236,14 +1265,14 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
       TSA_ACC(4, t_p0, t_p1);   // taking a job
       TSA_CNT(7, 1);
       my_jobs += 1;
-      my_evals += tsa_job(sch, s_scr[wv], lane, t, C, first, bucket_end, key_base, key_shift, &freed_slot TSA_ACC_ARG);
+      my_evals += tsa_job(sch, s_scr[wv], lane, t, C, first, bucket_end, key_base, key_shift, &spare TSA_ACC_ARG);
       // the job's stores are performed before the tile can be taken again (it may have been woken while it ran)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       {
         const unsigned sh = 2u * ((unsigned)t & 15u);
         int again = 0;
         if (lane == 0) again = (int)((atomicAnd(&s_st2[t >> 4], ~(2u << sh)) >> sh) & 1u);
-        if (__builtin_amdgcn_readfirstlane(again)) sch.push((unsigned)t, lane);   // key 0: as soon as possible
+        if (__builtin_amdgcn_readfirstlane(again)) sch.push((unsigned)t, 0u, lane, &spare);   // class 0: as soon as possible
       }
     }
     // ---- the bucket is at its fixed point (or the search is being abandoned) ----
@@ -1256,7 +1285,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     if (tid_r == 0) {
       // every cell with f < (bucket + 1) * B has its exact g (unless wake-ups were parked: then this bucket runs again)
       if (!spilled && s_best != INF && (long long)s_best < bucket_end) s_state = 1;
-      s_any = 0; s_spill = 0; s_idle = 0; s_tail = 0; s_hi = 0; s_open_pos = 0;
+      s_any = 0; s_spill = 0; s_idle = 0; s_open_pos = 0;
     }
     __syncthreads();
     if (s_state == 1) break;
@@ -1291,14 +1320,17 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   const rna_astar_result r{state == 1 ? TSA_FOUND : (state >= 4 ? state : 1), 0, state == 1 ? s_best : INF, s_expanded,
                            (s_jobs_done + WAVES - 1) / WAVES, s_bucket - s_bucket0 + 1};
   if (state != 1) {
-    if (tid == 0) results[q] = r;
+    if (tid == 0) {
+      results[q] = r;
+      if (!RETRY && state == 5 && A.retry_count) __hip_atomic_fetch_add(A.retry_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     return;
   }
   // found: the first wavefront traces the path over the exact field (the queue memory holds the LDS image of the walk)
   __syncthreads();
   if (wv != 0) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  tsa_backtrace_wave(A, S, sl, q, r, lane, s_ent, reinterpret_cast<unsigned char*>(s_ent + BW * (TJ + 2)));
+  tsa_backtrace_wave(A, S, sl, q, r, lane, s_node, reinterpret_cast<unsigned char*>(s_node + BW * (TJ + 2)));
 }
 
 // |{n : g(n) + h(n) <= f*}| per query from the pages still resident in HBM (measurement utility)
@@ -1403,41 +1435,77 @@ int tsa_stage_prepare(rna_engine* e, int slot) {
   return RNA_OK;
 }
 
+// one entry of the launch ring (AstarDevice::ring_mem): ticket | launch order | mask snapshot
+size_t tsa_ring_bytes(const rna_engine* e, int max_queries) {
+  return 256 + tsa_align256((size_t)max_queries * sizeof(int)) + tsa_align256((size_t)tsa_ntile(e) * MASK_STRIDE);
+}
+static_assert(sizeof(TsaLaunch) <= sizeof(AstarDevice::last_launch[0]), "AstarDevice::last_launch holds a TsaLaunch");
+
+// the second pass over the stage's last batch (the searches that outgrew their share of pages, on the stage's full-size
+// retry slots; workgroups without such a query end at once)
+int tsa_retry_launch(rna_engine* e, int slot, hipStream_t search_stream) {
+  AstarDevice& a = e->astar;
+  TsaLaunch A;
+  memcpy(&A, a.last_launch[slot], sizeof(A));
+  A.retry = 1;
+  A.retry_count = nullptr;
+  A.S2 = tsa_retry_view(e, slot, A.S);
+  if (a.depth > 1) hipLaunchKernelGGL((tsa_search_kernel<TSA_WAVES, true>), dim3(TSA_RETRY), dim3(TSA_WAVES * 64), a.last_lds[slot], search_stream, A);
+  else hipLaunchKernelGGL((tsa_search_kernel<16, true>), dim3(TSA_RETRY), dim3(16 * 64), a.last_lds[slot], search_stream, A);
+  RNA_HIP(e, hipGetLastError());
+  return RNA_OK;
+}
+
 int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init,
                const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len, rna_astar_result* res_dev) {
   AstarDevice& a = e->astar;
   const int rows = e->geom.size[0], cols = e->geom.size[1];
   const int ti = (rows + TI - 1) / TI, tj = (cols + TJ - 1) / TJ;
-  const TsaStage S = tsa_stage_view(e, slot);
-  // Snapshot of the neighbour masks as they are NOW (a later map update must not disturb a search in flight).  Pipelined:
-  // on the stage's own stream, behind an event of the engine stream (whatever changes the masks next waits for the
-  // snapshot, side_join) -- the engine stream's chain of map-update kernels is what gates the next batch, the stage has
-  // time.  Single stream: in place.
+  TsaStage S = tsa_stage_view(e, slot);
+  // Snapshot of the neighbour masks as they are NOW (a later map update must not disturb a search in flight) and the
+  // launch order of the batch.  Pipelined: into an entry of the launch ring, on the side stream behind an event of the
+  // engine stream (whatever changes the masks next waits for the snapshot, side_join) -- on the stage's own stream
+  // these two short kernels waited up to a millisecond for CU slots among the searches' workgroups, and the engine
+  // stream's next map update with them.  Single stream: in place.
+  hipStream_t prep_stream = search_stream;
+  int ring = -1;
   if (ev_init) {
+    ring = (int)(a.launches % (unsigned long long)a.ring_n);
+    char* base = a.ring_mem + (size_t)ring * a.ring_stride;
+    S.ticket = reinterpret_cast<int*>(base);
+    S.perm = reinterpret_cast<int*>(base + 256);
+    S.nbr_tm = reinterpret_cast<uint8_t*>(base + 256 + tsa_align256((size_t)a.max_queries * sizeof(int)));
+    { const int rc = side_stream(e, &prep_stream); if (rc != RNA_OK) return rc; }
     RNA_HIP(e, hipEventRecord(ev_init, init_stream));
-    RNA_HIP(e, hipStreamWaitEvent(search_stream, ev_init, 0));
+    RNA_HIP(e, hipStreamWaitEvent(prep_stream, ev_init, 0));
+    if (a.ring_used[ring]) RNA_HIP(e, hipStreamWaitEvent(prep_stream, a.ring_free[ring], 0));   // (thirteen launches ago at least: long over)
   }
   {
-    KernelTimer kt(e, RNA_K_ASTAR_INIT, search_stream);
-    hipLaunchKernelGGL(tsa_snapshot_kernel, dim3(std::min(ti * tj, 4096)), dim3(256), 0, search_stream, e->nbr, rows, cols, ti, tj, S.nbr_tm,
+    KernelTimer kt(e, RNA_K_ASTAR_INIT, prep_stream);
+    hipLaunchKernelGGL(tsa_snapshot_kernel, dim3(std::min(ti * tj, 4096)), dim3(256), 0, prep_stream, e->nbr, rows, cols, ti, tj, S.nbr_tm,
                        e->geom.start[0], e->geom.start[1]);
     RNA_HIP(e, hipGetLastError());
   }
   if (ev_init) {
-    RNA_HIP(e, hipEventRecord(a.snap_done[slot], search_stream));
+    RNA_HIP(e, hipEventRecord(a.snap_done[slot], prep_stream));
     a.snap_pending[slot] = true;
   }
   {
     // ticket and launch order (the pages of a slot are reset by the workgroup that takes the slot)
-    KernelTimer kt(e, RNA_K_ASTAR_RESET, search_stream);
+    KernelTimer kt(e, RNA_K_ASTAR_RESET, prep_stream);
     const int ranked = n <= 2048 ? 1 : 0;
-    hipLaunchKernelGGL(tsa_prepare_kernel, dim3(1), dim3(256), ranked ? (size_t)n * sizeof(int) : 0, search_stream, S, q_dev, n, rows, cols, ranked);
+    hipLaunchKernelGGL(tsa_prepare_kernel, dim3(1), dim3(256), ranked ? (size_t)n * sizeof(int) : 0, prep_stream, S, q_dev, n, rows, cols, ranked);
     RNA_HIP(e, hipGetLastError());
+  }
+  if (ev_init) {
+    RNA_HIP(e, hipEventRecord(a.ev_prep, prep_stream));
+    RNA_HIP(e, hipStreamWaitEvent(search_stream, a.ev_prep, 0));
   }
   {
     KernelTimer kt(e, RNA_K_ASTAR_SEARCH, search_stream);
     const size_t nt_bytes = (size_t)((ti * tj + 31) / 32) * sizeof(unsigned);
     TsaLaunch A;
+    memset(&A, 0, sizeof(A));
     A.rows = rows; A.cols = cols; A.tiles_i = ti; A.tiles_j = tj; A.s0 = e->geom.start[0]; A.s1 = e->geom.start[1];
     A.queries = q_dev; A.S = S; A.bucket_width = a.bucket_width; A.paths = paths_dev; A.max_path_len = max_len;
     A.rev_all = a.rev[slot]; A.rev_cap = a.rev_cap; A.results = res_dev;
@@ -1446,17 +1514,22 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     if (const char* pf = getenv("RNA_TSA_PRIO_FIRST")) A.prio_first = atoi(pf);   // developer knob
     size_t lds_dyn = 4 * nt_bytes;
     if (const char* pad = getenv("RNA_TSA_LDS_PAD")) lds_dyn += (size_t)atoi(pad);   // developer knob: fewer search workgroups per CU
+    // a search that outgrows its share of pages is searched again: pipelined, when the host sees the count
+    // (astar_settle); on the single stream, where nothing else competes for the CUs, right behind the first pass
+    const bool can_retry = a.g_retry[slot] != nullptr;
+    A.retry_count = (can_retry && ev_init && a.retry_flag) ? a.retry_flag + slot : nullptr;
+    if (A.retry_count) *A.retry_count = 0;
     if (a.depth > 1) hipLaunchKernelGGL((tsa_search_kernel<TSA_WAVES, false>), dim3(n), dim3(TSA_WAVES * 64), lds_dyn, search_stream, A);
     else hipLaunchKernelGGL((tsa_search_kernel<16, false>), dim3(n), dim3(16 * 64), lds_dyn, search_stream, A);
-    if (a.g_retry[slot]) {
-      // second pass: the searches that outgrew their share of pages, on the stage's full-size retry slots (workgroups
-      // without such a query end at once)
-      A.retry = 1;
-      A.S2 = tsa_retry_view(e, slot, S);
-      if (a.depth > 1) hipLaunchKernelGGL((tsa_search_kernel<TSA_WAVES, true>), dim3(TSA_RETRY), dim3(TSA_WAVES * 64), lds_dyn, search_stream, A);
-      else hipLaunchKernelGGL((tsa_search_kernel<16, true>), dim3(TSA_RETRY), dim3(16 * 64), lds_dyn, search_stream, A);
-    }
     RNA_HIP(e, hipGetLastError());
+    memcpy(a.last_launch[slot], &A, sizeof(A));
+    a.last_lds[slot] = lds_dyn;
+    a.retry_armed[slot] = A.retry_count != nullptr;
+    if (can_retry && !A.retry_count) { const int rc = tsa_retry_launch(e, slot, search_stream); if (rc != RNA_OK) return rc; }
+  }
+  if (ring >= 0) {
+    RNA_HIP(e, hipEventRecord(a.ring_free[ring], search_stream));
+    a.ring_used[ring] = true;
   }
   return RNA_OK;
 }
@@ -1468,6 +1541,8 @@ void tsa_stats_dump() {
   const double jobs = (double)st[7];
   if (jobs <= 0) return;
   const double busy = (double)(st[0] + st[1] + st[2]);
+  fprintf(stderr, "[tsa stats] per job us: loads issued + arrived %.2f (of load+halo), wake tests + queueing %.2f of which queueing %.2f (of results); jobs that queue wake-ups %.1f%%; a job that finds nothing %.2f us\n",
+          st[9] * 0.01 / jobs, st[6] * 0.01 / jobs, st[3] * 0.01 / jobs, 100.0 * (double)st[13] / jobs, st[15] * 0.01 / (double)std::max<unsigned long long>(1, st[10]));
   fprintf(stderr, "[tsa stats, tile kernel, all launches] jobs %.0f (%.1f%% no-op) | per job us: load+halo %.2f sweeps %.2f results %.2f | wave lifetime %.1f wave-ms, in jobs %.1f wave-ms (%.1f%%), taking jobs %.1f wave-ms (%.1f%%) | row evaluations per job %.1f, extra horizontal passes %.1f | shader clock while searching %.0f MHz\n",
           jobs, 100.0 * (double)st[10] / jobs, st[0] * 0.01 / jobs, st[1] * 0.01 / jobs, st[2] * 0.01 / jobs, st[5] * 1e-5, busy * 1e-5,
           100.0 * busy / (double)st[5], st[4] * 1e-5, 100.0 * (double)st[4] / (double)st[5], st[8] / jobs, st[11] / jobs,

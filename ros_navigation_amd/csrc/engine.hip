@@ -672,6 +672,18 @@ extern "C" int rna_get_position(const rna_engine* e, int32_t i, int32_t j, doubl
 
 namespace rna {
 
+int side_stream(rna_engine* e, hipStream_t* out) {
+  if (!e->vfh_stream) {
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    RNA_HIP(e, hipStreamCreateWithPriority(&e->vfh_stream, hipStreamNonBlocking, prio_hi));
+    RNA_HIP(e, hipEventCreateWithFlags(&e->ev_vfh_go, hipEventDisableTiming));
+    RNA_HIP(e, hipEventCreateWithFlags(&e->ev_vfh_done, hipEventDisableTiming));
+  }
+  *out = e->vfh_stream;
+  return RNA_OK;
+}
+
 int side_join(rna_engine* e) {
   if (e->vfh_pending) {
     RNA_HIP(e, hipStreamWaitEvent(e->stream, e->ev_vfh_done, 0));
@@ -691,7 +703,7 @@ int sync_all(rna_engine* e) {
   if (e->vfh_stream) RNA_HIP(e, hipStreamSynchronize(e->vfh_stream));
   for (int d = 0; d < AstarDevice::MAX_DEPTH; ++d)
     if (e->astar.side[d]) RNA_HIP(e, hipStreamSynchronize(e->astar.side[d]));
-  return RNA_OK;
+  return astar_settle(e);
 }
 
 int profile_flush(rna_engine* e) {

@@ -83,6 +83,23 @@ struct AstarDevice {
   bool busy[MAX_DEPTH] = {};
   unsigned long long stage_seq[MAX_DEPTH] = {};   // launch number of the stage's last batch (0: never used)
   hipEvent_t ev_init = nullptr;
+  // Pipelined launches: the mask snapshot, the launch order and the ticket of a batch live in an entry of a ring, not in
+  // the stage -- they are written on the engine's side stream (CUs the searches cannot take) as soon as the map is
+  // composed, before any stage has to be free; the search itself goes to a stage that IS free (the host waits for one).
+  static constexpr int MAX_RING = 2 * MAX_DEPTH;
+  int ring_n = 0;
+  char* ring_mem = nullptr;
+  size_t ring_stride = 0;
+  hipEvent_t ring_free[MAX_RING] = {};   // the search that read this entry last has finished
+  bool ring_used[MAX_RING] = {};
+  hipEvent_t ev_prep = nullptr;          // snapshot + launch order of the batch being launched are in place
+  // Searches that outgrew their share of pages: counted by the kernel in pinned host memory; the second pass over them is
+  // launched when the host sees the count (a launch per batch "in case" cost every stage 0.2 - 4 ms: its workgroups wait
+  // for CU slots like everybody else's)
+  int* retry_flag = nullptr;             // [MAX_DEPTH], host memory the device writes
+  bool retry_armed[MAX_DEPTH] = {};
+  size_t last_lds[MAX_DEPTH] = {};
+  alignas(8) unsigned char last_launch[MAX_DEPTH][384] = {};   // TsaLaunch of the stage's last batch
   unsigned long long launches = 0;
   int last_slot = 0;
   size_t field_stride = 0;         // words per query field incl. padding
@@ -199,6 +216,10 @@ inline void dev_free(T** p) {
 
 // the engine stream waits for the side work in flight (see rna_engine::vfh_stream); cheap when there is none
 int side_join(rna_engine* e);
+// the side stream (created on first use)
+int side_stream(rna_engine* e, hipStream_t* out);
+// grid A*: second pass over the searches of finished batches that ran out of pages (astar.hip)
+int astar_settle(rna_engine* e);
 // entry of a C-ABI call that enqueues on the engine stream: select the device, join the side work.  Calls that cannot
 // disturb it (the ray batch of the laser layer, the searches, the VFH+ step itself, getters) use RNA_ENTER_NOJOIN.
 #define RNA_ENTER(e)                                        \
@@ -225,6 +246,8 @@ constexpr int TSA_RETRY = 8;                                          // full-si
 size_t tsa_retry_pool_bytes(const rna_engine* e);
 size_t tsa_retry_aux_bytes(const rna_engine* e);
 int tsa_retry_prepare(rna_engine* e, int slot);
+size_t tsa_ring_bytes(const rna_engine* e, int max_queries);            // one entry of the launch ring
+int tsa_retry_launch(rna_engine* e, int slot, hipStream_t search_stream);
 int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init,
                const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len, rna_astar_result* res_dev);
 int tsa_settled(rna_engine* e, int slot, const rna_astar_query* q, const rna_astar_result* r, int n, int32_t* d_counts);

@@ -589,13 +589,7 @@ int launch_step(rna_engine* e, const rna_pose* poses_dev, const double* ranges_d
                 float* origin_dev, float* hist_dev, bool side = false) {
   hipStream_t st = e->stream;
   if (side) {
-    if (!e->vfh_stream) {
-      int prio_lo = 0, prio_hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-      RNA_HIP(e, hipStreamCreateWithPriority(&e->vfh_stream, hipStreamNonBlocking, prio_hi));
-      RNA_HIP(e, hipEventCreateWithFlags(&e->ev_vfh_go, hipEventDisableTiming));
-      RNA_HIP(e, hipEventCreateWithFlags(&e->ev_vfh_done, hipEventDisableTiming));
-    }
+    { hipStream_t ss; const int rc = side_stream(e, &ss); if (rc != RNA_OK) return rc; }
     RNA_HIP(e, hipEventRecord(e->ev_vfh_go, e->stream));
     RNA_HIP(e, hipStreamWaitEvent(e->vfh_stream, e->ev_vfh_go, 0));
     st = e->vfh_stream;

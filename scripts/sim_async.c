@@ -295,16 +295,26 @@ static int nb_running(int t) {
 }
 /* policy 4: the queue is a multiset of (key, tile) entries -- a wake-up always adds one; a tile has a "pending" bit D
    and a "running" bit R.  An entry whose tile has nothing pending when it is taken is stale and dropped. */
-typedef struct { long long key; int t; } entry;
+typedef struct { long long key; int t; long seq; } entry;
+static int clsn[4096], clsmax = 0, ringcap = 0, ringnc = 32; static long ringspill = 0;
+static int ringmode = 0, nodup = 0; static long eseq = 0; static long long* qcls;
 static entry* ents; static int nent = 0, maxent = 0; static long stale_pops = 0, pushes = 0;
 static uint8_t *Dbit;
 static void epush(int t, long long key) {
   long long k = key;
   if (kshift >= 0) { const long long lo = bend - bucket_w; k = key < lo ? 0 : (key - lo) >> kshift; }
-  ents[nent].key = k; ents[nent].t = t; nent++; pushes++;
+  if (ringcap > 0) { while (k < ringnc - 1 && clsn[k] >= ringcap) k++; if (k > ringnc - 1) k = ringnc - 1; if (clsn[k] >= ringcap) ringspill++; }
+  ents[nent].key = k; ents[nent].t = t; ents[nent].seq = eseq++; nent++; pushes++;
+  if (k >= 0 && k < 4096) { if (++clsn[k] > clsmax) clsmax = clsn[k]; }
   if (nent > maxent) maxent = nent;
 }
+static long long cls_of(long long key) { if (kshift < 0) return key; const long long lo = bend - bucket_w; return key < lo ? 0 : (key - lo) >> kshift; }
 static void wake4(int t, long long key) {
+  if (nodup && !running[t]) {
+    /* nodup 1: a pending tile keeps its first entry; 2: a duplicate only when the key class gets lower */
+    if (Dbit[t]) { if (nodup == 2 && cls_of(key) < qcls[t]) { qcls[t] = cls_of(key); epush(t, key); } return; }
+    Dbit[t] = 1; qcls[t] = cls_of(key); epush(t, key); return;
+  }
   Dbit[t] = 1;
   if (!running[t]) epush(t, key);   /* a running tile is queued again (lowest key) by the wavefront that runs it */
 }
@@ -316,10 +326,11 @@ static int pop4(int* spent) {
     int bi = -1;
     for (int k = 0; k < nent; ++k) {
       if (excl4 && nb_running(ents[k].t)) continue;
-      if (bi < 0 || ents[k].key < ents[bi].key || (ents[k].key == ents[bi].key && ents[k].t < ents[bi].t)) bi = k;
+      if (bi < 0 || ents[k].key < ents[bi].key || (ents[k].key == ents[bi].key && (ringmode == 1 ? ents[k].seq < ents[bi].seq : (ringmode == 2 ? ents[k].seq > ents[bi].seq : ents[k].t < ents[bi].t)))) bi = k;
     }
     if (bi < 0) return -1;   /* everything queued sits next to a running tile */
     const int t = ents[bi].t;
+    if (ents[bi].key >= 0 && ents[bi].key < 4096) clsn[ents[bi].key]--;
     ents[bi] = ents[--nent];
     if (running[t]) { (*spent)++; stale_pops++; continue; }   /* its runner sees D when it ends */
     if (!Dbit[t]) { (*spent)++; stale_pops++; continue; }
@@ -371,6 +382,10 @@ int main(int argc, char** argv) {
   const int subbins = argc > 6 ? atoi(argv[6]) : 0;
   if (getenv("SIM_HPASS")) extra_h = atoi(getenv("SIM_HPASS"));
   if (getenv("SIM_EXCL8")) excl8 = 1;
+  if (getenv("SIM_RINGCAP")) ringcap = atoi(getenv("SIM_RINGCAP"));   /* entries a class can hold: a push to a full class goes to the next one */
+  if (getenv("SIM_RINGNC")) ringnc = atoi(getenv("SIM_RINGNC"));
+  if (getenv("SIM_RING")) ringmode = atoi(getenv("SIM_RING"));   /* 2: last in, first out */     /* policy 4: entries of one key class leave in the order they came (a ring per class) */
+  if (getenv("SIM_NODUP")) nodup = atoi(getenv("SIM_NODUP"));
   if (getenv("SIM_FRESH")) fresh = 1;
   if (getenv("SIM_EXCL")) excl4 = 1;   /* policy 4: a tile does not start while one of its four edge neighbours runs */
   if (getenv("SIM_NODEC")) nodec = 1;                            /* a queued tile keeps the key of its first wake-up */
@@ -387,7 +402,7 @@ int main(int argc, char** argv) {
   g = malloc(sizeof(int32_t) * (size_t)rows * cols);
   first_f = calloc(ntile, 1); queued = calloc(ntile, 1); running = calloc(ntile, 1); dirty = calloc(ntile, 1); farflag = calloc(ntile, 1);
   popkey = calloc(ntile, sizeof(long long));
-  ents = malloc(sizeof(entry) * (1 << 22)); Dbit = calloc(ntile, 1);
+  ents = malloc(sizeof(entry) * (1 << 22)); Dbit = calloc(ntile, 1); qcls = calloc(ntile, sizeof(long long));
   qkey = malloc(sizeof(long long) * ntile); dkey = malloc(sizeof(long long) * ntile);
   qlist = malloc(sizeof(int) * (ntile + 8192));
   jobres* slot = malloc(sizeof(jobres) * (W > 4096 ? W : 4096));
@@ -411,7 +426,7 @@ int main(int argc, char** argv) {
     bend = (bucket + 1) * (long long)bucket_w;
     const int ts = (sj / TJ) * tiles_i + si / TI;
     first_f[ts] = 1;
-    memset(Dbit, 0, ntile); nent = 0;
+    memset(Dbit, 0, ntile); nent = 0; memset(clsn, 0, sizeof(clsn));
     if (policy == 4) wake4(ts, 0); else push(ts, 0);
     st.buckets = 1;
     double now = 0;
@@ -547,7 +562,8 @@ int main(int argc, char** argv) {
   printf("policy %d W %d bucket %d subbins %d: E %ld jobs/query %.0f (%.1f%% no-op) rows/job %.1f hpass/job %.1f | busy %.2f wave-ms/query, makespan mean %.2f ms max %.2f ms, wave efficiency %.0f%%, mismatches %ld\n",
          policy, W, bucket_w, subbins, totE, (double)tot.jobs / nq, 100.0 * tot.noop / tot.jobs, (double)tot.row_evals / tot.jobs, (double)tot.hextra / tot.jobs,
          tot.busy * 1e-3 / nq, sum_makespan * 1e-3 / nq, max_makespan * 1e-3, 100.0 * tot.busy / (sum_makespan * W), bad);
-  printf("  most entries queued at once: %d\n", policy == 4 ? maxent : maxlive);
+  printf("  most entries queued at once: %d (most in one key class: %d)\n", policy == 4 ? maxent : maxlive, clsmax);
+  if (ringcap) printf("  pushes that found every class from theirs on full: %ld\n", ringspill);
   if (policy == 4) printf("  entries pushed per job %.2f, stale entries dropped per job %.2f\n", (double)pushes / tot.jobs, (double)stale_pops / tot.jobs);
   return bad ? 1 : 0;
 }
