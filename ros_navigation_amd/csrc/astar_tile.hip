@@ -145,8 +145,8 @@ __device__ __forceinline__ int kdj_of(int k) { return k < 3 ? -1 : (k > 4 ? 1 : 
 // what belongs to the local pages 1..nalloc[q] of each query; the next launch on the stage resets exactly those
 // (the workgroup that takes the slot next does, before it searches) instead of rewriting 64 MiB per query.
 struct TsaStage {
-  unsigned* pages;      // [1 + max_queries*cap][1024]
-  unsigned* paux;       // [1 + max_queries*cap][64]
+  unsigned* pages;      // [max_queries][cap + 1][1024]: local page 0 of a slot stays "unreached" (what a tile without a page reads)
+  unsigned* paux;       // [max_queries][cap + 1][64]
   unsigned* tmap;       // [max_queries][ntile] tile -> local page, 0 = none
   unsigned* owner;      // [max_queries][cap + 1] local page -> tile
   int* nalloc;          // [max_queries] local pages handed out by the last search
@@ -254,18 +254,16 @@ __device__ unsigned long long g_tsa_stat[32];
 // Per-query context of a tile job (wave-uniform).
 struct TsaCtx {
   int rows, cols, tiles_i, tiles_j;
-  unsigned* pages;            // stage-wide page array
-  unsigned* paux;             // stage-wide edge-column copies
+  unsigned* pages;            // this query's pages: local page p at pages + (p << 10); page 0 stays "unreached"
+  unsigned* paux;             // this query's edge-column copies, AUX_WORDS per page
   unsigned* tmap;             // this query's tile -> local page table
   unsigned* owner;            // this query's local page -> tile list
-  size_t page_base;           // q * cap: global page = page_base + local page (local >= 1)
   int cap;
   int* nalloc;                // LDS: local pages handed out so far
   const uint8_t* nbr_tm;
   int gi, gj;
   int ts, sa, sb;             // start: tile, lane, row
   int tg, ga, gb;             // goal: tile, lane, row
-  __device__ __forceinline__ size_t gpage(unsigned local) const { return local ? page_base + local : 0; }
   __device__ __forceinline__ unsigned page_of(int t) const { return ld_l2(&tmap[t]); }
 };
 
@@ -347,17 +345,23 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   //         the tile itself (lane 8) ----
   unsigned nb_pg = 0u;
   int nb_t = -1;
-  if (lane < 8) {
-    const int nti = ti + kdi_of(lane), ntj = tj + kdj_of(lane);
-    if (nti >= 0 && ntj >= 0 && nti < tiles_i && ntj < tiles_j) { nb_t = ntj * tiles_i + nti; nb_pg = C.page_of(nb_t); }
-  } else if (lane == 8) {
-    nb_pg = C.page_of(t);   // final while this job runs: only the tile's own job changes it, and a tile never runs twice at once
+  {
+    // (arithmetic instead of kdi_of / kdj_of: their comparisons became a cascade of branches on the lane id.  The own
+    // page is final while this job runs: only the tile's own job changes it, and a tile never runs twice at once.)
+    const int kk = lane < 4 ? lane : (lane < 8 ? lane + 1 : 4);   // cell of the 3 x 3 block of tiles, row-major; lane 8: the centre
+    const int kj = (kk * 11) >> 5;                                // kk / 3
+    const int nti = ti + kk - 3 * kj - 1, ntj = tj + kj - 1;
+    if (lane < 9 && nti >= 0 && ntj >= 0 && nti < tiles_i && ntj < tiles_j) {
+      const int tt = ntj * tiles_i + nti;
+      nb_pg = C.page_of(tt);
+      nb_t = lane < 8 ? tt : -1;
+    }
   }
   unsigned pg = (unsigned)__builtin_amdgcn_readlane((int)nb_pg, 8);
   // ---- 2. everything the job reads, issued before the first wait ----
   int g0, g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15;
   {
-    const unsigned* own = C.pages + (C.gpage(pg) << 10);
+    const unsigned* own = C.pages + (pg << 10);
 #define TSA_LOAD(b) TSA_G(b) = (int)ld_l2(&own[(b) * TI + lane]);
     TSA_R16(TSA_LOAD)
 #undef TSA_LOAD
@@ -373,15 +377,15 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   unsigned eb = 0u;   // lanes 1..16 / 33..48: mask of the tile's own edge cell (0, xl-1) / (63, xl-1)
   {
     const unsigned pgN = (unsigned)__shfl((int)nb_pg, 1), pgS = (unsigned)__shfl((int)nb_pg, 6);
-    top = (int)ld_l2(&C.pages[(C.gpage(pgN) << 10) + (TJ - 1) * TI + lane]);
-    bot = (int)ld_l2(&C.pages[(C.gpage(pgS) << 10) + lane]);
+    top = (int)ld_l2(&C.pages[(pgN << 10) + (TJ - 1) * TI + lane]);
+    bot = (int)ld_l2(&C.pages[(pgS << 10) + lane]);
     const int xdir = xl == 0 ? (xr ? 2 : 0) : (xl <= TJ ? (xr ? 4 : 3) : (xr ? 7 : 5));
     const unsigned pgX = (unsigned)__shfl((int)nb_pg, xdir);
     const int xrow = xl == 0 ? TJ - 1 : (xl <= TJ ? xl - 1 : 0);
-    if (xl <= TJ + 1) X = (int)ld_l2(&C.paux[C.gpage(pgX) * AUX_WORDS + (xr ? 0 : 16) + xrow]);   // a left tile's column 63 / a right tile's column 0
+    if (xl <= TJ + 1) X = (int)ld_l2(&C.paux[pgX * AUX_WORDS + (xr ? 0 : 16) + xrow]);   // a left tile's column 63 / a right tile's column 0
     if (xcell) eb = C.nbr_tm[(size_t)t * MASK_STRIDE + TILE_WORDS + (xr ? 16 : 0) + xl - 1];
     // the tile's own columns 0 and 63 in the same layout (the copy it keeps for its neighbours)
-    if (xcell) gcol = (int)ld_l2(&C.paux[C.gpage(pg) * AUX_WORDS + (xr ? 16 : 0) + xl - 1]);
+    if (xcell) gcol = (int)ld_l2(&C.paux[pg * AUX_WORDS + (xr ? 16 : 0) + xl - 1]);
   }
   asm volatile("; TSA_MARK loads_issued");
   // ---- 3. this bucket's bound; which cells are free ----
@@ -393,9 +397,18 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   const long long lim_ll = bucket_end < (long long)best_in + 1 ? bucket_end : (long long)best_in + 1;   // pass on iff f < lim
   const int thr = KU - (int)(lim_ll > (long long)INF ? (long long)INF : lim_ll) + 1;
   const int dxl = abs(i0 + lane - gi);
-  // (the copy of dxl is made opaque at every use: otherwise the 16 row heuristics are hoisted out of the sweeps into 16 VGPRs again)
-#define TSA_H(b) ({ int dx_ = dxl; asm volatile("" : "+v"(dx_)); const int dy_ = abs(j0 + (b) - gj); \
-                    tsa_h24(max(dx_, dy_), min(dx_, dy_)); })
+  const int dx414 = dxl * (COST_D - COST_S);
+  // h + add of row b:  1000 max(dx, dy) + 414 min(dx, dy) = 586 max(dx, dy) + 414 dx + 414 dy -- one maximum, one 24-bit
+  // multiply-add and one addition of a scalar (414 dy + add) per use, with the lane's 414 dx kept in a register (five
+  // instructions when the minimum was formed as well; the second register is there since the row sets stopped spilling).
+  // (the copies of dxl / dx414 are made opaque at every use: otherwise the 16 row heuristics are hoisted out of the
+  // sweeps into 16 VGPRs again)
+#define TSA_HC(b, add) ({ int dx_ = dxl, dx4_ = dx414, j0_ = j0; asm volatile("" : "+v"(dx_), "+v"(dx4_), "+s"(j0_)); const int dy_ = abs(j0_ + (b) - gj); \
+                          const int m_ = max(dx_, dy_); int r_;                                                           \
+                          asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r_) : "v"(m_), "s"(2 * COST_S - COST_D), "v"(dx4_));   \
+                          r_ + ((COST_D - COST_S) * dy_ + (add)); })
+#define TSA_H(b) TSA_HC(b, 0)
+#define TSA_HT(b) TSA_HC(b, thr)   /* a cell passes on iff u >= h + thr */
   // bit b: this lane's cell in row b is free (and inside the map) -- from the snapshot, loaded with the masks
   const unsigned fbits = fbits_ld;
   TSA_T(t_h0);
@@ -421,7 +434,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   {
     int cT, cB, cX;
     {
-      const int pT = tsa_prop(top, TSA_H(-1), thr), pB = tsa_prop(bot, TSA_H(TJ), thr);
+      const int pT = top >= TSA_HT(-1) ? top : 0, pB = bot >= TSA_HT(TJ) ? bot : 0;
       const int hX = tsa_octile(xr ? i0 + TI : i0 - 1, j0 + xl - 1, gi, gj);
       const int pX = xl <= TJ + 1 ? tsa_prop(X, hX, thr) : 0;
       const int sTL = __builtin_amdgcn_readlane(pX, 0), sBL = __builtin_amdgcn_readlane(pX, TJ + 1);
@@ -480,7 +493,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       }                                                                                                          \
       if ((planted >> (b)) & 1u) up |= 1ull << C.sa;                                                             \
     }                                                                                                            \
-    TSA_PP(b) = tsa_prop(TSA_G(b), TSA_H(b), thr);                                                               \
+    TSA_PP(b) = TSA_G(b) >= TSA_HT(b) ? TSA_G(b) : 0;                                                             \
     if ((b) == 0 || (b) == TJ - 1) { if (up) { nd |= 1u << (b); TSA_ROW_CHANGED(b, up) } }                        \
     else if ((crow >> (b)) & 1u) { nd |= 1u << (b); TSA_ROW_CHANGED(b, up) }   /* (its own horizontal steps: evaluated in the first sweep) */ \
   }
@@ -522,7 +535,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     m_ = max3i(m_, lane_m1(TSA_PP(b)) + nS, lane_p1(TSA_PP(b)) + nS) & open_;                                    \
     unsigned long long up_ = __builtin_amdgcn_ballot_w64(m_ > TSA_G(b));                                         \
     if (up_) {                                                                                                   \
-      const int ht_ = TSA_H(b) + thr;   /* passes on iff u - h >= thr */                                         \
+      const int ht_ = TSA_HT(b);        /* passes on iff u - h >= thr */                                         \
       TSA_G(b) = max(TSA_G(b), m_);                                                                              \
       TSA_PP(b) = TSA_G(b) >= ht_ ? TSA_G(b) : 0;                                                                \
       /* the passes along the row, hand-scheduled: 8 vector + 4 scalar instructions per pass that moves something, 5 + 1 \
@@ -598,8 +611,8 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       pg = (unsigned)__builtin_amdgcn_readfirstlane(p);
       if (pg == 0u) return 0;
     }
-    unsigned* own = C.pages + (C.gpage(pg) << 10);
-    unsigned* ax = C.paux + C.gpage(pg) * AUX_WORDS + (lane ? 16 : 0);
+    unsigned* own = C.pages + (pg << 10);
+    unsigned* ax = C.paux + pg * AUX_WORDS + (lane ? 16 : 0);
     const bool edge_lane = lane == 0 || lane == TI - 1;
     // A reached cell whose g is about to leave the 30-bit range of the field word: a value written by this job is at
     // most lim + 1414 (its source passed on, i.e. g + h < lim), so the rows are only looked at when the bound is that far out.
@@ -650,7 +663,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       const int thr_best = KU - best_in;   // f <= best  <=>  u - h >= thr_best
       unsigned long long farm = 0ull;
 #define TSA_END(b)                                                                                               \
-  if ((look >> (b)) & 1u) farm |= __builtin_amdgcn_ballot_w64(TSA_G(b) != 0 && TSA_PP(b) == 0 && TSA_G(b) - TSA_H(b) >= thr_best);
+  if ((look >> (b)) & 1u) farm |= __builtin_amdgcn_ballot_w64(TSA_G(b) != 0 && TSA_PP(b) == 0 && TSA_G(b) >= TSA_HC(b, thr_best));
       TSA_R16(TSA_END)
 #undef TSA_END
       if (farm && lane == 0) sch.act_far(t);
@@ -954,7 +967,7 @@ __device__ __forceinline__ void tsa_backtrace_wave(const TsaLaunch& A, const Tsa
   const int rows = A.rows, cols = A.cols, tiles_i = A.tiles_i, tiles_j = A.tiles_j;
   const int ncell = rows * cols, ntile = tiles_i * tiles_j;
   const unsigned* tmap = S.tmap + (size_t)sl * ntile;
-  const size_t page_base = (size_t)sl * S.cap;
+  const size_t page_base = (size_t)sl * ((size_t)S.cap + 1);
   const int start = tsa_unwrap_lin(A.queries[q].start, rows, cols, A.s0, A.s1);
   const int goal = tsa_unwrap_lin(A.queries[q].goal, rows, cols, A.s0, A.s1);
   const int si = start % rows, sj = start / rows;
@@ -977,7 +990,7 @@ __device__ __forceinline__ void tsa_backtrace_wave(const TsaLaunch& A, const Tsa
     }
     auto gpage = [&](int src) -> size_t {
       const unsigned lp = (unsigned)__shfl((int)pgl, src);
-      return lp ? page_base + lp : (size_t)0;
+      return page_base + lp;
     };
     {
       const int xl = lane & 31;
@@ -1108,10 +1121,10 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
 
   TsaCtx C;
   C.rows = rows; C.cols = cols; C.tiles_i = tiles_i; C.tiles_j = tiles_j;
-  C.pages = S.pages; C.paux = S.paux;
+  C.pages = S.pages + (((size_t)sl * ((size_t)S.cap + 1)) << 10);
+  C.paux = S.paux + (size_t)sl * ((size_t)S.cap + 1) * AUX_WORDS;
   C.tmap = S.tmap + (size_t)sl * ntile;
   C.owner = S.owner + (size_t)sl * (S.cap + 1);
-  C.page_base = (size_t)sl * S.cap;
   C.cap = S.cap;
   C.nalloc = &s_nalloc;
   C.nbr_tm = S.nbr_tm;
@@ -1141,9 +1154,9 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     const int used_raw = S.nalloc[sl];
     const int used = used_raw < C.cap ? used_raw : C.cap;
     if (used > 0) {
-      uint4* pg4 = reinterpret_cast<uint4*>(C.pages + ((C.page_base + 1) << 10));
+      uint4* pg4 = reinterpret_cast<uint4*>(C.pages + (1 << 10));
       for (size_t w = tid; w < (size_t)used * (TILE_WORDS / 4); w += TSA_THREADS) pg4[w] = make_uint4(0u, 0u, 0u, 0u);
-      uint4* ax4 = reinterpret_cast<uint4*>(C.paux + (C.page_base + 1) * AUX_WORDS);
+      uint4* ax4 = reinterpret_cast<uint4*>(C.paux + AUX_WORDS);
       for (size_t w = tid; w < (size_t)used * (AUX_WORDS / 4); w += TSA_THREADS) ax4[w] = make_uint4(0u, 0u, 0u, 0u);
       for (int p = 1 + tid; p <= used; p += TSA_THREADS) C.tmap[C.owner[p]] = 0u;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1350,7 +1363,7 @@ __global__ void tsa_settled_kernel(int rows, int cols, int tiles_i, int tiles_j,
       const int p = 1 + (int)(w >> 10), l = (int)(w & 1023);
       const int t = (int)S.owner[(size_t)q * (S.cap + 1) + p];
       const int i = (t % tiles_i) * TI + (l & (TI - 1)), j = (t / tiles_i) * TJ + (l >> 6);
-      const unsigned u = S.pages[(((size_t)q * S.cap + p) << 10) + l];
+      const unsigned u = S.pages[(((size_t)q * ((size_t)S.cap + 1) + p) << 10) + l];
       if (u != 0u && i < rows && j < cols && (KU - (int)u) + tsa_octile(i, j, gi, gj) <= r.cost) ++cnt;
     }
   }
@@ -1366,7 +1379,7 @@ static inline int tsa_ntile(const rna_engine* e) {
 bool tsa_supported(const rna_engine* e) { return (size_t)tsa_ntile(e) <= (size_t)TSA_MAX_TILE_WORDS * 32; }
 int tsa_tiles(const rna_engine* e) { return tsa_ntile(e); }
 // HBM of one pipeline stage: pages and their edge-column copies (cap per query + the shared page 0) ...
-size_t tsa_pool_bytes(int max_queries, int cap) { return ((size_t)max_queries * cap + 1) * (TILE_WORDS + AUX_WORDS) * sizeof(unsigned); }
+size_t tsa_pool_bytes(int max_queries, int cap) { return (size_t)max_queries * ((size_t)cap + 1) * (TILE_WORDS + AUX_WORDS) * sizeof(unsigned); }
 // ... and one allocation that must start zeroed: ticket | nalloc | perm | mask snapshot | tmap | owner
 size_t tsa_aux_bytes(const rna_engine* e, int max_queries, int cap) {
   const size_t ntile = (size_t)tsa_ntile(e);
@@ -1380,7 +1393,7 @@ static TsaStage tsa_stage_view(const rna_engine* e, int slot) {
   TsaStage S;
   S.cap = a.page_cap;
   S.pages = reinterpret_cast<unsigned*>(a.g[slot]);
-  S.paux = S.pages + (((size_t)a.max_queries * S.cap + 1) << 10);
+  S.paux = S.pages + (((size_t)a.max_queries * ((size_t)S.cap + 1)) << 10);
   S.ticket = reinterpret_cast<int*>(base);
   base += 256;
   S.nalloc = reinterpret_cast<int*>(base);
@@ -1409,7 +1422,7 @@ static TsaStage tsa_retry_view(const rna_engine* e, int slot, const TsaStage& ma
   TsaStage S = main;
   S.cap = (int)ntile;
   S.pages = reinterpret_cast<unsigned*>(a.g_retry[slot]);
-  S.paux = S.pages + (((size_t)TSA_RETRY * S.cap + 1) << 10);
+  S.paux = S.pages + (((size_t)TSA_RETRY * ((size_t)S.cap + 1)) << 10);
   S.ticket = reinterpret_cast<int*>(base);
   base += 256;
   S.nalloc = reinterpret_cast<int*>(base);
@@ -1428,7 +1441,7 @@ int tsa_retry_prepare(rna_engine* e, int slot) {   // fresh retry pages: "unreac
 // fresh stage: pages "unreached" (everything else was zeroed by the caller's hipMemsetAsync)
 int tsa_stage_prepare(rna_engine* e, int slot) {
   const TsaStage S = tsa_stage_view(e, slot);
-  const size_t pages = (size_t)e->astar.max_queries * S.cap + 1;
+  const size_t pages = (size_t)e->astar.max_queries * ((size_t)S.cap + 1);
   hipLaunchKernelGGL(tsa_fill_pages_kernel, dim3(8192), dim3(256), 0, e->stream, reinterpret_cast<uint4*>(S.pages),
                      pages * (TILE_WORDS + AUX_WORDS) / 4);
   RNA_HIP(e, hipGetLastError());
