@@ -194,9 +194,10 @@ __global__ void __launch_bounds__(256) tsa_snapshot_kernel(const uint8_t* __rest
 // The ticket back to zero and the launch order of the batch, see below.
 // One small workgroup: it has to fit next to the search workgroups that fill every CU when batches are pipelined.
 __global__ void __launch_bounds__(256) tsa_prepare_kernel(TsaStage S, const rna_astar_query* __restrict__ queries, int n, int rows, int cols,
-                                                          int ranked) {
+                                                          int ranked, int* __restrict__ served) {
   extern __shared__ int s_key[];
   if (threadIdx.x == 0) *S.ticket = 0;
+  if (served && threadIdx.x < TSA_RETRY) served[threadIdx.x] = -1;   // no retry slot has served a query of this batch yet
   if (!ranked) {   // the ranking is O(n^2 / 256) per thread: large batches keep the caller's order
     for (int i = threadIdx.x; i < n; i += blockDim.x) S.perm[i] = i;
     return;
@@ -1091,6 +1092,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   __syncthreads();
   const int q = __builtin_amdgcn_readfirstlane(s_q);   // wave-uniform values belong in SGPRs: the tile jobs need every VGPR
   if (q < 0) return;
+  if (RETRY && threadIdx.x == 0) A.S2.ticket[8 + blockIdx.x] = q;   // (tsa_retry_served: the settled-cell count of q reads this slot)
   const TsaStage& S = RETRY ? A.S2 : A.S;
   const int sl = RETRY ? (int)blockIdx.x : q;   // the slot whose pages / tables this search uses
   // A batch lasts as long as its longest search, and a stage cannot take its next batch before: the searches expected
@@ -1349,9 +1351,17 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
 
 // |{n : g(n) + h(n) <= f*}| per query from the pages still resident in HBM (measurement utility)
 __global__ void tsa_settled_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_query* __restrict__ queries,
-                                   const rna_astar_result* __restrict__ results, TsaStage S, int32_t* __restrict__ counts, int s0, int s1) {
+                                   const rna_astar_result* __restrict__ results, TsaStage S_main, TsaStage S_retry, const int* __restrict__ served,
+                                   int32_t* __restrict__ counts, int s0, int s1) {
   __shared__ int s_cnt;
   const int q = blockIdx.x;
+  // a query that was searched again lives in the retry slot that served it
+  int sl = q;
+  bool retried = false;
+  if (served)
+    for (int r = 0; r < TSA_RETRY; ++r)
+      if (served[r] == q) { sl = r; retried = true; }
+  const TsaStage& S = retried ? S_retry : S_main;
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
   const rna_astar_result r = results[q];
@@ -1359,12 +1369,12 @@ __global__ void tsa_settled_kernel(int rows, int cols, int tiles_i, int tiles_j,
   if (r.status == 0 || r.status == 3) {
     const int goal = tsa_unwrap_lin(queries[q].goal, rows, cols, s0, s1);
     const int gi = goal % rows, gj = goal / rows;
-    const int used = S.nalloc[q];
+    const int used = S.nalloc[sl];
     for (size_t w = threadIdx.x; w < ((size_t)used << 10); w += blockDim.x) {
       const int p = 1 + (int)(w >> 10), l = (int)(w & 1023);
-      const int t = (int)S.owner[(size_t)q * (S.cap + 1) + p];
+      const int t = (int)S.owner[(size_t)sl * (S.cap + 1) + p];
       const int i = (t % tiles_i) * TI + (l & (TI - 1)), j = (t / tiles_i) * TJ + (l >> 6);
-      const unsigned u = S.pages[(((size_t)q * ((size_t)S.cap + 1) + p) << 10) + l];
+      const unsigned u = S.pages[(((size_t)sl * ((size_t)S.cap + 1) + p) << 10) + l];
       if (u != 0u && i < rows && j < cols && (KU - (int)u) + tsa_octile(i, j, gi, gj) <= r.cost) ++cnt;
     }
   }
@@ -1416,6 +1426,8 @@ size_t tsa_retry_aux_bytes(const rna_engine* e) {
   return 256 + tsa_align256(TSA_RETRY * sizeof(int)) + tsa_align256((size_t)TSA_RETRY * ntile * sizeof(unsigned)) +
          tsa_align256((size_t)TSA_RETRY * (ntile + 1) * sizeof(unsigned));
 }
+// [TSA_RETRY] ints in the retry view's ticket block: the query each retry slot served in the stage's current batch (-1: none)
+static int* tsa_retry_served(const rna_engine* e, int slot) { return reinterpret_cast<int*>(e->astar.tsa_aux_retry[slot]) + 8; }
 static TsaStage tsa_retry_view(const rna_engine* e, int slot, const TsaStage& main) {
   const AstarDevice& a = e->astar;
   const size_t ntile = (size_t)tsa_ntile(e);
@@ -1508,7 +1520,8 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     // ticket and launch order (the pages of a slot are reset by the workgroup that takes the slot)
     KernelTimer kt(e, RNA_K_ASTAR_RESET, prep_stream);
     const int ranked = n <= 2048 ? 1 : 0;
-    hipLaunchKernelGGL(tsa_prepare_kernel, dim3(1), dim3(256), ranked ? (size_t)n * sizeof(int) : 0, prep_stream, S, q_dev, n, rows, cols, ranked);
+    hipLaunchKernelGGL(tsa_prepare_kernel, dim3(1), dim3(256), ranked ? (size_t)n * sizeof(int) : 0, prep_stream, S, q_dev, n, rows, cols, ranked,
+                       a.g_retry[slot] ? tsa_retry_served(e, slot) : nullptr);
     RNA_HIP(e, hipGetLastError());
   }
   if (ev_init) {
@@ -1567,7 +1580,10 @@ void tsa_stats_dump() {
 int tsa_settled(rna_engine* e, int slot, const rna_astar_query* q, const rna_astar_result* r, int n, int32_t* d_counts) {
   const int rows = e->geom.size[0], cols = e->geom.size[1];
   const int ti = (rows + TI - 1) / TI, tj = (cols + TJ - 1) / TJ;
-  hipLaunchKernelGGL(tsa_settled_kernel, dim3(n), dim3(1024), 0, e->stream, rows, cols, ti, tj, q, r, tsa_stage_view(e, slot),
+  const TsaStage S = tsa_stage_view(e, slot);
+  const bool has_retry = e->astar.g_retry[slot] != nullptr;
+  hipLaunchKernelGGL(tsa_settled_kernel, dim3(n), dim3(1024), 0, e->stream, rows, cols, ti, tj, q, r, S,
+                     has_retry ? tsa_retry_view(e, slot, S) : S, has_retry ? tsa_retry_served(e, slot) : nullptr,
                      d_counts, e->geom.start[0], e->geom.start[1]);
   RNA_HIP(e, hipGetLastError());
   return RNA_OK;

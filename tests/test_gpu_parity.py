@@ -453,6 +453,7 @@ def test_astar_searches_that_outgrow_their_pages_are_retried(R):
             q["start"][5], q["goal"][5] = inside, inside + 3 * e.rows + 2   # a short search inside the box
             res, paths = e.astar(q, e.ncell)
             assert e.astar_effective_config()[1] == 6
+            settled = e.astar_settled(len(q))     # (a retried query is counted in the retry slot that served it)
             needed_retry = 0
             for k in range(len(q)):
                 ores, opath, _ = O.astar_query(nbr, e.rows, e.cols, q["start"][k], q["goal"][k])
@@ -460,6 +461,7 @@ def test_astar_searches_that_outgrow_their_pages_are_retried(R):
                 if ores.status == 0:
                     assert res["cost"][k] == ores.cost and res["path_len"][k] == ores.path_len
                     assert np.array_equal(paths[k, :ores.path_len], opath)
+                    assert settled[k] == ores.settled, (depth, seed, k, settled[k], ores.settled)
                 needed_retry += ores.settled > 6 * 1024
             assert res["status"][3] == 1 and needed_retry >= 1
     e.close()
