@@ -620,13 +620,19 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     // most lim + 1414 (its source passed on, i.e. g + h < lim), so the rows are only looked at when the bound is that far out.
     const bool ovf_possible = lim_ll + COST_D > (long long)KU - 4 * COST_D;
     unsigned long long ovfm = 0ull;
-#define TSA_STORE(b)                                                                              \
-  if ((rowchg >> (b)) & 1u) {                                                                     \
-    own[(b) * TI + lane] = (unsigned)TSA_G(b);                                                    \
-    if (ovf_possible) ovfm |= __builtin_amdgcn_ballot_w64((unsigned)(TSA_G(b) - 1) < (unsigned)(4 * COST_D - 1));   \
-  }
+    // (the lane offset as an unsigned value of known range: the stores then take the page pointer as scalar base and
+    // need no 64-bit vector address each)
+    const unsigned ulane = (unsigned)lane & 63u;
+#define TSA_STORE(b) if ((rowchg >> (b)) & 1u) own[(b) * TI + ulane] = (unsigned)TSA_G(b);
     TSA_R16(TSA_STORE)
 #undef TSA_STORE
+    if (ovf_possible) {
+      unsigned rowchg_o = rowchg;
+      asm volatile("" : "+s"(rowchg_o));
+#define TSA_OVF(b) if ((rowchg_o >> (b)) & 1u) ovfm |= __builtin_amdgcn_ballot_w64((unsigned)(TSA_G(b) - 1) < (unsigned)(4 * COST_D - 1));
+      TSA_R16(TSA_OVF)
+#undef TSA_OVF
+    }
     // the copies of columns 0 and 63 for the neighbours: lanes 0 and 63 only, one change of the exec mask for all rows
     // (an opaque copy of the row set for every loop over it: the compiler otherwise keeps the sixteen conditions of the
     // first loop as sixteen lane masks -- 32 scalar registers, spilled to a VGPR's lanes and read back one by one)
@@ -1546,7 +1552,8 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     const bool can_retry = a.g_retry[slot] != nullptr;
     A.retry_count = (can_retry && ev_init && a.retry_flag) ? a.retry_flag + slot : nullptr;
     if (A.retry_count) *A.retry_count = 0;
-    if (a.depth > 1) hipLaunchKernelGGL((tsa_search_kernel<TSA_WAVES, false>), dim3(n), dim3(TSA_WAVES * 64), lds_dyn, search_stream, A);
+    static const bool wide = getenv("RNA_TSA_WIDE") != nullptr;   // developer knob: 16 wavefronts per query in the pipeline too
+    if (a.depth > 1 && !wide) hipLaunchKernelGGL((tsa_search_kernel<TSA_WAVES, false>), dim3(n), dim3(TSA_WAVES * 64), lds_dyn, search_stream, A);
     else hipLaunchKernelGGL((tsa_search_kernel<16, false>), dim3(n), dim3(16 * 64), lds_dyn, search_stream, A);
     RNA_HIP(e, hipGetLastError());
     memcpy(a.last_launch[slot], &A, sizeof(A));
