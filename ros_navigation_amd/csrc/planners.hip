@@ -178,7 +178,7 @@ constexpr int RRT_ITER = 2000;          // rrt_planner.cpp:6
 #define RNA_RRT_SPEC 8
 #endif
 constexpr int RRT_SPEC = RNA_RRT_SPEC;  // wavefronts per query = samples evaluated speculatively per round
-static_assert(RRT_SPEC >= 1 && RRT_SPEC <= 10, "3 draws per sample must fit the 31-draw look-ahead");
+static_assert(RRT_SPEC >= 1 && RRT_SPEC <= 16, "one workgroup per query");   // (a round covers the samples whose draws lie inside the 62-draw window: at least 10 random ones, fewer wavefronts than samples just wait)
 
 // glibc rand() (random_r, TYPE_3) is the additive lagged recurrence o[n] = o[n-31] + o[n-3] mod 2^32 with
 // result o[n] >> 1.  A wavefront keeps the stream in registers: `d` holds 62 consecutive raw outputs, one per

@@ -467,6 +467,46 @@ def test_astar_searches_that_outgrow_their_pages_are_retried(R):
     e.close()
 
 
+def test_bench_configuration_answers_an_unreachable_goal(R):
+    """The default bench configuration (4096 x 4096, 256 queries per batch, thirteen stages) does not fit HBM with a page
+    per tile and query: the engine runs it with half a map's worth of pages per query.  A goal that cannot be reached
+    floods its whole component -- more tiles than that -- and the reference answers "no path" (status 1), it does not
+    fail: the search ends its first pass with status 5 internally, the host sees the count when the stage's stream is
+    idle and the second pass on a full-size retry slot answers.  Through the pipelined device entry point, as bench.py
+    uses it, with a second batch in flight behind the first."""
+    n = 4096
+    e = R.Engine(n * 0.05, n * 0.05, 0.05)
+    master = R.synth.obstacles_rect(n, n, density=0.30, seed=2)
+    m2 = master.reshape(n, n).copy()              # [j][i]
+    m2[2000:2013, 1500:1513] = 0.0
+    m2[2000, 1500:1513] = m2[2012, 1500:1513] = 180.0    # a closed box, 11 x 11 free cells inside
+    m2[2000:2013, 1500] = m2[2000:2013, 1512] = 180.0
+    master = m2.reshape(-1).copy()
+    e.upload(R.capi.LAYER_MASTER, master)
+    e.astar_pipeline_depth(13)
+    e.astar_configure(max_queries=256)
+    q = R.synth.astar_queries(256, master, n, n, seed=2)
+    inside = 2006 * n + 1506
+    q["goal"][7] = inside
+    hip = _Hip()
+    d_q = hip.upload(q)
+    bufs = [(hip.alloc(256 * 2048 * 4), hip.alloc(256 * 24)) for _ in range(2)]
+    for d_paths, d_res in bufs:
+        e.astar_device(d_q, 256, d_paths, 2048, d_res)
+    depth, pages, mq = e.astar_effective_config()
+    assert depth == 13 and mq == 256 and pages < (n // 64) * (n // 16), (depth, pages, mq)   # the premise: a share, not the whole map
+    e.synchronize()
+    for d_paths, d_res in bufs:
+        st = hip.download(d_res, np.int32, 256 * 6).reshape(256, 6)[:, 0]
+        assert st[7] == 1, st[7]                                   # "no path", not 5
+        assert np.all((np.delete(st, 7) == 0) | (np.delete(st, 7) == 3)), sorted(set(st.tolist()))   # (3: path longer than the 2048 cells asked for)
+    for d_paths, d_res in bufs:
+        hip.free(d_paths)
+        hip.free(d_res)
+    hip.free(d_q)
+    e.close()
+
+
 class _Hip:
     """device buffers for the *_device entry points, through the HIP runtime librna.so itself links"""
 
