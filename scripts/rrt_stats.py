@@ -23,3 +23,7 @@ print("rrt %d queries on %d^2: %.1f ms | samples total %d, median %d, p90 %d, ma
     nq, n, ms, s.sum(), s[len(s) // 2], s[int(len(s) * 0.9)], s[-1], int((s == s[-1]).sum()), res["tree_size"].sum(),
     int((res["status"] == 1).sum()), int((res["status"] == -1).sum())))
 print("us per sample on the longest query: %.2f" % (ms * 1e3 / s[-1]))
+ab = res["status"] == -1
+print("aborted queries: tree sizes", sorted(res["tree_size"][ab].tolist()))
+big = np.argsort(-res["samples"])[:24]
+print("the 24 queries with most samples: (samples, nodes, status)", [(int(res["samples"][k]), int(res["tree_size"][k]), int(res["status"][k])) for k in big])
