@@ -102,6 +102,7 @@ def test_default_bench_keeps_the_engine_stream_alive():
     assert k["himm_prep"] < 1.0 and k["vfh_step"] < 0.6 and k["compose_master"] < 0.6, k
     # the engine stream's chain (astar_search / astar_reset / astar_init run on the stages' own streams, vfh_step on the VFH+ stream)
     engine = sum(v for name, v in k.items() if name not in ("astar_search", "astar_reset", "astar_init", "vfh_step"))
-    assert engine < 2.0 and engine < d["config"]["ms_per_pass"], (k, d["config"]["ms_per_pass"])
-    assert d["value"] > 45000, d["value"]
+    # (measured 1.33 - 1.43 ms on three boxes in round 3, bracketed by events that cost ~35 us per kernel themselves)
+    assert engine < 1.8 and engine < d["config"]["ms_per_pass"], (k, d["config"]["ms_per_pass"])
+    assert d["value"] > 80000, d["value"]
     assert d["config"]["astar_allocated"]["pipeline_depth"] == d["config"]["astar_pipeline_depth"]
