@@ -1552,7 +1552,10 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     const bool can_retry = a.g_retry[slot] != nullptr;
     A.retry_count = (can_retry && ev_init && a.retry_flag) ? a.retry_flag + slot : nullptr;
     if (A.retry_count) *A.retry_count = 0;
-    static const bool wide = getenv("RNA_TSA_WIDE") != nullptr;   // developer knob: 16 wavefronts per query in the pipeline too
+    // 16 wavefronts per query where latency counts (one stream, or a batch too small to fill the chip: a lone search
+    // takes 9.1 instead of 12.9 ms), 8 where throughput does (16 in the pipeline: 91.6 k instead of 122.8 k cycles/s)
+    static const bool wide_env = getenv("RNA_TSA_WIDE") != nullptr;   // developer knob: 16 wavefronts per query always
+    const bool wide = wide_env || n <= 32;
     if (a.depth > 1 && !wide) hipLaunchKernelGGL((tsa_search_kernel<TSA_WAVES, false>), dim3(n), dim3(TSA_WAVES * 64), lds_dyn, search_stream, A);
     else hipLaunchKernelGGL((tsa_search_kernel<16, false>), dim3(n), dim3(16 * 64), lds_dyn, search_stream, A);
     RNA_HIP(e, hipGetLastError());

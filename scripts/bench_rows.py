@@ -111,6 +111,35 @@ out["config3_astar"] = dict(workload="4096x4096, 256 queries, one launch (pipeli
                             frac=alg / (prof["astar_search"] * 1e-3) / 1e9 / PEAK)
 e.close()
 
+# ---- latency: the bench's own map and query set, one batch alone, and its longest search alone -----
+n = 4096
+for depth in (1, 13):
+    e = R.Engine(n * 0.05, n * 0.05, 0.05)
+    master = R.synth.obstacles_rect(n, n, density=0.30, seed=2)
+    e.upload(R.capi.LAYER_MASTER, master)
+    q = R.synth.astar_queries(256, master, n, n, seed=2)
+    e.astar_pipeline_depth(depth)
+    e.astar_configure(max_queries=256)
+    res, _ = e.astar(q, 32768)
+    e.profile(True)
+    ts = []
+    for _ in range(3):
+        e.profile_reset()
+        e.astar(q, 32768)
+        ts.append(e.profile_get()["astar_search"][0])
+    k = int(np.argmax(res["expanded"]))
+    one = q[k:k + 1].copy()
+    e.astar(one, 32768)
+    t1 = []
+    for _ in range(3):
+        e.profile_reset()
+        e.astar(one, 32768)
+        t1.append(e.profile_get()["astar_search"][0])
+    out["astar_latency_depth%d" % depth] = dict(
+        workload="bench map (4096x4096, 30%% rectangles, seed 2), the bench's first query set; pipeline depth %d: %d wavefronts per query for the batch of 256, 16 for the lone query" % (depth, 16 if depth == 1 else 8),
+        batch_of_256_alone_ms=min(ts), longest_query_alone_ms=min(t1), longest_query=k)
+    e.close()
+
 # ---- config 4: RRT, 512 queries (one GPU's share of 4096) on 2048^2 ---------------------------------
 n = 2048
 e = R.Engine(n * 0.05, n * 0.05, 0.05)

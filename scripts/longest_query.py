@@ -1,5 +1,6 @@
-"""Developer probe: the longest searches of the bench's query set, each alone on the GPU, with 16 wavefronts per query
-(pipeline depth 1) and with 8 (a pipelined engine).  usage: python scripts/longest_query.py [grid] [how many]"""
+"""Developer probe: the longest searches of the bench's query set, each alone on the GPU (batches of <= 32 queries run 16
+wavefronts per query on any engine), and the whole batch of 256 at pipeline depth 1 (16 wavefronts per query) and on a
+pipelined engine (8).  usage: python scripts/longest_query.py [grid] [how many]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,8 +27,8 @@ for depth in (1, 2):
             r1, _ = e.astar(one, 32768)
             ts.append(e.profile_get()["astar_search"][0])
         print("depth %d (%d wavefronts per query): query %3d expanded %8d jobs/wave %5d buckets %3d  alone %.2f ms" % (
-            depth, 16 if depth == 1 else 8, k, res["expanded"][k], r1["rounds"][0], r1["buckets"][0], min(ts)))
+            depth, 16, k, res["expanded"][k], r1["rounds"][0], r1["buckets"][0], min(ts)))
     e.profile_reset()
     e.astar(q, 32768)
-    print("depth %d: the whole batch %.2f ms" % (depth, e.profile_get()["astar_search"][0]))
+    print("depth %d (%d wavefronts per query): the whole batch %.2f ms" % (depth, 16 if depth == 1 else 8, e.profile_get()["astar_search"][0]))
     e.close()
