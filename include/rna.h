@@ -361,7 +361,7 @@ typedef enum {
   RNA_K_VFH_STEP, RNA_K_ASTAR_SEARCH, RNA_K_ASTAR_INIT, RNA_K_RRT, RNA_K_OCCUPANCY, RNA_K_ASTAR_RESET, RNA_K_COUNT
 } rna_kernel_id;
 /* when enabled, every launch of the kernels above is bracketed by hipEvents on the stream it runs on (the engine
- * stream; astar_search and astar_reset: the pipeline stage's own stream) */
+ * stream; astar_search: the pipeline stage's own stream; astar_init / astar_reset / vfh_step: the side stream) */
 /* on: 0 off, 1 every slot, 2 only astar_search / astar_reset (an event record is a packet of its own on the stream:
  * bracketing the ten slots of the engine stream costs its chain of short kernels about 1 ms per replan pass) */
 int rna_profile_enable(rna_engine* e, int on);

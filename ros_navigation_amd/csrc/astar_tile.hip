@@ -1,6 +1,6 @@
 // astar_tile.hip -- tile-synchronous grid A* for gfx950 ("TSA"): the same contract and the same
 // label-correcting argument as astar.hip, but the relaxation runs in REGISTERS.  This file holds the
-// default search kernel of the engine: one workgroup (8 wavefronts) per query, rounds of tile jobs.
+// search kernel of the engine: one workgroup (8 or 16 wavefronts) per query, tile jobs taken from an open list in LDS.
 //
 // The search field lives in PAGES of one 64 x 16-cell tile each (4 KiB; word = KU - g, 0 = unreached, so that a
 // fresh page is all zeros and "better" is "larger").  A wavefront owns one tile at a time: lane = column (the
@@ -17,18 +17,19 @@
 //   3. stores the rows that changed (it is the only writer of its page: plain coalesced stores), and wakes a
 //      neighbouring tile only if one of its own edge cells beats -- by a step that cell's mask allows -- what the
 //      neighbour held when the job loaded its halo.  Neighbours PULL: nothing is ever written into another tile.
-// Rounds of jobs are separated by a workgroup barrier and alternate between the two colours of a checkerboard over the
-// tiles, so the four edge neighbours of a tile never run in the same round (the halo a job loads is final for the
-// moment, and the wake test is not fooled by a neighbour advancing in parallel); an f-bucket is finished when no tile
-// of either colour is flagged.
-// Pages are handed out by the job that first changes a tile; every query owns a contiguous run of `cap` pages and a
-// tile -> page table (tmap), so the 2-4 % of the map a search visits sits in a few MiB of HBM, and the next launch on
-// the same pipeline stage resets exactly the pages that were handed out.  Page 0 is shared, never written and always
+// There are no rounds: a tile that was woken sits in the query's open list in LDS with a key (the lowest f its waker
+// offers it), free wavefronts take the tile with the lowest key, and an f-bucket is at its fixed point when every
+// wavefront of the workgroup is idle (TsaLocalSched below; round 2 ran red-black rounds separated by workgroup barriers).
+// Pages are handed out by the job that first changes a tile; every query slot owns a contiguous run of `cap` + 1 pages and
+// a tile -> page table (tmap), so the 2-4 % of the map a search visits sits in a few MiB of HBM, and the workgroup that
+// takes the slot next resets exactly the pages that were handed out.  Local page 0 of a slot is never written and always
 // "unreached": reads of tiles without a page go there.
-// Exactness: every update is a max over (KU - length) of real paths and the schedule runs every bucket to its fixed
-// point, so at termination g is exact for f <= f*, which is all the canonical backtrace reads (DESIGN.md "Grid A*
-// contract").  scripts/sim_dense2.c is a CPU model of exactly this schedule (checked against the oracle's cost and E).
-// The round-1/2 worklist-in-LDS kernel this replaces, and the measurements behind the switch: DESIGN.md 5.
+// Exactness: every update is a max over (KU - length) of real paths, every improvement that can matter to a neighbour
+// sets its wake-up bit after the data is visible, and a bucket only ends with nothing pending -- so at termination g is
+// exact for f <= f* whatever the order of the jobs, which is all the canonical backtrace reads (DESIGN.md "Grid A*
+// contract").  scripts/sim_async.c is a CPU model of exactly this schedule (checked against the oracle's cost and E).
+// How the kernel got here (the LDS worklist kernel of round 1, the dense sweeps and red-black rounds of round 2):
+// docs/history.md; the measurements of round 3: DESIGN.md 5.
 #include "engine.hpp"
 #include <algorithm>
 #include <cstring>
@@ -1060,11 +1061,11 @@ __device__ __forceinline__ void tsa_backtrace_wave(const TsaLaunch& A, const Tsa
   if (lane == 0) A.results[q] = rna_astar_result{0, len, r.cost, r.expanded, r.rounds, r.buckets};
 }
 
-// One workgroup of 8 wavefronts per query, four of them per CU.  The kernel ends with the exact distance field in HBM and a provisional
-// result; the path is traced by tsa_backtrace_kernel (one wavefront per query, next kernel on the stream).
+// One workgroup of 8 wavefronts per query, four of them per CU.  The workgroup first resets the pages the slot's previous
+// search used, then searches; its first wavefront traces the path at the end (tsa_backtrace_wave).
 // WAVES = wavefronts per workgroup (= per query): 8 when batches are pipelined (four queries share a CU, the throughput
-// configuration), 16 for a single batch on the engine's own stream (one workgroup per CU anyway: its latency is what
-// counts).
+// configuration), 16 for a single batch on the engine's own stream and for batches of <= 32 queries (latency is what
+// counts there).
 template <int WAVES, bool RETRY>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(RNA_TSA_WAVES_PER_EU, RNA_TSA_WAVES_PER_EU))) tsa_search_kernel(const TsaLaunch A) {
   constexpr int TSA_THREADS = WAVES * 64;

@@ -78,7 +78,7 @@ struct AstarDevice {
   void* tsa_aux_retry[MAX_DEPTH] = {};   // for the second pass over searches that outgrew their pages (astar_tile.hip)
   hipStream_t side[MAX_DEPTH] = {};
   hipEvent_t done[MAX_DEPTH] = {}; // search of the batch that last used this set has finished
-  hipEvent_t snap_done[MAX_DEPTH] = {};   // the stage's mask snapshot (taken on the stage's stream) has been taken
+  hipEvent_t snap_done[MAX_DEPTH] = {};   // the mask snapshot of the stage's batch (taken on the side stream) has been taken
   bool snap_pending[MAX_DEPTH] = {};
   bool busy[MAX_DEPTH] = {};
   unsigned long long stage_seq[MAX_DEPTH] = {};   // launch number of the stage's last batch (0: never used)
@@ -125,9 +125,9 @@ struct rna_engine {
   int device = 0;
   int cu_count = 256;              // compute units of the device (MI355X: 256 = 8 XCDs x 32)
   hipStream_t stream = nullptr;
-  // Side work: the pipelined replan loop runs the VFH+ step on a stream of its own and the mask snapshot of a search
-  // launch on the stage's stream, so that neither sits in the engine stream's chain of map-update kernels.  Both only
-  // READ the map (master layer / neighbour masks); whatever may WRITE what they read joins them first (RNA_ENTER).
+  // Side work: the pipelined replan loop runs the VFH+ step and the mask snapshot + launch order of a search batch on
+  // a stream of their own, so that neither sits in the engine stream's chain of map-update kernels.  Both only READ
+  // the map (master layer / neighbour masks); whatever may WRITE what they read joins them first (RNA_ENTER).
   hipStream_t vfh_stream = nullptr;
   hipEvent_t ev_vfh_go = nullptr, ev_vfh_done = nullptr;
   bool vfh_pending = false;
@@ -189,7 +189,7 @@ struct KernelTimer {
     b = take(e);
     if (a) (void)hipEventRecord(a, st);
   }
-  // mode 2: only what runs on a pipeline stage's own stream.  An event record is a barrier packet of its own: on the
+  // mode 2: only the search and the launch-order kernel (stage / side stream).  An event record is a barrier packet of its own: on the
   // engine stream, whose chain of short kernels gates the next batch, the brackets of ten kernel slots cost ~1 ms per pass
   bool wanted() const { return e->profiling == 1 || (e->profiling == 2 && (id == RNA_K_ASTAR_SEARCH || id == RNA_K_ASTAR_RESET)); }
   ~KernelTimer() {

@@ -1,7 +1,7 @@
 """CPU-only (hipcc cross-compiles): the resource budgets of the grid-A* search kernel.  The tile job keeps a 64 x 16
 tile in registers (2 x 16 rows) and is bound by what one wavefront can issue, so throughput comes from EIGHT wavefronts
 per SIMD -- four workgroups (queries) of 8 wavefronts per CU: the kernel has to fit 64 VGPRs, must not spill in the
-tile job, and four workgroups' LDS (scratch per wavefront, the 2048-entry open list, four tile bit sets) has to fit a CU
+tile job, and four workgroups' LDS (scratch per wavefront, the open list's 3072 nodes / 256 class heads / tables, four tile bit sets) has to fit a CU
 for the bench's map.  (astar.hip keeps 32 of the 256 CUs out of the search streams' CU mask for the engine stream's
 short kernels.  Measured when the kernel needed 116 VGPRs -- four wavefronts per SIMD: 22 k instead of 36 k cycles/s;
 with the job's lane constants spilled to scratch: 33 k.)  The path backtrace runs inside the search kernel since round 3
