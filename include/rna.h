@@ -245,13 +245,17 @@ typedef struct {
 int rna_astar_configure(rna_engine* e, int max_queries, int queue_capacity, int bucket_width);
 /* Pipelined batches: with depth d > 1 consecutive rna_astar_batch_device calls run their searches on d
  * rotating internal streams (each with its own search fields), so the tail of one batch overlaps
- * the next batch and the next map update.  Outputs of a call are valid after rna_synchronize(); the
- * caller must give calls that may be in flight together distinct output buffers.  Default 4; up to 16. */
+ * the next batch and the next map update.  Outputs of a call are valid after rna_synchronize() -- not after a
+ * bare hipDeviceSynchronize(): searches that ran out of their share of pages are searched again by a second launch
+ * the host issues when it sees their count, at the latest inside rna_synchronize().  The call returns after
+ * enqueueing; while every stage is busy it blocks until one is free.  The caller must give calls that may be in
+ * flight together distinct output buffers.  Default 4; up to 16. */
 int rna_astar_set_pipeline_depth(rna_engine* e, int depth);
 /* The tile kernel keeps a search's distance field in 4 KiB pages (64 x 16 cells) handed out on first touch.  By
  * default every query may take one page per tile of the map (it can never run out; HBM is only touched where a
  * search goes; half a map's worth when the pipeline stages would not fit HBM otherwise).  A smaller share per query makes room for more queries / pipeline stages in flight; a search that
- * needs more ends with status 5.  0 = default. */
+ * needs more is searched again on one of 8 full-size retry slots per stage; only when more than 8 searches of one
+ * batch need that do the others end with status 5.  0 = default. */
 int rna_astar_set_page_cap(rna_engine* e, int pages_per_query);
 /* What the first batch (or rna_astar_configure after a map is loaded) actually allocated: pipeline stages, pages per
  * query and concurrent queries may have been reduced to fit 75 % of the free HBM.  Any pointer may be NULL; all three
