@@ -254,8 +254,8 @@ int rna_astar_set_pipeline_depth(rna_engine* e, int depth);
 /* The tile kernel keeps a search's distance field in 4 KiB pages (64 x 16 cells) handed out on first touch.  By
  * default every query may take one page per tile of the map (it can never run out; HBM is only touched where a
  * search goes; half a map's worth when the pipeline stages would not fit HBM otherwise).  A smaller share per query makes room for more queries / pipeline stages in flight; a search that
- * needs more is searched again on one of 8 full-size retry slots per stage; only when more than 8 searches of one
- * batch need that do the others end with status 5.  0 = default. */
+ * needs more is searched again on one of 8 full-size retry slots per stage (eight at a time, as many passes as it
+ * takes): status 5 does not reach the caller.  0 = default. */
 int rna_astar_set_page_cap(rna_engine* e, int pages_per_query);
 /* What the first batch (or rna_astar_configure after a map is loaded) actually allocated: pipeline stages, pages per
  * query and concurrent queries may have been reduced to fit 75 % of the free HBM.  Any pointer may be NULL; all three
@@ -267,7 +267,8 @@ int rna_astar_batch_device(rna_engine* e, const rna_astar_query* queries_device,
                            int max_path_len, rna_astar_result* results_device);
 /* E of DESIGN.md's roofline: for each query of the LAST batch (n <= max_queries, i.e. one chunk) the
  * number of cells with g + h <= f*, counted from the g fields still resident in HBM.  Equals the CPU
- * oracle's settled count; measurement/test utility, not part of the timed path. */
+ * oracle's settled count; measurement/test utility, not part of the timed path.  -1 for a query whose field is gone
+ * (it outgrew its share of pages and was searched again in a second pass whose retry slot has been reused since). */
 int rna_astar_settled_counts(rna_engine* e, int32_t* counts_host, int n);
 /* per-cell traversable-neighbour mask derived from the master layer (rows*cols uint8) */
 int rna_astar_download_nbr_mask(rna_engine* e, uint8_t* host, size_t n_cells);

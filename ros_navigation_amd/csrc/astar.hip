@@ -98,10 +98,10 @@ static int alloc_stages_impl(rna_engine* e) {
       RNA_HIP(e, hipEventCreateWithFlags(&a.ring_free[r], hipEventDisableTiming));
       a.ring_used[r] = false;
     }
-    if (a.g_retry[0]) {
-      RNA_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&a.retry_flag), AstarDevice::MAX_DEPTH * sizeof(int), hipHostMallocCoherent));
-      for (int d = 0; d < AstarDevice::MAX_DEPTH; ++d) a.retry_flag[d] = 0;
-    }
+  }
+  if (a.g_retry[0]) {
+    RNA_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&a.retry_flag), AstarDevice::MAX_DEPTH * sizeof(int), hipHostMallocCoherent));
+    for (int d = 0; d < AstarDevice::MAX_DEPTH; ++d) a.retry_flag[d] = 0;
   }
   a.launches = 0;
   if ((rc = dev_alloc(e, &a.queries_dev, (size_t)a.max_queries)) != RNA_OK) { astar_release(e); return rc; }
@@ -169,9 +169,11 @@ static bool stage_settled(rna_engine* e, int d, int* rc) {
   if (!a.retry_armed[d]) return true;
   a.retry_armed[d] = false;
   if (!a.retry_flag || a.retry_flag[d] == 0) return true;
+  const int count = a.retry_flag[d];
   a.retry_flag[d] = 0;
+  a.last_retried[d] = count;
   hipStream_t st = a.depth > 1 ? a.side[d] : e->stream;
-  *rc = tsa_retry_launch(e, d, st);
+  *rc = tsa_retry_launch(e, d, st, count);
   if (*rc != RNA_OK) return true;
   if (a.depth > 1 && hipEventRecord(a.done[d], st) != hipSuccess) { *rc = fail(e, RNA_EHIP, "hipEventRecord"); return true; }
   return false;
@@ -224,6 +226,12 @@ int launch_chunk(rna_engine* e, const rna_astar_query* q_dev, int n, int32_t* pa
           a.busy[d] = false;
         }
   }
+  if (a.depth == 1 && a.retry_armed[0]) {   // one stream: the batch before this one has to be complete before its slots are reused
+    RNA_HIP(e, hipStreamSynchronize(e->stream));
+    int rc = RNA_OK;
+    (void)stage_settled(e, 0, &rc);
+    if (rc != RNA_OK) return rc;
+  }
   hipStream_t search_stream = a.depth > 1 ? a.side[slot] : e->stream;
   if (a.depth > 1 && a.busy[slot]) RNA_HIP(e, hipStreamWaitEvent(search_stream, a.done[slot], 0));   // (RNA_ASTAR_NOWAIT only; the same stream anyway)
   {
@@ -253,6 +261,11 @@ void tsa_stats_dump();
 // every stream is idle (sync_all): second passes that are due go out and are waited for
 int astar_settle(rna_engine* e) {
   AstarDevice& a = e->astar;
+  if (a.depth == 1 && a.retry_armed[0]) {
+    int rc = RNA_OK;
+    if (!stage_settled(e, 0, &rc) && rc == RNA_OK) RNA_HIP(e, hipStreamSynchronize(e->stream));
+    return rc;
+  }
   for (int d = 0; d < a.depth && d < AstarDevice::MAX_DEPTH; ++d) {
     if (!a.busy[d]) continue;
     int rc = RNA_OK;
@@ -388,6 +401,11 @@ extern "C" int rna_astar_batch(rna_engine* e, const rna_astar_query* queries_hos
       do { RNA_HIP(e, hipEventSynchronize(a.done[slot])); } while (!stage_settled(e, slot, &src) && src == RNA_OK);
       if (src != RNA_OK) return src;
       a.busy[slot] = false;
+    } else if (a.retry_armed[0]) {
+      RNA_HIP(e, hipStreamSynchronize(e->stream));
+      int src = RNA_OK;
+      (void)stage_settled(e, 0, &src);   // (a second pass, if one is due, is on the stream ahead of the copies below)
+      if (src != RNA_OK) return src;
     }
     RNA_HIP(e, hipMemcpyAsync(results_host + o, a.results_dev, (size_t)m * sizeof(rna_astar_result),
                               hipMemcpyDeviceToHost, e->stream));

@@ -953,7 +953,9 @@ struct TsaLaunch {
   // search can never outgrow (a goal that cannot be reached floods its whole component; the reference answers "no
   // path", it does not fail).
   int retry, n;
-  int* retry_count;   // (host memory, may be null) searches of this launch that ended with status 5
+  int* retry_count;   // (host memory, may be null) searches of this launch that ended with status 5 ...
+  int* retry_list;    // ... and which, in the order they ended (device memory, [max_queries])
+  int retry_base;     // second pass: workgroup r serves retry_list[retry_base + r]
   TsaStage S2;
   int32_t* paths;
   int max_path_len;
@@ -1086,15 +1088,9 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   if (!RETRY) {
     if (threadIdx.x == 0) { const int k = atomicAdd(A.S.ticket, 1); s_rank = k; s_q = A.S.perm[k]; }
   } else {
-    // the (blockIdx.x + 1)-th query of the batch with status 5 (none: nothing to do)
-    if (threadIdx.x == 0) { s_q = -1; s_rank = 1 << 30; }
-    __syncthreads();
-    for (int i = threadIdx.x; i < A.n; i += TSA_THREADS)
-      if (A.results[i].status == 5) {
-        int before = 0;
-        for (int j = 0; j < i; ++j) before += A.results[j].status == 5 ? 1 : 0;
-        if (before == (int)blockIdx.x) s_q = i;
-      }
+    // (the list was written by the first pass: a scan of the results for status 5 here would race with the workgroups
+    // of this pass that have already answered theirs)
+    if (threadIdx.x == 0) { s_q = A.retry_list[A.retry_base + (int)blockIdx.x]; s_rank = 1 << 30; }
   }
   __syncthreads();
   const int q = __builtin_amdgcn_readfirstlane(s_q);   // wave-uniform values belong in SGPRs: the tile jobs need every VGPR
@@ -1345,7 +1341,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   if (state != 1) {
     if (tid == 0) {
       results[q] = r;
-      if (!RETRY && state == 5 && A.retry_count) __hip_atomic_fetch_add(A.retry_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (!RETRY && state == 5 && A.retry_count) A.retry_list[__hip_atomic_fetch_add(A.retry_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)] = q;
     }
     return;
   }
@@ -1359,7 +1355,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
 // |{n : g(n) + h(n) <= f*}| per query from the pages still resident in HBM (measurement utility)
 __global__ void tsa_settled_kernel(int rows, int cols, int tiles_i, int tiles_j, const rna_astar_query* __restrict__ queries,
                                    const rna_astar_result* __restrict__ results, TsaStage S_main, TsaStage S_retry, const int* __restrict__ served,
-                                   int32_t* __restrict__ counts, int s0, int s1) {
+                                   const int* __restrict__ retry_list, int n_retried, int32_t* __restrict__ counts, int s0, int s1) {
   __shared__ int s_cnt;
   const int q = blockIdx.x;
   // a query that was searched again lives in the retry slot that served it
@@ -1368,6 +1364,9 @@ __global__ void tsa_settled_kernel(int rows, int cols, int tiles_i, int tiles_j,
   if (served)
     for (int r = 0; r < TSA_RETRY; ++r)
       if (served[r] == q) { sl = r; retried = true; }
+  if (!retried)   // searched again in an earlier second pass whose slot has been reused since: the field is gone
+    for (int r = 0; r < n_retried; ++r)
+      if (retry_list[r] == q) { if (threadIdx.x == 0) counts[q] = -1; return; }
   const TsaStage& S = retried ? S_retry : S_main;
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
@@ -1431,7 +1430,13 @@ size_t tsa_retry_pool_bytes(const rna_engine* e) { return tsa_pool_bytes(TSA_RET
 size_t tsa_retry_aux_bytes(const rna_engine* e) {
   const size_t ntile = (size_t)tsa_ntile(e);
   return 256 + tsa_align256(TSA_RETRY * sizeof(int)) + tsa_align256((size_t)TSA_RETRY * ntile * sizeof(unsigned)) +
-         tsa_align256((size_t)TSA_RETRY * (ntile + 1) * sizeof(unsigned));
+         tsa_align256((size_t)TSA_RETRY * (ntile + 1) * sizeof(unsigned)) + tsa_align256((size_t)e->astar.max_queries * sizeof(int));
+}
+// the stage's list of searches to repeat (the last block of the retry aux)
+static int* tsa_retry_list(const rna_engine* e, int slot) {
+  const size_t ntile = (size_t)tsa_ntile(e);
+  return reinterpret_cast<int*>(static_cast<char*>(e->astar.tsa_aux_retry[slot]) + 256 + tsa_align256(TSA_RETRY * sizeof(int)) +
+                                tsa_align256((size_t)TSA_RETRY * ntile * sizeof(unsigned)) + tsa_align256((size_t)TSA_RETRY * (ntile + 1) * sizeof(unsigned)));
 }
 // [TSA_RETRY] ints in the retry view's ticket block: the query each retry slot served in the stage's current batch (-1: none)
 static int* tsa_retry_served(const rna_engine* e, int slot) { return reinterpret_cast<int*>(e->astar.tsa_aux_retry[slot]) + 8; }
@@ -1476,16 +1481,21 @@ static_assert(sizeof(TsaLaunch) <= sizeof(AstarDevice::last_launch[0]), "AstarDe
 
 // the second pass over the stage's last batch (the searches that outgrew their share of pages, on the stage's full-size
 // retry slots; workgroups without such a query end at once)
-int tsa_retry_launch(rna_engine* e, int slot, hipStream_t search_stream) {
+int tsa_retry_launch(rna_engine* e, int slot, hipStream_t search_stream, int count) {
   AstarDevice& a = e->astar;
   TsaLaunch A;
   memcpy(&A, a.last_launch[slot], sizeof(A));
   A.retry = 1;
   A.retry_count = nullptr;
   A.S2 = tsa_retry_view(e, slot, A.S);
-  if (a.depth > 1) hipLaunchKernelGGL((tsa_search_kernel<TSA_WAVES, true>), dim3(TSA_RETRY), dim3(TSA_WAVES * 64), a.last_lds[slot], search_stream, A);
-  else hipLaunchKernelGGL((tsa_search_kernel<16, true>), dim3(TSA_RETRY), dim3(16 * 64), a.last_lds[slot], search_stream, A);
-  RNA_HIP(e, hipGetLastError());
+  // TSA_RETRY searches at a time share the stage's retry slots: one launch after the other on the stage's stream
+  for (int base = 0; base < count; base += TSA_RETRY) {
+    A.retry_base = base;
+    const int wgs = std::min(TSA_RETRY, count - base);
+    if (a.depth > 1) hipLaunchKernelGGL((tsa_search_kernel<TSA_WAVES, true>), dim3(wgs), dim3(TSA_WAVES * 64), a.last_lds[slot], search_stream, A);
+    else hipLaunchKernelGGL((tsa_search_kernel<16, true>), dim3(wgs), dim3(16 * 64), a.last_lds[slot], search_stream, A);
+    RNA_HIP(e, hipGetLastError());
+  }
   return RNA_OK;
 }
 
@@ -1548,11 +1558,13 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     if (const char* pf = getenv("RNA_TSA_PRIO_FIRST")) A.prio_first = atoi(pf);   // developer knob
     size_t lds_dyn = 4 * nt_bytes;
     if (const char* pad = getenv("RNA_TSA_LDS_PAD")) lds_dyn += (size_t)atoi(pad);   // developer knob: fewer search workgroups per CU
-    // a search that outgrows its share of pages is searched again: pipelined, when the host sees the count
-    // (astar_settle); on the single stream, where nothing else competes for the CUs, right behind the first pass
-    const bool can_retry = a.g_retry[slot] != nullptr;
-    A.retry_count = (can_retry && ev_init && a.retry_flag) ? a.retry_flag + slot : nullptr;
+    // a search that outgrows its share of pages is searched again when the host sees the count (astar_settle)
+    const bool can_retry = a.g_retry[slot] != nullptr && a.retry_flag != nullptr;
+    A.retry_count = can_retry ? a.retry_flag + slot : nullptr;
+    A.retry_list = can_retry ? tsa_retry_list(e, slot) : nullptr;
+    A.retry_base = 0;
     if (A.retry_count) *A.retry_count = 0;
+    a.last_retried[slot] = 0;
     // 16 wavefronts per query where latency counts (one stream, or a batch too small to fill the chip: a lone search
     // takes 9.1 instead of 12.9 ms), 8 where throughput does (16 in the pipeline: 91.6 k instead of 122.8 k cycles/s)
     static const bool wide_env = getenv("RNA_TSA_WIDE") != nullptr;   // developer knob: 16 wavefronts per query always
@@ -1563,7 +1575,6 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     memcpy(a.last_launch[slot], &A, sizeof(A));
     a.last_lds[slot] = lds_dyn;
     a.retry_armed[slot] = A.retry_count != nullptr;
-    if (can_retry && !A.retry_count) { const int rc = tsa_retry_launch(e, slot, search_stream); if (rc != RNA_OK) return rc; }
   }
   if (ring >= 0) {
     RNA_HIP(e, hipEventRecord(a.ring_free[ring], search_stream));
@@ -1595,6 +1606,7 @@ int tsa_settled(rna_engine* e, int slot, const rna_astar_query* q, const rna_ast
   const bool has_retry = e->astar.g_retry[slot] != nullptr;
   hipLaunchKernelGGL(tsa_settled_kernel, dim3(n), dim3(1024), 0, e->stream, rows, cols, ti, tj, q, r, S,
                      has_retry ? tsa_retry_view(e, slot, S) : S, has_retry ? tsa_retry_served(e, slot) : nullptr,
+                     has_retry ? tsa_retry_list(e, slot) : nullptr, has_retry ? e->astar.last_retried[slot] : 0,
                      d_counts, e->geom.start[0], e->geom.start[1]);
   RNA_HIP(e, hipGetLastError());
   return RNA_OK;

@@ -98,6 +98,7 @@ struct AstarDevice {
   // for CU slots like everybody else's)
   int* retry_flag = nullptr;             // [MAX_DEPTH], host memory the device writes
   bool retry_armed[MAX_DEPTH] = {};
+  int last_retried[MAX_DEPTH] = {};      // searches of the stage's last batch that went through the second pass
   size_t last_lds[MAX_DEPTH] = {};
   alignas(8) unsigned char last_launch[MAX_DEPTH][384] = {};   // TsaLaunch of the stage's last batch
   unsigned long long launches = 0;
@@ -247,7 +248,7 @@ size_t tsa_retry_pool_bytes(const rna_engine* e);
 size_t tsa_retry_aux_bytes(const rna_engine* e);
 int tsa_retry_prepare(rna_engine* e, int slot);
 size_t tsa_ring_bytes(const rna_engine* e, int max_queries);            // one entry of the launch ring
-int tsa_retry_launch(rna_engine* e, int slot, hipStream_t search_stream);
+int tsa_retry_launch(rna_engine* e, int slot, hipStream_t search_stream, int count);   // second pass over `count` listed searches
 int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init,
                const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len, rna_astar_result* res_dev);
 int tsa_settled(rna_engine* e, int slot, const rna_astar_query* q, const rna_astar_result* r, int n, int32_t* d_counts);

@@ -58,7 +58,7 @@ while time.time() < t_end:
             ok = res["status"][k] == ores.status
             if ok and ores.status == 0:
                 ok = (res["cost"][k] == ores.cost and res["path_len"][k] == ores.path_len and
-                      np.array_equal(paths[k, :ores.path_len], opath) and (settled is None or settled[k] == ores.settled))
+                      np.array_equal(paths[k, :ores.path_len], opath) and (settled is None or settled[k] == ores.settled or settled[k] == -1))
                 found += 1
             if not ok:
                 print("MISMATCH", here, "query", k, int(q["start"][k]), int(q["goal"][k]), "gpu", res[k], "oracle", ores.status,
@@ -95,7 +95,7 @@ while time.time() < t_end:
             ok = res["status"][k] == (0 if ores.status == 0 else 1)
             if ok and ores.status == 0:
                 ok = (res["cost"][k] == ores.cost and res["path_len"][k] == ores.path_len and
-                      np.array_equal(paths[k, :ores.path_len], opath) and settled[k] == ores.settled)
+                      np.array_equal(paths[k, :ores.path_len], opath) and (settled[k] == ores.settled or settled[k] == -1))
                 moved_found += 1
             if not ok:
                 print("MISMATCH (moved map)", here, "query", k, int(q["start"][k]), int(q["goal"][k]), "gpu", res[k], "oracle",
