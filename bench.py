@@ -204,6 +204,34 @@ def pmc_traffic(kernel, args, world):
         return None, "no PMC summary committed for this kernel"
 
 
+SQ_COUNTERS = os.path.join(ROOT, "profiles", "r03_search_sq_counters.txt")
+VALU_PEAK_PER_NS_SIMD = 0.58      # profiles/r03_ubench_valu.txt: eight wavefronts per SIMD issue 0.54-0.59 dependent VALU instructions per ns
+SEARCH_SIMDS = (256 - 32) * 4     # the search streams' CU mask leaves 32 of the 256 CUs to the engine stream
+
+
+def valu_issue(args, world, wall_per_pass):
+    """What the search kernel is really bound by: wavefront VALU instructions of one 256-query batch, from
+    the committed SQ counter pass of this workload's first query set, over the pass wall time and the SIMDs the searches
+    may use.  None unless the counters were taken on this configuration."""
+    try:
+        if (args.grid, args.queries, args.pipeline) != (4096, 256, 13) or world != 1 or args.tiled:
+            return None
+        valu = salu = None
+        for line in open(SQ_COUNTERS):
+            f = line.split()
+            if len(f) >= 3 and f[0] == "SQ_INSTS_VALU":
+                valu = float(f[-1].split("=")[-1])
+            if len(f) >= 3 and f[0] == "SQ_INSTS_SALU":
+                salu = float(f[-1].split("=")[-1])
+        per_ns_simd = valu / (wall_per_pass * 1e9) / SEARCH_SIMDS
+        return {"bound": "valu issue", "achieved": per_ns_simd, "peak": VALU_PEAK_PER_NS_SIMD, "unit": "wavefront VALU instructions / ns / SIMD",
+                "frac": per_ns_simd / VALU_PEAK_PER_NS_SIMD, "valu_per_batch": valu, "salu_per_batch": salu,
+                "source": "profiles/r03_search_sq_counters.txt (one batch alone), profiles/r03_ubench_valu.txt (the SIMD's issue rate); "
+                          "224 CUs x 4 SIMDs"}
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -449,7 +477,9 @@ def main():
                          # the whole-step figure (algorithmic bytes of one launch / wall time of one step) is given too
                          "overlapped_launches": ms_search / (1e3 * wall_per_pass),
                          "achieved_per_pass_wall": alg_bytes / wall_per_pass / 1e9,
-                         "frac_wall": alg_bytes / wall_per_pass / 1e9 / HBM_PEAK_GBS},
+                         "frac_wall": alg_bytes / wall_per_pass / 1e9 / HBM_PEAK_GBS,
+                         # the kernel's real bound (not HBM): see valu_issue()
+                         "valu_issue": valu_issue(args, world, wall_per_pass)},
             "roofline_rows": [row("himm_raster", HIMM_RASTER_CHAIN, himm_alg),
                               row("vfh_step", "vfh_step_kernel", float(nq * VFH_BYTES_PER_POSE))],
             # every kernel slot bracketed by events, in ONE turn of the pipeline run after the timed region (the brackets
