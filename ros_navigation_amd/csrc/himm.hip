@@ -144,19 +144,40 @@ __device__ void sift_down(int* a, int start, int end) {
   }
 }
 
-__global__ void himm_collect_kernel(HimmSlot* __restrict__ slots, int n_slots, const int* __restrict__ next,
+__global__ void __launch_bounds__(1024) himm_collect_kernel(HimmSlot* __restrict__ slots, int n_slots, const int* __restrict__ next,
                                     int* __restrict__ seqs, unsigned* __restrict__ before,
                                     unsigned* __restrict__ after, int* __restrict__ total) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= n_slots) return;
-  HimmSlot sl = slots[h];
-  if (sl.cell < 0) return;
-  const int off = atomicAdd(total, sl.len);
+  HimmSlot sl = h < n_slots ? slots[h] : HimmSlot{-1, -1, 0, 0};
+  const bool live = sl.cell >= 0;
+  // One atomic per WORKGROUP on the shared running total: returning atomics on one L2 address take ~12 ns each, and the
+  // compiler's one-per-wavefront aggregation still left 4096 of them -- 49 of the kernel's 51 us.
+  int off = 0;
+  {
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int wv = threadIdx.x >> 6, nwv = (blockDim.x + 63) >> 6;
+    int incl = live ? sl.len : 0;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int run = 0;
+      for (int w = 0; w < nwv; ++w) { const int t = s_wave[w]; s_wave[w] = run; run += t; }
+      s_base = run > 0 ? atomicAdd(total, run) : 0;
+    }
+    __syncthreads();
+    off = s_base + s_wave[wv] + incl - (live ? sl.len : 0);
+  }
+  if (!live) return;
   slots[h].offset = off;
+
   int* a = seqs + off;
   int k = 0;
   for (int r = sl.head; r >= 0; r = next[r]) a[k++] = r;
   const int len = k;
+
   if (len <= 24) {  // insertion sort
     for (int i = 1; i < len; ++i) {
       const int v = a[i];
@@ -471,7 +492,8 @@ __global__ void himm_apply_kernel(int rows, HimmSlot* __restrict__ slots, int n_
   slots[h] = HimmSlot{-1, -1, 0, 0};                               // ... and the hash table empty for the next batch
   const int i = sl.cell % rows, j = sl.cell / rows;
   const int tile = (j >> 6) * tiles_i + (i >> 6);
-  if (dirty_tiles) reinterpret_cast<volatile unsigned char*>(dirty_tiles)[tile] = 1;
+  // (most of the ~50 marked cells of a tile find the flag set already: a cached read instead of a store each)
+  if (dirty_tiles && reinterpret_cast<volatile unsigned char*>(dirty_tiles)[tile] != 1) reinterpret_cast<volatile unsigned char*>(dirty_tiles)[tile] = 1;
 }
 
 int ensure_scratch(rna_engine* e, int n) {
@@ -526,7 +548,7 @@ int himm_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n) {
     // (the hash table is empty and *total is 0: himm_apply leaves them so, ensure_scratch starts them so)
     hipLaunchKernelGGL(himm_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, g, rays_dev, n, s.desc,
                        s.ncells, s.next, s.slots, n_slots - 1, s.mark_bitmap, win);
-    hipLaunchKernelGGL(himm_collect_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, e->stream, s.slots, n_slots,
+    hipLaunchKernelGGL(himm_collect_kernel, dim3((n_slots + 1023) / 1024), dim3(1024), 0, e->stream, s.slots, n_slots,
                        s.next, s.seqs, s.before, s.after, s.total);
     RNA_HIP(e, hipGetLastError());
   }
