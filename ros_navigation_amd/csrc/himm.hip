@@ -355,9 +355,12 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
   __shared__ unsigned s_mcnt[2 * HIMM_MTAB];   // ... clears before / after that mark
   __shared__ int s_touched, s_job;
   const int njobs = 2 * *n_active;
-  for (;;) {   // (tile, half) jobs by ticket
+  bool first_job = true;
+  for (;;) {   // (tile, half) jobs by ticket; the first one is the workgroup's own index (a thousand workgroups asking
+               // for a ticket at once queue up on one L2 address for ~12 ns each)
   __syncthreads();   // the previous job's LDS has been read
-  if (threadIdx.x == 0) s_job = atomicAdd(ticket, 1);
+  if (threadIdx.x == 0) s_job = first_job ? (int)blockIdx.x : (int)gridDim.x + atomicAdd(ticket, 1);
+  first_job = false;
   __syncthreads();
   const int job = s_job;
   if (job >= njobs) break;
