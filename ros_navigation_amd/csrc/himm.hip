@@ -569,7 +569,8 @@ int himm_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n) {
     hipLaunchKernelGGL(himm_bin_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, s.desc, s.ncells, n, e->tiles_i, off,
                        cursor, s.pairs);
     // (tile, half) jobs are taken by ticket: as many workgroups as can be resident and useful, not one per half tile
-    const int raster_wgs = std::min(2 * ntile, std::max(256, 4 * e->cu_count));
+    int raster_wgs = std::min(2 * ntile, std::max(256, 4 * e->cu_count));
+    if (const char* w = getenv("RNA_HIMM_RASTER_WGS")) raster_wgs = std::max(1, std::min(2 * ntile, atoi(w)));   // developer knob
     hipLaunchKernelGGL(himm_tile_raster_kernel, dim3(raster_wgs), dim3(HIMM_TR_THREADS), 0, e->stream, g.size[0], g.size[1], e->tiles_i, s.desc,
                        s.ncells, off, s.pairs, active, n_active, ticket, e->layer[layer], s.mark_bitmap, s.slots, n_slots - 1, s.seqs, s.before,
                        s.after, layer == RNA_LAYER_LASER ? e->dirty_tiles : nullptr, win);
