@@ -455,10 +455,14 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     }
     unsigned planted = 0u;
     if (t == C.ts) {   // the start cell: g = 0, whatever its mask says (a blocked start still answers start == goal)
-#define TSA_PLANT(b)                                                         \
-  if ((b) == C.sb && __builtin_amdgcn_readlane(TSA_G(b), C.sa) != KU) {      \
-    TSA_G(b) = lane == C.sa ? KU : TSA_G(b);                                 \
-    planted = 1u << (b);                                                     \
+      // (the row as a one-bit set tested with a shift: compared as `b == C.sb` the sixteen conditions were hoisted out of
+      // the job loop as sixteen lane masks, 32 spilled SGPRs)
+      unsigned srow = 1u << C.sb;
+      asm volatile("" : "+s"(srow));
+#define TSA_PLANT(b)                                                                        \
+  if (((srow >> (b)) & 1u) && __builtin_amdgcn_readlane(TSA_G(b), C.sa) != KU) {            \
+    TSA_G(b) = lane == C.sa ? KU : TSA_G(b);                                                \
+    planted = 1u << (b);                                                                    \
   }
       TSA_R16(TSA_PLANT)
 #undef TSA_PLANT
@@ -646,10 +650,10 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     }
     if (ovfm && lane == 0) sch.overflow();   // path costs beyond 2^30 - 5656: the search is abandoned (status 4)
     if (t == C.tg) {
-      unsigned rowchg_g = rowchg;
+      unsigned rowchg_g = rowchg & (1u << C.gb);   // (the goal's row, if it changed: see srow above)
       asm volatile("" : "+s"(rowchg_g));
 #define TSA_GOAL(b)                                                                               \
-  if ((b) == C.gb && ((rowchg_g >> (b)) & 1u)) {                                                    \
+  if ((rowchg_g >> (b)) & 1u) {                                                    \
     const int u = __builtin_amdgcn_readlane(TSA_G(b), C.ga); /* C.ga is wave-uniform */           \
     if (u != 0 && lane == 0) sch.improve_best(KU - u);                                            \
   }
