@@ -38,7 +38,7 @@ RosSeams::RosSeams(ros::NodeHandle& nh, MapProvider& mapProvider, Steerer* steer
       cmd.angular.z = ang;
       velPublisher_.publish(cmd);
     });
-    steerer_->setHistSink([this](const Histogram& h) {           // Steerer::pubHist (steerer.cpp:201-220)
+    steerer_->setHistSink([this](const core::Histogram& h) {           // Steerer::pubHist (steerer.cpp:201-220)
       move_control::Histogram msg;
       msg.num_bin = h.num_bin;
       msg.xData = h.xData;

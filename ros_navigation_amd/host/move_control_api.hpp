@@ -37,7 +37,9 @@ using grid_map::GridMap;
 using grid_map::Index;
 using grid_map::Length;
 using grid_map::Position;
-using core::Histogram;
+#if !__has_include(<move_control/Histogram.h>)
+using core::Histogram;   // (under catkin `move_control::Histogram` is the generated message: the API below says core::Histogram)
+#endif
 using core::OccupancyGrid;
 using core::RangeSample;
 typedef core::RrtPlanner RrtPlanner;            // rrt_planner.h:17-28: the signature is the reference's already
@@ -149,11 +151,12 @@ class VFH {
       int max_turnrate_0ms, int max_turnrate_1ms, double min_turn_radius_safety_factor, double free_space_cutoff_0ms,
       double obs_cutoff_0ms, double free_space_cutoff_1ms, double obs_cutoff_1ms, double weight_desired_dir,
       double weight_current_dir)
-      : core_(cell_size, window_diameter, sector_angle, safety_dist_0ms, safety_dist_1ms, max_speed, max_speed_narrow_opening,
+      : Hist(nullptr), OriginHist(nullptr),
+        core_(cell_size, window_diameter, sector_angle, safety_dist_0ms, safety_dist_1ms, max_speed, max_speed_narrow_opening,
               max_speed_wide_opening, max_acceleration, min_turnrate, max_turnrate_0ms, max_turnrate_1ms,
               min_turn_radius_safety_factor, free_space_cutoff_0ms, obs_cutoff_0ms, free_space_cutoff_1ms, obs_cutoff_1ms,
               weight_desired_dir, weight_current_dir),
-        Hist(nullptr), OriginHist(nullptr), haveLast_(false), sectorAngle_(sector_angle) {}
+        haveLast_(false), sectorAngle_(sector_angle) {}
   ~VFH() {}
   int Init() {
     own_.setGeometry(Length(1.0, 1.0), 0.05);
@@ -201,7 +204,7 @@ class Steerer {
  public:
   typedef std::function<bool(double& linear_x)> OdomSource;                         // nav_msgs/Odometry twist.twist.linear.x
   typedef std::function<void(double linear_x, double angular_z)> VelocitySink;      // geometry_msgs/Twist of pubVel
-  typedef std::function<void(const Histogram&)> HistSink;                           // move_control/Histogram of pubHist
+  typedef std::function<void(const core::Histogram&)> HistSink;                           // move_control/Histogram of pubHist
 
   Steerer(ros::NodeHandle& nh, MapProvider& mapProvider) : nh_(nh), mapProvider_(mapProvider), lastOdom_(0.0) {
     initVfh();
@@ -231,7 +234,7 @@ class Steerer {
     if (chosenSpeed) *chosenSpeed = speed;
     if (chosenTurnrate) *chosenTurnrate = turnrate;
     if (velSink_) velSink_(lin, ang);
-    if (histSink_) { Histogram h; vfhP_->core().pubHist(h); histSink_(h); }
+    if (histSink_) { core::Histogram h; vfhP_->core().pubHist(h); histSink_(h); }
     return true;
   }
   bool ifPlanReady() const { return steer_->ifPlanReady(); }

@@ -49,6 +49,19 @@ def test_ros_seams_rate_keeping_without_ros():
     assert out.returncode == 0 and "rate loop ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_ros_sources_compile_against_api_shaped_ros_headers():
+    """This image has no ROS, so ros/*.cpp would never meet a compiler: tests/cpp/ros_stub/ holds declarations shaped like
+    the roscpp / tf / message headers they use (nothing else), and g++ -fsyntax-only type-checks the seams and the three
+    node mains against them AND against move_control_api.hpp -- that is how the clash between the generated
+    `move_control::Histogram` message and the API's own struct of that name was found."""
+    stub = os.path.join(ROOT, "tests", "cpp", "ros_stub")
+    for src in ("ros_seams.cpp", "nav_graph_node_amd.cpp", "nav_node_amd.cpp", "nav_only_vfh_node_amd.cpp"):
+        out = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + stub, "-I" + os.path.join(ROOT, "include"),
+                              "-I" + os.path.join(ROOT, "ros_navigation_amd", "host"), "-I" + os.path.join(ROOT, "ros"),
+                              os.path.join(ROOT, "ros", src)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (src, out.stderr[-3000:])
+
+
 def test_ros_sources_are_guarded_and_name_the_reference_topics():
     """The ROS nodes cannot be built here (no ROS in this image): what can be checked is that every ROS source compiles to
     nothing without <ros/ros.h> (seams) or refuses loudly (node mains), and that topics, frames and rates are the reference's."""
