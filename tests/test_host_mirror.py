@@ -62,6 +62,22 @@ def test_ros_sources_compile_against_api_shaped_ros_headers():
         assert out.returncode == 0, (src, out.stderr[-3000:])
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/move_control/src"), reason="the reference tree is only present in the build container")
+def test_the_references_own_node_mains_compile_unchanged_against_the_api():
+    """The drop-in claim at source level: move_control's three node mains (nav_graph_node.cpp, nav_node.cpp,
+    nav_only_vfh_node.cpp), read where they lie and NOT modified, type-check against move_control_api.hpp through the
+    forwarding headers in ros_navigation_amd/host/compat (the reference's header names and using-directives) and the
+    API-shaped ROS headers of tests/cpp/ros_stub -- constructors, members and every call they make exist with the
+    signatures they use."""
+    stub = os.path.join(ROOT, "tests", "cpp", "ros_stub")
+    host = os.path.join(ROOT, "ros_navigation_amd", "host")
+    for src in ("nav_graph_node.cpp", "nav_node.cpp", "nav_only_vfh_node.cpp"):
+        out = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + stub, "-I" + os.path.join(ROOT, "include"), "-I" + host,
+                              "-I" + os.path.join(host, "compat"), os.path.join("/root/reference/move_control/src", src)],
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (src, out.stderr[-3000:])
+
+
 def test_ros_sources_are_guarded_and_name_the_reference_topics():
     """The ROS nodes cannot be built here (no ROS in this image): what can be checked is that every ROS source compiles to
     nothing without <ros/ros.h> (seams) or refuses loudly (node mains), and that topics, frames and rates are the reference's."""
