@@ -27,33 +27,62 @@ RosSeams::RosSeams(ros::NodeHandle& nh, MapProvider& mapProvider, Steerer* steer
   addRangeTopic("/front_right_range");
   addRangeTopic("/front_range");
   addLaserTopic("/laser_scan");
-  if (steerer_) {
-    odomSub_ = nh_.subscribe<nav_msgs::Odometry>("/odom", 1, &RosSeams::odomCb, this);
-    velPublisher_ = nh_.advertise<geometry_msgs::Twist>("/mobile_base/commands/velocity", 5);
-    histPublisher_ = nh_.advertise<move_control::Histogram>("hist", 5);
-    steerer_->setOdomSource([this](double& v) { return odomLinearX_.get(v); });
-    steerer_->setVelocitySink([this](double lin, double ang) {   // Steerer::pubVel (steerer.cpp:193-199)
-      geometry_msgs::Twist cmd;
-      cmd.linear.x = lin;
-      cmd.angular.z = ang;
-      velPublisher_.publish(cmd);
-    });
-    steerer_->setHistSink([this](const core::Histogram& h) {           // Steerer::pubHist (steerer.cpp:201-220)
-      move_control::Histogram msg;
-      msg.num_bin = h.num_bin;
-      msg.xData = h.xData;
-      msg.yData = h.yData;
-      msg.yBinData = h.yBinData;
-      msg.yLowThreshold = h.yLowThreshold;
-      msg.yHighThreshold = h.yHighThreshold;
-      histPublisher_.publish(msg);
-    });
+  if (steerer_) wireSteerer();
+}
+
+void RosSeams::wireSteerer() {
+  odomSub_ = nh_.subscribe<nav_msgs::Odometry>("/odom", 1, &RosSeams::odomCb, this);
+  velPublisher_ = nh_.advertise<geometry_msgs::Twist>("/mobile_base/commands/velocity", 5);
+  histPublisher_ = nh_.advertise<move_control::Histogram>("hist", 5);
+  steerer_->setOdomSource([this](double& v) { return odomLinearX_.get(v); });
+  steerer_->setVelocitySink([this](double lin, double ang) {   // Steerer::pubVel (steerer.cpp:193-199)
+    geometry_msgs::Twist cmd;
+    cmd.linear.x = lin;
+    cmd.angular.z = ang;
+    velPublisher_.publish(cmd);
+  });
+  steerer_->setHistSink([this](const core::Histogram& h) {     // Steerer::pubHist (steerer.cpp:201-220)
+    move_control::Histogram msg;
+    msg.num_bin = h.num_bin;
+    msg.xData = h.xData;
+    msg.yData = h.yData;
+    msg.yBinData = h.yBinData;
+    msg.yLowThreshold = h.yLowThreshold;
+    msg.yHighThreshold = h.yHighThreshold;
+    histPublisher_.publish(msg);
+  });
+}
+
+// a Steerer constructed after the seams (move_control's own node mains, -DRNA_ROS_AUTOWIRE): wire it, and if the map
+// loops run already start its 5 Hz loop as Steerer's constructor does in the reference (steerer.cpp:35-44)
+void RosSeams::attachSteerer(Steerer& s) {
+  steerer_ = &s;
+  wireSteerer();
+  if (started_ && !vfhLoop_) {
+    const RateLoop::Ok ok = [this] { return nh_.ok(); };
+    vfhLoop_.reset(new RateLoop(5.0, [this] { steerer_->spinOnce(); }, ok, rosNow, rosSleep));   // steerer.cpp:137
+    vfhLoop_->start();
   }
 }
+
+void RosSeams::detachSteerer() {
+  if (vfhLoop_) { vfhLoop_->stop(); vfhLoop_.reset(); }
+  steerer_ = nullptr;
+}
+
+namespace detail {
+// see move_control_api.hpp: what MapProvider's constructor calls when the node was compiled with -DRNA_ROS_AUTOWIRE
+std::shared_ptr<RosWiring> rosAutowire(ros::NodeHandle& nh, MapProvider& mapProvider) {
+  std::shared_ptr<RosSeams> seams(new RosSeams(nh, mapProvider, nullptr));
+  seams->start();
+  return seams;
+}
+}  // namespace detail
 
 RosSeams::~RosSeams() { stop(); }
 
 void RosSeams::start() {
+  started_ = true;
   const RateLoop::Ok ok = [this] { return nh_.ok(); };
   updateLoop_.reset(new RateLoop(mapProvider_.updateRate(), [this] { mapProvider_.spinUpdateOnce(); }, ok, rosNow, rosSleep));
   updateLoop_->start();

@@ -42,14 +42,17 @@
 
 namespace move_control {
 
-class RosSeams {
+class RosSeams : public detail::RosWiring {
  public:
-  // steerer may be null (a node that only maps)
+  // steerer may be null (a node that only maps, or a Steerer attached later)
   RosSeams(ros::NodeHandle& nh, MapProvider& mapProvider, Steerer* steerer);
   ~RosSeams();
   // the reference starts its threads in the constructors of MapProvider / Steerer; here the node does, once it is wired
+  // (or rosAutowire() / attachSteerer() do, for move_control's own node mains built with -DRNA_ROS_AUTOWIRE)
   void start();
   void stop();
+  void attachSteerer(Steerer& s) override;
+  void detachSteerer() override;
   tf::TransformListener& tf() { return tf_; }
 
  private:
@@ -61,6 +64,8 @@ class RosSeams {
   void publishGrid(const char* topic, const OccupancyGrid& grid);
   void addLaserTopic(const std::string& topic);
   void addRangeTopic(const std::string& topic);
+  void wireSteerer();
+  bool started_ = false;
 
   ros::NodeHandle& nh_;
   MapProvider& mapProvider_;

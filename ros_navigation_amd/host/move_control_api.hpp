@@ -46,6 +46,24 @@ typedef core::RrtPlanner RrtPlanner;            // rrt_planner.h:17-28: the sign
 typedef core::GridAStarPlanner GridAStarPlanner;
 using core::taileredPlan;
 
+class MapProvider;
+class Steerer;
+namespace detail {
+// What the reference's MapProvider / Steerer constructors do through ROS (subscriptions, publishers, tf, their three
+// threads) lives in ros/ros_seams.cpp.  A node either wires it itself (ros/*_amd.cpp: `RosSeams seams(nh, mapProvider,
+// &steerer); seams.start();`) or -- to run move_control's OWN node mains unchanged -- is compiled with
+// -DRNA_ROS_AUTOWIRE and linked with rna_ros_seams: the constructors below then call rosAutowire(), which creates the
+// seams, wires them and starts the loops, as the reference's constructors do.
+struct RosWiring {
+  virtual ~RosWiring() {}
+  virtual void attachSteerer(Steerer& s) = 0;   // odometry, velocity / hist publishers, the 5 Hz VFH loop
+  virtual void detachSteerer() = 0;             // (the Steerer is going away: its loop stops first)
+};
+#if defined(RNA_ROS_AUTOWIRE)
+std::shared_ptr<RosWiring> rosAutowire(ros::NodeHandle& nh, MapProvider& mapProvider);   // ros/ros_seams.cpp
+#endif
+}  // namespace detail
+
 class MapProvider {
  public:
   typedef std::function<bool(Position&, double&)> PoseSource;                       // tf: position and yaw of base_link in odom
@@ -55,8 +73,12 @@ class MapProvider {
       : nh_(nh), core_(mapLength, 0.05 /* initParameter: resolution_ */), ifMovingWithRobot_(ifMoving),
         updateRate_(5), publishRate_(1), moveMapRate_(2), cyclesSincePublish_(0) {
     core_.getMap().setFrameId("odom");   // initParameter / initMap (map_provider.cpp:130-149): centre (0, 0), frame odom
+#if defined(RNA_ROS_AUTOWIRE)
+    wiring_ = detail::rosAutowire(nh, *this);   // (last: everything the loops touch exists)
+#endif
   }
-  ~MapProvider() {}
+  ~MapProvider() { wiring_.reset(); }            // the loops stop before the map goes
+  detail::RosWiring* rosWiring() { return wiring_.get(); }
 
   bool getRobotPos(Position& pos) { double a; return getRobotPos(pos, a); }
   bool getRobotPos(Position& pos, double& orientAngle) {   // map_provider.cpp:151-175 (false when tf has no transform)
@@ -139,6 +161,7 @@ class MapProvider {
   unsigned cyclesSincePublish_;
   PoseSource poseSource_;
   MapSink mapSink_;
+  std::shared_ptr<detail::RosWiring> wiring_;
 };
 
 // VFH with the reference's constructor, Init() and 7-argument Update_VFH (vfh.h:185-253).  The instance owns a small
@@ -209,8 +232,9 @@ class Steerer {
   Steerer(ros::NodeHandle& nh, MapProvider& mapProvider) : nh_(nh), mapProvider_(mapProvider), lastOdom_(0.0) {
     initVfh();
     steer_.reset(new core::Steerer(mapProvider_.core(), vfhP_->core()));
+    if (detail::RosWiring* w = mapProvider_.rosWiring()) w->attachSteerer(*this);   // (-DRNA_ROS_AUTOWIRE only)
   }
-  ~Steerer() {}
+  ~Steerer() { if (detail::RosWiring* w = mapProvider_.rosWiring()) w->detachSteerer(); }
   void acceptPlan(std::vector<Position>& plan) {   // steerer.cpp:27-33
     std::lock_guard<std::mutex> lock(planMutex_);
     steer_->acceptPlan(plan);

@@ -72,10 +72,11 @@ def test_the_references_own_node_mains_compile_unchanged_against_the_api():
     stub = os.path.join(ROOT, "tests", "cpp", "ros_stub")
     host = os.path.join(ROOT, "ros_navigation_amd", "host")
     for src in ("nav_graph_node.cpp", "nav_node.cpp", "nav_only_vfh_node.cpp"):
-        out = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + stub, "-I" + os.path.join(ROOT, "include"), "-I" + host,
-                              "-I" + os.path.join(host, "compat"), os.path.join("/root/reference/move_control/src", src)],
-                             capture_output=True, text=True, timeout=300)
-        assert out.returncode == 0, (src, out.stderr[-3000:])
+        for extra in ([], ["-DRNA_ROS_AUTOWIRE"]):   # (the second: the constructors wire themselves to ROS and start their loops, ros/ros_seams.cpp)
+            out = subprocess.run(["g++", "-std=c++17", "-fsyntax-only"] + extra + ["-I" + stub, "-I" + os.path.join(ROOT, "include"), "-I" + host,
+                                  "-I" + os.path.join(host, "compat"), os.path.join("/root/reference/move_control/src", src)],
+                                 capture_output=True, text=True, timeout=300)
+            assert out.returncode == 0, (src, extra, out.stderr[-3000:])
 
 
 def test_ros_sources_are_guarded_and_name_the_reference_topics():
