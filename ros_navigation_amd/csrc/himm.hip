@@ -551,7 +551,7 @@ int himm_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n) {
     // (the hash table is empty and *total is 0: himm_apply leaves them so, ensure_scratch starts them so)
     hipLaunchKernelGGL(himm_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, g, rays_dev, n, s.desc,
                        s.ncells, s.next, s.slots, n_slots - 1, s.mark_bitmap, win);
-    hipLaunchKernelGGL(himm_collect_kernel, dim3((n_slots + 1023) / 1024), dim3(1024), 0, e->stream, s.slots, n_slots,
+    hipLaunchKernelGGL(himm_collect_kernel, dim3((n_slots + 511) / 512), dim3(512), 0, e->stream, s.slots, n_slots,
                        s.next, s.seqs, s.before, s.after, s.total);
     RNA_HIP(e, hipGetLastError());
   }
