@@ -1214,7 +1214,8 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
       int t = -1;
       bool first = false;
       // ---- 1. a tile of the open set (runs as "first") ----
-      if (!open_blocked && lds_ldi(&s_open_left) > 0) {
+      const int open_left = lds_ldi(&s_open_left);   // (a hint: read once per turn)
+      if (!open_blocked && open_left > 0) {
         const int pos = lds_ldi(&s_open_pos);
         const unsigned w = pos + lane < nt_words ? lds_ld(&s_open[pos + lane]) : 0u;
         const unsigned long long nz = __builtin_amdgcn_ballot_w64(w != 0u);
@@ -1253,7 +1254,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
         open_blocked = false;
         const unsigned e = sch.pop(lane, &spare);
         if (e == POP_EMPTY) {
-          if (lds_ldi(&s_open_left) > 0) { __builtin_amdgcn_s_sleep(2); continue; }   // (the open tile that was running)
+          if (open_left > 0) { __builtin_amdgcn_s_sleep(2); continue; }   // (the open tile that was running)
           if (lane == 0) atomicAdd(&s_idle, 1);
           idle = true;
           continue;
@@ -1261,25 +1262,23 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
         const int tt = (int)(e & 0xffffu);
         const unsigned sh = 2u * ((unsigned)tt & 15u);
         int r = 0;   // 0: not ours (running or stale), 1: ours, 2: ours and first
-        if (lane == 0 && ((lds_ld(&s_st2[tt >> 4]) >> sh) & 3u) == 1u) {   // (a look first: most entries that are not ours are stale or their tile is running)
-          const unsigned old = atomicOr(&s_st2[tt >> 4], 2u << sh) >> sh;
-          if (!(old & 2u)) {
-            const unsigned old2 = atomicAnd(&s_st2[tt >> 4], ~(1u << sh)) >> sh;
-            if (old2 & 1u) {
-              r = 1;
-              if (lds_ldi(&s_open_left) > 0 && ((atomicAnd(&s_open[tt >> 5], ~(1u << (tt & 31))) >> (tt & 31)) & 1u)) {
-                atomicSub(&s_open_left, 1);
-                atomicSub(&s_count, 1);
-                r = 2;
-              }
-            } else {   // stale entry: nothing pending.  Give the tile back (a wake-up may have arrived meanwhile)
-              const unsigned old3 = atomicAnd(&s_st2[tt >> 4], ~(2u << sh)) >> sh;
-              if (old3 & 1u) r = -1;
-            }
+        if (lane == 0) {
+          // pending and not running -> running, nothing pending, in ONE compare-and-swap on the tile's two bits (a look
+          // first: most entries that are not ours are stale or their tile is running; an entry whose tile has nothing
+          // pending is dropped -- a wake-up that arrives later brings its own)
+          unsigned w = lds_ld(&s_st2[tt >> 4]);
+          while (((w >> sh) & 3u) == 1u) {
+            const unsigned got = atomicCAS(&s_st2[tt >> 4], w, (w | (2u << sh)) & ~(1u << sh));
+            if (got == w) { r = 1; break; }
+            w = got;   // (another tile of the word changed)
+          }
+          if (r == 1 && open_left > 0 && ((atomicAnd(&s_open[tt >> 5], ~(1u << (tt & 31))) >> (tt & 31)) & 1u)) {
+            atomicSub(&s_open_left, 1);
+            atomicSub(&s_count, 1);
+            r = 2;
           }
         }
         r = __builtin_amdgcn_readfirstlane(r);
-        if (r == -1) { sch.push((unsigned)tt, 0u, lane, &spare); continue; }
         if (r <= 0) continue;
         t = tt;
         first = r == 2;
