@@ -90,81 +90,84 @@ def _tiled_worker(rank, world, port, out, mode="full", cfg=None):
         torch.cuda.set_device(0)
         dist = D.init("gloo")
         cfg = cfg or SMALL
-        rows, cols, res = cfg["rows"], cfg["cols"], 0.05
-        lx, ly = rows * res, cols * res
-        e = R.Engine(lx, ly, res)
-        e.astar_pipeline_depth(1)
-        e.astar_configure(max_queries=8)
-        g = Or.make_geom(lx, ly, res)
-        L = D.TileLayout.for_world(rows, cols, world)
-        halo = D.vfh_halo(res)
-        i0, ni, j0, nj = L.window(rank)
-        full = R.synth.obstacles_rect(rows, cols, density=cfg["density"], seed=21, side=cfg["side"])
-        e.upload(R.capi.LAYER_LASER, full)
-        e.compose_master(1)
-        e.himm_set_window(i0, j0, ni, nj)
-        # poses: uniform ones plus a row of robots right on both sides of every window border
-        poses = R.synth.poses(cfg["poses"], lx, ly, seed=3, margin=0.9)
-        edge = R.synth.poses(cfg["edge_poses"], lx, ly, seed=4, margin=0.9)
-        for k in range(len(edge)):                      # the same poses on every rank
-            wi0, wni = L.window(k % world)[:2]
-            bi = (wi0 if k % 2 else wi0 + wni - 1) + (k % 5) - 2
-            bi = min(max(bi, 18), rows - 19)
-            edge["x"][k] = e.get_position(bi, 0)[0]
-        poses = np.concatenate([poses, edge])
-        idx = np.array([e.get_index(p["x"], p["y"]) for p in poses])
-        mine = poses[L.owner(idx[:, 0], idx[:, 1]) == rank].copy()
-        e.vfh_init(len(mine))
-        oracles = [Or.OracleVfh() for _ in range(len(mine))]
-        checked = {"vfh": 0, "astar": 0, "halo_bytes": 0, "gather_bytes": 0}
-        for rnd in range(cfg["rounds"]):
-            rays = R.synth.rays(cfg["ray_poses"], cfg["rays_per_pose"], lx, ly, seed=30 + rnd, lmin=cfg["lmin"], lmax=6.0,
-                                margin=cfg["margin"])
-            Or.himm_update(g, full, rays.view(Or.RAY_DTYPE))          # whole-map truth (laser == master)
-            e.update_map(rays, compose_mode=0)                         # this rank's window only
-            checked["halo_bytes"] += D.exchange_halo(e, R.capi.LAYER_MASTER, L, rank, halo, dist, tracked=(mode == "dirty"))
-            vout, origin, hist = e.vfh_step(mine)
-            for k in range(len(mine)):
-                p = mine[k]
-                cs, ct = oracles[k].step_pose(g, full, p["x"], p["y"], p["yaw"], int(p["current_speed"]),
-                                              p["goal_direction"], p["goal_distance"], p["goal_tolerance"], float(p["dt"]))
-                assert (vout["chosen_speed"][k], vout["chosen_turnrate"][k]) == (cs, ct), (rnd, k)
-                assert origin[k].tobytes() == oracles[k].origin_hist().tobytes(), (rnd, k)
-                assert hist[k].tobytes() == oracles[k].hist().tobytes(), (rnd, k)
-                checked["vfh"] += 1
-            mine["current_speed"] = vout["chosen_speed"]
-            if mode == "dirty":      # only the tiles this update changed travel; masks of exactly those are refreshed
-                checked["gather_bytes"] += D.gather_dirty(e, (R.capi.LAYER_LASER, R.capi.LAYER_MASTER), L, rank, dist)
-                e.compose_master(0)
-                lz = e.download(R.capi.LAYER_LASER)
-                assert np.array_equal(np.isnan(lz), np.isnan(full)) and np.array_equal(lz[~np.isnan(lz)], full[~np.isnan(full)]), rnd
-            else:
-                checked["gather_bytes"] += D.gather_layer(e, R.capi.LAYER_MASTER, L, rank, dist)
-            got = e.download(R.capi.LAYER_MASTER)
-            assert np.array_equal(np.isnan(got), np.isnan(full)) and np.array_equal(got[~np.isnan(got)], full[~np.isnan(full)]), rnd
-            queries = R.synth.astar_queries(cfg["queries"], full, rows, cols, seed=40 + rnd)
-            lo, hi = D.shard_bounds(len(queries), rank, world)
-            res_, paths = e.astar(queries[lo:hi], cfg["max_path"])
-            _, nbr = Or.astar_masks(full, rows, cols)
-            assert np.array_equal(e.nbr_mask(), nbr), rnd
-            gw = np.empty(rows * cols, np.int32)
-            for k, q in enumerate(queries[lo:hi]):
-                ores, opath, _ = Or.astar_query(nbr, rows, cols, q["start"], q["goal"], g_work=gw)
-                assert res_["status"][k] == ores.status, (rnd, k)
-                if ores.status == 0:
-                    assert res_["cost"][k] == ores.cost and np.array_equal(paths[k, :ores.path_len], opath), (rnd, k)
-                checked["astar"] += 1
-        e.close()
+        results = {}
+        for mode in (mode if isinstance(mode, tuple) else (mode,)):   # several modes in one pair of processes: a spawn costs a torch import each
+            rows, cols, res = cfg["rows"], cfg["cols"], 0.05
+            lx, ly = rows * res, cols * res
+            e = R.Engine(lx, ly, res)
+            e.astar_pipeline_depth(1)
+            e.astar_configure(max_queries=8)
+            g = Or.make_geom(lx, ly, res)
+            L = D.TileLayout.for_world(rows, cols, world)
+            halo = D.vfh_halo(res)
+            i0, ni, j0, nj = L.window(rank)
+            full = R.synth.obstacles_rect(rows, cols, density=cfg["density"], seed=21, side=cfg["side"])
+            e.upload(R.capi.LAYER_LASER, full)
+            e.compose_master(1)
+            e.himm_set_window(i0, j0, ni, nj)
+            # poses: uniform ones plus a row of robots right on both sides of every window border
+            poses = R.synth.poses(cfg["poses"], lx, ly, seed=3, margin=0.9)
+            edge = R.synth.poses(cfg["edge_poses"], lx, ly, seed=4, margin=0.9)
+            for k in range(len(edge)):                      # the same poses on every rank
+                wi0, wni = L.window(k % world)[:2]
+                bi = (wi0 if k % 2 else wi0 + wni - 1) + (k % 5) - 2
+                bi = min(max(bi, 18), rows - 19)
+                edge["x"][k] = e.get_position(bi, 0)[0]
+            poses = np.concatenate([poses, edge])
+            idx = np.array([e.get_index(p["x"], p["y"]) for p in poses])
+            mine = poses[L.owner(idx[:, 0], idx[:, 1]) == rank].copy()
+            e.vfh_init(len(mine))
+            oracles = [Or.OracleVfh() for _ in range(len(mine))]
+            checked = {"vfh": 0, "astar": 0, "halo_bytes": 0, "gather_bytes": 0}
+            for rnd in range(cfg["rounds"]):
+                rays = R.synth.rays(cfg["ray_poses"], cfg["rays_per_pose"], lx, ly, seed=30 + rnd, lmin=cfg["lmin"], lmax=6.0,
+                                    margin=cfg["margin"])
+                Or.himm_update(g, full, rays.view(Or.RAY_DTYPE))          # whole-map truth (laser == master)
+                e.update_map(rays, compose_mode=0)                         # this rank's window only
+                checked["halo_bytes"] += D.exchange_halo(e, R.capi.LAYER_MASTER, L, rank, halo, dist, tracked=(mode == "dirty"))
+                vout, origin, hist = e.vfh_step(mine)
+                for k in range(len(mine)):
+                    p = mine[k]
+                    cs, ct = oracles[k].step_pose(g, full, p["x"], p["y"], p["yaw"], int(p["current_speed"]),
+                                                  p["goal_direction"], p["goal_distance"], p["goal_tolerance"], float(p["dt"]))
+                    assert (vout["chosen_speed"][k], vout["chosen_turnrate"][k]) == (cs, ct), (rnd, k)
+                    assert origin[k].tobytes() == oracles[k].origin_hist().tobytes(), (rnd, k)
+                    assert hist[k].tobytes() == oracles[k].hist().tobytes(), (rnd, k)
+                    checked["vfh"] += 1
+                mine["current_speed"] = vout["chosen_speed"]
+                if mode == "dirty":      # only the tiles this update changed travel; masks of exactly those are refreshed
+                    checked["gather_bytes"] += D.gather_dirty(e, (R.capi.LAYER_LASER, R.capi.LAYER_MASTER), L, rank, dist)
+                    e.compose_master(0)
+                    lz = e.download(R.capi.LAYER_LASER)
+                    assert np.array_equal(np.isnan(lz), np.isnan(full)) and np.array_equal(lz[~np.isnan(lz)], full[~np.isnan(full)]), rnd
+                else:
+                    checked["gather_bytes"] += D.gather_layer(e, R.capi.LAYER_MASTER, L, rank, dist)
+                got = e.download(R.capi.LAYER_MASTER)
+                assert np.array_equal(np.isnan(got), np.isnan(full)) and np.array_equal(got[~np.isnan(got)], full[~np.isnan(full)]), rnd
+                queries = R.synth.astar_queries(cfg["queries"], full, rows, cols, seed=40 + rnd)
+                lo, hi = D.shard_bounds(len(queries), rank, world)
+                res_, paths = e.astar(queries[lo:hi], cfg["max_path"])
+                _, nbr = Or.astar_masks(full, rows, cols)
+                assert np.array_equal(e.nbr_mask(), nbr), rnd
+                gw = np.empty(rows * cols, np.int32)
+                for k, q in enumerate(queries[lo:hi]):
+                    ores, opath, _ = Or.astar_query(nbr, rows, cols, q["start"], q["goal"], g_work=gw)
+                    assert res_["status"][k] == ores.status, (rnd, k)
+                    if ores.status == 0:
+                        assert res_["cost"][k] == ores.cost and np.array_equal(paths[k, :ores.path_len], opath), (rnd, k)
+                    checked["astar"] += 1
+            e.close()
+            results[mode] = checked
         dist.barrier()
         dist.destroy_process_group()
-        out.put((rank, "ok", checked, len(mine)))
+        out.put((rank, "ok", results, len(mine)))
     except BaseException as ex:  # noqa: BLE001 -- reported to the parent, which fails the test
         import traceback
         out.put((rank, "fail", traceback.format_exc(), repr(ex)))
 
 
-@pytest.mark.parametrize("mode", ["full", "dirty"])
-def test_tiled_loop_two_ranks_on_one_gpu_matches_the_whole_map_oracle(mode):
+def test_tiled_loop_two_ranks_on_one_gpu_matches_the_whole_map_oracle():
+    """both hand-over modes (whole owner windows / only the changed tiles), one after the other in ONE pair of processes"""
     import torch.multiprocessing as mp
     world = 2
     with socket.socket() as s:
@@ -172,22 +175,23 @@ def test_tiled_loop_two_ranks_on_one_gpu_matches_the_whole_map_oracle(mode):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_tiled_worker, args=(r, world, port, out, mode)) for r in range(world)]
+    procs = [ctx.Process(target=_tiled_worker, args=(r, world, port, out, ("full", "dirty"))) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(out.get(timeout=600) for _ in range(world))
+    res = sorted(out.get(timeout=900) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
     for r in res:
         assert r[1] == "ok", r[2]
     assert sum(r[3] for r in res) == 96                       # every pose served by exactly one rank
-    assert all(r[2]["vfh"] == 3 * r[3] and r[2]["astar"] == 36 for r in res)
-    # 2 x 1 layout: one 16-row strip of 192 columns per rank per round, the other window per gather
-    assert all(r[2]["halo_bytes"] == 3 * 16 * 192 * 4 for r in res)
-    if mode == "full":
-        assert all(r[2]["gather_bytes"] == 3 * 128 * 192 * 4 for r in res)
-    else:                                                     # whole 64 x 64 tiles, and fewer bytes than the windows
-        assert all(r[2]["gather_bytes"] % (4096 * 4) == 0 and 0 < r[2]["gather_bytes"] <= 3 * 128 * 192 * 4 for r in res)
+    for mode in ("full", "dirty"):
+        assert all(r[2][mode]["vfh"] == 3 * r[3] and r[2][mode]["astar"] == 36 for r in res)
+        # 2 x 1 layout: one 16-row strip of 192 columns per rank per round, the other window per gather
+        assert all(r[2][mode]["halo_bytes"] == 3 * 16 * 192 * 4 for r in res)
+        if mode == "full":
+            assert all(r[2][mode]["gather_bytes"] == 3 * 128 * 192 * 4 for r in res)
+        else:                                                     # whole 64 x 64 tiles, and fewer bytes than the windows
+            assert all(r[2][mode]["gather_bytes"] % (4096 * 4) == 0 and 0 < r[2][mode]["gather_bytes"] <= 3 * 128 * 192 * 4 for r in res)
 
 
 def test_config5_full_size_two_ranks_vfh_and_astar_legs():
@@ -211,9 +215,9 @@ def test_config5_full_size_two_ranks_vfh_and_astar_legs():
     for r in res:
         assert r[1] == "ok", r[2]
     assert sum(r[3] for r in res) == 64 and all(r[3] >= 16 for r in res)
-    assert all(r[2]["vfh"] == r[3] and r[2]["astar"] == 8 for r in res)
-    assert all(r[2]["halo_bytes"] == 16 * 8192 * 4 for r in res)          # one 16-row strip of 8192 columns
-    assert all(0 < r[2]["gather_bytes"] < 4096 * 8192 * 4 // 8 for r in res)   # dirty tiles only: far less than a window
+    assert all(r[2]["dirty"]["vfh"] == r[3] and r[2]["dirty"]["astar"] == 8 for r in res)
+    assert all(r[2]["dirty"]["halo_bytes"] == 16 * 8192 * 4 for r in res)          # one 16-row strip of 8192 columns
+    assert all(0 < r[2]["dirty"]["gather_bytes"] < 4096 * 8192 * 4 // 8 for r in res)   # dirty tiles only: far less than a window
 
 
 def test_config5_full_size_windowed_himm_union_is_the_whole_map_update():
