@@ -199,6 +199,7 @@ __global__ void __launch_bounds__(256) tsa_prepare_kernel(TsaStage S, const rna_
   extern __shared__ int s_key[];
   if (threadIdx.x == 0) *S.ticket = 0;
   if (served && threadIdx.x < TSA_RETRY) served[threadIdx.x] = -1;   // no retry slot has served a query of this batch yet
+  if (served && threadIdx.x == TSA_RETRY) served[TSA_RETRY] = 0;     // ... and none has asked for one (tsa_retry_count)
   if (!ranked) {   // the ranking is O(n^2 / 256) per thread: large batches keep the caller's order
     for (int i = threadIdx.x; i < n; i += blockDim.x) S.perm[i] = i;
     return;
@@ -957,7 +958,7 @@ struct TsaLaunch {
   // search can never outgrow (a goal that cannot be reached floods its whole component; the reference answers "no
   // path", it does not fail).
   int retry, n;
-  int* retry_count;   // (host memory, may be null) searches of this launch that ended with status 5 ...
+  int* retry_count;   // (device memory, may be null) searches of this launch that ended with status 5 ...
   int* retry_list;    // ... and which, in the order they ended (device memory, [max_queries])
   int retry_base;     // second pass: workgroup r serves retry_list[retry_base + r]
   TsaStage S2;
@@ -1344,7 +1345,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   if (state != 1) {
     if (tid == 0) {
       results[q] = r;
-      if (!RETRY && state == 5 && A.retry_count) A.retry_list[__hip_atomic_fetch_add(A.retry_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)] = q;
+      if (!RETRY && state == 5 && A.retry_count) A.retry_list[atomicAdd(A.retry_count, 1)] = q;
     }
     return;
   }
@@ -1443,6 +1444,9 @@ static int* tsa_retry_list(const rna_engine* e, int slot) {
 }
 // [TSA_RETRY] ints in the retry view's ticket block: the query each retry slot served in the stage's current batch (-1: none)
 static int* tsa_retry_served(const rna_engine* e, int slot) { return reinterpret_cast<int*>(e->astar.tsa_aux_retry[slot]) + 8; }
+// the int behind them: searches of the stage's current batch that ended with status 5 (copied to pinned host memory
+// behind the search, so that the host sees it when the stage's stream is idle -- no PCIe atomics needed)
+static int* tsa_retry_count(const rna_engine* e, int slot) { return tsa_retry_served(e, slot) + TSA_RETRY; }
 static TsaStage tsa_retry_view(const rna_engine* e, int slot, const TsaStage& main) {
   const AstarDevice& a = e->astar;
   const size_t ntile = (size_t)tsa_ntile(e);
@@ -1563,10 +1567,10 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     if (const char* pad = getenv("RNA_TSA_LDS_PAD")) lds_dyn += (size_t)atoi(pad);   // developer knob: fewer search workgroups per CU
     // a search that outgrows its share of pages is searched again when the host sees the count (astar_settle)
     const bool can_retry = a.g_retry[slot] != nullptr && a.retry_flag != nullptr;
-    A.retry_count = can_retry ? a.retry_flag + slot : nullptr;
+    A.retry_count = can_retry ? tsa_retry_count(e, slot) : nullptr;
     A.retry_list = can_retry ? tsa_retry_list(e, slot) : nullptr;
     A.retry_base = 0;
-    if (A.retry_count) *A.retry_count = 0;
+    if (can_retry) a.retry_flag[slot] = 0;
     a.last_retried[slot] = 0;
     // 16 wavefronts per query where latency counts (one stream, or a batch too small to fill the chip: a lone search
     // takes 9.1 instead of 12.9 ms), 8 where throughput does (16 in the pipeline: 91.6 k instead of 122.8 k cycles/s)
@@ -1578,6 +1582,8 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     memcpy(a.last_launch[slot], &A, sizeof(A));
     a.last_lds[slot] = lds_dyn;
     a.retry_armed[slot] = A.retry_count != nullptr;
+    // the count travels to pinned host memory behind the search (before the stage's `done` event)
+    if (A.retry_count) RNA_HIP(e, hipMemcpyAsync(a.retry_flag + slot, A.retry_count, sizeof(int), hipMemcpyDeviceToHost, search_stream));
   }
   if (ring >= 0) {
     RNA_HIP(e, hipEventRecord(a.ring_free[ring], search_stream));

@@ -93,10 +93,11 @@ struct AstarDevice {
   hipEvent_t ring_free[MAX_RING] = {};   // the search that read this entry last has finished
   bool ring_used[MAX_RING] = {};
   hipEvent_t ev_prep = nullptr;          // snapshot + launch order of the batch being launched are in place
-  // Searches that outgrew their share of pages: counted by the kernel in pinned host memory; the second pass over them is
+  // Searches that outgrew their share of pages: counted by the kernel (the count is copied to pinned host memory behind
+  // the search); the second pass over them is
   // launched when the host sees the count (a launch per batch "in case" cost every stage 0.2 - 4 ms: its workgroups wait
   // for CU slots like everybody else's)
-  int* retry_flag = nullptr;             // [MAX_DEPTH], host memory the device writes
+  int* retry_flag = nullptr;             // [MAX_DEPTH], pinned host memory: copied from the stage's device counter behind each search
   bool retry_armed[MAX_DEPTH] = {};
   int last_retried[MAX_DEPTH] = {};      // searches of the stage's last batch that went through the second pass
   size_t last_lds[MAX_DEPTH] = {};
