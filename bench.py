@@ -109,10 +109,16 @@ def spawn_ranks(args):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    # what the ranks report about their parent (`config.launcher`): it has loaded neither torch nor the engine, and no
+    # HIP / HSA runtime is mapped into it
+    with open("/proc/self/maps") as f:
+        maps = f.read()
+    hip_free = not any(m in sys.modules for m in ("torch", "ros_navigation_amd")) and "libamdhip64" not in maps and "libhsa-runtime" not in maps
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   RNA_BENCH_PARENT="%d:%d" % (os.getpid(), 1 if hip_free else 0))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     for p in procs:
@@ -242,6 +248,9 @@ def main():
         if args.gpus == 1:
             os.environ["RNA_BENCH_FORCE_DIST"] = "1"
         spawn_ranks(args)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:   # (before the heavy imports: a mis-launch fails in milliseconds)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s (launch with --nproc-per-node %d or drop the launcher)"
+                         % (args.gpus, os.environ.get("WORLD_SIZE", "1"), args.gpus))
     import numpy as np
     import torch
     from ros_navigation_amd import capi as _capi
@@ -429,10 +438,22 @@ def main():
     settled_per_launch = float(np.mean(settled_sets))
 
     t_max = D.max_over_ranks(elapsed, "cpu" if share else dev) if use_dist else elapsed
+    # every rank's shard of the global batch and the cycles it served in the timed region, for the line rank 0 prints
+    shard_rows = [[lo, hi, nq * args.steps * args.pipeline]]
+    windows = [list(layout.window(rank))] if layout is not None else None
+    if use_dist and world > 1:
+        t = torch.zeros(world, 7, dtype=torch.int64, device="cpu" if share else dev)
+        t[rank, :3] = torch.tensor(shard_rows[0], dtype=torch.int64)
+        if layout is not None:
+            t[rank, 3:] = torch.tensor(windows[0], dtype=torch.int64)
+        dist.all_reduce(t)
+        shard_rows = t[:, :3].cpu().tolist()
+        windows = t[:, 3:].cpu().tolist() if layout is not None else None
 
     if rank == 0:
         passes = args.steps * args.pipeline
-        cycles = args.queries * world * passes
+        cycles = sum(r[2] for r in shard_rows)      # all ranks' cycles (= queries x world x passes)
+        assert cycles == args.queries * world * passes
         ms_search = prof["astar_search"][0] / max(1, prof["astar_search"][1])
         alg_bytes = settled_per_launch * ASTAR_BYTES_PER_SETTLED
         achieved = alg_bytes / (ms_search * 1e-3) / 1e9 if ms_search > 0 else 0.0
@@ -465,6 +486,11 @@ def main():
                        "astar_bucket_width": args.bucket_width or 96000, "astar_pipeline_depth": args.pipeline,
                        "astar_allocated": dict(zip(("pipeline_depth", "pages_per_query", "max_queries"), e.astar_effective_config())),
                        "timed_seconds": t_max,
+                       "shards": [r[:2] for r in shard_rows], "cycles_by_rank": [r[2] for r in shard_rows],
+                       "launcher": ({"spawned_by_bench": True, "parent_pid": int(os.environ["RNA_BENCH_PARENT"].split(":")[0]),
+                                     "parent_is_my_parent": int(os.environ["RNA_BENCH_PARENT"].split(":")[0]) == os.getppid(),
+                                     "parent_hip_free": os.environ["RNA_BENCH_PARENT"].split(":")[1] == "1"}
+                                    if "RNA_BENCH_PARENT" in os.environ else {"spawned_by_bench": False}),
                        "parallelism": ("query-sharded x%d" % world) if layout is None else
                                       ("one map tiled %d x %d (windowed HIMM, %d-cell halo exchange, all-gather of owner "
                                        "windows), A* query-sharded x%d" % (layout.ti, layout.tj, halo, world))},
@@ -488,7 +514,7 @@ def main():
             "kernel_ms_per_pass_timed_region": {k: (v[0] / passes) for k, v in prof.items() if v[1]},
         }
         if layout is not None:
-            out["tiled"] = {"layout": [layout.ti, layout.tj], "halo_cells": halo,
+            out["tiled"] = {"layout": [layout.ti, layout.tj], "halo_cells": halo, "windows": windows,
                             "halo_bytes_per_pass_rank0": xfer[0] / passes,
                             "gather_bytes_per_pass_rank0": xfer[1] / passes}
         if not args.no_cpu and world == 1:   # rank 0 at N=1 only

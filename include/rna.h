@@ -28,7 +28,8 @@ extern "C" {
 /* 2: rna_laser_scan carries the end pose (80 bytes), rna_astar_result.expanded / .rounds changed meaning (cells written,
  *    tile jobs per wavefront), statuses 4 / 5, profile slot astar_reset, default bucket width 96000.  A host checks
  *    rna_abi_version() == RNA_ABI_VERSION after loading the library (capi.py and move_control_amd.hpp do). */
-#define RNA_ABI_VERSION 2
+/* 3: rna_synchronize_map, rna_hw_queue_advice (round 4); no existing signature changed. */
+#define RNA_ABI_VERSION 3
 
 typedef enum {
   RNA_OK = 0,
@@ -69,8 +70,18 @@ int rna_layer_download(rna_engine* e, int layer, float* host, size_t n_cells);
 int rna_layer_fill(rna_engine* e, int layer, float value);
 /* device pointer of a layer (rows*cols float32, column-major) for zero-copy producers/consumers */
 void* rna_layer_device_ptr(rna_engine* e, int layer);
-void* rna_stream(rna_engine* e);           /* hipStream_t of this engine */
+/* hipStream_t of the engine's MAP stream: map updates, compose, pack / unpack, uploads and the host-pointer calls run
+ * on it.  It is not the only stream: with a pipeline depth > 1 the A* searches run on the stages' own streams and
+ * rna_vfh_step_batch_device on an internal side stream, so work a caller chains on rna_stream() is ordered with the
+ * map, NOT with the outputs of those two calls -- they are valid after rna_synchronize() (or, for VFH+, after
+ * rna_synchronize_map()). */
+void* rna_stream(rna_engine* e);
+/* everything the engine has in flight: the map stream, the VFH+ side stream, every A* pipeline stage, and the second
+ * passes over searches that ran out of pages (issued here if they are still due) */
 int rna_synchronize(rna_engine* e);
+/* the map stream and the VFH+ side stream only: searches in flight keep running (a tiled host's per-pass exchange,
+ * a consumer of the VFH+ commands).  Does not make A* outputs valid. */
+int rna_synchronize_map(rna_engine* e);
 /* GridMap::getIndex / getPosition / isInside (gmc/src/GridMap.cpp:227-240) -- host-side math */
 int rna_get_index(const rna_engine* e, double x, double y, int32_t index[2]);   /* 1 inside, 0 outside */
 int rna_get_position(const rna_engine* e, int32_t i, int32_t j, double position[2]);
@@ -211,6 +222,8 @@ int rna_vfh_hist_size(const rna_engine* e);
  * VFH::OriginHist and VFH::Hist after the step. */
 int rna_vfh_step_batch(rna_engine* e, const rna_pose* poses_host, int n, rna_vfh_out* out_host,
                        float* origin_hist_host, float* hist_host);
+/* (_device: with a pipeline depth > 1 the step runs on an internal side stream behind the map stream -- its outputs are
+ * valid after rna_synchronize_map() / rna_synchronize(), not for work merely enqueued on rna_stream() after the call) */
 int rna_vfh_step_batch_device(rna_engine* e, const rna_pose* poses_device, int n, rna_vfh_out* out_device,
                               float* origin_hist_device, float* hist_device);
 /* VFH::Update_VFH fed with caller-provided range scans (double[361][2] per robot, as the reference
@@ -227,10 +240,11 @@ int rna_vfh_update_batch(rna_engine* e, const double* ranges_host /* n*361*2 */,
 typedef struct { int32_t start, goal; } rna_astar_query;
 typedef struct {
   int32_t status;      /* 0 found, 1 no path, 2 invalid query, 3 path longer than max_path_len,
-                          4 path cost beyond the field's 30-bit g range (>= 1.07e9), 5 the query's share of search pages was
-                          used up AND the batch's eight full-size retry slots were taken by other such queries (pages are
-                          only limited after rna_astar_set_page_cap or when HBM is short; a goal that cannot be reached
-                          floods its component -- it is searched again on a retry slot and answers 1, not 5) */
+                          4 path cost beyond the field's 30-bit g range (>= 1.07e9), 5 TRANSIENT: the query's share of search
+                          pages was used up (pages are only limited after rna_astar_set_page_cap or when HBM is short) and it
+                          waits for its second pass on a full-size retry slot -- visible only in a device result buffer read
+                          before rna_synchronize(); never final (a goal that cannot be reached floods its component, is
+                          searched again and answers 1) */
   int32_t path_len;    /* cells, start..goal inclusive */
   int32_t cost;        /* 1000/1414 integer cost of the path */
   int32_t expanded;    /* cells the device wrote (64 per row of a tile a job changed; >= the oracle's settled count) */
@@ -249,8 +263,17 @@ int rna_astar_configure(rna_engine* e, int max_queries, int queue_capacity, int 
  * bare hipDeviceSynchronize(): searches that ran out of their share of pages are searched again by a second launch
  * the host issues when it sees their count, at the latest inside rna_synchronize().  The call returns after
  * enqueueing; while every stage is busy it blocks until one is free.  The caller must give calls that may be in
- * flight together distinct output buffers.  Default 4; up to 16. */
+ * flight together distinct output buffers.  Default 4; up to 16.
+ * Hardware queues: every stage's stream wants a hardware queue of its own, and the HIP runtime multiplexes all of a
+ * process's streams over GPU_MAX_HW_QUEUES (default 4) of them, read from the environment at its first call.  librna.so
+ * sets GPU_MAX_HW_QUEUES=8 when it is loaded and the variable is unset (RNA_KEEP_HW_QUEUES=1 turns that off); when the
+ * value in force is too small for `depth` the call still succeeds -- searches then share queues and overlap less --
+ * and rna_last_error() holds the one-line advice of rna_hw_queue_advice(). */
 int rna_astar_set_pipeline_depth(rna_engine* e, int depth);
+/* Host-only (no engine, no GPU): 0 and an empty string when GPU_MAX_HW_QUEUES, as this process's environment has it,
+ * leaves the stages of `pipeline_depth` a hardware queue each (depth <= 2, or >= 8 queues); 1 and one line of advice in
+ * buf otherwise. */
+int rna_hw_queue_advice(int pipeline_depth, char* buf, size_t cap);
 /* The tile kernel keeps a search's distance field in 4 KiB pages (64 x 16 cells) handed out on first touch.  By
  * default every query may take one page per tile of the map (it can never run out; HBM is only touched where a
  * search goes; half a map's worth when the pipeline stages would not fit HBM otherwise).  A smaller share per query makes room for more queries / pipeline stages in flight; a search that

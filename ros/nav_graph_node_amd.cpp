@@ -5,6 +5,7 @@
 // their constructors -- subscriptions, publishers, tf, the three threads -- is RosSeams.  Topics, frames and rates are
 // the reference's: move_base_simple/goal in; plan, global_map, local_map, hist, /mobile_base/commands/velocity out.
 #if __has_include(<ros/ros.h>)
+#include <cstdlib>
 #include <ros/ros.h>
 #include <geometry_msgs/PoseStamped.h>
 #include <nav_msgs/Path.h>
@@ -65,6 +66,7 @@ void NavGraph::publishPlan() {
 }  // namespace move_control
 
 int main(int argc, char* argv[]) {
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);   // before the first HIP call: the A* pipeline stages want a hardware queue each
   ros::init(argc, argv, "mapTester");
   ros::NodeHandle nh;
   move_control::NavGraph nav(nh);

@@ -3,6 +3,7 @@
 // the plan (taileredPlan :192-204), publishes it and hands it to the Steerer; it plans again every planInterval_ (20 s)
 // until the goal is reached (loopPlan :109-126).  ROS wiring of MapProvider / Steerer: RosSeams.
 #if __has_include(<ros/ros.h>)
+#include <cstdlib>
 #include <ros/ros.h>
 #include <geometry_msgs/PoseStamped.h>
 #include <nav_msgs/Path.h>
@@ -140,6 +141,7 @@ bool Nav::ifGoalAchieved() {
 }  // namespace move_control
 
 int main(int argc, char* argv[]) {
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);   // before the first HIP call: the A* pipeline stages want a hardware queue each
   ros::init(argc, argv, "mapTester");
   ros::NodeHandle nh;
   move_control::Nav nav(nh);

@@ -2,6 +2,7 @@
 // engine: a 4 m map that follows the robot, no global planner -- the plan handed to the Steerer is the straight line
 // from the robot to the goal, VFH+ does the rest.  ROS wiring of MapProvider / Steerer: RosSeams.
 #if __has_include(<ros/ros.h>)
+#include <cstdlib>
 #include <ros/ros.h>
 #include <geometry_msgs/PoseStamped.h>
 
@@ -40,6 +41,7 @@ class NavVfh {
 }  // namespace move_control
 
 int main(int argc, char* argv[]) {
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);   // before the first HIP call: the A* pipeline stages want a hardware queue each
   ros::init(argc, argv, "mapTester");
   ros::NodeHandle nh;
   move_control::NavVfh nav(nh);

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("RNA_LIB") or "librna.so")   # RNA_LIB: developer switch to an alternative build
 
 RNA_OK = 0
-ABI_VERSION = 2   # include/rna.h: RNA_ABI_VERSION
+ABI_VERSION = 3   # include/rna.h: RNA_ABI_VERSION
 STATUS = {0: "RNA_OK", -1: "RNA_EINVAL", -2: "RNA_ENOMEM", -3: "RNA_EHIP", -4: "RNA_ECAPACITY",
           -5: "RNA_ESTATE", -6: "RNA_ENODEVICE"}
 LAYER_MASTER, LAYER_LASER, LAYER_RANGE = 0, 1, 2
@@ -25,7 +25,7 @@ KERNELS = ["himm_prep", "himm_raster", "himm_apply", "compose_master", "nbr_mask
 SYMBOLS = [
     "rna_create", "rna_destroy", "rna_last_error", "rna_abi_version", "rna_get_geometry",
     "rna_layer_upload", "rna_layer_download", "rna_layer_fill", "rna_layer_device_ptr", "rna_stream",
-    "rna_synchronize", "rna_get_index", "rna_get_position", "rna_geometry_index", "rna_geometry_position", "rna_line_cells",
+    "rna_synchronize", "rna_synchronize_map", "rna_hw_queue_advice", "rna_get_index", "rna_get_position", "rna_geometry_index", "rna_geometry_position", "rna_line_cells",
     "rna_circle_cells", "rna_submap_cells", "rna_clone",
     "rna_himm_update", "rna_himm_update_device", "rna_compose_master", "rna_update_map",
     "rna_update_map_device", "rna_move", "rna_himm_set_window", "rna_layer_pack_region", "rna_layer_unpack_region", "rna_last_dirty_tiles", "rna_layer_pack_tiles",
@@ -127,6 +127,8 @@ def lib():
     L.rna_stream.argtypes = [vp]
     L.rna_stream.restype = vp
     L.rna_synchronize.argtypes = [vp]
+    L.rna_synchronize_map.argtypes = [vp]
+    L.rna_hw_queue_advice.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
     L.rna_get_index.argtypes = [vp, C.c_double, C.c_double, C.POINTER(C.c_int32)]
     L.rna_get_position.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     gp, ip = C.POINTER(Geometry), C.POINTER(C.c_int32)
@@ -345,6 +347,10 @@ class Engine:
 
     def synchronize(self):
         self._check(self._L.rna_synchronize(self.h))
+
+    def synchronize_map(self):
+        """the map stream (+ the VFH+ side stream) only: A* batches in flight keep running"""
+        self._check(self._L.rna_synchronize_map(self.h))
 
     def get_index(self, x, y):
         out = (C.c_int32 * 2)()

@@ -129,8 +129,8 @@ int ensure_config(rna_engine* e) {
   if (a.depth < 1) a.depth = 1;
   if (a.depth > AstarDevice::MAX_DEPTH) a.depth = AstarDevice::MAX_DEPTH;
   // fit into free HBM (25 % headroom): fewer pages per query (half a map's worth), fewer pipeline stages, fewer pages
-  // still -- a search that needs more than its share is searched again on a full-size retry slot (astar_tile.hip), status
-  // 5 only when more than TSA_RETRY searches of one batch do --, then fewer concurrent queries
+  // still -- a search that needs more than its share is searched again on a full-size retry slot (astar_tile.hip: eight
+  // at a time, as many passes as it takes; status 5 is transient and never final) --, then fewer concurrent queries
   size_t free_b = 0, total_b = 0;
   RNA_HIP(e, hipMemGetInfo(&free_b, &total_b));
   const int ntile = tsa_tiles(e);
@@ -333,6 +333,8 @@ extern "C" int rna_astar_set_pipeline_depth(rna_engine* e, int depth) {
     astar_release(e);
     e->astar.depth = depth;
   }
+  char advice[320];
+  if (rna_hw_queue_advice(depth, advice, sizeof(advice))) e->err = advice;   // (still RNA_OK: correct, only slower)
   return RNA_OK;
 }
 

@@ -6,6 +6,7 @@
 #include "engine.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -651,6 +652,34 @@ extern "C" int rna_synchronize(rna_engine* e) {
   if (!e) return RNA_EINVAL;
   RNA_ENTER(e);
   return sync_all(e);
+}
+
+extern "C" int rna_synchronize_map(rna_engine* e) {
+  if (!e) return RNA_EINVAL;
+  RNA_ENTER_NOJOIN(e);
+  RNA_HIP(e, hipStreamSynchronize(e->stream));
+  if (e->vfh_stream) RNA_HIP(e, hipStreamSynchronize(e->vfh_stream));
+  return RNA_OK;
+}
+
+// GPU_MAX_HW_QUEUES is read by the HIP runtime at its first call: set it when the library is loaded (a host links or
+// dlopens librna.so before it touches the GPU) unless the host has chosen a value itself.  Priority 101: before the
+// constructors that register this library's code objects with the runtime.
+__attribute__((constructor(101))) static void rna_default_hw_queues() {
+  if (!getenv("RNA_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+
+extern "C" int rna_hw_queue_advice(int pipeline_depth, char* buf, size_t cap) {
+  if (buf && cap) buf[0] = 0;
+  if (pipeline_depth <= 2) return 0;
+  const char* v = getenv("GPU_MAX_HW_QUEUES");
+  const int have = v ? atoi(v) : 4;   // the runtime's default
+  if (have >= 8) return 0;
+  if (buf && cap)
+    snprintf(buf, cap, "A* pipeline depth %d needs GPU_MAX_HW_QUEUES >= 8 in the environment before the first HIP call (%s%s): "
+             "the stages' streams share %d hardware queues and their searches overlap less", pipeline_depth,
+             v ? "it is " : "unset, the runtime's default is 4", v ? v : "", have);
+  return 1;
 }
 
 extern "C" int rna_get_index(const rna_engine* e, double x, double y, int32_t index[2]) {

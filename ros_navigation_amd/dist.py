@@ -217,9 +217,14 @@ def _gather_dirty_device(grid, layers, layout, rank, dist, tile):
     tiles_i, tiles_j = grid.tile_grid()
     win = layout.window(rank)
     lst_all = torch.empty(tiles_i * tiles_j, dtype=torch.int32, device=dev)
-    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    # (torch.empty: nothing torch's stream would still have to write -- the engine memsets the counter on its own stream,
+    # which nothing orders with a torch fill kernel)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    torch.cuda.current_stream(dev).synchronize()         # (the allocator may hand out memory a torch kernel is still using)
     grid.last_dirty_tiles_device(win, lst_all.data_ptr(), count.data_ptr())
-    grid.synchronize()                                   # the engine stream wrote list and count; torch's stream reads them
+    # the MAP stream wrote list and count; torch's stream reads them.  Only that stream is waited for: the A* batches
+    # of earlier passes stay in flight (rna_synchronize would drain the whole search pipeline on every pass)
+    grid.synchronize_map()
     counts_t = [torch.zeros_like(count) for _ in range(layout.world)]
     dist.all_gather(counts_t, count)
     counts = [int(c.item()) for c in counts_t]           # 4 * world bytes: the one host visit
@@ -232,7 +237,7 @@ def _gather_dirty_device(grid, layers, layout, rank, dist, tile):
     pad = torch.zeros(cap * tile * tile, dtype=torch.float32, device=dev)
     torch.cuda.current_stream(dev).synchronize()
     grid.pack_tiles_device(layers[0], lst.data_ptr(), counts[rank], win, pad.data_ptr())
-    grid.synchronize()
+    grid.synchronize_map()
     parts = [torch.empty_like(pad) for _ in range(layout.world)]
     dist.all_gather(parts, pad)
     torch.cuda.current_stream(dev).synchronize()
@@ -242,7 +247,7 @@ def _gather_dirty_device(grid, layers, layout, rank, dist, tile):
             continue
         grid.unpack_tiles_device(layers, lists[r].data_ptr(), counts[r], layout.window(r), parts[r].data_ptr())
         got += counts[r] * tile * tile * 4
-    grid.synchronize()                                   # lists / parts may be freed by torch after this call returns
+    grid.synchronize_map()                               # lists / parts may be freed by torch after this call returns
     return got
 
 

@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def capi():
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "ros_navigation_amd", "csrc"), "-j4", "-s"])
+    import _build
+    _build.native()
     from ros_navigation_amd import capi
     return capi
 
@@ -144,3 +145,38 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "rna_oracle" not in txt and "_oracle" not in txt and "librna_oracle" not in txt, f
+
+
+def test_hw_queue_advice_text_and_the_load_time_default(capi):
+    """Library-side guard for the hardware queues of a pipelined engine: librna.so sets GPU_MAX_HW_QUEUES=8 when it is
+    loaded with the variable unset (in time for any host that loads it before touching the GPU), leaves a host's own
+    value alone, and rna_hw_queue_advice says in one line when the value in force is too small for a pipeline depth --
+    the text rna_astar_set_pipeline_depth leaves in rna_last_error."""
+    import sys
+    L = capi.lib()
+    buf = C.create_string_buffer(400)
+    old = os.environ.get("GPU_MAX_HW_QUEUES")
+    try:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+        assert L.rna_hw_queue_advice(13, buf, 400) == 0 and buf.value == b""
+        os.environ["GPU_MAX_HW_QUEUES"] = "4"
+        assert L.rna_hw_queue_advice(13, buf, 400) == 1
+        text = buf.value.decode()
+        assert "depth 13" in text and "GPU_MAX_HW_QUEUES >= 8" in text and "it is 4" in text and "before the first HIP call" in text
+        assert "\n" not in text
+        assert L.rna_hw_queue_advice(2, buf, 400) == 0 and buf.value == b""      # two stages fit the default four queues
+        del os.environ["GPU_MAX_HW_QUEUES"]
+        assert L.rna_hw_queue_advice(4, buf, 400) == 1 and "unset" in buf.value.decode()
+        assert L.rna_hw_queue_advice(4, None, 0) == 1                               # no buffer: just the answer
+        assert L.rna_hw_queue_advice(4, buf, 8) == 1 and len(buf.value) <= 7       # truncated, terminated
+    finally:
+        if old is None:
+            os.environ.pop("GPU_MAX_HW_QUEUES", None)
+        else:
+            os.environ["GPU_MAX_HW_QUEUES"] = old
+    prog = ("import ctypes, sys; ctypes.CDLL(%r); g = ctypes.CDLL(None).getenv; g.restype = ctypes.c_char_p; "
+            "print(g(b'GPU_MAX_HW_QUEUES'))" % capi.LIB_PATH)
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "RNA_KEEP_HW_QUEUES")}
+    assert subprocess.check_output([sys.executable, "-c", prog], env=env, text=True).strip() == "b'8'"
+    assert subprocess.check_output([sys.executable, "-c", prog], env=dict(env, GPU_MAX_HW_QUEUES="5"), text=True).strip() == "b'5'"
+    assert subprocess.check_output([sys.executable, "-c", prog], env=dict(env, RNA_KEEP_HW_QUEUES="1"), text=True).strip() == "None"

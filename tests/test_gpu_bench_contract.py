@@ -4,6 +4,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -22,8 +23,12 @@ def run_bench(extra, env=None):
     return json.loads(lines[0])
 
 
-def test_bench_line_contract_on_a_small_grid():
-    d = run_bench(["--cpu-seconds", "0.5"])
+def test_bench_line_contract_on_a_small_grid_through_the_spawn_path_with_rccl():
+    """The JSON line's contract -- on the exact code an N-GPU run takes: a parent that never touches a GPU (GPUs counted
+    from the KFD topology, no torch import) starts the rank with Popen, the rank initialises RCCL (`nccl` backend), runs
+    the barriers around the timed region and the max over ranks -- forced at world size 1, un-shared, so that it has run
+    on hardware (one subprocess serves both checks: a bench start-up costs a torch import and a map set-up each)."""
+    d = run_bench(["--cpu-seconds", "0.5"], env={"RNA_BENCH_FORCE_SPAWN": "1"})
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "roofline_rows", "cpu_baseline"):
         assert k in d, k
@@ -49,23 +54,66 @@ def test_bench_line_contract_on_a_small_grid():
     # what the engine really allocated (stages / pages per query / concurrent queries may shrink to fit HBM) is reported
     alloc = cfg["astar_allocated"]
     assert alloc["pipeline_depth"] == cfg["astar_pipeline_depth"] and alloc["pages_per_query"] > 0 and alloc["max_queries"] == 32
+    la = cfg["launcher"]
+    assert la["spawned_by_bench"] and la["parent_is_my_parent"] and la["parent_hip_free"]
+    assert cfg["shards"] == [[0, 32]] and cfg["cycles_by_rank"] == [32 * PASSES]
 
 
-def test_bench_gpus_2_spawns_two_ranks():
-    """`--gpus 2` without a launcher: the parent starts both ranks itself (here on the one GPU of the test box, gloo
-    barrier) and rank 0 reports n_gpus == 2 with both ranks' cycles in `value`."""
-    d = run_bench(["--gpus", "2", "--no-cpu"], env={"RNA_BENCH_SHARE_GPU": "1"})
-    assert d["n_gpus"] == 2 and d["cpu_baseline"] is None
-    assert abs(d["value"] - 2 * 32 * PASSES / (d["ms_per_step"] * 5e-3)) < 1e-6 * d["value"]
-    assert "query-sharded x2" in d["config"]["parallelism"]
+# The 8-GPU bench runs once, unattended, at the end of a round: its two launch modes are rehearsed here at world size 8
+# with all ranks sharing the test box's GPU (RCCL refuses two ranks on one device, so the barrier and the max over ranks
+# go through gloo -- the RCCL leg of the same code runs in the test above), on a 1024 x 1024 grid.
+WORLD8 = ["--grid", "1024", "--queries", "32", "--steps", "3", "--warmup", "1", "--pipeline", "3", "--ray-poses", "8", "--rays-per-pose", "200",
+          "--gpus", "8", "--no-cpu"]
 
 
-def test_bench_spawn_path_with_rccl_at_world_one():
-    """The exact code an N-GPU run takes -- a parent that never touches a GPU (GPUs counted from the KFD topology, no
-    torch import) starts the rank with Popen, the rank initialises RCCL (`nccl` backend), runs the barriers around the
-    timed region and the max over ranks -- forced at world size 1, un-shared, so that it has run once on hardware."""
-    d = run_bench(["--no-cpu"], env={"RNA_BENCH_FORCE_SPAWN": "1"})
-    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["astar_paths_found"] > 0
+def run_world8(extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + WORLD8 + extra, capture_output=True, text=True,
+                         timeout=900, cwd=ROOT, env=dict(os.environ, RNA_BENCH_SHARE_GPU="1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]      # ONE line, from rank 0
+    return json.loads(lines[0])
+
+
+def check_world8_common(d):
+    cfg = d["config"]
+    passes = 3 * 3
+    assert d["n_gpus"] == 8 and d["cpu_baseline"] is None and d["scaling"] == "weak"
+    la = cfg["launcher"]
+    assert la["spawned_by_bench"] and la["parent_is_my_parent"] and la["parent_hip_free"]      # 8 ranks, started by a HIP-free parent
+    # the shards of the global batch (8 x 32 cycles per pass): disjoint, complete, in rank order
+    assert cfg["shards"] == [[32 * r, 32 * (r + 1)] for r in range(8)]
+    assert cfg["cycles_by_rank"] == [32 * passes] * 8
+    # value = the cycles ALL ranks served / the slowest rank's time
+    total = sum(cfg["cycles_by_rank"])
+    assert abs(d["value"] - total / cfg["timed_seconds"]) < 1e-6 * d["value"]
+    assert abs(d["ms_per_step"] * 3e-3 - cfg["timed_seconds"]) < 1e-9
+    assert cfg["astar_queries_answered"] == cfg["astar_queries_checked"] and cfg["astar_paths_found"] > 0
+
+
+def test_world8_rehearsal_query_sharded():
+    """SURVEY 8e mode 1 as the driver launches it at N = 8 (`bench.py --gpus 8`): replicated maps, sharded cycles"""
+    d = run_world8([])
+    check_world8_common(d)
+    assert "query-sharded x8" in d["config"]["parallelism"] and "tiled" not in d
+
+
+def test_world8_rehearsal_one_map_tiled_2x4():
+    """SURVEY 8e mode 2 / BASELINE config 5's layout (`--gpus 8 --tiled`): one map in 2 x 4 windows, every window at
+    least as wide as the VFH+ halo, the windows a partition of the map, strips and dirty tiles really travelling"""
+    d = run_world8(["--tiled"])
+    check_world8_common(d)
+    t = d["tiled"]
+    assert t["layout"] == [2, 4] and t["halo_cells"] == 16
+    wins = t["windows"]
+    assert len(wins) == 8 and all(w[1] >= t["halo_cells"] and w[3] >= t["halo_cells"] for w in wins)
+    cover = np.zeros((1024, 1024), np.int32)
+    for i0, ni, j0, nj in wins:
+        cover[i0:i0 + ni, j0:j0 + nj] += 1
+    assert (cover == 1).all()
+    assert wins == [[512 * (r // 4), 512, 256 * (r % 4), 256] for r in range(8)]
+    assert t["halo_bytes_per_pass_rank0"] > 0 and t["gather_bytes_per_pass_rank0"] > 0
+    assert "one map tiled 2 x 4" in d["config"]["parallelism"]
 
 
 def test_parent_of_the_ranks_counts_gpus_without_opening_hip():
@@ -104,5 +152,7 @@ def test_default_bench_keeps_the_engine_stream_alive():
     engine = sum(v for name, v in k.items() if name not in ("astar_search", "astar_reset", "astar_init", "vfh_step"))
     # (measured 1.33 - 1.43 ms on three boxes in round 3, bracketed by events that cost ~35 us per kernel themselves)
     assert engine < 1.8 and engine < d["config"]["ms_per_pass"], (k, d["config"]["ms_per_pass"])
-    assert d["value"] > 80000, d["value"]
+    # a cliff guard, not a benchmark: the rate when the engine stream starved was 22 k, with too few hardware queues 31 k
+    # (this kernel runs at 125 k+); RNA_TEST_BENCH_FLOOR overrides it on a shared or throttled box
+    assert d["value"] > float(os.environ.get("RNA_TEST_BENCH_FLOOR", "50000")), d["value"]
     assert d["config"]["astar_allocated"]["pipeline_depth"] == d["config"]["astar_pipeline_depth"]

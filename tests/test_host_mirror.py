@@ -1,51 +1,34 @@
 """C++ host mirror (reference class names over the C ABI): compiles everywhere, runs on the GPU box."""
 import os
 import subprocess
+import uuid
 
+import numpy as np
 import pytest
 
+import _build
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp")
-EXE = "/tmp/rna_host_mirror_test"
-NODE_SRC = os.path.join(ROOT, "tests", "cpp", "nav_graph_node_shaped.cpp")
-NODE_EXE = "/tmp/rna_nav_graph_node_shaped"
-NAV_SRC = os.path.join(ROOT, "tests", "cpp", "nav_node_shaped.cpp")
-NAV_EXE = "/tmp/rna_nav_node_shaped"
-RATE_SRC = os.path.join(ROOT, "tests", "cpp", "rate_loop_test.cpp")
-RATE_EXE = "/tmp/rna_rate_loop_test"
-
-
-def build(src=SRC, exe=EXE):
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "ros_navigation_amd", "csrc"), "-j4", "-s"])
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "librna_oracle.so"])
-    lib = os.path.join(ROOT, "ros_navigation_amd")
-    orc = os.path.join(ROOT, "oracle")
-    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-Wno-reorder", src, "-o", exe, "-L" + lib, "-lrna", "-L" + orc,
-                           "-lrna_oracle", "-Wl,-rpath," + lib, "-Wl,-rpath," + orc, "-lm", "-lpthread"])
 
 
 def test_host_mirror_compiles_against_the_c_abi():
-    build()
-    assert os.path.exists(EXE)
+    assert os.path.exists(_build.cpp("host_mirror_test"))
 
 
 def test_node_main_with_the_reference_signatures_compiles():
     """nav_graph_node.cpp's members, constructor initialiser list and goalCb, verbatim, against move_control_api.hpp"""
-    build(NODE_SRC, NODE_EXE)
-    assert os.path.exists(NODE_EXE)
+    assert os.path.exists(_build.cpp("nav_graph_node_shaped"))
 
 
 def test_nav_node_main_with_the_reference_signatures_compiles():
     """nav_node.cpp's members, constructor and makePlan / taileredPlan / ifGoalAchieved (the RRT flow), against move_control_api.hpp"""
-    build(NAV_SRC, NAV_EXE)
-    assert os.path.exists(NAV_EXE)
+    assert os.path.exists(_build.cpp("nav_node_shaped"))
 
 
 def test_ros_seams_rate_keeping_without_ros():
     """ros/rate_loop.hpp -- what ros/ros_seams.cpp runs the reference's three loops on -- with a simulated clock: 5 / 2 / 5 Hz
     kept the way ros::Rate keeps them, overruns counted, latest-message cache, 0.2 s scan rate limit"""
-    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-pthread", RATE_SRC, "-o", RATE_EXE])
-    out = subprocess.run([RATE_EXE], capture_output=True, text=True, timeout=60)
+    out = subprocess.run([_build.cpp("rate_loop_test")], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and "rate loop ok" in out.stdout, out.stdout + out.stderr
 
 
@@ -100,43 +83,28 @@ def test_ros_sources_are_guarded_and_name_the_reference_topics():
 @pytest.mark.gpu
 def test_nav_node_rrt_flow_through_the_reference_signatures_on_gpu():
     """mapTest's planning flow (10 m window -> RrtPlanner -> taileredPlan -> Steerer) on the default 600 x 600 map, against the oracle"""
-    build(NAV_SRC, NAV_EXE)
-    out = subprocess.run([NAV_EXE], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([_build.cpp("nav_node_shaped")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "nav_node-shaped main OK" in out.stdout, out.stdout + out.stderr
 
 
 @pytest.mark.gpu
 def test_config1_moving_map_loop_through_the_reference_signatures_on_gpu():
     """BASELINE config 1 as shipped: 80 x 80 map following the robot, update / move / VFH+ loop, against the oracle"""
-    build(NODE_SRC, NODE_EXE)
-    out = subprocess.run([NODE_EXE], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([_build.cpp("nav_graph_node_shaped")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "nav_graph_node-shaped main OK" in out.stdout, out.stdout + out.stderr
 
 
 @pytest.mark.gpu
 def test_host_mirror_matches_oracle_on_gpu():
-    build()
-    out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([_build.cpp("host_mirror_test")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "host mirror OK" in out.stdout, out.stdout + out.stderr
-
-
-RCCL_SRC = os.path.join(ROOT, "examples", "tiled_host.cpp")
-RCCL_EXE = "/tmp/rna_tiled_host"
-
-
-def build_tiled_host():
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "ros_navigation_amd", "csrc"), "-j4", "-s"])
-    lib = os.path.join(ROOT, "ros_navigation_amd")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", RCCL_SRC, "-o", RCCL_EXE, "-L" + lib, "-lrna_rccl", "-lrna",
-                           "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
 
 
 def test_rccl_tiled_host_compiles_against_rocm_rccl():
     """include/rna_rccl.h + csrc/rccl_tiled.hip (ncclSend / ncclRecv / ncclAllGather on the pack / unpack buffers) and
     the C++ host example build against ROCm's rccl headers; the exchange semantics are proven by the gloo tests of
     ros_navigation_amd/dist.py, which packs and unpacks through the same C ABI."""
-    build_tiled_host()
-    assert os.path.exists(RCCL_EXE)
+    assert os.path.exists(_build.cpp("tiled_host"))
 
 
 def test_cmake_configures_the_targets():
@@ -154,9 +122,80 @@ def test_cmake_configures_the_targets():
         shutil.rmtree(d, ignore_errors=True)
 
 
+def read_tiled_dump(path):
+    """records of examples/tiled_host.cpp's RNA_TILED_DUMP file: (tag, round, bytes)"""
+    recs = []
+    with open(path, "rb") as f:
+        while True:
+            head = f.read(16)
+            if len(head) < 16:
+                break
+            tag, rnd = np.frombuffer(head[:8], "<i4")
+            n = int(np.frombuffer(head[8:], "<i8")[0])
+            recs.append((int(tag), int(rnd), f.read(n)))
+    return recs
+
+
+def test_tiled_host_id_file_bootstrap_ignores_a_stale_file():
+    """examples/id_bootstrap.hpp on the CPU: a file left by an earlier job (another session token) is never taken for
+    this job's -- round 3's rank > 0 read whatever /tmp/rna_nccl_id held --, a reader times out rather than accept it,
+    takes the right one the moment rank 0 publishes it, and never sees half a file."""
+    out = subprocess.run([_build.cpp("id_bootstrap_test")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "id bootstrap ok" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.gpu
-def test_rccl_tiled_host_runs_as_a_single_rank():
-    """one rank = one GPU: ncclCommInitRank with world 1, every exchange a no-op, the rest of the loop for real"""
-    build_tiled_host()
-    out = subprocess.run([RCCL_EXE, "0", "1", "/tmp/rna_nccl_id", "1024", "2"], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and "tiled_host rank 0/1 OK" in out.stdout, out.stdout + out.stderr
+def test_rccl_tiled_host_runs_as_a_single_rank_and_matches_the_oracle(tmp_path):
+    """one rank = one GPU: ncclCommInitRank with world 1, every exchange a no-op, the rest of the loop for real -- and
+    every output of it (laser / master layers, VFH+ commands and histograms of both rounds, A* statuses, costs and
+    paths) against the oracle, from the inputs the program dumped.  The program names its phase on stderr and its own
+    watchdog ends it after 60 s without progress (exit 3): a hang fails this test in a minute and says where."""
+    import _oracle as O
+    exe = _build.cpp("tiled_host")
+    dump = str(tmp_path / "tiled.dump")
+    n, rounds = 1024, 2
+    out = subprocess.run([exe, "0", "1", str(tmp_path / "nccl_id"), str(n), str(rounds), uuid.uuid4().hex], capture_output=True, text=True,
+                         timeout=280, env=dict(os.environ, RNA_TILED_DUMP=dump))
+    assert out.returncode == 0 and "tiled_host rank 0/1 OK" in out.stdout, out.stdout + out.stderr[-3000:]
+    from ros_navigation_amd import capi
+    recs = read_tiled_dump(dump)
+    head = np.frombuffer(recs[0][2], "<i4")
+    assert recs[0][0] == 0 and list(head[:8]) == [n, rounds, 0, 1, 0, n, 0, n]
+    by = {}
+    for tag, rnd, data in recs[1:]:
+        by.setdefault((tag, rnd), []).append(data)
+    g = O.make_geom(n * 0.05, n * 0.05, 0.05)
+    laser = np.zeros(n * n, np.float32)
+    oracles = None
+    gw = np.empty(n * n, np.int32)
+    found = 0
+    for r in range(rounds):
+        rays = np.frombuffer(by[(1, r)][0], capi.RAY_DTYPE)
+        assert len(rays) == 20000
+        O.himm_update(g, laser, rays.view(O.RAY_DTYPE))
+        poses = np.frombuffer(by[(2, r)][0], capi.POSE_DTYPE)
+        vout = np.frombuffer(by[(3, r)][0], capi.VFH_OUT_DTYPE)
+        origin = np.frombuffer(by[(4, r)][0], "<f4").reshape(len(poses), 72)
+        hist = np.frombuffer(by[(5, r)][0], "<f4").reshape(len(poses), 72)
+        if oracles is None:
+            oracles = [O.OracleVfh() for _ in range(len(poses))]
+        for k, p in enumerate(poses):
+            cs, ct = oracles[k].step_pose(g, laser, p["x"], p["y"], p["yaw"], int(p["current_speed"]), p["goal_direction"],
+                                          p["goal_distance"], p["goal_tolerance"], float(p["dt"]))
+            assert (vout["chosen_speed"][k], vout["chosen_turnrate"][k]) == (cs, ct), (r, k)
+            assert origin[k].tobytes() == oracles[k].origin_hist().tobytes() and hist[k].tobytes() == oracles[k].hist().tobytes(), (r, k)
+        queries = np.frombuffer(by[(6, r)][0], capi.ASTAR_QUERY_DTYPE)
+        results = np.frombuffer(by[(7, r)][0], capi.ASTAR_RESULT_DTYPE)
+        assert len(queries) == 32 and len(by[(8, r)]) == 32
+        _, nbr = O.astar_masks(laser, n, n)
+        for k, q in enumerate(queries):
+            ores, opath, _ = O.astar_query(nbr, n, n, q["start"], q["goal"], g_work=gw)
+            assert results["status"][k] == ores.status, (r, k)
+            if ores.status == 0:
+                path = np.frombuffer(by[(8, r)][k], "<i4")
+                assert results["cost"][k] == ores.cost and np.array_equal(path, opath), (r, k)
+                found += 1
+    assert found > 0 and ("%d paths" % found) in out.stdout
+    for tag in (9, 10):     # the final laser and master layers
+        got = np.frombuffer(by[(tag, rounds)][0], "<f4")
+        assert np.array_equal(np.isnan(got), np.isnan(laser)) and np.array_equal(got[~np.isnan(got)], laser[~np.isnan(laser)]), tag
