@@ -9,7 +9,8 @@
 // (every exchange degenerates to a no-op).
 //
 // The program says where it is: every phase goes to stderr, unbuffered, and a watchdog thread ends the process with
-// exit code 3 and the name of the phase when a phase makes no progress for RNA_TILED_WATCHDOG_S seconds (default 60)
+// exit code 3 and the name of the phase when a phase makes no progress for RNA_TILED_WATCHDOG_S seconds (default 60; five
+// times that while the HIP and RCCL runtimes start up)
 // -- a hang names its phase instead of eating a test's timeout.  RNA_TILED_DUMP=<file> writes every input and output
 // (rays, poses, VFH+ results, queries, paths, the final layers) so that a test can check them against the oracle.
 #include <hip/hip_runtime.h>
@@ -32,6 +33,7 @@
 namespace {
 
 std::atomic<unsigned long long> g_beat{0};
+std::atomic<int> g_slack{1};   // the runtimes' own start-up phases get 5 x the watchdog limit, see phase()
 const char* volatile g_phase = "start";
 int g_rank = 0;
 int g_round = -1;
@@ -39,8 +41,11 @@ const std::chrono::steady_clock::time_point g_t0 = std::chrono::steady_clock::no
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - g_t0).count(); }
 
-void phase(const char* name) {
+// `slow_start`: a phase that first touches the HIP / RCCL runtimes (on a box whose image was just pulled, paging in
+// librccl.so's 570 MB of code objects takes minutes -- slow, not stuck)
+void phase(const char* name, bool slow_start = false) {
   g_phase = name;
+  g_slack.store(slow_start ? 5 : 1);
   g_beat.fetch_add(1);
   std::fprintf(stderr, "[tiled_host %d %8.3f s] round %d: %s\n", g_rank, now_s(), g_round, name);
 }
@@ -52,9 +57,10 @@ void watchdog(double limit_s) {
     std::this_thread::sleep_for(std::chrono::milliseconds(250));
     const unsigned long long b = g_beat.load();
     if (b != seen) { seen = b; since = now_s(); continue; }
-    if (now_s() - since > limit_s) {
+    const double limit = limit_s * g_slack.load();
+    if (now_s() - since > limit) {
       std::fprintf(stderr, "[tiled_host %d] WATCHDOG: no progress for %.0f s in phase \"%s\" of round %d -- giving up (exit 3)\n", g_rank,
-                   limit_s, g_phase, g_round);
+                   limit, g_phase, g_round);
       _exit(3);   // (never a re-exec: the process has initialised the GPU)
     }
   }
@@ -93,14 +99,14 @@ int main(int argc, char** argv) {
     if (!g_dump) { std::fprintf(stderr, "cannot write %s\n", d); return 1; }
   }
 
-  phase("hipGetDeviceCount");
+  phase("hipGetDeviceCount", true);
   int ndev = 0;
   OK(hipGetDeviceCount(&ndev));
   if (ndev <= 0) { std::fprintf(stderr, "tiled_host needs a GPU\n"); return 1; }
   const int dev = rank % ndev;
   OK(hipSetDevice(dev));
 
-  phase("ncclUniqueId");
+  phase("ncclUniqueId", true);
   const uint64_t token = rna_bootstrap::session_token(session);
   ncclUniqueId id;
   if (rank == 0) {
@@ -110,11 +116,11 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "[tiled_host %d] no ncclUniqueId of this session in %s\n", rank, id_file);
     return 1;
   }
-  phase("ncclCommInitRank");
+  phase("ncclCommInitRank", true);
   ncclComm_t comm;
   OK(ncclCommInitRank(&comm, world, id, rank));
 
-  phase("rna_create");
+  phase("rna_create", true);
   const double res = 0.05, len = n * res;
   rna_engine* e = nullptr;
   OK(rna_create(&e, len, len, res, 0.0, 0.0, dev));

@@ -25,10 +25,10 @@ def run_fuzzer(script, seconds, seed):
 
 @pytest.mark.parametrize("seed", [301, 302])
 def test_fuzz_grid_astar_fixed_seed(seed):
-    text = run_fuzzer("fuzz_astar.py", 20, seed)
+    text = run_fuzzer("fuzz_astar.py", 15, seed)
     maps = int(text.split("):")[1].split("maps")[0])
     assert maps >= 10, text     # the budget was spent on searches, not on start-up
 
 
 def test_fuzz_map_update_and_vfh_fixed_seed():
-    run_fuzzer("fuzz_himm_vfh.py", 20, 303)
+    run_fuzzer("fuzz_himm_vfh.py", 15, 303)

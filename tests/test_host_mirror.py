@@ -149,13 +149,14 @@ def test_rccl_tiled_host_runs_as_a_single_rank_and_matches_the_oracle(tmp_path):
     """one rank = one GPU: ncclCommInitRank with world 1, every exchange a no-op, the rest of the loop for real -- and
     every output of it (laser / master layers, VFH+ commands and histograms of both rounds, A* statuses, costs and
     paths) against the oracle, from the inputs the program dumped.  The program names its phase on stderr and its own
-    watchdog ends it after 60 s without progress (exit 3): a hang fails this test in a minute and says where."""
+    watchdog ends it after 60 s without progress (exit 3; 300 s while the HIP / RCCL runtimes start up, which on a box
+    whose image was just pulled means paging in librccl.so's 570 MB): a hang fails this test and says where."""
     import _oracle as O
     exe = _build.cpp("tiled_host")
     dump = str(tmp_path / "tiled.dump")
     n, rounds = 1024, 2
     out = subprocess.run([exe, "0", "1", str(tmp_path / "nccl_id"), str(n), str(rounds), uuid.uuid4().hex], capture_output=True, text=True,
-                         timeout=280, env=dict(os.environ, RNA_TILED_DUMP=dump))
+                         timeout=500, env=dict(os.environ, RNA_TILED_DUMP=dump))
     assert out.returncode == 0 and "tiled_host rank 0/1 OK" in out.stdout, out.stdout + out.stderr[-3000:]
     from ros_navigation_amd import capi
     recs = read_tiled_dump(dump)
