@@ -813,7 +813,10 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
 #endif
 constexpr int TSA_NP = RNA_TSA_NODES;   // (scripts/sim_async.c: ~3 400 entries at once in the worst of the bench's queries, stale ones included; more: see `spill`)
 constexpr int TSA_BMW = TSA_NP / 32;
-constexpr int TSA_QC = 1024;            // lines of the tile -> queued class table
+#ifndef RNA_TSA_QC
+#define RNA_TSA_QC 1024
+#endif
+constexpr int TSA_QC = RNA_TSA_QC;      // lines of the tile -> queued class table (a power of two)
 constexpr unsigned POP_EMPTY = 0xffffffffu;
 static_assert(TSA_NP % 32 == 0 && TSA_NP < 0xffff, "node indices are 16 bits, 0xffff = none");
 static_assert(TSA_NP * 4 >= (TI + 2) * (TJ + 2) * 4 + TILE_WORDS, "the backtrace's LDS image lives in the queue memory");

@@ -387,9 +387,11 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
   }
   if (threadIdx.x == 0) s_touched = 0;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int w = 0; w < 64; ++w) { s_mrank[w] = (unsigned short)run; run += __popc(s_mark[w]); }
+  if (threadIdx.x < 64) {   // marked cells in the words before this one: a prefix sum across the first wavefront
+    const int mine_n = __popc(s_mark[threadIdx.x]);
+    int incl = mine_n;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if ((int)threadIdx.x >= o) incl += v; }
+    s_mrank[threadIdx.x] = (unsigned short)(incl - mine_n);
   }
   __syncthreads();
   // one hash probe per marked cell of the half tile
@@ -406,6 +408,10 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
   __syncthreads();
   const int* mine = pairs + tile_off[t];
   bool touched = false;
+  // this job's cells: the half tile cut to the owner window (tiled single map, SURVEY 8e mode 2: the line is rasterised
+  // on the GLOBAL geometry and only the cells of this GPU's window are written)
+  const int ilo = max(i0, win.x), ihi = min(i0 + 64, win.y), jlo = max(j0, win.z), jhi = min(j0 + 32, win.w);
+  if (ilo < ihi && jlo < jhi)
   for (int base = 0; base < np; base += HIMM_TR_THREADS) {
     // The rays of a scan are consecutive in the list and leave their origin a quarter of a degree apart: taken lane by
     // lane, the 64 lanes of a wavefront would walk the same few cells for dozens of steps and their LDS adds would
@@ -415,42 +421,60 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
     if (p >= np) continue;
     const int r = mine[p];
     const RayWalk w(desc[r], ncells[r]);
-    // the ray's cells whose major coordinate lies in this tile
-    const int tM = w.xmajor ? ti : tj;
-    int k_lo = w.s > 0 ? (tM << 6) - w.M0 : w.M0 - ((tM << 6) + 63);
-    int k_hi = w.s > 0 ? (tM << 6) + 63 - w.M0 : w.M0 - (tM << 6);
+    // The ray's cells inside this job's rectangle are ONE run of k: the major coordinate moves by one per cell, the minor
+    // one is monotone (it has stepped q(k) = floor((num0 + k * add) / den) times after k cells).  Both bounds in closed
+    // form -- the walk below then has no test per cell.  (Round 3 walked every cell of the ray's 64-cell tile column in
+    // both half-tile jobs and tested each against tile, half and window: twice the cells, three times the instructions;
+    // on the 32 CUs the search streams leave to this kernel it took 0.67 ms per batch.)
+    const int Mlo = w.xmajor ? ilo : jlo, Mhi = w.xmajor ? ihi : jhi, mlo = w.xmajor ? jlo : ilo, mhi = w.xmajor ? jhi : ihi;
+    int k_lo = w.s > 0 ? Mlo - w.M0 : w.M0 - (Mhi - 1);
+    int k_hi = w.s > 0 ? Mhi - 1 - w.M0 : w.M0 - Mlo;
     if (k_lo < 0) k_lo = 0;
     if (k_hi > w.nc - 1) k_hi = w.nc - 1;
+    // minor steps allowed: q in [qa, qb]
+    int qa = w.sm > 0 ? mlo - w.m0 : w.m0 - (mhi - 1);
+    const int qb = w.sm > 0 ? mhi - 1 - w.m0 : w.m0 - mlo;
+    if (qb < 0) continue;
+    if (qa < 0) qa = 0;
+    if (w.add > 0) {
+      // q(k) >= qa  <=>  k >= ceil((qa * den - num0) / add);  q(k) <= qb  <=>  k <= floor(((qb + 1) * den - num0 - 1) / add)
+      // (den, add, q < 46 341: the products fit 32 unsigned bits, see RayWalk::minor)
+      const unsigned need = (unsigned)qa * (unsigned)w.den;
+      if (need > (unsigned)w.num0) {
+        const int ka = (int)((need - (unsigned)w.num0 + (unsigned)w.add - 1u) / (unsigned)w.add);
+        if (ka > k_lo) k_lo = ka;
+      }
+      const unsigned lim = ((unsigned)qb + 1u) * (unsigned)w.den - (unsigned)w.num0 - 1u;
+      const int kb = (int)(lim / (unsigned)w.add);
+      if (kb < k_hi) k_hi = kb;
+    } else if (qa > 0) {
+      continue;   // the minor coordinate never moves and lies outside
+    }
     if (k_lo > k_hi) continue;
+    touched = true;
     // integer Bresenham from cell k_lo on (LineIterator.cpp:133-149): minor steps when the numerator passes den
-    // (starting every lane at a different cell of its range, to keep the rays of one scan from piling their first
-    // clears onto the same LDS words, was measured: the second pair of 64-bit divisions costs more than it saves)
     const unsigned acc = (unsigned)w.num0 + (unsigned)k_lo * (unsigned)w.add;   // < 2^32, see RayWalk::minor
     const unsigned q = w.den > 0 ? acc / (unsigned)w.den : 0u;
     int m = w.m0 + (int)q * w.sm;
     int num = w.den > 0 ? (int)(acc - q * (unsigned)w.den) : 0;
     int M = w.major(k_lo);
+    // LDS index of a cell: (j & 31) * 64 + (i & 63); one step along the major / minor axis moves it by a constant
+    const int dM = w.xmajor ? w.s : w.s * 64, dm = w.xmajor ? w.sm * 64 : w.sm;
+    int lc = w.xmajor ? ((m - j0) << 6) + (M - i0) : ((M - j0) << 6) + (m - i0);
     for (int k = k_lo; k <= k_hi; ++k) {
-      const int i = w.xmajor ? M : m, j = w.xmajor ? m : M;
-      // the other tile of this tile column / the other half are somebody else's; tiled single map (SURVEY 8e mode
-      // 2): the line is rasterised on the GLOBAL geometry and only the cells of this GPU's window are written
-      if ((i >> 6) == ti && (j >> 5) == (j0 >> 5) && i >= win.x && i < win.y && j >= win.z && j < win.w) {
-        touched = true;
-        const int lc = ((j & 31) << 6) + (i & 63);
-        const unsigned mw = s_mark[lc >> 5];
-        if ((mw >> (lc & 31)) & 1u) {
-          const int rank = s_mrank[lc >> 5] + __popc(mw & ((1u << (lc & 31)) - 1u));
-          const int off = rank < HIMM_MTAB ? s_moff[rank] : -1;
-          // the clear belongs to the interval before the first mark with seq >= r
-          if (off >= 0) atomicAdd(&s_mcnt[2 * rank + (s_mseq[rank] < r ? 1 : 0)], 1u);
-          else himm_count_marked_clear(j * rows + i, r, slots, slot_mask, seqs, before, after);
-        } else {
-          atomicAdd(&s_cnt[lc], 1u);   // unmarked cell: clears commute, only their number matters
-        }
+      const unsigned mw = s_mark[lc >> 5];
+      if ((mw >> (lc & 31)) & 1u) {
+        const int rank = s_mrank[lc >> 5] + __popc(mw & ((1u << (lc & 31)) - 1u));
+        const int off = rank < HIMM_MTAB ? s_moff[rank] : -1;
+        // the clear belongs to the interval before the first mark with seq >= r
+        if (off >= 0) atomicAdd(&s_mcnt[2 * rank + (s_mseq[rank] < r ? 1 : 0)], 1u);
+        else himm_count_marked_clear((j0 + (lc >> 6)) * rows + i0 + (lc & 63), r, slots, slot_mask, seqs, before, after);
+      } else {
+        atomicAdd(&s_cnt[lc], 1u);   // unmarked cell: clears commute, only their number matters
       }
       num += w.add;
-      if (num >= w.den && w.den > 0) { num -= w.den; m += w.sm; }
-      M += w.s;
+      lc += dM;
+      if (num >= w.den && w.den > 0) { num -= w.den; lc += dm; }
     }
   }
   if (touched) s_touched = 1;
