@@ -31,6 +31,9 @@ struct HimmScratch {
   int* total = nullptr;          // allocation cursor into seqs
   unsigned* mark_bitmap = nullptr;  // 1 bit per cell: cell holds >= 1 mark in the current batch
   int* pairs = nullptr;          // (tile, ray) pairs grouped by tile: the rays each 64 x 64 tile has to rasterise
+  size_t pairs_cap = 0;          // ints allocated for them
+  bool pairs_checked = false;    // pairs_cap is below the worst case: every batch's pair count is read back before it is used
+  int* pairs_total_host = nullptr;   // pinned: the count of the batch being launched (pairs_checked only)
   int* tile_bins = nullptr;      // [3][ntile]: pair count, offset and fill cursor per tile
   int win[4] = {0, 0, 0, 0};     // owner window [i0, i1) x [j0, j1) in buffer indices; i1 == 0: whole map
 };

@@ -271,7 +271,7 @@ __global__ void himm_bin_count_kernel(const int4* __restrict__ desc, const int* 
 // ticket instead of one workgroup per half tile of the map -- of the 8192 half tiles of a 4096^2 map a 100 k-ray batch
 // touches ~1500, and next to the search workgroups that fill every CU each EMPTY workgroup still had to wait for a slot.
 __global__ void __launch_bounds__(1024) himm_bin_scan_kernel(int* __restrict__ tile_count, int ntile, int* __restrict__ tile_off,
-                                                             int* __restrict__ tile_cursor, int* __restrict__ active,
+                                                             int* __restrict__ tile_cursor, int4* __restrict__ active,
                                                              int* __restrict__ n_active, int* __restrict__ ticket) {
   __shared__ int s_part[1024];
   __shared__ int s_act[1024];
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(1024) himm_bin_scan_kernel(int* __restrict__ t
   for (int t = lo; t < hi; ++t) {
     const int c = tile_count[t];
     tile_off[t] = run; tile_cursor[t] = 0; run += c;
-    if (c > 0) active[arun++] = t;
+    if (c > 0) active[arun++] = make_int4(t, run - c, c, 0);   // the rasteriser's job record: tile, first pair, pairs -- one load
     tile_count[t] = 0;   // (counts: zero again for the next batch)
   }
   if (threadIdx.x == 1023) { tile_off[ntile] = s_part[1023]; *n_active = s_act[1023]; *ticket = 0; }
@@ -321,6 +321,21 @@ __global__ void himm_bin_fill_kernel(const int4* __restrict__ desc, const int* _
 // counters in HBM (hash probe + binary search: a chain of dependent loads).
 constexpr int HIMM_MTAB = 256;   // marked cells per half tile with an LDS entry
 
+#ifdef RNA_HIMM_STATS
+// developer build: where a rasteriser job's time goes (100 MHz ticks of thread 0, summed over all jobs), printed by himm_release
+__device__ unsigned long long g_himm_stat[16];
+#define HST(var) const unsigned long long var = wall_clock64()
+#define HACC(slot, a, b) do { if (threadIdx.x == 0) atomicAdd(&g_himm_stat[slot], (unsigned long long)((b) - (a))); } while (0)
+#define HCNT(slot, v) do { if (threadIdx.x == 0) atomicAdd(&g_himm_stat[slot], (unsigned long long)(v)); } while (0)
+#else
+#define HST(var)
+#define HACC(slot, a, b)
+#define HCNT(slot, v)
+#endif
+
+// a workgroup barrier that orders LDS only: global loads that are in flight stay in flight (himm_tile_raster_kernel)
+__device__ __forceinline__ void himm_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ void himm_count_marked_clear(int cell, int r, const HimmSlot* __restrict__ slots, int slot_mask,
                                                         const int* __restrict__ seqs, unsigned* __restrict__ before,
                                                         unsigned* __restrict__ after) {
@@ -337,90 +352,131 @@ __device__ __forceinline__ void himm_count_marked_clear(int cell, int r, const H
   else atomicAdd(&after[off + len - 1], 1u);
 }
 
-constexpr int HIMM_TR_THREADS = 512;   // (a power of two: the lane -> ray permutation of the rasteriser relies on it) // 8 wavefronts: two per SIMD next to the four of a resident search workgroup
+#ifndef RNA_HIMM_TR_ROWS
+#define RNA_HIMM_TR_ROWS 32   // rows (j) of a 64 x 64 tile per job: 32 = half-tile jobs (8 KB of counters), 64 = whole tiles (16 KB)
+#endif
+constexpr int HIMM_TR_ROWS = RNA_HIMM_TR_ROWS;
+#ifndef RNA_HIMM_TR_THREADS
+#define RNA_HIMM_TR_THREADS 512
+#endif
+constexpr int HIMM_TR_THREADS = RNA_HIMM_TR_THREADS;   // (a power of two: the lane -> ray permutation of the rasteriser relies on it) // 8 wavefronts: two per SIMD next to the four of a resident search workgroup
 __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int rows, int cols, int tiles_i, const int4* __restrict__ desc,
                                                                const int* __restrict__ ncells,
                                                                const int* __restrict__ tile_off, const int* __restrict__ pairs,
-                                                               const int* __restrict__ active, const int* __restrict__ n_active,
+                                                               const int4* __restrict__ active, const int* __restrict__ n_active,
                                                                int* __restrict__ ticket,
                                                                float* __restrict__ layer, const unsigned* __restrict__ mark_bitmap,
                                                                const HimmSlot* __restrict__ slots, int slot_mask,
                                                                const int* __restrict__ seqs, unsigned* __restrict__ before,
                                                                unsigned* __restrict__ after, unsigned* __restrict__ dirty_tiles, int4 win) {
-  __shared__ unsigned s_cnt[32 * 64];   // clears per cell of this half tile, index (j & 31) * 64 + (i & 63)
-  __shared__ unsigned s_mark[64];       // mark bits of the half tile: word lc >> 5, bit lc & 31
-  __shared__ unsigned short s_mrank[64];   // marked cells in the words before this one
+  __shared__ unsigned s_cnt[HIMM_TR_ROWS * 64];   // clears per cell of this job's rows, index (j - j0) * 64 + (i & 63)
+  __shared__ unsigned s_mark[HIMM_TR_ROWS * 2];   // mark bits of those cells: word lc >> 5, bit lc & 31
+  __shared__ unsigned short s_mrank[HIMM_TR_ROWS * 2];   // marked cells in the words before this one
   __shared__ int s_moff[HIMM_MTAB];     // per marked cell (by rank): offset of its marks in seqs / before / after, -1: not a single-mark cell
   __shared__ int s_mseq[HIMM_MTAB];     // ... the ray sequence number of its one mark
   __shared__ unsigned s_mcnt[2 * HIMM_MTAB];   // ... clears before / after that mark
   __shared__ int s_touched, s_job;
-  const int njobs = 2 * *n_active;
-  bool first_job = true;
-  for (;;) {   // (tile, half) jobs by ticket; the first one is the workgroup's own index (a thousand workgroups asking
-               // for a ticket at once queue up on one L2 address for ~12 ns each)
-  __syncthreads();   // the previous job's LDS has been read
-  if (threadIdx.x == 0) s_job = first_job ? (int)blockIdx.x : (int)gridDim.x + atomicAdd(ticket, 1);
-  first_job = false;
-  __syncthreads();
-  const int job = s_job;
+  __shared__ int4 s_rec;
+  constexpr int JPT = 64 / HIMM_TR_ROWS, NW = HIMM_TR_ROWS * 2;   // jobs per 64 x 64 tile; words of mark bits per job
+  const int njobs = JPT * *n_active;
+  // Which ray of a round a lane takes (-1: none).  A round is up to HIMM_TR_THREADS rays; a shorter one is dealt to the
+  // first `span` lanes only (span = the next power of two, at least a wavefront): half the tiles of a batch hold fewer
+  // than a hundred rays, and spread over all eight wavefronts each of them walked its 64 steps for a dozen lanes.
+  // Inside the span the lanes take every 33rd ray (x -> 33 x mod span is a bijection), see the walk below.
+  auto ray_of_lane = [](int rem) -> int {
+    int span = HIMM_TR_THREADS;
+    if (rem < HIMM_TR_THREADS) { span = 64; while (span < rem) span <<= 1; }
+    if ((int)threadIdx.x >= span) return -1;
+    const int p = (int)((threadIdx.x * 33u) & (unsigned)(span - 1));
+    return p < rem ? p : -1;
+  };
+  // (tile, part) jobs by ticket; the first one is the workgroup's own index (a thousand workgroups asking for a ticket at
+  // once queue up on one L2 address for ~12 ns each).
+  // A job is a chain of dependent memory round trips (ticket, job record, mark bits, the marked cells' slots, the rays,
+  // the cells to rewrite) with little arithmetic in between, and the 32 CUs the search streams leave to this kernel hold
+  // few workgroups -- 17 us per job on an idle CU, of which the arithmetic is 3.  So: the ticket and the record of the
+  // NEXT job are fetched by thread 0 while this job runs; the barriers only order LDS (s_waitcnt lgkmcnt(0) + s_barrier:
+  // __syncthreads() would drain the global loads in flight at every barrier), so each step's loads are issued before the
+  // previous step's LDS work; and the cells to rewrite are loaded all at once.
+  int job = (int)blockIdx.x;
+  int4 rec = job < njobs ? active[job / JPT] : make_int4(0, 0, 0, 0);   // tile, its first (tile, ray) pair, its pairs (> 0)
+  for (;;) {
   if (job >= njobs) break;
-  const int t = active[job >> 1], half = job & 1;
-  const int np = tile_off[t + 1] - tile_off[t];   // rays registered with this tile (> 0)
+  HST(t_0);
+  int next_ticket = 0;
+  if (threadIdx.x == 0) next_ticket = atomicAdd(ticket, 1);   // (in flight until the walk is over)
+  const int t = rec.x, part = job % JPT, np = rec.z;
+  const int* mine = pairs + rec.y;
   const int ti = t % tiles_i, tj = t / tiles_i;
-  const int i0 = ti << 6, j0 = (tj << 6) + (half << 5);
-  for (int c = threadIdx.x; c < 32 * 64; c += HIMM_TR_THREADS) s_cnt[c] = 0u;
-  for (int c = threadIdx.x; c < 2 * HIMM_MTAB; c += HIMM_TR_THREADS) s_mcnt[c] = 0u;
-  if (threadIdx.x < HIMM_MTAB) s_moff[threadIdx.x] = -1;
-  if (threadIdx.x < 64) {
+  const int i0 = ti << 6, j0 = (tj << 6) + part * HIMM_TR_ROWS;
+  // round trip 1: this lane's first ray and the half tile's mark bits
+  const int p0 = ray_of_lane(np);
+  const int r0 = p0 >= 0 ? mine[p0] : -1;
+  unsigned bits = 0u;
+  if (threadIdx.x < NW) {
     // the tile's 64 cells of column j are two words of the bitmap when rows is a multiple of 32; gathered bit by
     // bit otherwise
     const int jl = threadIdx.x >> 1, wi = threadIdx.x & 1;
     const int j = j0 + jl, ib = i0 + (wi << 5);
-    unsigned bits = 0u;
     if (j < cols && ib < rows) {
       const size_t cell = (size_t)j * rows + ib;
       if ((cell & 31) == 0 && ib + 32 <= rows) bits = mark_bitmap[cell >> 5];
       else
         for (int b = 0; b < 32 && ib + b < rows; ++b) bits |= ((mark_bitmap[(cell + b) >> 5] >> ((cell + b) & 31)) & 1u) << b;
     }
-    s_mark[threadIdx.x] = bits;
   }
+  for (int c = threadIdx.x; c < HIMM_TR_ROWS * 64; c += HIMM_TR_THREADS) s_cnt[c] = 0u;
+  for (int c = threadIdx.x; c < 2 * HIMM_MTAB; c += HIMM_TR_THREADS) s_mcnt[c] = 0u;
+  for (int c = threadIdx.x; c < HIMM_MTAB; c += HIMM_TR_THREADS) s_moff[c] = -1;
   if (threadIdx.x == 0) s_touched = 0;
-  __syncthreads();
-  if (threadIdx.x < 64) {   // marked cells in the words before this one: a prefix sum across the first wavefront
-    const int mine_n = __popc(s_mark[threadIdx.x]);
+  // round trip 2: the ray itself (used after the marked cells have been looked up)
+  int4 d0 = make_int4(0, 0, 0, 0);
+  int nc0 = 0;
+  if (r0 >= 0) { d0 = desc[r0]; nc0 = ncells[r0]; }
+  if (threadIdx.x < NW) s_mark[threadIdx.x] = bits;
+  himm_lds_barrier();
+  HST(t_1);
+  if (threadIdx.x < 64) {   // marked cells in the words before this one: a prefix sum across the first wavefront (NW / 64 words per lane)
+    constexpr int PER = NW / 64;
+    int mine_n = 0;
+    for (int k = 0; k < PER; ++k) mine_n += __popc(s_mark[threadIdx.x * PER + k]);
     int incl = mine_n;
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if ((int)threadIdx.x >= o) incl += v; }
-    s_mrank[threadIdx.x] = (unsigned short)(incl - mine_n);
+    int run = incl - mine_n;
+    for (int k = 0; k < PER; ++k) { s_mrank[threadIdx.x * PER + k] = (unsigned short)run; run += __popc(s_mark[threadIdx.x * PER + k]); }
   }
-  __syncthreads();
-  // one hash probe per marked cell of the half tile
-  for (int w = threadIdx.x >> 5, b = threadIdx.x & 31; w < 64; w += HIMM_TR_THREADS / 32) {
+  himm_lds_barrier();
+  // one hash probe per marked cell of the half tile (also round trip 2): the slot is one 16-byte load, and a cell with
+  // a single mark has that mark's ray in `head`
+  for (int w = threadIdx.x >> 5, b = threadIdx.x & 31; w < NW; w += HIMM_TR_THREADS / 32) {
     if (!((s_mark[w] >> b) & 1u)) continue;
+    const int lc = (w << 5) + b;
+    s_cnt[lc] = 0x80000000u;   // "marked": seen by the walk in the value its add returns (zeroed before the first barrier)
     const int rank = s_mrank[w] + __popc(s_mark[w] & ((1u << b) - 1u));
     if (rank >= HIMM_MTAB) continue;
-    const int lc = (w << 5) + b;
     const int cell = (j0 + (lc >> 6)) * rows + i0 + (lc & 63);
     unsigned h = hash_cell((unsigned)cell) & (unsigned)slot_mask;
-    while (slots[h].cell != cell) h = (h + 1) & (unsigned)slot_mask;
-    if (slots[h].len == 1) { s_moff[rank] = slots[h].offset; s_mseq[rank] = seqs[slots[h].offset]; }
+    int4 sl = *reinterpret_cast<const int4*>(&slots[h]);   // cell, head, len, offset
+    while (sl.x != cell) { h = (h + 1) & (unsigned)slot_mask; sl = *reinterpret_cast<const int4*>(&slots[h]); }
+    if (sl.z == 1) { s_moff[rank] = sl.w; s_mseq[rank] = sl.y; }
   }
-  __syncthreads();
-  const int* mine = pairs + tile_off[t];
+  HST(t_2);
+  himm_lds_barrier();
+  HST(t_3);
   bool touched = false;
   // this job's cells: the half tile cut to the owner window (tiled single map, SURVEY 8e mode 2: the line is rasterised
   // on the GLOBAL geometry and only the cells of this GPU's window are written)
-  const int ilo = max(i0, win.x), ihi = min(i0 + 64, win.y), jlo = max(j0, win.z), jhi = min(j0 + 32, win.w);
+  const int ilo = max(i0, win.x), ihi = min(i0 + 64, win.y), jlo = max(j0, win.z), jhi = min(j0 + HIMM_TR_ROWS, win.w);
   if (ilo < ihi && jlo < jhi)
   for (int base = 0; base < np; base += HIMM_TR_THREADS) {
     // The rays of a scan are consecutive in the list and leave their origin a quarter of a degree apart: taken lane by
     // lane, the 64 lanes of a wavefront would walk the same few cells for dozens of steps and their LDS adds would
     // serialise on the address.  The lanes take every 33rd ray instead (x -> 33 x mod 512 is a bijection): neighbouring
     // lanes are 7.6 degrees apart and part after a few cells.
-    const int p = base + (int)((threadIdx.x * 33u) & (unsigned)(HIMM_TR_THREADS - 1));
-    if (p >= np) continue;
-    const int r = mine[p];
-    const RayWalk w(desc[r], ncells[r]);
+    const int pl = base == 0 ? p0 : ray_of_lane(np - base);
+    if (pl < 0) continue;
+    const int r = base == 0 ? r0 : mine[base + pl];
+    const RayWalk w(base == 0 ? d0 : desc[r], base == 0 ? nc0 : ncells[r]);
     // The ray's cells inside this job's rectangle are ONE run of k: the major coordinate moves by one per cell, the minor
     // one is monotone (it has stepped q(k) = floor((num0 + k * add) / den) times after k cells).  Both bounds in closed
     // form -- the walk below then has no test per cell.  (Round 3 walked every cell of the ray's 64-cell tile column in
@@ -461,41 +517,83 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
     // LDS index of a cell: (j & 31) * 64 + (i & 63); one step along the major / minor axis moves it by a constant
     const int dM = w.xmajor ? w.s : w.s * 64, dm = w.xmajor ? w.sm * 64 : w.sm;
     int lc = w.xmajor ? ((m - j0) << 6) + (M - i0) : ((M - j0) << 6) + (m - i0);
+    // One LDS operation per cell: the counter of a MARKED cell carries bit 31 (set by the prologue), and the add returns
+    // the old value -- which is looked at one step later, when the next cell's add is already on its way (with a read of
+    // the mark bits in front of every add a step was two dependent LDS round trips, ~300 cycles; 8.7 of a job's 14.5 us).
+    // A marked cell's clear belongs to an interval between that cell's marks, not to s_cnt (whose value for such a cell
+    // is never used).
+    auto marked_clear = [&](int c) {
+      const unsigned mw = s_mark[c >> 5];
+      const int rank = s_mrank[c >> 5] + __popc(mw & ((1u << (c & 31)) - 1u));
+      const int off = rank < HIMM_MTAB ? s_moff[rank] : -1;
+      // the clear belongs to the interval before the first mark with seq >= r
+      if (off >= 0) atomicAdd(&s_mcnt[2 * rank + (s_mseq[rank] < r ? 1 : 0)], 1u);
+      else himm_count_marked_clear((j0 + (c >> 6)) * rows + i0 + (c & 63), r, slots, slot_mask, seqs, before, after);
+    };
+    unsigned old_prev = 0u;
+    int lc_prev = 0;
     for (int k = k_lo; k <= k_hi; ++k) {
-      const unsigned mw = s_mark[lc >> 5];
-      if ((mw >> (lc & 31)) & 1u) {
-        const int rank = s_mrank[lc >> 5] + __popc(mw & ((1u << (lc & 31)) - 1u));
-        const int off = rank < HIMM_MTAB ? s_moff[rank] : -1;
-        // the clear belongs to the interval before the first mark with seq >= r
-        if (off >= 0) atomicAdd(&s_mcnt[2 * rank + (s_mseq[rank] < r ? 1 : 0)], 1u);
-        else himm_count_marked_clear((j0 + (lc >> 6)) * rows + i0 + (lc & 63), r, slots, slot_mask, seqs, before, after);
-      } else {
-        atomicAdd(&s_cnt[lc], 1u);   // unmarked cell: clears commute, only their number matters
-      }
+      const unsigned old = atomicAdd(&s_cnt[lc], 1u);
+      if (old_prev >> 31) marked_clear(lc_prev);
+      old_prev = old;
+      lc_prev = lc;
       num += w.add;
       lc += dM;
       if (num >= w.den && w.den > 0) { num -= w.den; lc += dm; }
     }
+    if (old_prev >> 31) marked_clear(lc_prev);
   }
+  HST(t_4);
   if (touched) s_touched = 1;
-  __syncthreads();
-  if (!s_touched) continue;
-  // flags exist for the laser layer only ("laser differs from master here")
-  if (threadIdx.x == 0 && dirty_tiles) reinterpret_cast<volatile unsigned char*>(dirty_tiles)[t] = 1;
-  if (threadIdx.x < HIMM_MTAB && s_moff[threadIdx.x] >= 0) {
-    const unsigned kb = s_mcnt[2 * threadIdx.x], ka = s_mcnt[2 * threadIdx.x + 1];
-    if (kb) atomicAdd(&before[s_moff[threadIdx.x]], kb);
-    if (ka) atomicAdd(&after[s_moff[threadIdx.x]], ka);
+  // the next job: its ticket has long arrived; its record is loaded now, next to the cells this job rewrites
+  int4 rec_next = make_int4(0, 0, 0, 0);
+  int job_next = 0;
+  if (threadIdx.x == 0) {
+    job_next = (int)gridDim.x + next_ticket;
+    if (job_next < njobs) rec_next = active[job_next / JPT];
   }
-  // apply: lanes run along i (contiguous in the column-major layer); only lines that hold a counted cell are touched
-  for (int c = threadIdx.x; c < 32 * 64; c += HIMM_TR_THREADS) {
-    const unsigned k = s_cnt[c];
-    if (k == 0u) continue;
-    const int i = i0 + (c & 63), j = j0 + (c >> 6);
-    float* p = &layer[(size_t)j * rows + i];
-    const float v = *p, nv = himm_clear_n(v, k);
-    if (__float_as_int(nv) != __float_as_int(v)) *p = nv;
+  himm_lds_barrier();
+  HST(t_5);
+  if (s_touched) {
+    // flags exist for the laser layer only ("laser differs from master here")
+    if (threadIdx.x == 0 && dirty_tiles) reinterpret_cast<volatile unsigned char*>(dirty_tiles)[t] = 1;
+    for (int c = threadIdx.x; c < HIMM_MTAB; c += HIMM_TR_THREADS)
+      if (s_moff[c] >= 0) {
+        const unsigned kb = s_mcnt[2 * c], ka = s_mcnt[2 * c + 1];
+        if (kb) atomicAdd(&before[s_moff[c]], kb);
+        if (ka) atomicAdd(&after[s_moff[c]], ka);
+      }
+    // apply: lanes run along i (contiguous in the column-major layer); only cells that were counted are touched.  All of
+    // a thread's cells are loaded before the first is used (one memory round trip, not one per cell).
+    constexpr int PER_T = HIMM_TR_ROWS * 64 / HIMM_TR_THREADS;
+    unsigned kk[PER_T];
+    float vv[PER_T];
+#pragma unroll
+    for (int u = 0; u < PER_T; ++u) {
+      kk[u] = s_cnt[threadIdx.x + u * HIMM_TR_THREADS];
+      if (kk[u] >> 31) kk[u] = 0u;   // a marked cell: rewritten by himm_apply from its interval counters
+    }
+#pragma unroll
+    for (int u = 0; u < PER_T; ++u) {
+      const int c = threadIdx.x + u * HIMM_TR_THREADS;
+      vv[u] = kk[u] ? layer[(size_t)(j0 + (c >> 6)) * rows + i0 + (c & 63)] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < PER_T; ++u) {
+      if (kk[u] == 0u) continue;
+      const int c = threadIdx.x + u * HIMM_TR_THREADS;
+      const float nv = himm_clear_n(vv[u], kk[u]);
+      if (__float_as_int(nv) != __float_as_int(vv[u])) layer[(size_t)(j0 + (c >> 6)) * rows + i0 + (c & 63)] = nv;
+    }
   }
+  HST(t_6);
+  if (threadIdx.x == 0) { s_job = job_next; s_rec = rec_next; }
+  himm_lds_barrier();   // this job's LDS has been read; the next job is known
+  HST(t_7);
+  HACC(0, t_0, t_1); HACC(1, t_1, t_2); HACC(2, t_2, t_3); HACC(3, t_3, t_4); HACC(4, t_4, t_5); HACC(5, t_5, t_6); HACC(6, t_6, t_7);
+  HCNT(7, 1); HCNT(8, np);
+  job = s_job;
+  rec = s_rec;
   }   // next job
 }
 
@@ -523,6 +621,27 @@ __global__ void himm_apply_kernel(int rows, HimmSlot* __restrict__ slots, int n_
   if (dirty_tiles && reinterpret_cast<volatile unsigned char*>(dirty_tiles)[tile] != 1) reinterpret_cast<volatile unsigned char*>(dirty_tiles)[tile] = 1;
 }
 
+// (tile, ray) pairs of a batch.  Worst case: a ray is registered with at most two tiles per 64-cell tile column it crosses,
+// i.e. 2 * ceil(max(rows, cols) / 64) + 2 pairs -- 130 ints per ray on a 4096^2 map although the bench's rays make 2.3.
+// While that is small (<= 256 MB) it is simply allocated: nothing to check, nothing to wait for.  Beyond (a million
+// rays on a large map: 0.5 GB and up, out of the HBM the A* page pools are sized from) the buffer starts at 16 pairs per
+// ray, every batch's exact count -- the binning prefix sum's total -- is read back (4 bytes) before the pairs are written,
+// and the buffer grows when a batch needs more.
+static size_t himm_pairs_worst(const rna_engine* e, size_t cap_rays) {
+  return cap_rays * (size_t)(2 * ((std::max(e->geom.size[0], e->geom.size[1]) + 63) / 64) + 2);
+}
+static size_t himm_pairs_initial(const rna_engine* e, size_t cap_rays, bool* checked) {
+  const size_t worst = himm_pairs_worst(e, cap_rays);
+  size_t limit = (size_t)64 << 20;   // ints
+  if (const char* v = getenv("RNA_HIMM_PAIRS_LIMIT")) limit = (size_t)atoll(v);   // developer knob (tests): ints allocated without checking
+  *checked = worst > limit;
+  return *checked ? std::min(worst, std::max(cap_rays * 16, limit / 4)) : worst;
+}
+
+// tile_bins: count [ntile] | offset [ntile + 1] | cursor [ntile] | number of tiles with rays | ticket | (16-byte aligned)
+// job records of the tiles with rays, int4 [ntile]
+static size_t himm_bins_active_at(size_t ntile) { return (3 * ntile + 3 + 3) & ~(size_t)3; }
+
 int ensure_scratch(rna_engine* e, int n) {
   HimmScratch& s = e->himm;
   int rc;
@@ -533,8 +652,9 @@ int ensure_scratch(rna_engine* e, int n) {
     if ((rc = dev_alloc(e, &s.total, 1)) != RNA_OK) return rc;
     // per 64 x 64 tile: count | offset (ntile + 1) | cursor | list of the tiles with rays, then their number and the
     // rasteriser's ticket; the counts are all zero between batches (the scan leaves them so)
-    if ((rc = dev_alloc(e, &s.tile_bins, (size_t)4 * e->tiles_i * e->tiles_j + 3)) != RNA_OK) return rc;
-    RNA_HIP(e, hipMemsetAsync(s.tile_bins, 0, ((size_t)4 * e->tiles_i * e->tiles_j + 3) * sizeof(int), e->stream));
+    const size_t bins = himm_bins_active_at((size_t)e->tiles_i * e->tiles_j) + (size_t)4 * e->tiles_i * e->tiles_j;
+    if ((rc = dev_alloc(e, &s.tile_bins, bins)) != RNA_OK) return rc;
+    RNA_HIP(e, hipMemsetAsync(s.tile_bins, 0, bins * sizeof(int), e->stream));
   }
   if (n <= s.cap_rays) return RNA_OK;
   int cap = 1024;
@@ -547,13 +667,15 @@ int ensure_scratch(rna_engine* e, int n) {
       (rc = dev_alloc(e, &s.ncells, (size_t)cap)) != RNA_OK || (rc = dev_alloc(e, &s.next, (size_t)cap)) != RNA_OK ||
       (rc = dev_alloc(e, &s.seqs, (size_t)cap)) != RNA_OK || (rc = dev_alloc(e, &s.before, (size_t)cap)) != RNA_OK ||
       (rc = dev_alloc(e, &s.after, (size_t)cap)) != RNA_OK || (rc = dev_alloc(e, &s.slots, (size_t)cap * 2)) != RNA_OK ||
-      // a ray is registered with at most two tiles per 64-cell tile column it crosses
-      (rc = dev_alloc(e, &s.pairs, (size_t)cap * (size_t)(2 * ((std::max(e->geom.size[0], e->geom.size[1]) + 63) / 64) + 2))) != RNA_OK) {
+      (rc = dev_alloc(e, &s.pairs, himm_pairs_initial(e, (size_t)cap, &s.pairs_checked))) != RNA_OK) {
     const std::string why = e->err;
     (void)himm_release(e);
     e->err = why;
     return rc;
   }
+  s.pairs_cap = himm_pairs_initial(e, (size_t)cap, &s.pairs_checked);
+  if (s.pairs_checked && !s.pairs_total_host)
+    RNA_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&s.pairs_total_host), sizeof(int), hipHostMallocDefault));
   s.n_slots = cap * 2;
   s.cap_rays = cap;
   hipLaunchKernelGGL(himm_init_slots_kernel, dim3((s.n_slots + 255) / 256), dim3(256), 0, e->stream, s.slots, s.n_slots, s.total);
@@ -585,16 +707,28 @@ int himm_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n) {
     int* count = s.tile_bins;
     int* off = s.tile_bins + ntile;
     int* cursor = s.tile_bins + 2 * ntile + 1;
-    int* active = s.tile_bins + 3 * ntile + 1;
-    int* n_active = s.tile_bins + 4 * ntile + 1;
-    int* ticket = s.tile_bins + 4 * ntile + 2;
+    int* n_active = s.tile_bins + 3 * ntile + 1;
+    int* ticket = s.tile_bins + 3 * ntile + 2;
+    int4* active = reinterpret_cast<int4*>(s.tile_bins + himm_bins_active_at((size_t)ntile));
     hipLaunchKernelGGL(himm_bin_count_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, s.desc, s.ncells, n, e->tiles_i, count);
     hipLaunchKernelGGL(himm_bin_scan_kernel, dim3(1), dim3(1024), 0, e->stream, count, ntile, off, cursor, active, n_active, ticket);
+    if (s.pairs_checked) {   // the buffer is smaller than the worst case: this batch's exact pair count, before anything is written
+      RNA_HIP(e, hipMemcpyAsync(s.pairs_total_host, off + ntile, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+      RNA_HIP(e, hipStreamSynchronize(e->stream));
+      const size_t need = (size_t)*s.pairs_total_host;
+      if (need > s.pairs_cap) {
+        const size_t grown = std::min(himm_pairs_worst(e, (size_t)s.cap_rays), need + need / 4);
+        int rc = dev_alloc(e, &s.pairs, grown);
+        if (rc != RNA_OK) { s.pairs_cap = 0; s.cap_rays = 0; return rc; }   // (the next call starts from nothing)
+        s.pairs_cap = grown;
+      }
+    }
     hipLaunchKernelGGL(himm_bin_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, s.desc, s.ncells, n, e->tiles_i, off,
                        cursor, s.pairs);
     // (tile, half) jobs are taken by ticket: as many workgroups as can be resident and useful, not one per half tile
-    int raster_wgs = std::min(2 * ntile, std::max(256, 4 * e->cu_count));
-    if (const char* w = getenv("RNA_HIMM_RASTER_WGS")) raster_wgs = std::max(1, std::min(2 * ntile, atoi(w)));   // developer knob
+    // (measured in the loop, next to the searches: 256 / 512 / 1024 workgroups -> 0.59 / 0.54 / 0.60 ms per batch)
+    int raster_wgs = std::min((64 / HIMM_TR_ROWS) * ntile, std::max(256, 2 * e->cu_count));
+    if (const char* w = getenv("RNA_HIMM_RASTER_WGS")) raster_wgs = std::max(1, std::min((64 / HIMM_TR_ROWS) * ntile, atoi(w)));   // developer knob
     hipLaunchKernelGGL(himm_tile_raster_kernel, dim3(raster_wgs), dim3(HIMM_TR_THREADS), 0, e->stream, g.size[0], g.size[1], e->tiles_i, s.desc,
                        s.ncells, off, s.pairs, active, n_active, ticket, e->layer[layer], s.mark_bitmap, s.slots, n_slots - 1, s.seqs, s.before,
                        s.after, layer == RNA_LAYER_LASER ? e->dirty_tiles : nullptr, win);
@@ -615,9 +749,22 @@ int himm_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n) {
 namespace rna {
 int himm_release(rna_engine* e) {
   HimmScratch& s = e->himm;
+#ifdef RNA_HIMM_STATS
+  {
+    unsigned long long st[16];
+    if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_himm_stat), sizeof(st)) == hipSuccess && st[7] > 0) {
+      const double j = (double)st[7];
+      fprintf(stderr, "[himm raster stats] jobs %.0f, rays per job %.1f | thread 0, us per job: loads + zeroing -> barrier 1 %.2f, rank + probes %.2f, "
+              "barrier 3 %.2f, walk %.2f, barrier 4 %.2f, flush + apply %.2f, last barrier %.2f\n", j, st[8] / j, st[0] * 0.01 / j,
+              st[1] * 0.01 / j, st[2] * 0.01 / j, st[3] * 0.01 / j, st[4] * 0.01 / j, st[5] * 0.01 / j, st[6] * 0.01 / j);
+    }
+  }
+#endif
   dev_free(&s.rays_dev); dev_free(&s.desc); dev_free(&s.ncells); dev_free(&s.next); dev_free(&s.slots);
   dev_free(&s.seqs); dev_free(&s.before); dev_free(&s.after); dev_free(&s.total); dev_free(&s.mark_bitmap);
   dev_free(&s.pairs); dev_free(&s.tile_bins);
+  if (s.pairs_total_host) { (void)hipHostFree(s.pairs_total_host); s.pairs_total_host = nullptr; }
+  s.pairs_cap = 0;
   s.cap_rays = 0;
   s.n_slots = 0;
   return RNA_OK;

@@ -1131,6 +1131,33 @@ def test_himm_full_ray_batch_on_4096_matches_oracle(R):
     e.close()
 
 
+def test_himm_pair_buffer_below_the_worst_case_is_checked_and_grows(R, monkeypatch):
+    """The (tile, ray) pair buffer of the rasteriser is allocated for the worst case (a ray registered with two tiles per
+    64-cell tile column of the map) only while that is small; beyond a limit it starts at 16 pairs per ray, every batch's
+    exact pair count is read back before the pairs are written, and the buffer grows when a batch needs more.  Forced
+    here with a tiny limit: short rays first (fit), then rays across the whole map (20 tile columns each: must grow)."""
+    monkeypatch.setenv("RNA_HIMM_PAIRS_LIMIT", "4096")
+    n = 1280
+    L = n * 0.05
+    e = R.Engine(L, L, 0.05)
+    g = O.make_geom(L, L, 0.05)
+    laser = R.synth.obstacles_rect(n, n, density=0.2, seed=5)
+    e.upload(R.capi.LAYER_LASER, laser)
+    ref = laser.copy()
+    short = R.synth.rays(4, 250, L, L, seed=11, lmax=3.0)
+    rng = np.random.default_rng(12)
+    long_ = np.zeros(1000, R.capi.RAY_DTYPE)                      # border to border, every direction
+    a = rng.uniform(0, 2 * np.pi, len(long_))
+    long_["sx"], long_["sy"] = 0.49 * L * np.cos(a), 0.49 * L * np.sin(a)
+    long_["ex"], long_["ey"] = -long_["sx"] + rng.uniform(-1, 1, len(long_)), -long_["sy"] + rng.uniform(-1, 1, len(long_))
+    long_["clear_end"] = rng.integers(0, 2, len(long_))
+    for rays in (short, long_, short, long_):
+        O.himm_update(g, ref, rays.view(O.RAY_DTYPE))
+        e.update_map(rays, compose_mode=0)
+        assert same_f32(e.download(R.capi.LAYER_LASER), ref)
+    e.close()
+
+
 def test_vfh_config2_full_batch_matches_oracle(R):
     """Config 2 as BASELINE.json states it: 1024 x 1024 grid (2 % occupied, 10 % unknown), 1024 poses, Steerer
     parameters, two consecutive steps (the second one exercises the stateful binary histogram)."""
