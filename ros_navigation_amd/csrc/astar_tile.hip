@@ -532,12 +532,23 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   // along the lanes would otherwise advance one cell per sweep) -- at most RNA_TSA_HPASS passes, then the row is
   // flagged for the next sweep (AGAIN).  The loop body is 8 vector and 3 scalar instructions per pass: the row's free
   // mask and its pass-on threshold h + thr are formed once per evaluation.
+  /* developer builds: extra instructions per row evaluation, to measure which issue port the kernel is sensitive to */
+#define TSA_STR_(x) #x
+#define TSA_STR(x) TSA_STR_(x)
+#if defined(RNA_TSA_PAD_VALU)
+#define TSA_PAD asm volatile(".rept " TSA_STR(RNA_TSA_PAD_VALU) "\n v_nop\n .endr")
+#elif defined(RNA_TSA_PAD_SALU)
+#define TSA_PAD { int pad_ = 0; asm volatile(".rept " TSA_STR(RNA_TSA_PAD_SALU) "\n s_add_u32 %0, %0, 1\n .endr" : "+s"(pad_) : : "scc"); }
+#else
+#define TSA_PAD
+#endif
 #define TSA_VERT(b, src, kA, kC)                                                                                                   \
   max3i(TSA_PP(src) + nS, (lane_m1(TSA_PP(src)) + nD) & TSA_OPEN(TSA_MKW(b), 8 * ((b) & 3) + (kA)),                                \
         (lane_p1(TSA_PP(src)) + nD) & TSA_OPEN(TSA_MKW(b), 8 * ((b) & 3) + (kC)))
 #define TSA_ROW(b, VERT, AGVAR)                                                                                     \
   {                                                                                                              \
     TSA_STAT_INC(evals);                                                                                         \
+    TSA_PAD;                                                                                                     \
     const int open_ = TSA_OPEN(fbits, b);                                                                        \
     int m_ = VERT;                                                                                               \
     m_ = max3i(m_, lane_m1(TSA_PP(b)) + nS, lane_p1(TSA_PP(b)) + nS) & open_;                                    \
