@@ -484,29 +484,43 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     const unsigned crow = cl | cr | planted;
     if (upT) g0 = max(g0, cT);
     if (upB) g15 = max(g15, cB);
-    // a column candidate goes from its lane of cX into lane 0 / 63 of the row's register through the scalar unit
-#define TSA_APPLY(b)                                                                                             \
-  {                                                                                                              \
-    unsigned long long up = (b) == 0 ? upT : ((b) == TJ - 1 ? upB : 0ull);                                        \
-    if ((crow >> (b)) & 1u) {                                                                                    \
-      if ((cl >> (b)) & 1u) {                                                                                    \
-        const int c_ = max(__builtin_amdgcn_readlane(cX, (b) + 1), __builtin_amdgcn_readlane(TSA_G(b), 0));       \
-        asm volatile("v_writelane_b32 %0, %1, 0" : "+v"(TSA_G(b)) : "s"(c_));                                    \
-        up |= 1ull;                                                                                              \
-      }                                                                                                          \
-      if ((cr >> (b)) & 1u) {                                                                                    \
-        const int c_ = max(__builtin_amdgcn_readlane(cX, 33 + (b)), __builtin_amdgcn_readlane(TSA_G(b), TI - 1)); \
-        asm volatile("v_writelane_b32 %0, %1, 63" : "+v"(TSA_G(b)) : "s"(c_));                                   \
-        up |= 1ull << (TI - 1);                                                                                  \
-      }                                                                                                          \
-      if ((planted >> (b)) & 1u) up |= 1ull << C.sa;                                                             \
+    // a column candidate goes from its lane of cX into lane 0 / 63 of the row's register through the scalar unit: only
+    // rows named in cl / cr, and most jobs have none (round 3 tested every row for it, twice, inside the per-row block
+    // below: 14 scalar instructions per row; the kernel is as sensitive to a scalar instruction as to 0.6 vector ones)
+    if (cl | cr) {
+#define TSA_APPLY_COL(b)                                                                                         \
+  if (((cl | cr) >> (b)) & 1u) {                                                                                 \
+    if ((cl >> (b)) & 1u) {                                                                                      \
+      const int c_ = max(__builtin_amdgcn_readlane(cX, (b) + 1), __builtin_amdgcn_readlane(TSA_G(b), 0));         \
+      asm volatile("v_writelane_b32 %0, %1, 0" : "+v"(TSA_G(b)) : "s"(c_));                                      \
     }                                                                                                            \
-    TSA_PP(b) = TSA_G(b) >= TSA_HT(b) ? TSA_G(b) : 0;                                                             \
-    if ((b) == 0 || (b) == TJ - 1) { if (up) { nd |= 1u << (b); TSA_ROW_CHANGED(b, up) } }                        \
-    else if ((crow >> (b)) & 1u) { nd |= 1u << (b); TSA_ROW_CHANGED(b, up) }   /* (its own horizontal steps: evaluated in the first sweep) */ \
+    if ((cr >> (b)) & 1u) {                                                                                      \
+      const int c_ = max(__builtin_amdgcn_readlane(cX, 33 + (b)), __builtin_amdgcn_readlane(TSA_G(b), TI - 1));   \
+      asm volatile("v_writelane_b32 %0, %1, 63" : "+v"(TSA_G(b)) : "s"(c_));                                     \
+    }                                                                                                            \
   }
-    TSA_R16(TSA_APPLY)
-#undef TSA_APPLY
+      TSA_R16(TSA_APPLY_COL)
+#undef TSA_APPLY_COL
+    }
+    // what each cell may pass on in this bucket: sixteen rows, no branches
+#define TSA_APPLY_PP(b) TSA_PP(b) = TSA_G(b) >= TSA_HT(b) ? TSA_G(b) : 0;
+    TSA_R16(TSA_APPLY_PP)
+#undef TSA_APPLY_PP
+    // the rows the halo changed, as whole words: each is evaluated in the first sweep (its own horizontal steps) and
+    // flags the rows next to it
+    {
+      const unsigned chg = crow | (upT ? 1u : 0u) | (upB ? 1u << (TJ - 1) : 0u);
+      nd |= (chg | (chg << 1)) & 0xffffu;
+      nu |= chg >> 1;
+      rowchg |= chg;
+      const unsigned long long l0 = 1ull, l63 = 1ull << (TI - 1), lsa = planted ? 1ull << C.sa : 0ull;
+      qany |= upT | upB | (cl ? l0 : 0ull) | (cr ? l63 : 0ull) | lsa;
+      // cells of rows 0 / 15 that changed and may pass their value on (they wake the tiles beyond)
+      const unsigned long long up0 = upT | ((cl & 1u) ? l0 : 0ull) | ((cr & 1u) ? l63 : 0ull) | ((planted & 1u) ? lsa : 0ull);
+      const unsigned long long up15 = upB | ((cl >> (TJ - 1)) ? l0 : 0ull) | ((cr >> (TJ - 1)) ? l63 : 0ull) | ((planted >> (TJ - 1)) ? lsa : 0ull);
+      if (up0) q0 |= up0 & __builtin_amdgcn_ballot_w64(pp0 != 0);
+      if (up15) q15 |= up15 & __builtin_amdgcn_ballot_w64(pp15 != 0);
+    }
     __builtin_amdgcn_wave_barrier();
   }
   asm volatile("; TSA_MARK halo_end");
@@ -685,12 +699,23 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     unsigned look = first ? 0xffffu : rowchg;
     asm volatile("" : "+s"(look));
     if (look && (long long)best_in + 1 > bucket_end && !sch.is_far(t)) {
-      const int thr_best = KU - best_in;   // f <= best  <=>  u - h >= thr_best
       unsigned long long farm = 0ull;
+      if (best_in == INF) {
+        // no path known yet: every reached cell matters, so "held back" is all there is to test -- and what a cell may
+        // pass on is its value or 0, i.e. a reached cell is held back iff g ^ pp != 0: two vector instructions per row,
+        // no heuristic (this is the case of almost every job: the goal is reached in a search's last bucket)
+        int acc = 0;
+#define TSA_END(b) if ((look >> (b)) & 1u) acc |= TSA_G(b) ^ TSA_PP(b);
+        TSA_R16(TSA_END)
+#undef TSA_END
+        farm = __builtin_amdgcn_ballot_w64(acc != 0);
+      } else {
+        const int thr_best = KU - best_in;   // f <= best  <=>  u - h >= thr_best
 #define TSA_END(b)                                                                                               \
   if ((look >> (b)) & 1u) farm |= __builtin_amdgcn_ballot_w64(TSA_G(b) != 0 && TSA_PP(b) == 0 && TSA_G(b) >= TSA_HC(b, thr_best));
-      TSA_R16(TSA_END)
+        TSA_R16(TSA_END)
 #undef TSA_END
+      }
       if (farm && lane == 0) sch.act_far(t);
     }
     // (b) a first job: cells the previous bucket's bound held back may pass their values on now although they did not
