@@ -334,7 +334,7 @@ struct TsaCtx {
 #define TSA_MKW(b) TSA_CAT(TSA_MK_, b)   // the mask word that holds row b's byte, at bit 8 * (b & 3)
 template <class Sched>
 __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane_in, const int t, const TsaCtx& C,
-                                       const bool first, const long long bucket_end, const int key_base, const int key_shift, int* spare TSA_ACC_PARAM) {
+                                       const bool first, const unsigned bucket_end, const int key_base, const int key_shift, int* spare TSA_ACC_PARAM) {
   // an opaque copy of the lane id per job (and one more for the results phase): everything derived from it is then
   // recomputed here instead of being hoisted out of the job loop, kept alive across the sweeps and spilled to scratch
   int lane = lane_in;
@@ -382,7 +382,10 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     const unsigned pgN = (unsigned)__shfl((int)nb_pg, 1), pgS = (unsigned)__shfl((int)nb_pg, 6);
     top = (int)ld_l2(&C.pages[(pgN << 10) + (TJ - 1) * TI + lane]);
     bot = (int)ld_l2(&C.pages[(pgS << 10) + lane]);
-    const int xdir = xl == 0 ? (xr ? 2 : 0) : (xl <= TJ ? (xr ? 4 : 3) : (xr ? 7 : 5));
+    // direction of the tile a halo-column lane reads: NW W SW = 0 3 5 on the left, NE E SE = 2 4 7 on the right
+    // (arithmetic: as nested selections it became three levels of exec-mask branches)
+    const int xz = (xl > 0 ? 1 : 0) + (xl > TJ ? 1 : 0);
+    const int xdir = 3 * xz - (xz >> 1) + (xr ? 2 - (xz & 1) : 0);
     const unsigned pgX = (unsigned)__shfl((int)nb_pg, xdir);
     const int xrow = xl == 0 ? TJ - 1 : (xl <= TJ ? xl - 1 : 0);
     if (xl <= TJ + 1) X = (int)ld_l2(&C.paux[pgX * AUX_WORDS + (xr ? 0 : 16) + xrow]);   // a left tile's column 63 / a right tile's column 0
@@ -397,8 +400,11 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   // |dj| and four vector instructions) instead of living in 16 registers: the kernel has to fit 64 VGPRs so that eight
   // wavefronts share a SIMD.
   const int best_in = sch.best();
-  const long long lim_ll = bucket_end < (long long)best_in + 1 ? bucket_end : (long long)best_in + 1;   // pass on iff f < lim
-  const int thr = KU - (int)(lim_ll > (long long)INF ? (long long)INF : lim_ll) + 1;
+  // pass on iff f < lim = min(end of the bucket, best + 1), in unsigned 32 bits: `bucket_end` arrives clamped to 2^31,
+  // best + 1 <= 2^31 (as 64-bit integers these few scalar values cost vector compares and four spilled registers)
+  const unsigned best1 = (unsigned)best_in + 1u;
+  const unsigned lim_u = bucket_end < best1 ? bucket_end : best1;
+  const int thr = KU - (int)(lim_u > (unsigned)INF ? (unsigned)INF : lim_u) + 1;
   const int dxl = abs(i0 + lane - gi);
   const int dx414 = dxl * (COST_D - COST_S);
   // h + add of row b:  1000 max(dx, dy) + 414 min(dx, dy) = 586 max(dx, dy) + 414 dx + 414 dy -- one maximum, one 24-bit
@@ -649,7 +655,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     const bool edge_lane = lane == 0 || lane == TI - 1;
     // A reached cell whose g is about to leave the 30-bit range of the field word: a value written by this job is at
     // most lim + 1414 (its source passed on, i.e. g + h < lim), so the rows are only looked at when the bound is that far out.
-    const bool ovf_possible = lim_ll + COST_D > (long long)KU - 4 * COST_D;
+    const bool ovf_possible = lim_u > (unsigned)(KU - 5 * COST_D);
     unsigned long long ovfm = 0ull;
     // (the lane offset as an unsigned value of known range: the stores then take the page pointer as scalar base and
     // need no 64-bit vector address each)
@@ -664,15 +670,15 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       TSA_R16(TSA_OVF)
 #undef TSA_OVF
     }
-    // the copies of columns 0 and 63 for the neighbours: lanes 0 and 63 only, one change of the exec mask for all rows
-    // (an opaque copy of the row set for every loop over it: the compiler otherwise keeps the sixteen conditions of the
-    // first loop as sixteen lane masks -- 32 scalar registers, spilled to a VGPR's lanes and read back one by one)
-    unsigned rowchg_e = rowchg;
-    asm volatile("" : "+s"(rowchg_e));
+    // the copies of columns 0 and 63 for the neighbours: lanes 0 and 63 store their sixteen cells as four 16-byte words,
+    // changed or not (an unchanged cell is rewritten with the value it has: this job is the only writer) -- one store
+    // per changed row under sixteen scalar tests cost 32 scalar instructions and twice the store instructions
     if (edge_lane) {
-#define TSA_STORE_EDGE(b) if ((rowchg_e >> (b)) & 1u) ax[b] = (unsigned)TSA_G(b);
-      TSA_R16(TSA_STORE_EDGE)
-#undef TSA_STORE_EDGE
+      uint4* a4 = reinterpret_cast<uint4*>(ax);
+      a4[0] = make_uint4((unsigned)g0, (unsigned)g1, (unsigned)g2, (unsigned)g3);
+      a4[1] = make_uint4((unsigned)g4, (unsigned)g5, (unsigned)g6, (unsigned)g7);
+      a4[2] = make_uint4((unsigned)g8, (unsigned)g9, (unsigned)g10, (unsigned)g11);
+      a4[3] = make_uint4((unsigned)g12, (unsigned)g13, (unsigned)g14, (unsigned)g15);
     }
     if (ovfm && lane == 0) sch.overflow();   // path costs beyond 2^30 - 5656: the search is abandoned (status 4)
     if (t == C.tg) {
@@ -698,7 +704,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     //     with f <= best passes on: nothing is held back that matters.
     unsigned look = first ? 0xffffu : rowchg;
     asm volatile("" : "+s"(look));
-    if (look && (long long)best_in + 1 > bucket_end && !sch.is_far(t)) {
+    if (look && best1 > bucket_end && !sch.is_far(t)) {
       unsigned long long farm = 0ull;
       if (best_in == INF) {
         // no path known yet: every reached cell matters, so "held back" is all there is to test -- and what a cell may
@@ -1238,6 +1244,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   for (;;) {   // one pass per f-bucket (or per re-run of a bucket whose queue overflowed)
     const int bucket = lds_ldi(&s_bucket);
     const long long bucket_end = ((long long)bucket + 1) * A.bucket_width;
+    const unsigned bucket_end_u = bucket_end > 0x80000000LL ? 0x80000000u : (unsigned)bucket_end;   // (everything >= 2^31 is "beyond any f")
     const long long key_base_ll = (long long)KU - (long long)bucket * A.bucket_width;   // KU - (f at the bucket's start)
     const int key_base = key_base_ll < -(long long)INF ? -INF : (int)key_base_ll;
     bool idle = false;   // this wavefront is counted in s_idle
@@ -1327,7 +1334,13 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
       TSA_ACC(4, t_p0, t_p1);   // taking a job
       TSA_CNT(7, 1);
       my_jobs += 1;
-      my_evals += tsa_job(sch, s_scr[wv], lane, t, C, first, bucket_end, key_base, key_shift, &spare TSA_ACC_ARG);
+#if defined(RNA_TSA_JOBPRIO)
+      __builtin_amdgcn_s_setprio(RNA_TSA_JOBPRIO);        // developer build: issue priority of a wavefront inside a job ...
+#endif
+      my_evals += tsa_job(sch, s_scr[wv], lane, t, C, first, bucket_end_u, key_base, key_shift, &spare TSA_ACC_ARG);
+#if defined(RNA_TSA_JOBPRIO)
+      __builtin_amdgcn_s_setprio(RNA_TSA_IDLEPRIO);       // ... and while it takes the next one / polls
+#endif
       // the job's stores are performed before the tile can be taken again (it may have been woken while it ran)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       {
