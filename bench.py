@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/
 ASTAR_BYTES_PER_SETTLED = 44   # 8 neighbour occupancy reads x 4 B + 12 B g/parent/flag RMW
 VFH_BYTES_PER_POSE = 4 * 31 * 31 + 2 * 72 * 4 + 32
 ROTATE = int(os.environ.get("RNA_BENCH_ROTATE", "4"))   # distinct ray batches / pose sets / query sets the steps cycle through (developer override)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
 
 
 def parse():
@@ -204,13 +204,14 @@ def pmc_traffic(kernel, args, world):
         ks = [find(name) for name in ([kernel] if isinstance(kernel, str) else kernel)]   # a slot's chain: one launch each
         lo = sum(k["fetch_size_kb_avg"] + k["write_size_kb_avg"] for k in ks) * 1024.0
         hi = sum(2.0 * k["fetch_size_kb_avg"] + k["write_size_kb_avg"] for k in ks) * 1024.0
-        return [lo, hi], "profiles/r03_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " \
+        return [lo, hi], "profiles/r04_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " \
                          "[(FETCH+WRITE), (2*FETCH+WRITE)] x 1024 B per launch"
     except Exception:
         return None, "no PMC summary committed for this kernel"
 
 
-SQ_COUNTERS = os.path.join(ROOT, "profiles", "r03_search_sq_counters.txt")
+SQ_COUNTERS = os.path.join(ROOT, "profiles", "r04_search_sq_counters.txt")
+JOB_STATS = os.path.join(ROOT, "profiles", "r04_search_job_stats.txt")
 VALU_PEAK_PER_NS_SIMD = 0.58      # profiles/r03_ubench_valu.txt: eight wavefronts per SIMD issue 0.54-0.59 dependent VALU instructions per ns
 SEARCH_SIMDS = (256 - 32) * 4     # the search streams' CU mask leaves 32 of the 256 CUs to the engine stream
 
@@ -232,8 +233,37 @@ def valu_issue(args, world, wall_per_pass):
         per_ns_simd = valu / (wall_per_pass * 1e9) / SEARCH_SIMDS
         return {"bound": "valu issue", "achieved": per_ns_simd, "peak": VALU_PEAK_PER_NS_SIMD, "unit": "wavefront VALU instructions / ns / SIMD",
                 "frac": per_ns_simd / VALU_PEAK_PER_NS_SIMD, "valu_per_batch": valu, "salu_per_batch": salu,
-                "source": "profiles/r03_search_sq_counters.txt (one batch alone), profiles/r03_ubench_valu.txt (the SIMD's issue rate); "
+                "source": "profiles/r04_search_sq_counters.txt (one batch alone), profiles/r03_ubench_valu.txt (the SIMD's issue rate); "
                           "224 CUs x 4 SIMDs"}
+    except Exception:
+        return None
+
+
+def work_inflation(args, world, settled_per_launch):
+    """How much work the search kernel does per cell the oracle settles (the committed counter / timer files of THIS
+    configuration; None otherwise): wavefront instructions per settled cell from the SQ counter pass of one batch, tile
+    jobs per touched tile and the share of jobs that find nothing better in their halo from the -DRNA_TSA_STATS build
+    under the bench's load.  Reported so that the next reader can track the inflation without reading DESIGN.md."""
+    import re
+    try:
+        if (args.grid, args.queries, args.pipeline) != (4096, 256, 13) or world != 1 or args.tiled:
+            return None
+        valu = salu = None
+        for line in open(SQ_COUNTERS):
+            f = line.split()
+            if len(f) >= 3 and f[0] in ("SQ_INSTS_VALU", "SQ_INSTS_SALU"):
+                v = float(f[-1].split("=")[-1])
+                valu, salu = (v, salu) if f[0] == "SQ_INSTS_VALU" else (valu, v)
+        out = {"instructions_per_settled_cell": (valu + salu) / settled_per_launch, "valu_per_settled_cell": valu / settled_per_launch,
+               "salu_per_settled_cell": salu / settled_per_launch,
+               "source": "profiles/r04_search_sq_counters.txt (SQ_INSTS_VALU + SQ_INSTS_SALU of one 256-query batch) / this run's settled cells per launch"}
+        text = open(JOB_STATS).read()
+        m = re.search(r"jobs per touched tile ([0-9.]+), jobs that find nothing ([0-9.]+) of all", text)
+        if m:
+            out["jobs_per_touched_tile"] = float(m.group(1))
+            out["noop_job_frac"] = float(m.group(2))
+            out["source"] += "; profiles/r04_search_job_stats.txt (phase timers and job counts of the stats build under the bench's load)"
+        return out
     except Exception:
         return None
 
@@ -505,7 +535,8 @@ def main():
                          "achieved_per_pass_wall": alg_bytes / wall_per_pass / 1e9,
                          "frac_wall": alg_bytes / wall_per_pass / 1e9 / HBM_PEAK_GBS,
                          # the kernel's real bound (not HBM): see valu_issue()
-                         "valu_issue": valu_issue(args, world, wall_per_pass)},
+                         "valu_issue": valu_issue(args, world, wall_per_pass),
+                         "work_inflation": work_inflation(args, world, settled_per_launch)},
             "roofline_rows": [row("himm_raster", HIMM_RASTER_CHAIN, himm_alg),
                               row("vfh_step", "vfh_step_kernel", float(nq * VFH_BYTES_PER_POSE))],
             # every kernel slot bracketed by events, in ONE turn of the pipeline run after the timed region (the brackets

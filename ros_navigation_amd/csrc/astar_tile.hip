@@ -1387,6 +1387,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   tsa_acc[5] = wall_clock64() - t_life0;   // wave lifetime inside the search loop
   tsa_acc[12] = __builtin_amdgcn_s_memtime() - c_life0;   // the same in shader clock ticks
   if (lane == 0) for (int k = 0; k < 16; ++k) atomicAdd(&g_tsa_stat[k], tsa_acc[k]);
+  if (tid == 0) { atomicAdd(&g_tsa_stat[16], (unsigned long long)s_nalloc); atomicAdd(&g_tsa_stat[17], 1ull); }   // tiles this search touched; searches
 #endif
   // what the next search in this slot has to reset
   if (tid == 0) S.nalloc[sl] = s_nalloc < C.cap ? s_nalloc : C.cap;
@@ -1653,6 +1654,8 @@ void tsa_stats_dump() {
   const double busy = (double)(st[0] + st[1] + st[2]);
   fprintf(stderr, "[tsa stats] per job us: loads issued + arrived %.2f (of load+halo), wake tests + queueing %.2f of which queueing %.2f (of results); jobs that queue wake-ups %.1f%%; a job that finds nothing %.2f us\n",
           st[9] * 0.01 / jobs, st[6] * 0.01 / jobs, st[3] * 0.01 / jobs, 100.0 * (double)st[13] / jobs, st[15] * 0.01 / (double)std::max<unsigned long long>(1, st[10]));
+  fprintf(stderr, "[tsa stats] searches %.0f, tiles touched %.0f (%.1f per search), jobs per touched tile %.2f, jobs that find nothing %.3f of all\n", (double)st[17],
+          (double)st[16], (double)st[16] / (double)std::max<unsigned long long>(1, st[17]), jobs / (double)std::max<unsigned long long>(1, st[16]), (double)st[10] / jobs);
   fprintf(stderr, "[tsa stats, tile kernel, all launches] jobs %.0f (%.1f%% no-op) | per job us: load+halo %.2f sweeps %.2f results %.2f | wave lifetime %.1f wave-ms, in jobs %.1f wave-ms (%.1f%%), taking jobs %.1f wave-ms (%.1f%%) | row evaluations per job %.1f, extra horizontal passes %.1f | shader clock while searching %.0f MHz\n",
           jobs, 100.0 * (double)st[10] / jobs, st[0] * 0.01 / jobs, st[1] * 0.01 / jobs, st[2] * 0.01 / jobs, st[5] * 1e-5, busy * 1e-5,
           100.0 * busy / (double)st[5], st[4] * 1e-5, 100.0 * (double)st[4] / (double)st[5], st[8] / jobs, st[11] / jobs,

@@ -150,8 +150,9 @@ def test_default_bench_keeps_the_engine_stream_alive():
     assert k["himm_prep"] < 1.0 and k["vfh_step"] < 0.6 and k["compose_master"] < 0.6, k
     # the engine stream's chain (astar_search / astar_reset / astar_init run on the stages' own streams, vfh_step on the VFH+ stream)
     engine = sum(v for name, v in k.items() if name not in ("astar_search", "astar_reset", "astar_init", "vfh_step"))
-    # (measured 1.33 - 1.43 ms on three boxes in round 3, bracketed by events that cost ~35 us per kernel themselves)
-    assert engine < 1.8 and engine < d["config"]["ms_per_pass"], (k, d["config"]["ms_per_pass"])
+    # (measured 1.08 - 1.22 ms in round 4 -- 1.33 - 1.43 in round 3 --, bracketed by events that cost ~35 us per kernel
+    # themselves; the same kernels take 0.5 ms on the 32 reserved CUs alone, the rest is waiting for wave slots)
+    assert engine < 1.5 and engine < d["config"]["ms_per_pass"], (k, d["config"]["ms_per_pass"])
     # a cliff guard, not a benchmark: the rate when the engine stream starved was 22 k, with too few hardware queues 31 k
     # (this kernel runs at 125 k+); RNA_TEST_BENCH_FLOOR overrides it on a shared or throttled box
     assert d["value"] > float(os.environ.get("RNA_TEST_BENCH_FLOOR", "50000")), d["value"]
