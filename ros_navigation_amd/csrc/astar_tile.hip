@@ -69,8 +69,15 @@ __device__ __forceinline__ int tsa_octile(int i, int j, int gi, int gj) {
   const int mx = dx > dy ? dx : dy, mn = dx > dy ? dy : dx;
   return COST_S * mx + (COST_D - COST_S) * mn;
 }
+// Loads of the search field.  A query's pages, edge copies and page table are read and written by ONE workgroup (the
+// slot is its alone), whose wavefronts share a CU and therefore a vector L1 that is coherent among them (workgroups are
+// not split over CUs: no -mtgsplit); RNA_TSA_SCOPE selects the scope the loads are coherent at -- agent: every load
+// goes to L2 (sc1), workgroup: it may hit the CU's L1.
+#ifndef RNA_TSA_SCOPE
+#define RNA_TSA_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
 __device__ __forceinline__ unsigned ld_l2(const unsigned* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, RNA_TSA_SCOPE);
 }
 // buffer linear index <-> map-space (unwrapped) linear index (gmc/src/GridMapMath.cpp:467-476, 70-81)
 __device__ __forceinline__ int tsa_unwrap_lin(int lin, int rows, int cols, int s0, int s1) {
@@ -612,17 +619,27 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   }
 #define TSA_DOWN(b) if ((nd >> (b)) & 1u) { nd &= ~(1u << (b)); TSA_ROW(b, TSA_VERT(b, TSA_CAT(TSA_DEC_, b), 0, 2), nu) }
 #define TSA_UP(b) if ((nu >> (b)) & 1u) { nu &= ~(1u << (b)); TSA_ROW(b, TSA_VERT(b, TSA_CAT(TSA_INC_, b), 5, 7), nd) }
+  // (the rows are tested four at a time first: the flags of a job cluster -- a front touches neighbouring rows --, and
+  // two scalar instructions per skipped row were a seventh of the kernel's scalar work)
   for (;;) {
     if (nd != 0u) {
-      if (nd & 1u) { nd &= ~1u; TSA_ROW(0, 0, nu) }
-      TSA_DOWN(1) TSA_DOWN(2) TSA_DOWN(3) TSA_DOWN(4) TSA_DOWN(5) TSA_DOWN(6) TSA_DOWN(7) TSA_DOWN(8)
-      TSA_DOWN(9) TSA_DOWN(10) TSA_DOWN(11) TSA_DOWN(12) TSA_DOWN(13) TSA_DOWN(14) TSA_DOWN(15)
+      if (nd & 0x000fu) {
+        if (nd & 1u) { nd &= ~1u; TSA_ROW(0, 0, nu) }
+        TSA_DOWN(1) TSA_DOWN(2) TSA_DOWN(3)
+      }
+      if (nd & 0x00f0u) { TSA_DOWN(4) TSA_DOWN(5) TSA_DOWN(6) TSA_DOWN(7) }
+      if (nd & 0x0f00u) { TSA_DOWN(8) TSA_DOWN(9) TSA_DOWN(10) TSA_DOWN(11) }
+      if (nd & 0xf000u) { TSA_DOWN(12) TSA_DOWN(13) TSA_DOWN(14) TSA_DOWN(15) }
     }
     if (!(nd | nu)) break;
     if (nu != 0u) {
-      if ((nu >> 15) & 1u) { nu &= ~(1u << 15); TSA_ROW(15, 0, nd) }
-      TSA_UP(14) TSA_UP(13) TSA_UP(12) TSA_UP(11) TSA_UP(10) TSA_UP(9) TSA_UP(8) TSA_UP(7)
-      TSA_UP(6) TSA_UP(5) TSA_UP(4) TSA_UP(3) TSA_UP(2) TSA_UP(1) TSA_UP(0)
+      if (nu & 0xf000u) {
+        if ((nu >> 15) & 1u) { nu &= ~(1u << 15); TSA_ROW(15, 0, nd) }
+        TSA_UP(14) TSA_UP(13) TSA_UP(12)
+      }
+      if (nu & 0x0f00u) { TSA_UP(11) TSA_UP(10) TSA_UP(9) TSA_UP(8) }
+      if (nu & 0x00f0u) { TSA_UP(7) TSA_UP(6) TSA_UP(5) TSA_UP(4) }
+      if (nu & 0x000fu) { TSA_UP(3) TSA_UP(2) TSA_UP(1) TSA_UP(0) }
     }
     if (!(nd | nu)) break;
   }
@@ -645,7 +662,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       if (lane == 0) {
         p = atomicAdd(C.nalloc, 1) + 1;
         if (p > C.cap) { p = 0; sch.pool_exhausted(); }
-        else { C.owner[p] = (unsigned)t; __hip_atomic_store(&C.tmap[t], (unsigned)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else { C.owner[p] = (unsigned)t; __hip_atomic_store(&C.tmap[t], (unsigned)p, __ATOMIC_RELAXED, RNA_TSA_SCOPE); }
       }
       pg = (unsigned)__builtin_amdgcn_readfirstlane(p);
       if (pg == 0u) return 0;
