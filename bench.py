@@ -248,15 +248,18 @@ def work_inflation(args, world, settled_per_launch):
     try:
         if (args.grid, args.queries, args.pipeline) != (4096, 256, 13) or world != 1 or args.tiled:
             return None
-        valu = salu = None
+        valu = salu = settled = None
         for line in open(SQ_COUNTERS):
             f = line.split()
             if len(f) >= 3 and f[0] in ("SQ_INSTS_VALU", "SQ_INSTS_SALU"):
                 v = float(f[-1].split("=")[-1])
                 valu, salu = (v, salu) if f[0] == "SQ_INSTS_VALU" else (valu, v)
-        out = {"instructions_per_settled_cell": (valu + salu) / settled_per_launch, "valu_per_settled_cell": valu / settled_per_launch,
-               "salu_per_settled_cell": salu / settled_per_launch,
-               "source": "profiles/r04_search_sq_counters.txt (SQ_INSTS_VALU + SQ_INSTS_SALU of one 256-query batch) / this run's settled cells per launch"}
+            if len(f) >= 2 and f[0] == "SETTLED_CELLS_OF_THE_BATCH":
+                settled = float(f[1])
+        out = {"instructions_per_settled_cell": (valu + salu) / settled, "valu_per_settled_cell": valu / settled,
+               "salu_per_settled_cell": salu / settled,
+               "source": "profiles/r04_search_sq_counters.txt: SQ_INSTS_VALU + SQ_INSTS_SALU of one 256-query batch alone (the first query set on the "
+                         "untouched bench map) / the cells the oracle settles for that batch"}
         text = open(JOB_STATS).read()
         m = re.search(r"jobs per touched tile ([0-9.]+), jobs that find nothing ([0-9.]+) of all", text)
         if m:

@@ -25,4 +25,10 @@ for k, d in acc.items():
         for c, v in sorted(d.items()):
             print("   %-28s launches=%d avg=%.6g" % (c, len(v), sum(v) / len(v)))
 PY
+# the settled cells of the batch the counters belong to (scripts/astar_stats.py prints mean and maximum per query)
+python3 - <<PY >> $OUT/summary.txt
+import re
+m = re.search(r"settled mean/max=(\d+)/", open("$OUT/log1.txt").read())
+if m: print("   %-28s %d  (256 queries x the mean the same run reports)" % ("SETTLED_CELLS_OF_THE_BATCH", int(m.group(1)) * 256))
+PY
 cat $OUT/summary.txt
