@@ -284,6 +284,11 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:   # (before the heavy imports: a mis-launch fails in milliseconds)
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s (launch with --nproc-per-node %d or drop the launcher)"
                          % (args.gpus, os.environ.get("WORLD_SIZE", "1"), args.gpus))
+    # stdout is for the ONE JSON line: libraries that write to file descriptor 1 themselves (RCCL prints a five-line
+    # version banner there through C stdio, flushed when the process exits, i.e. AFTER the line) get stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     from ros_navigation_amd import capi as _capi
@@ -555,7 +560,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, R, master, ray_sets[0], pose_sets[0], query_sets[0], n, n, length)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     e.close()
     if use_dist:
         dist.barrier()

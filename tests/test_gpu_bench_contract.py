@@ -18,8 +18,8 @@ def run_bench(extra, env=None):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + extra, capture_output=True, text=True,
                          timeout=600, cwd=ROOT, env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-1500:]     # ONE line on stdout (RCCL's version banner and the like go to stderr)
     return json.loads(lines[0])
 
 
@@ -70,8 +70,8 @@ def run_world8(extra):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + WORLD8 + extra, capture_output=True, text=True,
                          timeout=900, cwd=ROOT, env=dict(os.environ, RNA_BENCH_SHARE_GPU="1"))
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]      # ONE line, from rank 0
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]      # ONE line, from rank 0, nothing else on stdout
     return json.loads(lines[0])
 
 
