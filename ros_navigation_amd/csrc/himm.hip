@@ -310,8 +310,9 @@ __global__ void himm_bin_fill_kernel(const int4* __restrict__ desc, const int* _
   });
 }
 
-// Two workgroups per 64 x 64 tile that at least one ray crosses, one per half (32 columns j): 8 KB of counters each, so
-// that they fit into the LDS a resident A* search workgroup leaves free on its CU (tests/test_kernel_budgets.py).
+// Two jobs per 64 x 64 tile that at least one ray crosses, one per half (32 columns j): 8 KB of counters each -- a
+// workgroup of 8 wavefronts and 12.4 KB of LDS is what fits a CU that has lost one of its four search workgroups
+// (tests/test_kernel_budgets.py; whole-tile jobs with 16 KB were measured no faster).
 // One LANE per ray: the lane loads its ray (256 independent loads per round instead of a dependent chain per ray),
 // steps along its cells inside the tile with the integer Bresenham recurrence and counts clears in LDS.  A clear that
 // lands on a MARKED cell (ray end points) belongs to an interval between that cell's marks.  The half tile's marked

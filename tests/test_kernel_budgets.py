@@ -54,3 +54,18 @@ def test_eight_search_wavefronts_fit_a_simd():
     largest_lds = search["LDS"] + 4 * 4 * 2048                          # the largest supported map (65536 tiles): at least two per CU
     assert 2 * largest_lds <= LDS_PER_CU, largest_lds
     assert not any("tsa_backtrace_kernel" in k or "tsa_reset_kernel" in k for k in tile)   # both live inside the search kernel now
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_the_rasteriser_fits_a_cu_that_has_lost_one_search_workgroup():
+    """Outside its reserve of 32 CUs the map update can only use what the searches leave: a CU whose four search
+    workgroups are all resident has no wave slot free, one that has lost a workgroup has eight -- exactly a rasteriser
+    workgroup (8 wavefronts, half-tile jobs with 8 KiB of clear counters).  Its LDS and registers must fit there."""
+    himm = resources("himm.hip")
+    raster = next(v for k, v in himm.items() if "himm_tile_raster_kernel" in k)
+    tile = resources("astar_tile.hip")
+    search = next(v for k, v in tile.items() if "tsa_search_kernelILi8ELb0E" in k)
+    bench_search_lds = search["LDS"] + 4 * 4 * ((64 * 256 + 31) // 32)
+    assert raster["LDS"] <= 16 * 1024, raster
+    assert 3 * bench_search_lds + raster["LDS"] <= LDS_PER_CU, (bench_search_lds, raster["LDS"])
+    assert alloc(raster["VGPRs"]) * 8 <= VGPRS_PER_SIMD and raster["ScratchSize"] == 0, raster     # 8 wavefronts per SIMD
