@@ -368,7 +368,10 @@ __device__ unsigned long long g_rrt_stat[8];
 struct RrtSlot { double wx, wy; int near, blocked; };
 
 // 4 wavefronts per SIMD (<= 128 VGPRs): two 8-wavefront workgroups per CU, 512 queries resident on the chip
-__global__ void __launch_bounds__(64 * RRT_SPEC) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef RNA_RRT_WAVES_PER_EU
+#define RNA_RRT_WAVES_PER_EU 4
+#endif
+__global__ void __launch_bounds__(64 * RRT_SPEC) __attribute__((amdgpu_waves_per_eu(RNA_RRT_WAVES_PER_EU, RNA_RRT_WAVES_PER_EU)))
 rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __restrict__ queries, int n,
            int* __restrict__ tree_parent,
            double* __restrict__ paths, int max_path_len, rna_rrt_result* __restrict__ results) {
