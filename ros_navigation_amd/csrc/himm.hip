@@ -274,29 +274,37 @@ __global__ void __launch_bounds__(1024) himm_bin_scan_kernel(int* __restrict__ t
                                                              int* __restrict__ tile_cursor, int4* __restrict__ active,
                                                              int* __restrict__ n_active, int* __restrict__ ticket) {
   __shared__ int s_part[1024];
-  __shared__ int s_act[1024];
+  __shared__ int s_act[1024];    // tiles with many rays: their jobs go first (the longest jobs must not be the last ones started)
+  __shared__ int s_act2[1024];   // the other tiles with rays
+  constexpr int HEAVY = 512;     // rays: more than one round of a rasteriser workgroup
   const int per = (ntile + 1023) / 1024;
   const int lo = threadIdx.x * per, hi = min(ntile, lo + per);
-  int sum = 0, nact = 0;
-  for (int t = lo; t < hi; ++t) { const int c = tile_count[t]; sum += c; nact += c > 0; }
+  int sum = 0, nact = 0, nact2 = 0;
+  for (int t = lo; t < hi; ++t) { const int c = tile_count[t]; sum += c; nact += c >= HEAVY; nact2 += c > 0 && c < HEAVY; }
   s_part[threadIdx.x] = sum;
   s_act[threadIdx.x] = nact;
+  s_act2[threadIdx.x] = nact2;
   __syncthreads();
   for (int o = 1; o < 1024; o <<= 1) {
-    const int v = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0, a = threadIdx.x >= o ? s_act[threadIdx.x - o] : 0;
+    const bool in = threadIdx.x >= o;
+    const int v = in ? s_part[threadIdx.x - o] : 0, a = in ? s_act[threadIdx.x - o] : 0, a2 = in ? s_act2[threadIdx.x - o] : 0;
     __syncthreads();
     s_part[threadIdx.x] += v;
     s_act[threadIdx.x] += a;
+    s_act2[threadIdx.x] += a2;
     __syncthreads();
   }
-  int run = s_part[threadIdx.x] - sum, arun = s_act[threadIdx.x] - nact;
+  const int n_heavy = s_act[1023];
+  int run = s_part[threadIdx.x] - sum, arun = s_act[threadIdx.x] - nact, arun2 = n_heavy + s_act2[threadIdx.x] - nact2;
   for (int t = lo; t < hi; ++t) {
     const int c = tile_count[t];
     tile_off[t] = run; tile_cursor[t] = 0; run += c;
-    if (c > 0) active[arun++] = make_int4(t, run - c, c, 0);   // the rasteriser's job record: tile, first pair, pairs -- one load
+    // the rasteriser's job record: tile, first pair, pairs -- one load
+    if (c >= HEAVY) active[arun++] = make_int4(t, run - c, c, 0);
+    else if (c > 0) active[arun2++] = make_int4(t, run - c, c, 0);
     tile_count[t] = 0;   // (counts: zero again for the next batch)
   }
-  if (threadIdx.x == 1023) { tile_off[ntile] = s_part[1023]; *n_active = s_act[1023]; *ticket = 0; }
+  if (threadIdx.x == 1023) { tile_off[ntile] = s_part[1023]; *n_active = s_act[1023] + s_act2[1023]; *ticket = 0; }
 }
 
 __global__ void himm_bin_fill_kernel(const int4* __restrict__ desc, const int* __restrict__ ncells, int n, int tiles_i,
