@@ -514,9 +514,22 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
         const bool within = dd2 < 0.1599 ? true : (dd2 > 0.1601 ? false : glibc_hypot(ddx, ddy) < strideStep);
         if (within) { wx = rx; wy = ry; }
         else {
-          const double a = atan2(ry - npy, rx - npx);
+#ifdef RNA_RRT_LIBM_STEER
+          const double a = atan2(ry - npy, rx - npx);   // as written in the reference (rrt_planner.cpp:45-47), with the device's libm
           wx = npx + strideStep * cos(a);
           wy = npy + strideStep * sin(a);
+#else
+          // cos(atan2(dy, dx)) = dx / hypot(dx, dy): one square root and two divisions, all IEEE-rounded, instead of three
+          // double-precision libm calls -- which are what held the kernel at 127 VGPRs (78 without them: twelve
+          // wavefronts per query instead of eight fit the chip).  Against glibc's atan2 / cos / sin the offset differs in
+          // its last bits either way (the device libm's does too, DESIGN.md 4 "What stays open"): the sum with the node's
+          // coordinate then rounds differently for a few per cent of the nodes, by one ulp, which only matters at the
+          // last-bit ties scripts/fuzz_rrt.py classifies.
+          const double sdx = rx - npx, sdy = ry - npy;
+          const double sh = sqrt(sdx * sdx + sdy * sdy);
+          wx = npx + strideStep * (sdx / sh);
+          wy = npy + strideStep * (sdy / sh);
+#endif
         }
         RRT_T(t3);
         RRT_ACC(2, t2, t3);
