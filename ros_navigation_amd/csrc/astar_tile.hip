@@ -441,9 +441,34 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   unsigned long long q0 = 0ull, q15 = 0ull, qany = 0ull;   // cells of row 0 / row 15 that changed and may pass their value on; lanes that changed in any row
   int pp0, pp1, pp2, pp3, pp4, pp5, pp6, pp7, pp8, pp9, pp10, pp11, pp12, pp13, pp14, pp15;
   // a row took better values in the lanes `up`: flag the rows next to it, remember which cells wake neighbours
-#define TSA_ROW_CHANGED(b, up)                                                                                   \
+  // DIR: 0 = the row was evaluated in a down sweep (its vertical candidates came from the row above), 1 = in an up
+  // sweep; `pure`: every lane that improved took a VERTICAL candidate and no pass along the row moved anything after.
+  // Such a row cannot improve the row its values came from: a candidate back into that row is the source row's own
+  // value minus two steps (>= 2000), and inside the source row -- which is at the fixed point of its horizontal steps --
+  // the same cell is reached from the same source within two horizontal steps (<= 2000) whenever the return is legal
+  // (a diagonal step needs both orthogonal cells free, which are exactly the cells of the in-row route; a cell of that
+  // route that is held back by the bucket bound holds back its successor as well: f does not decrease along it).  So
+  // the row BEHIND the sweep is not flagged -- half of all row evaluations used to be such echoes that found nothing
+  // (scripts/sim_async.c, SIM_VPURE: 19.4 -> 13.4 evaluations per job, cost and settled count still the oracle's).
+  // (DIR == 2: a change from the halo, both neighbours are flagged; the flag behind the sweep is set by five scalar
+  // instructions in inline assembly -- the compiler's version went through a vector select and a readfirstlane)
+#define TSA_FLAG_BEHIND(word, bit, hsrc, left)                                                                   \
+  if ((bit) != 0u) {                                                                                             \
+    unsigned t_;                                                                                                 \
+    asm volatile("s_cmp_lg_u64 %[h], 0\n\t"                                                                      \
+                 "s_cselect_b32 %[t], %[b], 0\n\t"                                                               \
+                 "s_cmp_lg_u32 %[l], %[i]\n\t"                                                                   \
+                 "s_cselect_b32 %[t], %[b], %[t]\n\t"                                                            \
+                 "s_or_b32 %[w], %[w], %[t]"                                                                     \
+                 : [w] "+s"(word), [t] "=&s"(t_)                                                                 \
+                 : [h] "s"(hsrc), [l] "s"(left), [b] "n"(bit), [i] "n"(1u << (RNA_TSA_HPASS - 1))                \
+                 : "scc");                                                                                       \
+  }
+#define TSA_ROW_CHANGED(b, up, DIR, hsrc, left)                                                                  \
   {                                                                                                              \
-    nd |= (2u << (b)) & 0xffffu; nu |= (1u << (b)) >> 1; rowchg |= 1u << (b);                                     \
+    if ((DIR) == 0) { nd |= (2u << (b)) & 0xffffu; TSA_FLAG_BEHIND(nu, (1u << (b)) >> 1, hsrc, left) }           \
+    else { nu |= (1u << (b)) >> 1; TSA_FLAG_BEHIND(nd, (2u << (b)) & 0xffffu, hsrc, left) }                      \
+    rowchg |= 1u << (b);                                                                                         \
     qany |= (up);                                                                                                \
     if ((b) == 0) q0 |= (up) & __builtin_amdgcn_ballot_w64(TSA_PP(b) != 0);                                      \
     if ((b) == TJ - 1) q15 |= (up) & __builtin_amdgcn_ballot_w64(TSA_PP(b) != 0);                                \
@@ -572,15 +597,17 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
 #define TSA_VERT(b, src, kA, kC)                                                                                                   \
   max3i(TSA_PP(src) + nS, (lane_m1(TSA_PP(src)) + nD) & TSA_OPEN(TSA_MKW(b), 8 * ((b) & 3) + (kA)),                                \
         (lane_p1(TSA_PP(src)) + nD) & TSA_OPEN(TSA_MKW(b), 8 * ((b) & 3) + (kC)))
-#define TSA_ROW(b, VERT, AGVAR)                                                                                     \
+#define TSA_ROW(b, VERT, AGVAR, DIR)                                                                                \
   {                                                                                                              \
     TSA_STAT_INC(evals);                                                                                         \
     TSA_PAD;                                                                                                     \
     const int open_ = TSA_OPEN(fbits, b);                                                                        \
-    int m_ = VERT;                                                                                               \
-    m_ = max3i(m_, lane_m1(TSA_PP(b)) + nS, lane_p1(TSA_PP(b)) + nS) & open_;                                    \
+    const int mv_ = VERT;                                                                                        \
+    const int m_ = max3i(mv_, lane_m1(TSA_PP(b)) + nS, lane_p1(TSA_PP(b)) + nS) & open_;                         \
     unsigned long long up_ = __builtin_amdgcn_ballot_w64(m_ > TSA_G(b));                                         \
     if (up_) {                                                                                                   \
+      /* lanes that improved by a candidate from the row's own neighbours (it beats the vertical one) */          \
+      const unsigned long long hsrc_ = up_ & __builtin_amdgcn_ballot_w64(m_ > (mv_ & open_));                    \
       const int ht_ = TSA_HT(b);        /* passes on iff u - h >= thr */                                         \
       TSA_G(b) = max(TSA_G(b), m_);                                                                              \
       TSA_PP(b) = TSA_G(b) >= ht_ ? TSA_G(b) : 0;                                                                \
@@ -614,17 +641,17 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
             : "vcc", "scc");                                                                                     \
       }                                                                                                          \
       TSA_STAT_HP(left_);                                                                                        \
-      TSA_ROW_CHANGED(b, up_)                                                                                    \
+      TSA_ROW_CHANGED(b, up_, DIR, hsrc_, left_)                                                                 \
     }                                                                                                            \
   }
-#define TSA_DOWN(b) if ((nd >> (b)) & 1u) { nd &= ~(1u << (b)); TSA_ROW(b, TSA_VERT(b, TSA_CAT(TSA_DEC_, b), 0, 2), nu) }
-#define TSA_UP(b) if ((nu >> (b)) & 1u) { nu &= ~(1u << (b)); TSA_ROW(b, TSA_VERT(b, TSA_CAT(TSA_INC_, b), 5, 7), nd) }
+#define TSA_DOWN(b) if ((nd >> (b)) & 1u) { nd &= ~(1u << (b)); TSA_ROW(b, TSA_VERT(b, TSA_CAT(TSA_DEC_, b), 0, 2), nu, 0) }
+#define TSA_UP(b) if ((nu >> (b)) & 1u) { nu &= ~(1u << (b)); TSA_ROW(b, TSA_VERT(b, TSA_CAT(TSA_INC_, b), 5, 7), nd, 1) }
   // (the rows are tested four at a time first: the flags of a job cluster -- a front touches neighbouring rows --, and
   // two scalar instructions per skipped row were a seventh of the kernel's scalar work)
   for (;;) {
     if (nd != 0u) {
       if (nd & 0x000fu) {
-        if (nd & 1u) { nd &= ~1u; TSA_ROW(0, 0, nu) }
+        if (nd & 1u) { nd &= ~1u; TSA_ROW(0, 0, nu, 0) }
         TSA_DOWN(1) TSA_DOWN(2) TSA_DOWN(3)
       }
       if (nd & 0x00f0u) { TSA_DOWN(4) TSA_DOWN(5) TSA_DOWN(6) TSA_DOWN(7) }
@@ -634,7 +661,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     if (!(nd | nu)) break;
     if (nu != 0u) {
       if (nu & 0xf000u) {
-        if ((nu >> 15) & 1u) { nu &= ~(1u << 15); TSA_ROW(15, 0, nd) }
+        if ((nu >> 15) & 1u) { nu &= ~(1u << 15); TSA_ROW(15, 0, nd, 1) }
         TSA_UP(14) TSA_UP(13) TSA_UP(12)
       }
       if (nu & 0x0f00u) { TSA_UP(11) TSA_UP(10) TSA_UP(9) TSA_UP(8) }
