@@ -46,8 +46,12 @@ constexpr int MASK_STRIDE = TILE_WORDS + 32 + 128;  // snapshot bytes per tile: 
 #ifndef RNA_TSA_WAVES
 #define RNA_TSA_WAVES 8   // wavefronts per workgroup = per query; 8 wavefronts per SIMD -> four workgroups per CU (16 x 2: 60.5 k, 8 x 4: 63.5 k, 4 x 8: 42.4 k)
 #endif
+#ifndef RNA_TSA_SUPER
+#define RNA_TSA_SUPER 0   // 1: a row that is still moving after RNA_TSA_HPASS one-cell passes goes on in log steps (TSA_SUPER below;
+                          // exact, measured: 6 / 8 / 12 passes first -> 134.7 / 133.6 / 132.0 k against 134.1 k without -- off)
+#endif
 #ifndef RNA_TSA_HPASS
-#define RNA_TSA_HPASS 16  // extra passes of a changed row along itself (2 / 4 / 8: 48.1 / 49.0 / 50.6 k cycles/s; 8 / 16: 55.8 / 56.7 k)
+#define RNA_TSA_HPASS (RNA_TSA_SUPER ? 8 : 16)  // extra passes of a changed row along itself (2 / 4 / 8: 48.1 / 49.0 / 50.6 k cycles/s; 8 / 16: 55.8 / 56.7 k)
 #endif
 #ifndef RNA_TSA_REDBLACK
 #define RNA_TSA_REDBLACK 1   // rounds alternate between the two checkerboard colours of the tiles
@@ -597,6 +601,63 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
 #define TSA_VERT(b, src, kA, kC)                                                                                                   \
   max3i(TSA_PP(src) + nS, (lane_m1(TSA_PP(src)) + nD) & TSA_OPEN(TSA_MKW(b), 8 * ((b) & 3) + (kA)),                                \
         (lane_p1(TSA_PP(src)) + nD) & TSA_OPEN(TSA_MKW(b), 8 * ((b) & 3) + (kC)))
+  // A front that travels ALONG a row advances one cell per pass: 9 % of the row evaluations ran out of their 16 passes and
+  // made 68 % of all passes (scripts/sim_async.c), and crossing the tile that way takes 64 passes per row where crossing it
+  // the other way takes 16 row evaluations for all 64 lanes at once.  So after RNA_TSA_HPASS one-cell passes that all moved
+  // something the row goes on in LOG STEPS: a super-pass is one one-cell pass (wave shifts: it crosses the 16-lane DPP
+  // rows) followed by shifts of 2, 4 and 8 lanes inside the DPP rows, each in both directions -- values travel up to 15
+  // cells per super-pass.  A shift by d is a legal shortcut for d one-cell steps iff the d cells up to the target are
+  // free (run masks: mR_d = AND of the free bits of lanes l-d+1..l, by doubling on the scalar unit) and every cell in
+  // between may pass the value on -- f does not decrease along a path (consistent heuristic), so it is enough to test the
+  // LAST cell in between: candidate + 1000 >= h + thr of the lane next to the target (htl_ / htr_).
+  // Measured (profiles/r04_ab_log_step_rows.txt): a super-pass is ~70 instructions and crosses one 16-lane DPP row, so a run
+  // of 20-30 cells costs about what its one-cell passes cost (12 each); with the 26 KB of cold code the 32 copies add, the
+  // kernel is 0.4 % faster at best.  Shifts across the whole wavefront (ds_bpermute) would make it one super-pass per row.
+#if RNA_TSA_SUPER
+#define TSA_HP_OUT_OF_PASSES
+#define TSA_SUPER_STEP(b, d, mr, ml)                                                                             \
+  {                                                                                                              \
+    const int cr_ = __builtin_amdgcn_update_dpp(0, TSA_PP(b), 0x110 + (d), 0xF, 0xF, true) - (d) * COST_S;       \
+    const int cl_ = __builtin_amdgcn_update_dpp(0, TSA_PP(b), 0x100 + (d), 0xF, 0xF, true) - (d) * COST_S;       \
+    const unsigned long long okr_ = __builtin_amdgcn_ballot_w64(cr_ >= htl_) & (mr);                            \
+    const unsigned long long okl_ = __builtin_amdgcn_ballot_w64(cl_ >= htr_) & (ml);                            \
+    const int tr_ = __builtin_amdgcn_inverse_ballot_w64(okr_) ? cr_ : 0;                                         \
+    const int tl_ = __builtin_amdgcn_inverse_ballot_w64(okl_) ? cl_ : 0;                                         \
+    TSA_G(b) = max3i(TSA_G(b), tr_, tl_);                                                                        \
+    TSA_PP(b) = TSA_G(b) >= ht_ ? TSA_G(b) : 0;                                                                  \
+  }
+#define TSA_SUPER(b, AGVAR)                                                                                      \
+  if (left_ == 0u) {   /* the one-cell passes ran out while the row was still moving */                         \
+    const unsigned long long o_ = __builtin_amdgcn_ballot_w64(open_ != 0);                                       \
+    const unsigned long long mr2_ = o_ & (o_ << 1), ml2_ = o_ & (o_ >> 1);                                       \
+    const unsigned long long mr4_ = mr2_ & (mr2_ << 2), ml4_ = ml2_ & (ml2_ >> 2);                               \
+    const unsigned long long mr8_ = mr4_ & (mr4_ << 4), ml8_ = ml4_ & (ml4_ >> 4);                               \
+    /* h + thr of the lane before / after, minus one step: candidate >= it  <=>  the cell in between passes on */ \
+    const int htl_ = lane_m1(ht_, INF) - COST_S, htr_ = lane_p1(ht_, INF) - COST_S;                              \
+    int sp_ = 0;                                                                                                 \
+    for (;;) {                                                                                                   \
+      const int gold_ = TSA_G(b);                                                                                \
+      {                                                                                                          \
+        const int c1_ = max(lane_m1(TSA_PP(b)) + nS, lane_p1(TSA_PP(b)) + nS) & open_;                           \
+        TSA_G(b) = max(TSA_G(b), c1_);                                                                           \
+      }                                                                                                          \
+      /* no one-cell step moves anything: the row is at its fixed point (a longer shortcut that improved its     \
+         target would have a first cell along its way that a one-cell step improves) */                          \
+      const unsigned long long mv1_ = __builtin_amdgcn_ballot_w64(TSA_G(b) != gold_);                            \
+      TSA_CNT(14, 1);                                                                                            \
+      if (!mv1_) break;                                                                                          \
+      TSA_PP(b) = TSA_G(b) >= ht_ ? TSA_G(b) : 0;                                                                \
+      TSA_SUPER_STEP(b, 2, mr2_, ml2_)                                                                           \
+      TSA_SUPER_STEP(b, 4, mr4_, ml4_)                                                                           \
+      TSA_SUPER_STEP(b, 8, mr8_, ml8_)                                                                           \
+      up_ |= __builtin_amdgcn_ballot_w64(TSA_G(b) != gold_);                                                     \
+      if (++sp_ == 8) { AGVAR |= 1u << (b); break; }   /* (a value crosses the tile in five) */                   \
+    }                                                                                                            \
+  }
+#else
+#define TSA_HP_OUT_OF_PASSES "s_bitset1_b32 %[ag], %[bit]\n"   /* out of passes: the row is looked at again in the next sweep */
+#define TSA_SUPER(b, AGVAR)
+#endif
 #define TSA_ROW(b, VERT, AGVAR, DIR)                                                                                \
   {                                                                                                              \
     TSA_STAT_INC(evals);                                                                                         \
@@ -633,7 +694,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
             "v_cndmask_b32 %[pp], 0, %[g], vcc\n\t"                                                               \
             "s_lshr_b32 %[left], %[left], 1\n\t"                                                                  \
             "s_cbranch_scc1 .Lhp_top%=\n\t"                                                                       \
-            "s_bitset1_b32 %[ag], %[bit]\n"   /* out of passes: the row is looked at again in the next sweep */  \
+            TSA_HP_OUT_OF_PASSES                                                                                  \
             ".Lhp_done%=:"                                                                                        \
             : [g] "+v"(TSA_G(b)), [pp] "+v"(TSA_PP(b)), [all] "+s"(up_), [left] "+s"(left_), [ag] "+s"(AGVAR),    \
               [t1] "=&v"(t1_), [t2] "=&v"(t2_)                                                                   \
@@ -641,6 +702,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
             : "vcc", "scc");                                                                                     \
       }                                                                                                          \
       TSA_STAT_HP(left_);                                                                                        \
+      TSA_SUPER(b, AGVAR)                                                                                        \
       TSA_ROW_CHANGED(b, up_, DIR, hsrc_, left_)                                                                 \
     }                                                                                                            \
   }
