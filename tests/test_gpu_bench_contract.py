@@ -157,3 +157,19 @@ def test_default_bench_keeps_the_engine_stream_alive():
     # (this kernel runs at 125 k+); RNA_TEST_BENCH_FLOOR overrides it on a shared or throttled box
     assert d["value"] > float(os.environ.get("RNA_TEST_BENCH_FLOOR", "50000")), d["value"]
     assert d["config"]["astar_allocated"]["pipeline_depth"] == d["config"]["astar_pipeline_depth"]
+
+
+def test_bench_under_torchrun_as_the_driver_launches_it():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` -- the launcher of the driver's N > 1 runs
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, no spawning by bench.py itself) -- with the two ranks
+    sharing the test box's GPU: one JSON line on stdout, both ranks' cycles in `value`."""
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29617", os.path.join(ROOT, "bench.py")] + SMALL + ["--gpus", "2", "--no-cpu"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, RNA_BENCH_SHARE_GPU="1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["launcher"] == {"spawned_by_bench": False}
+    assert d["config"]["shards"] == [[0, 32], [32, 64]] and d["config"]["cycles_by_rank"] == [32 * PASSES] * 2
+    assert abs(d["value"] - 2 * 32 * PASSES / d["config"]["timed_seconds"]) < 1e-6 * d["value"]
