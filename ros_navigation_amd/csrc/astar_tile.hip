@@ -47,11 +47,13 @@ constexpr int MASK_STRIDE = TILE_WORDS + 32 + 128;  // snapshot bytes per tile: 
 #define RNA_TSA_WAVES 8   // wavefronts per workgroup = per query; 8 wavefronts per SIMD -> four workgroups per CU (16 x 2: 60.5 k, 8 x 4: 63.5 k, 4 x 8: 42.4 k)
 #endif
 #ifndef RNA_TSA_SUPER
-#define RNA_TSA_SUPER 0   // 1: a row that is still moving after RNA_TSA_HPASS one-cell passes goes on in log steps (TSA_SUPER below;
-                          // exact, measured: 6 / 8 / 12 passes first -> 134.7 / 133.6 / 132.0 k against 134.1 k without -- off)
+#define RNA_TSA_SUPER 2   // what a row does that is still moving after RNA_TSA_HPASS one-cell passes along itself:
+                          // 0: it is looked at again in the next sweep            134.4 k cycles/s (profiles/r04_ab_row_scan.txt)
+                          // 1: log steps inside the 16-lane DPP rows (TSA_SUPER)  134.7 k at best
+                          // 2: its fixed point in one prefix-maximum scan          144.1 k (tsa_row_fixpoint)
 #endif
 #ifndef RNA_TSA_HPASS
-#define RNA_TSA_HPASS (RNA_TSA_SUPER ? 8 : 16)  // extra passes of a changed row along itself (2 / 4 / 8: 48.1 / 49.0 / 50.6 k cycles/s; 8 / 16: 55.8 / 56.7 k)
+#define RNA_TSA_HPASS (RNA_TSA_SUPER == 2 ? 4 : (RNA_TSA_SUPER ? 8 : 16))  // one-cell passes first (mode 2: 3 / 4 / 5 -> 144.1 / 144.0 / 143.6 k; mode 0: 8 / 16 -> 55.8 / 56.7 k in round 2)
 #endif
 #ifndef RNA_TSA_REDBLACK
 #define RNA_TSA_REDBLACK 1   // rounds alternate between the two checkerboard colours of the tiles
@@ -281,6 +283,76 @@ struct TsaCtx {
   __device__ __forceinline__ unsigned page_of(int t) const { return ld_l2(&tmap[t]); }
 };
 
+// ---- a whole row to the fixed point of its horizontal steps in one go (RNA_TSA_SUPER == 2) ----
+// Along a row of free cells a value decays by 1000 per cell, so the fixed point is the upper envelope of cones:
+// u'(l) = max over sources s of the same free run of pp(s) - 1000 |l - s|.  With key(s) = pp(s) + 1000 s the right-moving
+// half is an inclusive PREFIX MAXIMUM of the keys, restarted at every blocked cell (u'(l) = best key - 1000 l); the
+// left-moving half the same on the lanes in reverse order (two ds_bpermute).  The restart is the top of the key: the
+// number of blocked cells before the lane -- it never decreases along the lanes, a lane's own entry carries its own count,
+// so the maximum of a prefix is the best key of the lane's own run.  The scan is the usual DPP one (row_shr 1 / 2 / 4 / 8,
+// row_bcast 15 / 31), six v_max_u32 per direction; with 64-bit keys (count, value) it was 30 instructions per direction
+// and +2.6 % instead of +7.1 %.  A cell takes the value only if the cell before it on the way may pass it on (f does not
+// decrease along a path, so that one test covers every cell in between): value + 1000 >= h + thr of the neighbour lane.
+// One application from the values as they are is the fixed point: what a cell receives this way it cannot hand back
+// better than its source hands it directly.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned tsa_scan_step(unsigned v) {
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+  return o > v ? o : v;
+}
+// inclusive prefix maximum over the 64 lanes: four shifts inside the 16-lane DPP rows, then lane 15 of rows 0 and 2 to
+// rows 1 and 3 and lane 31 to rows 2 and 3
+__device__ __forceinline__ unsigned tsa_prefix_max(unsigned v) {
+  v = tsa_scan_step<0x111, 0xF>(v);
+  v = tsa_scan_step<0x112, 0xF>(v);
+  v = tsa_scan_step<0x114, 0xF>(v);
+  v = tsa_scan_step<0x118, 0xF>(v);
+  v = tsa_scan_step<0x142, 0xA>(v);
+  return tsa_scan_step<0x143, 0xC>(v);
+}
+// The key of a cell that passes its value on: 7 bits of "blocked cells before me" above 25 bits of value.  The value
+// is pp - thr + 1 + 1000 * position = (lim - cost) + 1000 * position, in [1, 2^25) as long as lim + 63000 < 2^25
+// (TSA_SCAN_LIM; searches beyond it -- paths of more than 33 000 straight cells -- keep to one-cell passes).
+constexpr int TSA_SCAN_SHIFT = 25;
+[[maybe_unused]] constexpr unsigned TSA_SCAN_LIM = (1u << TSA_SCAN_SHIFT) - 63u * (unsigned)COST_S - 1u;
+__device__ __forceinline__ unsigned long long tsa_row_fixpoint(int& g, int& pp, const int open_, const int ht_, const int thr, const int lane) {
+  const int gold = g;
+  const unsigned long long blk = ~__builtin_amdgcn_ballot_w64(open_ != 0);
+  int best = 0;
+  // A direction in which no one-cell step improves anything is at its fixed point already (the first cell of a longer
+  // improving run would be improved by that step), and a front that travels along a row mostly travels one way.
+#ifndef RNA_TSA_SCAN_BOTH
+  if (__builtin_amdgcn_ballot_w64(((lane_m1(pp) - COST_S) & open_) > g))
+#endif
+  {
+    // right-moving: sources at lower lanes.  A source in an earlier free run has a smaller count, so the maximum is the
+    // best source of the lane's own run -- or the lane's own empty key, count << 25.
+    const int off = COST_S * lane + 1 - thr;
+    const unsigned c = __builtin_amdgcn_mbcnt_hi((unsigned)(blk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)blk, 0u)) << TSA_SCAN_SHIFT;
+    const unsigned t = tsa_prefix_max(c + (pp != 0 ? (unsigned)(pp + off) : 0u)) - c;
+    const int cand = (int)t - off;
+    best = (t != 0u && cand + COST_S >= lane_m1(ht_, INF)) ? cand : 0;
+  }
+#ifndef RNA_TSA_SCAN_BOTH
+  if (__builtin_amdgcn_ballot_w64(((lane_p1(pp) - COST_S) & open_) > g))
+#endif
+  {
+    // left-moving: the same on the lanes in reverse order (lane p of the reversed wave is lane 63 - p)
+    const unsigned long long blk_rev = __builtin_bitreverse64(blk);
+    const int rl = 63 - lane;
+    const int off = COST_S * rl + 1 - thr;
+    const unsigned c = __builtin_amdgcn_mbcnt_hi((unsigned)(blk_rev >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)blk_rev, 0u)) << TSA_SCAN_SHIFT;
+    const unsigned key = pp != 0 ? (unsigned)(pp + off) : 0u;
+    const unsigned t_rev = tsa_prefix_max(c + (unsigned)__builtin_amdgcn_ds_bpermute(rl << 2, (int)key)) - c;
+    const unsigned t = (unsigned)__builtin_amdgcn_ds_bpermute(rl << 2, (int)t_rev);
+    const int cand = (int)t - off;
+    best = max(best, (t != 0u && cand + COST_S >= lane_p1(ht_, INF)) ? cand : 0);
+  }
+  g = max(g, best & open_);
+  pp = g >= ht_ ? g : 0;
+  return __builtin_amdgcn_ballot_w64(g != gold);
+}
+
 // One tile job, executed by one wavefront (lane = this wave's lane id = the cell's column inside the tile).
 // `sch` supplies the scheduler-specific pieces: best() / improve_best(g) (upper bound on f*), act_cur(tile) /
 // act_far(tile) (run the tile in the next round / when the next bucket opens), pool_exhausted().  `pg` is the tile's
@@ -416,6 +488,9 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   const unsigned best1 = (unsigned)best_in + 1u;
   const unsigned lim_u = bucket_end < best1 ? bucket_end : best1;
   const int thr = KU - (int)(lim_u > (unsigned)INF ? (unsigned)INF : lim_u) + 1;
+#if RNA_TSA_SUPER >= 2
+  const bool scan_ok = lim_u < TSA_SCAN_LIM;   // the keys of tsa_row_fixpoint fit
+#endif
   const int dxl = abs(i0 + lane - gi);
   const int dx414 = dxl * (COST_D - COST_S);
   // h + add of row b:  1000 max(dx, dy) + 414 min(dx, dy) = 586 max(dx, dy) + 414 dx + 414 dy -- one maximum, one 24-bit
@@ -612,8 +687,19 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   // LAST cell in between: candidate + 1000 >= h + thr of the lane next to the target (htl_ / htr_).
   // Measured (profiles/r04_ab_log_step_rows.txt): a super-pass is ~70 instructions and crosses one 16-lane DPP row, so a run
   // of 20-30 cells costs about what its one-cell passes cost (12 each); with the 26 KB of cold code the 32 copies add, the
-  // kernel is 0.4 % faster at best.  Shifts across the whole wavefront (ds_bpermute) would make it one super-pass per row.
-#if RNA_TSA_SUPER
+  // kernel is 0.4 % faster at best.  Mode 2 replaces the log steps by one scan over the whole wavefront.
+#if RNA_TSA_SUPER == 2
+#define TSA_HP_OUT_OF_PASSES
+#define TSA_SUPER(b, AGVAR)                                                                                      \
+  if (left_ == 0u) {   /* the one-cell passes ran out while the row was still moving: the rest in one scan */     \
+    if (scan_ok) {                                                                                               \
+      TSA_CNT(14, 1);                                                                                            \
+      up_ |= tsa_row_fixpoint(TSA_G(b), TSA_PP(b), open_, ht_, thr, lane);                                       \
+    } else {                                                                                                     \
+      AGVAR |= 1u << (b);                                                                                        \
+    }                                                                                                            \
+  }
+#elif RNA_TSA_SUPER
 #define TSA_HP_OUT_OF_PASSES
 #define TSA_SUPER_STEP(b, d, mr, ml)                                                                             \
   {                                                                                                              \
