@@ -295,20 +295,25 @@ struct TsaCtx {
 // decrease along a path, so that one test covers every cell in between): value + 1000 >= h + thr of the neighbour lane.
 // One application from the values as they are is the fixed point: what a cell receives this way it cannot hand back
 // better than its source hands it directly.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned tsa_scan_step(unsigned v) {
-  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
-  return o > v ? o : v;
-}
 // inclusive prefix maximum over the 64 lanes: four shifts inside the 16-lane DPP rows, then lane 15 of rows 0 and 2 to
-// rows 1 and 3 and lane 31 to rows 2 and 3
+// rows 1 and 3 and lane 31 to rows 2 and 3.  (In assembly: a lane without a source keeps its value, so each step is ONE
+// v_max_u32 with a DPP operand; from __builtin_amdgcn_update_dpp the compiler made copy + v_mov_dpp + v_max of it.)
 __device__ __forceinline__ unsigned tsa_prefix_max(unsigned v) {
-  v = tsa_scan_step<0x111, 0xF>(v);
-  v = tsa_scan_step<0x112, 0xF>(v);
-  v = tsa_scan_step<0x114, 0xF>(v);
-  v = tsa_scan_step<0x118, 0xF>(v);
-  v = tsa_scan_step<0x142, 0xA>(v);
-  return tsa_scan_step<0x143, 0xC>(v);
+  asm("s_nop 1\n\t"   // two wait states between a vector write and a DPP read of the same register
+      "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return v;
 }
 // The key of a cell that passes its value on: 7 bits of "blocked cells before me" above 25 bits of value.  The value
 // is pp - thr + 1 + 1000 * position = (lim - cost) + 1000 * position, in [1, 2^25) as long as lim + 63000 < 2^25
