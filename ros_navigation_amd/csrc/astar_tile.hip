@@ -501,10 +501,11 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   // h + add of row b:  1000 max(dx, dy) + 414 min(dx, dy) = 586 max(dx, dy) + 414 dx + 414 dy -- one maximum, one 24-bit
   // multiply-add and one addition of a scalar (414 dy + add) per use, with the lane's 414 dx kept in a register (five
   // instructions when the minimum was formed as well; the second register is there since the row sets stopped spilling).
-  // (the two vector instructions are volatile asm and the row offset an opaque copy: otherwise the 16 row heuristics
-  // are hoisted out of the sweeps into 16 VGPRs -- or their scalar halves into 32 SGPRs -- again)
+  // (all three instructions are volatile asm: otherwise the 16 row heuristics are hoisted out of the sweeps into 16 VGPRs --
+  // or their scalar halves into 32 SGPRs -- again.  |jg + b| is ONE s_absdiff_i32; as abs() of an opaque copy it was a
+  // copy, an addition, a negation and a maximum.)
   const int jg = j0 - gj;
-#define TSA_HC(b, add) ({ int jg_ = jg; asm volatile("" : "+s"(jg_)); const int dy_ = abs(jg_ + (b)); int m_, r_;                  \
+#define TSA_HC(b, add) ({ int dy_, m_, r_; asm volatile("s_absdiff_i32 %0, %1, %2" : "=s"(dy_) : "s"(jg), "n"(-(b)) : "scc");   /* |jg + b| */ \
                           asm volatile("v_max_i32 %0, %1, %2" : "=v"(m_) : "s"(dy_), "v"(dxl));                           \
                           asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r_) : "v"(m_), "s"(2 * COST_S - COST_D), "v"(dx414)); \
                           r_ + ((COST_D - COST_S) * dy_ + (add)); })
