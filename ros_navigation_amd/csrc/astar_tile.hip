@@ -145,6 +145,19 @@ __device__ __forceinline__ int tsa_h24(int mx, int mn) {
   asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(mn), "s"(COST_D - COST_S), "v"(a));
   return r;
 }
+// 29 t + 8191 lane with full-rate 24-bit multiplies (a start for the free-node probe; the compiler's version was a
+// quarter-rate v_mul_lo_u32 and a 64-bit multiply-add)
+__device__ __forceinline__ unsigned tsa_seed24(unsigned t, unsigned lane) {
+  unsigned a, r;
+  asm("v_mul_u32_u24 %0, %1, 29" : "=v"(a) : "v"(t));
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(lane), "s"(8191u), "v"(a));
+  return r;
+}
+// the octile heuristic of a cell through tsa_h24 (offsets below 2^24: the map has at most 2^30 cells)
+__device__ __forceinline__ int tsa_octile24(int i, int j, int gi, int gj) {
+  const int dx = abs(i - gi), dy = abs(j - gj);
+  return tsa_h24(max(dx, dy), min(dx, dy));
+}
 // u if the cell may pass its value on in this bucket (f < lim  <=>  u - h >= thr), else "unreached"
 __device__ __forceinline__ int tsa_prop(int u, int h, int thr) { return (u - h >= thr) ? u : 0; }
 
@@ -332,7 +345,7 @@ __device__ __forceinline__ unsigned long long tsa_row_fixpoint(int& g, int& pp, 
   {
     // right-moving: sources at lower lanes.  A source in an earlier free run has a smaller count, so the maximum is the
     // best source of the lane's own run -- or the lane's own empty key, count << 25.
-    const int off = COST_S * lane + 1 - thr;
+    const int off = (int)__umul24((unsigned)lane, (unsigned)COST_S) + 1 - thr;   // (full-rate 24-bit multiplies: v_mul_lo_u32 is quarter rate)
     const unsigned c = __builtin_amdgcn_mbcnt_hi((unsigned)(blk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)blk, 0u)) << TSA_SCAN_SHIFT;
     const unsigned t = tsa_prefix_max(c + (pp != 0 ? (unsigned)(pp + off) : 0u)) - c;
     const int cand = (int)t - off;
@@ -345,7 +358,7 @@ __device__ __forceinline__ unsigned long long tsa_row_fixpoint(int& g, int& pp, 
     // left-moving: the same on the lanes in reverse order (lane p of the reversed wave is lane 63 - p)
     const unsigned long long blk_rev = __builtin_bitreverse64(blk);
     const int rl = 63 - lane;
-    const int off = COST_S * rl + 1 - thr;
+    const int off = (int)__umul24((unsigned)rl, (unsigned)COST_S) + 1 - thr;
     const unsigned c = __builtin_amdgcn_mbcnt_hi((unsigned)(blk_rev >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)blk_rev, 0u)) << TSA_SCAN_SHIFT;
     const unsigned key = pp != 0 ? (unsigned)(pp + off) : 0u;
     const unsigned t_rev = tsa_prefix_max(c + (unsigned)__builtin_amdgcn_ds_bpermute(rl << 2, (int)key)) - c;
@@ -440,10 +453,14 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     // (arithmetic instead of kdi_of / kdj_of: their comparisons became a cascade of branches on the lane id.  The own
     // page is final while this job runs: only the tile's own job changes it, and a tile never runs twice at once.)
     const int kk = lane < 4 ? lane : (lane < 8 ? lane + 1 : 4);   // cell of the 3 x 3 block of tiles, row-major; lane 8: the centre
-    const int kj = (kk * 11) >> 5;                                // kk / 3
-    const int nti = ti + kk - 3 * kj - 1, ntj = tj + kj - 1;
+    // kj = kk / 3 = (11 kk) >> 5 and kk - 3 kj with full-rate 24-bit multiplies (the compiler took v_mul_lo_u32 for both)
+    int kj, ki;
+    asm("v_mul_u32_u24 %0, %1, 11" : "=v"(kj) : "v"(kk));
+    kj >>= 5;
+    asm("v_mad_i32_i24 %0, %1, -3, %2" : "=v"(ki) : "v"(kj), "v"(kk));
+    const int nti = ti + ki - 1, ntj = tj + kj - 1;
     if (lane < 9 && nti >= 0 && ntj >= 0 && nti < tiles_i && ntj < tiles_j) {
-      const int tt = ntj * tiles_i + nti;
+      const int tt = (int)__umul24((unsigned)ntj, (unsigned)tiles_i) + nti;   // (ntj >= 0 here; at most 2^20 tiles)
       nb_pg = C.page_of(tt);
       nb_t = lane < 8 ? tt : -1;
     }
@@ -457,9 +474,13 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     TSA_R16(TSA_LOAD)
 #undef TSA_LOAD
   }
-  const uint4 mv = *reinterpret_cast<const uint4*>(C.nbr_tm + (size_t)t * MASK_STRIDE + lane * 16);
+  // (the tile's snapshot through a scalar base and 32-bit lane offsets of known range: as `base + lane * 16` and
+  // `(ushort*)(base + 1056)[lane]` the second address was a 64-bit multiply-add per lane)
+  const uint8_t* const snap = C.nbr_tm + (size_t)t * MASK_STRIDE;
+  const unsigned ulane_ld = (unsigned)lane & 63u;
+  const uint4 mv = *reinterpret_cast<const uint4*>(snap + (ulane_ld << 4));
   const unsigned mk0 = mv.x, mk1 = mv.y, mk2 = mv.z, mk3 = mv.w;   // byte b of this lane = neighbour mask of cell (lane, b)
-  const unsigned fbits_ld = reinterpret_cast<const unsigned short*>(C.nbr_tm + (size_t)t * MASK_STRIDE + TILE_WORDS + 32)[lane];
+  const unsigned fbits_ld = *reinterpret_cast<const unsigned short*>(snap + TILE_WORDS + 32 + (ulane_ld << 1));
   // X: the two halo columns and the four corners.  Lanes 0..17 hold the left one top-down (lane 0 = corner (-1,-1),
   // lanes 1..16 = rows 0..15, lane 17 = corner (-1,16)), lanes 32..49 the right one.
   const int xl = lane & 31;
@@ -477,7 +498,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     const unsigned pgX = (unsigned)__shfl((int)nb_pg, xdir);
     const int xrow = xl == 0 ? TJ - 1 : (xl <= TJ ? xl - 1 : 0);
     if (xl <= TJ + 1) X = (int)ld_l2(&C.paux[pgX * AUX_WORDS + (xr ? 0 : 16) + xrow]);   // a left tile's column 63 / a right tile's column 0
-    if (xcell) eb = C.nbr_tm[(size_t)t * MASK_STRIDE + TILE_WORDS + (xr ? 16 : 0) + xl - 1];
+    if (xcell) eb = snap[TILE_WORDS + ((ulane_ld & 31u) - 1u) + (ulane_ld & 32u ? 16u : 0u)];   // (xl - 1 + (xr ? 16 : 0))
     // the tile's own columns 0 and 63 in the same layout (the copy it keeps for its neighbours)
     if (xcell) gcol = (int)ld_l2(&C.paux[pg * AUX_WORDS + (xr ? 16 : 0) + xl - 1]);
   }
@@ -497,7 +518,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   const bool scan_ok = lim_u < TSA_SCAN_LIM;   // the keys of tsa_row_fixpoint fit
 #endif
   const int dxl = abs(i0 + lane - gi);
-  const int dx414 = dxl * (COST_D - COST_S);
+  const int dx414 = (int)__umul24((unsigned)dxl, (unsigned)(COST_D - COST_S));
   // h + add of row b:  1000 max(dx, dy) + 414 min(dx, dy) = 586 max(dx, dy) + 414 dx + 414 dy -- one maximum, one 24-bit
   // multiply-add and one addition of a scalar (414 dy + add) per use, with the lane's 414 dx kept in a register (five
   // instructions when the minimum was formed as well; the second register is there since the row sets stopped spilling).
@@ -562,7 +583,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     int cT, cB, cX;
     {
       const int pT = top >= TSA_HT(-1) ? top : 0, pB = bot >= TSA_HT(TJ) ? bot : 0;
-      const int hX = tsa_octile(xr ? i0 + TI : i0 - 1, j0 + xl - 1, gi, gj);
+      const int hX = tsa_octile24(xr ? i0 + TI : i0 - 1, j0 + xl - 1, gi, gj);
       const int pX = xl <= TJ + 1 ? tsa_prop(X, hX, thr) : 0;
       const int sTL = __builtin_amdgcn_readlane(pX, 0), sBL = __builtin_amdgcn_readlane(pX, TJ + 1);
       const int sTR = __builtin_amdgcn_readlane(pX, 32), sBR = __builtin_amdgcn_readlane(pX, 32 + TJ + 1);
@@ -993,7 +1014,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       colw = ((lo & 1u) ? 1u : 0u) | ((lo & 0x1fffeu) ? 2u : 0u) | ((lo & 0x20000u) ? 4u : 0u) |
              ((hi & 1u) ? 8u : 0u) | ((hi & 0x20000u) ? 32u : 0u) | ((hi & 0x1fffeu) ? 16u : 0u);
       if (im) {   // one key per side: the corner tiles of a side share it
-        const int hX_ = tsa_octile(xr_ ? i0 + TI : i0 - 1, j0 + xl_ - 1, gi, gj);
+        const int hX_ = tsa_octile24(xr_ ? i0 + TI : i0 - 1, j0 + xl_ - 1, gi, gj);
         wave_halves_max_i32(imp ? ux_ - hX_ : (int)0x80000000, kfW, kfE);
       }
       __builtin_amdgcn_wave_barrier();
@@ -1141,7 +1162,7 @@ struct TsaLocalSched {
     *spare = -1;
     int idx = -1;
     if (q) {
-      idx = (reuse >= 0 && lane == __builtin_ctzll(qm)) ? reuse : node_alloc((unsigned)t * 29u + (unsigned)lane * 8191u);
+      idx = (reuse >= 0 && lane == __builtin_ctzll(qm)) ? reuse : node_alloc(tsa_seed24((unsigned)t, (unsigned)lane));
       if (idx >= 0) {
         link(idx, (unsigned)t, cls);
       } else {
