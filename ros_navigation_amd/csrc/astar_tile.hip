@@ -518,18 +518,19 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   const bool scan_ok = lim_u < TSA_SCAN_LIM;   // the keys of tsa_row_fixpoint fit
 #endif
   const int dxl = abs(i0 + lane - gi);
-  const int dx414 = (int)__umul24((unsigned)dxl, (unsigned)(COST_D - COST_S));
+  const int dx414 = (int)__umul24((unsigned)dxl, (unsigned)(COST_D - COST_S)) + thr;   // 414 dx + thr: the usual addend rides in the lane's register
   // h + add of row b:  1000 max(dx, dy) + 414 min(dx, dy) = 586 max(dx, dy) + 414 dx + 414 dy -- one maximum, one 24-bit
   // multiply-add and one addition of a scalar (414 dy + add) per use, with the lane's 414 dx kept in a register (five
   // instructions when the minimum was formed as well; the second register is there since the row sets stopped spilling).
   // (all three instructions are volatile asm: otherwise the 16 row heuristics are hoisted out of the sweeps into 16 VGPRs --
   // or their scalar halves into 32 SGPRs -- again.  |jg + b| is ONE s_absdiff_i32; as abs() of an opaque copy it was a
-  // copy, an addition, a negation and a maximum.)
+  // copy, an addition, a negation and a maximum.  With thr inside the lane's register the scalar part of the common case,
+  // h + thr, is that and one s_mulk_i32.)
   const int jg = j0 - gj;
 #define TSA_HC(b, add) ({ int dy_, m_, r_; asm volatile("s_absdiff_i32 %0, %1, %2" : "=s"(dy_) : "s"(jg), "n"(-(b)) : "scc");   /* |jg + b| */ \
                           asm volatile("v_max_i32 %0, %1, %2" : "=v"(m_) : "s"(dy_), "v"(dxl));                           \
                           asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r_) : "v"(m_), "s"(2 * COST_S - COST_D), "v"(dx414)); \
-                          r_ + ((COST_D - COST_S) * dy_ + (add)); })
+                          r_ + ((COST_D - COST_S) * dy_ + ((add) - thr)); })
 #define TSA_H(b) TSA_HC(b, 0)
 #define TSA_HT(b) TSA_HC(b, thr)   /* a cell passes on iff u >= h + thr */
   // bit b: this lane's cell in row b is free (and inside the map) -- from the snapshot, loaded with the masks
