@@ -633,19 +633,30 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     // rows named in cl / cr, and most jobs have none (round 3 tested every row for it, twice, inside the per-row block
     // below: 14 scalar instructions per row; the kernel is as sensitive to a scalar instruction as to 0.6 vector ones)
     if (cl | cr) {
+      // A named cell's candidate beat the tile's own column as loaded, and rows 1..14 have not changed since: it is
+      // written as it is.  Rows 0 and 15 may just have taken cT / cB: they take the larger of the two; a planted start
+      // cell is planted again afterwards.
 #define TSA_APPLY_COL(b)                                                                                         \
   if (((cl | cr) >> (b)) & 1u) {                                                                                 \
+    const bool keep_ = (b) == 0 || (b) == TJ - 1;                                                                \
     if ((cl >> (b)) & 1u) {                                                                                      \
-      const int c_ = max(__builtin_amdgcn_readlane(cX, (b) + 1), __builtin_amdgcn_readlane(TSA_G(b), 0));         \
+      int c_ = __builtin_amdgcn_readlane(cX, (b) + 1);                                                           \
+      if (keep_) c_ = max(c_, __builtin_amdgcn_readlane(TSA_G(b), 0));                                           \
       asm volatile("v_writelane_b32 %0, %1, 0" : "+v"(TSA_G(b)) : "s"(c_));                                      \
     }                                                                                                            \
     if ((cr >> (b)) & 1u) {                                                                                      \
-      const int c_ = max(__builtin_amdgcn_readlane(cX, 33 + (b)), __builtin_amdgcn_readlane(TSA_G(b), TI - 1));   \
+      int c_ = __builtin_amdgcn_readlane(cX, 33 + (b));                                                          \
+      if (keep_) c_ = max(c_, __builtin_amdgcn_readlane(TSA_G(b), TI - 1));                                      \
       asm volatile("v_writelane_b32 %0, %1, 63" : "+v"(TSA_G(b)) : "s"(c_));                                     \
     }                                                                                                            \
   }
       TSA_R16(TSA_APPLY_COL)
 #undef TSA_APPLY_COL
+      if (planted) {
+#define TSA_REPLANT(b) if ((planted >> (b)) & 1u) TSA_G(b) = lane == C.sa ? KU : TSA_G(b);
+        TSA_R16(TSA_REPLANT)
+#undef TSA_REPLANT
+      }
     }
     // what each cell may pass on in this bucket: sixteen rows, no branches
 #define TSA_APPLY_PP(b) TSA_PP(b) = TSA_G(b) >= TSA_HT(b) ? TSA_G(b) : 0;
@@ -782,7 +793,8 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     unsigned long long up_ = __builtin_amdgcn_ballot_w64(m_ > TSA_G(b));                                         \
     if (up_) {                                                                                                   \
       /* lanes that improved by a candidate from the row's own neighbours (it beats the vertical one) */          \
-      const unsigned long long hsrc_ = up_ & __builtin_amdgcn_ballot_w64(m_ > (mv_ & open_));                    \
+      unsigned long long hsrc_ = up_ & __builtin_amdgcn_ballot_w64(m_ > (mv_ & open_));                          \
+      asm volatile("" : "+s"(hsrc_));   /* formed here: the pass loop then updates up_ in place, no copy */        \
       const int ht_ = TSA_HT(b);        /* passes on iff u - h >= thr */                                         \
       TSA_G(b) = max(TSA_G(b), m_);                                                                              \
       TSA_PP(b) = TSA_G(b) >= ht_ ? TSA_G(b) : 0;                                                                \
