@@ -29,7 +29,7 @@ extern "C" {
  *    tile jobs per wavefront), statuses 4 / 5, profile slot astar_reset, default bucket width 96000.  A host checks
  *    rna_abi_version() == RNA_ABI_VERSION after loading the library (capi.py and move_control_amd.hpp do). */
 /* 3: rna_synchronize_map, rna_hw_queue_advice (round 4); no existing signature changed. */
-#define RNA_ABI_VERSION 3
+#define RNA_ABI_VERSION 4
 
 typedef enum {
   RNA_OK = 0,
@@ -344,6 +344,26 @@ int rna_scan_to_rays(rna_engine* e, const rna_laser_scan* scans_host, int n_scan
 int rna_scan_to_rays_device(rna_engine* e, const rna_laser_scan* scans_device, int n_scans, const float* ranges_device,
                             int max_beams_per_scan, rna_ray* rays_device, int max_rays, int* n_rays_device);
 
+/* The same with the sensor's FULL pose (a tilted or rolled mount, a sensor above the base): what tf's lookupTransform
+ * (map frame <- header.frame_id) returns at the two times, translation and rotation quaternion (x, y, z, w) as
+ * StampedTransform::getOrigin / getRotation give them.  Every beam's point (x, y, 0 in the sensor frame, float32) goes
+ * through the transform interpolated for its index -- translation by tf::Vector3::setInterpolate3, rotation by
+ * tf::Quaternion::slerp (shortest arc) -- and the map keeps x and y of the result, as LaserMapUpdater reads only the
+ * cloud's x and y fields (mc/src/laser_map_updater.cpp:53-60, 78-99).  The ray origin is the start translation's x, y
+ * (tf::transformPoint of the frame's origin, :101-116).  For a planar pose (rotation about z) the result equals
+ * rna_scan_to_rays' up to the rounding of the two formulations. */
+typedef struct {
+  float angle_min, angle_max, angle_increment, range_min, range_max;
+  int32_t n_ranges;
+  int64_t ranges_offset;   /* first range of this scan in the concatenated ranges array */
+  double t[3], q[4];       /* sensor frame in the map frame at header.stamp: translation, quaternion x y z w */
+  double t_end[3], q_end[4];   /* ... at the end time (see rna_laser_scan) */
+} rna_laser_scan_tf;
+int rna_scan_to_rays_tf(rna_engine* e, const rna_laser_scan_tf* scans_host, int n_scans, const float* ranges_host,
+                        size_t n_ranges_total, rna_ray* rays_host, int max_rays, int* n_rays);
+int rna_scan_to_rays_tf_device(rna_engine* e, const rna_laser_scan_tf* scans_device, int n_scans, const float* ranges_device,
+                               int max_beams_per_scan, rna_ray* rays_device, int max_rays, int* n_rays_device);
+
 /* One sensor_msgs/Range reading (sonar) plus the planar sensor pose tf reports for its stamp. */
 typedef struct {
   float range, max_range;  /* msg->range, msg->max_range */
@@ -354,6 +374,13 @@ typedef struct {
  * go to rna_himm_update(e, RNA_LAYER_RANGE, ...) -- the "range" MapUpdater of MapProvider's factory
  * (mc/src/map_provider.cpp:12-15,262-266); master is composed from the laser layer only (:216-223). */
 int rna_range_to_rays(const rna_range_reading* readings, int n, rna_ray* rays);
+/* The same with the sensor's full pose (translation + quaternion x y z w, as above): start = T * (0, 0, 0),
+ * end = T * (range, 0, 0), x and y kept. */
+typedef struct {
+  float range, max_range;
+  double t[3], q[4];
+} rna_range_reading_tf;
+int rna_range_to_rays_tf(const rna_range_reading_tf* readings, int n, rna_ray* rays);
 
 /* ---- message formats either side of the path ------------------------------------------------- */
 /* GridMapRosConverter::toOccupancyGrid (grid_map-master/grid_map_ros/src/GridMapRosConverter.cpp:251-287)

@@ -219,8 +219,17 @@ typedef struct {
 } og_scan;
 int og_simplify_scan(int n, float angle_increment, int* sel, int cap, float* out_increment);
 int og_scan_to_rays(const og_scan* s, const float* ranges, og_ray* out, int cap);   /* returns the number of rays */
+typedef struct {
+  float angle_min, angle_max, angle_increment, range_min, range_max;
+  int32_t n_ranges;
+  int64_t ranges_offset;
+  double t[3], q[4];           /* tf: sensor frame in the map frame at header.stamp (translation, quaternion x y z w) */
+  double t_end[3], q_end[4];   /* ... at the end time */
+} og_scan_tf;
+int og_scan_to_rays_tf(const og_scan_tf* s, const float* ranges, og_ray* out, int cap);
 /* sonar: RangeMapUpdater::bufferIncomingMsg (range_map_updater.cpp:38-76) */
 void og_range_to_ray(float range, float max_range, double x, double y, double yaw, og_ray* out);
+void og_range_to_ray_tf(float range, float max_range, const double t[3], const double q[4], og_ray* out);
 
 /* ---- message formats either side of the path (msgs.c) ---- */
 /* GridMapRosConverter::toOccupancyGrid / fromOccupancyGrid (grid_map_ros/src/GridMapRosConverter.cpp:205-287) */

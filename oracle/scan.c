@@ -19,6 +19,8 @@
  *                   the yaw interpolated along the shortest arc;
  *   transform:      p' = R(yaw_i) p + t_i in double on the float32 point, stored as float32 again.
  * (A scan of one beam divides by zero there; defined here: ratio = 0.)
+ * og_scan_to_rays_tf takes the two transforms as tf reports them (translation + quaternion) and restates slerp, the
+ * quaternion's matrix and the transform of the point from tf's LinearMath headers: any mount, not only planar ones.
  * PARITY UNPINNED: no reference test covers this path and the dependencies cannot be built here.
  * Reference quirks kept: the point's index refers to the SIMPLIFIED scan but ifClearEnd looks it
  * up in the ORIGINAL ranges (laser_map_updater.cpp:62-69); the simplified scan starts with
@@ -51,45 +53,105 @@ int og_simplify_scan(int n, float angle_increment, int* sel, int cap, float* out
   return m;
 }
 
-int og_scan_to_rays(const og_scan* s, const float* ranges, og_ray* out, int cap) {
-  const float* r = ranges + s->ranges_offset;
-  int n = s->n_ranges;
-  float inc = s->angle_increment;
+/* tf::Quaternion::dot / length2 (tf/LinearMath/Quaternion.h) */
+static double q_dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+
+/* tf::Quaternion::slerp(q, t) with angleShortestPath (tf/LinearMath/Quaternion.h), as laser_geometry calls it through
+ * tf::slerp(quat_start, quat_end, ratio):
+ *   theta = angleShortestPath(q) / 2, angleShortestPath = acos(+-dot / sqrt(length2 * q.length2)) * 2 (the sign that makes
+ *   the dot product non-negative); theta == 0 returns *this; else d = 1 / sin(theta), s0 = sin((1 - t) theta),
+ *   s1 = sin(t theta) and every component (a * s0 + +-b * s1) * d. */
+static void q_slerp(const double* a, const double* b, double t, double* out) {
+  const double sl = sqrt(q_dot(a, a) * q_dot(b, b));
+  const double dt = q_dot(a, b);
+  const double theta = (dt < 0 ? acos(-dt / sl) * 2.0 : acos(dt / sl) * 2.0) / 2.0;
+  if (theta != 0.0) {
+    const double d = 1.0 / sin(theta);
+    const double s0 = sin((1.0 - t) * theta);
+    const double s1 = sin(t * theta);
+    if (dt < 0) for (int k = 0; k < 4; ++k) out[k] = (a[k] * s0 + -b[k] * s1) * d;
+    else for (int k = 0; k < 4; ++k) out[k] = (a[k] * s0 + b[k] * s1) * d;
+  } else {
+    for (int k = 0; k < 4; ++k) out[k] = a[k];
+  }
+}
+
+/* tf::Matrix3x3::setRotation(q) (tf/LinearMath/Matrix3x3.h), rows 0 and 1, then tf::Transform::operator*(Vector3):
+ * row.dot(p) + origin, x and y only (LaserMapUpdater reads the cloud's x and y fields, laser_map_updater.cpp:53-60) */
+static void q_apply_xy(const double* q, double tx, double ty, double x, double y, double z, double* ox, double* oy) {
+  const double d = q_dot(q, q);
+  const double s = 2.0 / d;
+  const double xs = q[0] * s, ys = q[1] * s, zs = q[2] * s;
+  const double wx = q[3] * xs, wy = q[3] * ys, wz = q[3] * zs;
+  const double xx = q[0] * xs, xy = q[0] * ys, xz = q[0] * zs;
+  const double yy = q[1] * ys, yz = q[1] * zs, zz = q[2] * zs;
+  *ox = ((1.0 - (yy + zz)) * x + (xy - wz) * y + (xz + wy) * z) + tx;
+  *oy = ((xy + wz) * x + (1.0 - (xx + zz)) * y + (yz - wx) * z) + ty;
+}
+
+/* both pose forms share everything but the per-beam transform: exactly one of `pl` (planar) and `tf` (full) is given */
+static int scan_to_rays_core(const og_scan* pl, const og_scan_tf* tf, const float* ranges, og_ray* out, int cap) {
+  const float angle_min = pl ? pl->angle_min : tf->angle_min, angle_increment = pl ? pl->angle_increment : tf->angle_increment;
+  const float range_min = pl ? pl->range_min : tf->range_min, range_max = pl ? pl->range_max : tf->range_max;
+  const int n_ranges = pl ? pl->n_ranges : tf->n_ranges;
+  const float* r = ranges + (pl ? pl->ranges_offset : tf->ranges_offset);
+  int n = n_ranges;
+  float inc = angle_increment;
   static int sel_buf[1 << 16];
   int* sel = NULL;
-  if (s->angle_increment < 0.017) {   /* laser_map_updater.cpp:82 */
-    n = og_simplify_scan(s->n_ranges, s->angle_increment, sel_buf, 1 << 16, &inc);
+  if (angle_increment < 0.017) {   /* laser_map_updater.cpp:82 */
+    n = og_simplify_scan(n_ranges, angle_increment, sel_buf, 1 << 16, &inc);
     if (n > (1 << 16)) n = 1 << 16;
     sel = sel_buf;
   }
-  const double range_cutoff = s->range_max;
-  double dyaw = fmod(s->yaw_end - s->yaw, 2.0 * M_PI);   /* shortest arc, as a quaternion slerp turns */
-  if (dyaw > M_PI) dyaw -= 2.0 * M_PI;
-  if (dyaw < -M_PI) dyaw += 2.0 * M_PI;
+  const double range_cutoff = range_max;
+  double dyaw = 0.0;
+  if (pl) {
+    dyaw = fmod(pl->yaw_end - pl->yaw, 2.0 * M_PI);   /* shortest arc, as a quaternion slerp turns */
+    if (dyaw > M_PI) dyaw -= 2.0 * M_PI;
+    if (dyaw < -M_PI) dyaw += 2.0 * M_PI;
+  }
   const double ranges_norm = n > 1 ? 1.0 / ((double)n - 1.0) : 0.0;
+  const double sx = pl ? pl->x : tf->t[0], sy = pl ? pl->y : tf->t[1];   /* tf::transformPoint of (0, 0, 0), :101-116 */
   int m = 0;
   for (int i = 0; i < n; ++i) {
     const float range = r[sel ? sel[i] : i];
-    if (!(range < range_cutoff && range >= s->range_min)) continue;
-    const double a = s->angle_min + (double)i * inc;
+    if (!(range < range_cutoff && range >= range_min)) continue;
+    const double a = angle_min + (double)i * inc;
     const float px = (float)(range * cos(a)), py = (float)(range * sin(a));
     const double ratio = (double)i * ranges_norm, keep = 1.0 - ratio;
-    const double yaw_i = s->yaw + ratio * dyaw;
-    const double cy = cos(yaw_i), sy = sin(yaw_i);
-    const double tx = keep * s->x + ratio * s->x_end, ty = keep * s->y + ratio * s->y_end;
-    const float gx = (float)(cy * (double)px - sy * (double)py + tx);
-    const float gy = (float)(sy * (double)px + cy * (double)py + ty);
-    const float orig = i < s->n_ranges ? r[i] : r[s->n_ranges - 1];   /* msg->ranges[index] of the ORIGINAL scan */
+    double mx, my;
+    if (pl) {
+      const double yaw_i = pl->yaw + ratio * dyaw;
+      const double cy = cos(yaw_i), sy_ = sin(yaw_i);
+      const double tx = keep * pl->x + ratio * pl->x_end, ty = keep * pl->y + ratio * pl->y_end;
+      mx = cy * (double)px - sy_ * (double)py + tx;
+      my = sy_ * (double)px + cy * (double)py + ty;
+    } else {
+      double q[4];
+      q_slerp(tf->q, tf->q_end, ratio, q);
+      /* tf::Vector3::setInterpolate3(v0, v1, rt): s = 1 - rt; s * v0 + rt * v1 */
+      const double tx = keep * tf->t[0] + ratio * tf->t_end[0], ty = keep * tf->t[1] + ratio * tf->t_end[1];
+      q_apply_xy(q, tx, ty, (double)px, (double)py, 0.0, &mx, &my);
+    }
+    const float gx = (float)mx, gy = (float)my;
+    const float orig = i < n_ranges ? r[i] : r[n_ranges - 1];   /* msg->ranges[index] of the ORIGINAL scan */
     if (m < cap) {
-      out[m].sx = s->x; out[m].sy = s->y;
+      out[m].sx = sx; out[m].sy = sy;
       out[m].ex = gx; out[m].ey = gy;
-      out[m].clear_end = (isinf(orig) || orig == s->range_max) ? 1 : 0;
+      out[m].clear_end = (isinf(orig) || orig == range_max) ? 1 : 0;
       out[m]._pad = 0;
     }
     ++m;
   }
   return m;
 }
+
+int og_scan_to_rays(const og_scan* s, const float* ranges, og_ray* out, int cap) { return scan_to_rays_core(s, NULL, ranges, out, cap); }
+/* the sensor's full pose as tf::TransformListener::lookupTransform reports it (translation, quaternion x y z w) at the scan's
+ * start and end time: a tilted, rolled or raised mount.  tf's LinearMath (ROS Indigo tf 1.11.x, not under /root/reference)
+ * restated above -- PARITY UNPINNED like the planar path. */
+int og_scan_to_rays_tf(const og_scan_tf* s, const float* ranges, og_ray* out, int cap) { return scan_to_rays_core(NULL, s, ranges, out, cap); }
 
 /* RangeMapUpdater::bufferIncomingMsg (range_map_updater.cpp:38-76): in.point = (0,0,0) -> start, then
  * in.point.x = msg->range -> end, both through tf::transformPoint (double; planar pose restated as R(yaw) p + t as
@@ -105,5 +167,13 @@ void og_range_to_ray(float range, float max_range, double x, double y, double ya
   out->ey = s * px + c * py + y;
   if (range < max_range) out->clear_end = 0;
   else out->clear_end = 1;
+  out->_pad = 0;
+}
+
+/* the same for a full sensor pose: start = T * (0, 0, 0), end = T * (range, 0, 0), x and y kept */
+void og_range_to_ray_tf(float range, float max_range, const double t[3], const double q[4], og_ray* out) {
+  q_apply_xy(q, t[0], t[1], 0.0, 0.0, 0.0, &out->sx, &out->sy);
+  q_apply_xy(q, t[0], t[1], (double)range, 0.0, 0.0, &out->ex, &out->ey);
+  out->clear_end = (range < max_range) ? 0 : 1;
   out->_pad = 0;
 }

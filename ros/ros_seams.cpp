@@ -108,20 +108,32 @@ bool RosSeams::robotPose(Position& pos, double& yaw) {
 }
 
 bool RosSeams::sensorPose(const std::string& frame, const ros::Time& stamp, double& x, double& y, double& yaw) {
+  double t[3], q[4];
+  if (!sensorTransform(frame, stamp, t, q)) return false;
+  x = t[0];
+  y = t[1];
+  yaw = tf::getYaw(tf::Quaternion(q[0], q[1], q[2], q[3]));
+  return true;
+}
+
+// the whole transform map <- frame as tf reports it (translation, quaternion x y z w): sensors are not assumed to be mounted
+// level -- the engine interpolates and applies it the way laser_geometry / tf::transformPoint do (rna_scan_to_rays_tf)
+bool RosSeams::sensorTransform(const std::string& frame, const ros::Time& stamp, double t[3], double q[4]) {
   if (!tf_.waitForTransform(mapFrameId_, frame, stamp, ros::Duration(1))) {
     ROS_ERROR_THROTTLE(1.0, "map provider can't transform from %s to %s at %f", mapFrameId_.c_str(), frame.c_str(), stamp.toSec());
     return false;
   }
-  tf::StampedTransform t;
+  tf::StampedTransform st;
   try {
-    tf_.lookupTransform(mapFrameId_, frame, stamp, t);
+    tf_.lookupTransform(mapFrameId_, frame, stamp, st);
   } catch (tf::TransformException& ex) {
     ROS_WARN("Failure %s\n", ex.what());
     return false;
   }
-  x = t.getOrigin().x();
-  y = t.getOrigin().y();
-  yaw = tf::getYaw(t.getRotation());
+  const tf::Vector3& o = st.getOrigin();
+  const tf::Quaternion r = st.getRotation();
+  t[0] = o.x(); t[1] = o.y(); t[2] = o.z();
+  q[0] = r.x(); q[1] = r.y(); q[2] = r.z(); q[3] = r.w();
   return true;
 }
 
@@ -146,7 +158,7 @@ void RosSeams::addRangeTopic(const std::string& topic) {   // RangeMapUpdater::a
 // and at the end of the scan run on the GPU (rna_scan_to_rays)
 void RosSeams::laserCb(const sensor_msgs::LaserScanConstPtr& msg) {
   if (!laserEvery_.take(rosNow())) return;
-  rna_laser_scan s;
+  rna_laser_scan_tf s;
   s.angle_min = msg->angle_min;
   s.angle_max = msg->angle_max;
   s.angle_increment = msg->angle_increment;
@@ -154,24 +166,25 @@ void RosSeams::laserCb(const sensor_msgs::LaserScanConstPtr& msg) {
   s.range_max = msg->range_max;
   s.n_ranges = (int32_t)msg->ranges.size();
   s.ranges_offset = 0;
-  if (!sensorPose(msg->header.frame_id, msg->header.stamp, s.x, s.y, s.yaw)) return;
+  if (!sensorTransform(msg->header.frame_id, msg->header.stamp, s.t, s.q)) return;
   // laser_geometry's high-fidelity projection asks tf for the end of the (decimated) scan as well
   const int beams = rna_scan_projected_beams(s.n_ranges, s.angle_increment);
   const ros::Time end = msg->header.stamp + ros::Duration((beams > 0 ? beams - 1 : 0) * (double)msg->time_increment);
-  if (msg->time_increment == 0.0f || !sensorPose(msg->header.frame_id, end, s.x_end, s.y_end, s.yaw_end)) {
-    s.x_end = s.x; s.y_end = s.y; s.yaw_end = s.yaw;
+  if (msg->time_increment == 0.0f || !sensorTransform(msg->header.frame_id, end, s.t_end, s.q_end)) {
+    for (int k = 0; k < 3; ++k) s.t_end[k] = s.t[k];
+    for (int k = 0; k < 4; ++k) s.q_end[k] = s.q[k];
   }
-  std::vector<rna_laser_scan> scans(1, s);
+  std::vector<rna_laser_scan_tf> scans(1, s);
   mapProvider_.bufferScans(scans, msg->ranges);
 }
 
 // RangeMapUpdater::bufferIncomingMsg (range_map_updater.cpp:38-76)
 void RosSeams::rangeCb(const sensor_msgs::RangeConstPtr& msg) {
-  rna_range_reading r;
+  rna_range_reading_tf r;
   r.range = msg->range;
   r.max_range = msg->max_range;
-  if (!sensorPose(msg->header.frame_id, msg->header.stamp, r.x, r.y, r.yaw)) return;
-  std::vector<rna_range_reading> one(1, r);
+  if (!sensorTransform(msg->header.frame_id, msg->header.stamp, r.t, r.q)) return;
+  std::vector<rna_range_reading_tf> one(1, r);
   mapProvider_.bufferRanges(one);
 }
 

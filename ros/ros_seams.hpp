@@ -58,6 +58,7 @@ class RosSeams : public detail::RosWiring {
  private:
   bool robotPose(Position& pos, double& yaw);
   bool sensorPose(const std::string& frame, const ros::Time& stamp, double& x, double& y, double& yaw);
+  bool sensorTransform(const std::string& frame, const ros::Time& stamp, double t[3], double q[4]);
   void laserCb(const sensor_msgs::LaserScanConstPtr& msg);
   void rangeCb(const sensor_msgs::RangeConstPtr& msg);
   void odomCb(const nav_msgs::OdometryConstPtr& msg);

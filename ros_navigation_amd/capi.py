@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("RNA_LIB") or "librna.so")   # RNA_LIB: developer switch to an alternative build
 
 RNA_OK = 0
-ABI_VERSION = 3   # include/rna.h: RNA_ABI_VERSION
+ABI_VERSION = 4   # include/rna.h: RNA_ABI_VERSION
 STATUS = {0: "RNA_OK", -1: "RNA_EINVAL", -2: "RNA_ENOMEM", -3: "RNA_EHIP", -4: "RNA_ECAPACITY",
           -5: "RNA_ESTATE", -6: "RNA_ENODEVICE"}
 LAYER_MASTER, LAYER_LASER, LAYER_RANGE = 0, 1, 2
@@ -38,6 +38,7 @@ SYMBOLS = [
     "rna_graph_astar_batch", "rna_rrt_batch", "rna_rrt_batch_device",
     "rna_to_occupancy_grid", "rna_to_occupancy_grid_device", "rna_from_occupancy_grid", "rna_vfh_hist_msg_batch",
     "rna_tailor_plan", "rna_follow_plan", "rna_get_submap", "rna_get_submap_device", "rna_create_submap", "rna_scan_to_rays", "rna_scan_to_rays_device", "rna_scan_projected_beams", "rna_range_to_rays",
+    "rna_scan_to_rays_tf", "rna_scan_to_rays_tf_device", "rna_range_to_rays_tf",
     "rna_profile_enable", "rna_profile_reset", "rna_profile_get", "rna_kernel_name",
 ]
 
@@ -76,6 +77,11 @@ SCAN_DTYPE = np.dtype([("angle_min", "<f4"), ("angle_max", "<f4"), ("angle_incre
                        ("range_max", "<f4"), ("n_ranges", "<i4"), ("ranges_offset", "<i8"), ("x", "<f8"), ("y", "<f8"),
                        ("yaw", "<f8"), ("x_end", "<f8"), ("y_end", "<f8"), ("yaw_end", "<f8")])
 RANGE_READING_DTYPE = np.dtype([("range", "<f4"), ("max_range", "<f4"), ("x", "<f8"), ("y", "<f8"), ("yaw", "<f8")])
+# the same records with the sensor's full pose (translation + quaternion x y z w): include/rna.h rna_laser_scan_tf / rna_range_reading_tf
+SCAN_TF_DTYPE = np.dtype([("angle_min", "<f4"), ("angle_max", "<f4"), ("angle_increment", "<f4"), ("range_min", "<f4"),
+                          ("range_max", "<f4"), ("n_ranges", "<i4"), ("ranges_offset", "<i8"), ("t", "<f8", (3,)), ("q", "<f8", (4,)),
+                          ("t_end", "<f8", (3,)), ("q_end", "<f8", (4,))])
+RANGE_READING_TF_DTYPE = np.dtype([("range", "<f4"), ("max_range", "<f4"), ("t", "<f8", (3,)), ("q", "<f8", (4,))])
 ASTAR_QUERY_DTYPE = np.dtype([("start", "<i4"), ("goal", "<i4")])
 ASTAR_RESULT_DTYPE = np.dtype([("status", "<i4"), ("path_len", "<i4"), ("cost", "<i4"), ("expanded", "<i4"),
                                ("rounds", "<i4"), ("buckets", "<i4")])
@@ -188,6 +194,9 @@ def lib():
     L.rna_scan_to_rays.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp, C.c_int, C.POINTER(C.c_int)]
     L.rna_scan_to_rays_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
     L.rna_range_to_rays.argtypes = [vp, C.c_int, vp]
+    L.rna_scan_to_rays_tf.argtypes = [vp, vp, C.c_int, vp, C.c_size_t, vp, C.c_int, C.POINTER(C.c_int)]
+    L.rna_scan_to_rays_tf_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
+    L.rna_range_to_rays_tf.argtypes = [vp, C.c_int, vp]
     L.rna_profile_enable.argtypes = [vp, C.c_int]
     L.rna_profile_reset.argtypes = [vp]
     L.rna_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -216,6 +225,17 @@ def range_to_rays(readings):
     rc = lib().rna_range_to_rays(_ptr(readings), len(readings), _ptr(rays))
     if rc != 0:
         raise RnaError("rna_range_to_rays failed (%d)" % rc)
+    return rays
+
+
+def range_to_rays_tf(readings):
+    """rna_range_to_rays for sensors with a full pose (RANGE_READING_TF_DTYPE)."""
+    readings = np.ascontiguousarray(readings)
+    assert readings.dtype == RANGE_READING_TF_DTYPE
+    rays = np.zeros(len(readings), RAY_DTYPE)
+    rc = lib().rna_range_to_rays_tf(_ptr(readings), len(readings), _ptr(rays))
+    if rc != 0:
+        raise RnaError("rna_range_to_rays_tf failed (%d)" % rc)
     return rays
 
 
@@ -610,6 +630,18 @@ class Engine:
         n = C.c_int(0)
         self._check(self._L.rna_scan_to_rays(self.h, _ptr(scans), len(scans), _ptr(ranges), ranges.size, _ptr(rays), max_rays,
                                              C.byref(n)))
+        return rays[:n.value]
+
+    def scan_to_rays_tf(self, scans, ranges, max_rays=None):
+        """scan_to_rays for sensors with a full pose (SCAN_TF_DTYPE: tf's translation + quaternion at both ends of the scan)."""
+        scans = np.ascontiguousarray(scans, SCAN_TF_DTYPE)
+        ranges = np.ascontiguousarray(ranges, np.float32)
+        if max_rays is None:
+            max_rays = int(scans["n_ranges"].sum()) + 1
+        rays = np.zeros(max_rays, RAY_DTYPE)
+        n = C.c_int(0)
+        self._check(self._L.rna_scan_to_rays_tf(self.h, _ptr(scans), len(scans), _ptr(ranges), ranges.size, _ptr(rays), max_rays,
+                                                C.byref(n)))
         return rays[:n.value]
 
     def to_occupancy_grid(self, layer, data_min=0.0, data_max=255.0):

@@ -1,9 +1,10 @@
 // scan.hip -- laser ingestion as a device pre-pass: sensor_msgs/LaserScan
 // batches go straight into rna_ray records, in scan order then beam order, ready for
 // rna_update_map_device.  Replaces LaserMapUpdater::bufferIncomingMsg
-// (move_control/src/laser_map_updater.cpp:37-75): simplifyLaserScan (:118-143), the planar,
-// time-constant case of laser_geometry::LaserProjection::transformLaserScanToPointCloud (:78-99) and
-// the ray origin from tf::transformPoint (:101-116).  laser_geometry / tf are external ROS packages
+// (move_control/src/laser_map_updater.cpp:37-75): simplifyLaserScan (:118-143),
+// laser_geometry::LaserProjection::transformLaserScanToPointCloud (:78-99) -- for a planar sensor pose
+// (rna_laser_scan: x, y, yaw) and for the full transform tf reports (rna_laser_scan_tf: translation + quaternion, a
+// tilted or raised mount) -- and the ray origin from tf::transformPoint (:101-116).  laser_geometry / tf are external ROS packages
 // (move_control/package.xml:16-29, not version-pinned): see oracle/scan.c for the restated algorithm
 // and the reference quirks that are kept.
 #include "engine.hpp"
@@ -15,17 +16,70 @@ namespace {
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_MAX_BEAMS = 8192;   // simplified beams per scan held in LDS
 
+// The transform of beam i of n (ratio = i / (n - 1)) applied to the projected float32 point (px, py, 0): map-frame x, y.
+// Planar pose: position linearly, yaw along the shortest arc; a constant pose (end == start) reduces to one rotation.
+__device__ __forceinline__ void beam_to_map(const rna_laser_scan& sc, double ratio, float px, float py, double& gx, double& gy) {
+  double dyaw = fmod(sc.yaw_end - sc.yaw, 2.0 * M_PI);
+  if (dyaw > M_PI) dyaw -= 2.0 * M_PI;
+  if (dyaw < -M_PI) dyaw += 2.0 * M_PI;
+  const double keep = 1.0 - ratio;
+  const double yaw_i = sc.yaw + ratio * dyaw;
+  const double cy = cos(yaw_i), sy = sin(yaw_i);
+  const double tx = keep * sc.x + ratio * sc.x_end, ty = keep * sc.y + ratio * sc.y_end;
+  gx = cy * (double)px - sy * (double)py + tx;
+  gy = sy * (double)px + cy * (double)py + ty;
+}
+__device__ __forceinline__ void scan_origin(const rna_laser_scan& sc, double& ox, double& oy) { ox = sc.x; oy = sc.y; }
+
+// Full transform, as tf's LinearMath does it in double (tf/LinearMath/{Quaternion,Matrix3x3,Transform}.h; oracle/scan.c
+// restates the same lines): Vector3::setInterpolate3, Quaternion::slerp through angleShortestPath, Matrix3x3::setRotation,
+// Transform::operator*.
+__device__ __forceinline__ double quat_dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+__device__ __forceinline__ void beam_to_map(const rna_laser_scan_tf& sc, double ratio, float px, float py, double& gx, double& gy) {
+  const double* q0 = sc.q;
+  const double* q1 = sc.q_end;
+  // v.setInterpolate3(origin_start, origin_end, ratio)
+  const double keep = 1.0 - ratio;
+  const double tx = keep * sc.t[0] + ratio * sc.t_end[0], ty = keep * sc.t[1] + ratio * sc.t_end[1];
+  // slerp(quat_start, quat_end, ratio)
+  double q[4] = {q0[0], q0[1], q0[2], q0[3]};
+  {
+    const double sl = sqrt(quat_dot(q0, q0) * quat_dot(q1, q1));
+    const double dt = quat_dot(q0, q1);
+    const double theta = (dt < 0 ? acos(-dt / sl) * 2.0 : acos(dt / sl) * 2.0) / 2.0;   // angleShortestPath(q) / 2
+    if (theta != 0.0) {
+      const double d = 1.0 / sin(theta);
+      const double s0 = sin((1.0 - ratio) * theta);
+      const double s1 = sin(ratio * theta);
+      if (dt < 0) { for (int k = 0; k < 4; ++k) q[k] = (q0[k] * s0 + -q1[k] * s1) * d; }
+      else { for (int k = 0; k < 4; ++k) q[k] = (q0[k] * s0 + q1[k] * s1) * d; }
+    }
+  }
+  // Matrix3x3::setRotation(q), rows 0 and 1
+  const double dd = quat_dot(q, q);
+  const double s = 2.0 / dd;
+  const double xs = q[0] * s, ys = q[1] * s, zs = q[2] * s;
+  const double wx = q[3] * xs, wy = q[3] * ys, wz = q[3] * zs;
+  const double xx = q[0] * xs, xy = q[0] * ys, xz = q[0] * zs;
+  const double yy = q[1] * ys, yz = q[1] * zs, zz = q[2] * zs;
+  const double x = (double)px, y = (double)py, z = 0.0;
+  gx = ((1.0 - (yy + zz)) * x + (xy - wz) * y + (xz + wy) * z) + tx;
+  gy = ((xy + wz) * x + (1.0 - (xx + zz)) * y + (yz - wx) * z) + ty;
+}
+__device__ __forceinline__ void scan_origin(const rna_laser_scan_tf& sc, double& ox, double& oy) { ox = sc.t[0]; oy = sc.t[1]; }
+
 // One workgroup per scan.  Thread 0 replays the decimation (a sequential float accumulation), then all
 // threads project, filter and transform the beams; an ordered block-wide compaction keeps beam order.
+template <class Scan>
 __global__ void __launch_bounds__(SCAN_THREADS)
-scan_to_rays_kernel(const rna_laser_scan* __restrict__ scans, const float* __restrict__ ranges, int max_rays_per_scan,
+scan_to_rays_kernel(const Scan* __restrict__ scans, const float* __restrict__ ranges, int max_rays_per_scan,
                     rna_ray* __restrict__ staged, int* __restrict__ counts) {
   __shared__ unsigned short s_sel[SCAN_MAX_BEAMS];
   __shared__ int s_n;
   __shared__ float s_inc;
   __shared__ int s_wave_cnt[SCAN_THREADS / 64];
   __shared__ int s_base;
-  const rna_laser_scan sc = scans[blockIdx.x];
+  const Scan sc = scans[blockIdx.x];
   const float* r = ranges + sc.ranges_offset;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const bool simplify = sc.angle_increment < 0.017;   // laser_map_updater.cpp:82
@@ -55,12 +109,10 @@ scan_to_rays_kernel(const rna_laser_scan* __restrict__ scans, const float* __res
   const int n = s_n;
   const float inc = s_inc;
   const double range_cutoff = sc.range_max;
-  // tf's start / end transforms interpolated per beam (laser_geometry's high-fidelity projection): position linearly,
-  // yaw along the shortest arc; a constant pose (end == start) reduces to one rotation
-  double dyaw = fmod(sc.yaw_end - sc.yaw, 2.0 * M_PI);
-  if (dyaw > M_PI) dyaw -= 2.0 * M_PI;
-  if (dyaw < -M_PI) dyaw += 2.0 * M_PI;
+  // tf's start / end transforms interpolated per beam (laser_geometry's high-fidelity projection)
   const double ranges_norm = n > 1 ? 1.0 / ((double)n - 1.0) : 0.0;
+  double ox, oy;
+  scan_origin(sc, ox, oy);
   rna_ray* out = staged + (size_t)blockIdx.x * max_rays_per_scan;
   for (int i0 = 0; i0 < n; i0 += SCAN_THREADS) {
     const int i = i0 + tid;
@@ -72,13 +124,11 @@ scan_to_rays_kernel(const rna_laser_scan* __restrict__ scans, const float* __res
       if (valid) {
         const double a = sc.angle_min + (double)i * inc;
         const float px = (float)(range * cos(a)), py = (float)(range * sin(a));   // projectLaser_: float32 point
-        const double ratio = (double)i * ranges_norm, keep = 1.0 - ratio;
-        const double yaw_i = sc.yaw + ratio * dyaw;
-        const double cy = cos(yaw_i), sy = sin(yaw_i);
-        const double tx = keep * sc.x + ratio * sc.x_end, ty = keep * sc.y + ratio * sc.y_end;
-        ray.sx = sc.x; ray.sy = sc.y;
-        ray.ex = (double)(float)(cy * (double)px - sy * (double)py + tx);         // tf transform, float32 again
-        ray.ey = (double)(float)(sy * (double)px + cy * (double)py + ty);
+        double gx, gy;
+        beam_to_map(sc, (double)i * ranges_norm, px, py, gx, gy);
+        ray.sx = ox; ray.sy = oy;
+        ray.ex = (double)(float)gx;                                               // tf transform, float32 again
+        ray.ey = (double)(float)gy;
         const float orig = r[i < sc.n_ranges ? i : sc.n_ranges - 1];              // ORIGINAL ranges[index], :62-69
         ray.clear_end = (isinf(orig) || orig == sc.range_max) ? 1 : 0;
         ray._pad = 0;
@@ -134,7 +184,8 @@ extern "C" int rna_scan_projected_beams(int n_ranges, float angle_increment) {
   return m;
 }
 
-extern "C" int rna_scan_to_rays_device(rna_engine* e, const rna_laser_scan* scans_device, int n_scans,
+template <class Scan>
+static int scan_to_rays_device_t(rna_engine* e, const Scan* scans_device, int n_scans,
                                        const float* ranges_device, int max_beams_per_scan, rna_ray* rays_device, int max_rays,
                                        int* n_rays_device) {
   if (!e || n_scans < 0 || max_rays < 0 || max_beams_per_scan <= 0 || !n_rays_device) return RNA_EINVAL;
@@ -150,7 +201,7 @@ extern "C" int rna_scan_to_rays_device(rna_engine* e, const rna_laser_scan* scan
   int rc = dev_alloc(e, &staged, (size_t)n_scans * max_beams_per_scan);
   if (rc == RNA_OK) rc = dev_alloc(e, &counts, (size_t)n_scans);
   if (rc == RNA_OK) {
-    hipLaunchKernelGGL(scan_to_rays_kernel, dim3(n_scans), dim3(SCAN_THREADS), 0, e->stream, scans_device, ranges_device,
+    hipLaunchKernelGGL(scan_to_rays_kernel<Scan>, dim3(n_scans), dim3(SCAN_THREADS), 0, e->stream, scans_device, ranges_device,
                        max_beams_per_scan, staged, counts);
     hipLaunchKernelGGL(scan_pack_kernel, dim3(1), dim3(256), 0, e->stream, staged, counts, n_scans, max_beams_per_scan,
                        rays_device, max_rays, n_rays_device);
@@ -165,7 +216,8 @@ extern "C" int rna_scan_to_rays_device(rna_engine* e, const rna_laser_scan* scan
   return RNA_OK;
 }
 
-extern "C" int rna_scan_to_rays(rna_engine* e, const rna_laser_scan* scans_host, int n_scans, const float* ranges_host,
+template <class Scan>
+static int scan_to_rays_host_t(rna_engine* e, const Scan* scans_host, int n_scans, const float* ranges_host,
                                 size_t n_ranges_total, rna_ray* rays_host, int max_rays, int* n_rays) {
   if (!e || n_scans < 0 || max_rays < 0 || !n_rays) return RNA_EINVAL;
   *n_rays = 0;
@@ -173,14 +225,14 @@ extern "C" int rna_scan_to_rays(rna_engine* e, const rna_laser_scan* scans_host,
   if (!scans_host || !ranges_host || (max_rays > 0 && !rays_host)) return RNA_EINVAL;
   int max_beams = 1;
   for (int s = 0; s < n_scans; ++s) {
-    const rna_laser_scan& sc = scans_host[s];
+    const Scan& sc = scans_host[s];
     if (sc.n_ranges < 0 || sc.ranges_offset < 0 || (size_t)sc.ranges_offset + (size_t)sc.n_ranges > n_ranges_total)
       return fail(e, RNA_EINVAL, "rna_scan_to_rays: scan ranges outside the ranges array");
     if (sc.n_ranges > max_beams) max_beams = sc.n_ranges;
   }
   if (max_beams > SCAN_MAX_BEAMS) return fail(e, RNA_EINVAL, "rna_scan_to_rays: more than 8192 beams per scan");
   RNA_ENTER(e);
-  rna_laser_scan* d_scans = nullptr;
+  Scan* d_scans = nullptr;
   float* d_ranges = nullptr;
   rna_ray* d_rays = nullptr;
   int* d_n = nullptr;
@@ -190,10 +242,10 @@ extern "C" int rna_scan_to_rays(rna_engine* e, const rna_laser_scan* scans_host,
   if (rc == RNA_OK) rc = dev_alloc(e, &d_n, (size_t)1);
   hipError_t st = hipSuccess;
   if (rc == RNA_OK) {
-    st = hipMemcpyAsync(d_scans, scans_host, sizeof(rna_laser_scan) * n_scans, hipMemcpyHostToDevice, e->stream);
+    st = hipMemcpyAsync(d_scans, scans_host, sizeof(Scan) * n_scans, hipMemcpyHostToDevice, e->stream);
     if (st == hipSuccess && n_ranges_total)
       st = hipMemcpyAsync(d_ranges, ranges_host, sizeof(float) * n_ranges_total, hipMemcpyHostToDevice, e->stream);
-    if (st == hipSuccess) rc = rna_scan_to_rays_device(e, d_scans, n_scans, d_ranges, max_beams, d_rays, max_rays, d_n);
+    if (st == hipSuccess) rc = scan_to_rays_device_t<Scan>(e, d_scans, n_scans, d_ranges, max_beams, d_rays, max_rays, d_n);
     if (st == hipSuccess && rc == RNA_OK) st = hipMemcpyAsync(n_rays, d_n, sizeof(int), hipMemcpyDeviceToHost, e->stream);
     if (st == hipSuccess && rc == RNA_OK) st = hipStreamSynchronize(e->stream);
     if (st == hipSuccess && rc == RNA_OK) {
@@ -206,6 +258,25 @@ extern "C" int rna_scan_to_rays(rna_engine* e, const rna_laser_scan* scans_host,
   if (st != hipSuccess) return fail(e, RNA_EHIP, hipGetErrorString(st));
   if (*n_rays > max_rays) return fail(e, RNA_ECAPACITY, "rna_scan_to_rays: max_rays too small (n_rays holds the required count)");
   return RNA_OK;
+}
+
+extern "C" int rna_scan_to_rays_device(rna_engine* e, const rna_laser_scan* scans_device, int n_scans,
+                                       const float* ranges_device, int max_beams_per_scan, rna_ray* rays_device, int max_rays,
+                                       int* n_rays_device) {
+  return scan_to_rays_device_t(e, scans_device, n_scans, ranges_device, max_beams_per_scan, rays_device, max_rays, n_rays_device);
+}
+extern "C" int rna_scan_to_rays(rna_engine* e, const rna_laser_scan* scans_host, int n_scans, const float* ranges_host,
+                                size_t n_ranges_total, rna_ray* rays_host, int max_rays, int* n_rays) {
+  return scan_to_rays_host_t(e, scans_host, n_scans, ranges_host, n_ranges_total, rays_host, max_rays, n_rays);
+}
+extern "C" int rna_scan_to_rays_tf_device(rna_engine* e, const rna_laser_scan_tf* scans_device, int n_scans,
+                                          const float* ranges_device, int max_beams_per_scan, rna_ray* rays_device, int max_rays,
+                                          int* n_rays_device) {
+  return scan_to_rays_device_t(e, scans_device, n_scans, ranges_device, max_beams_per_scan, rays_device, max_rays, n_rays_device);
+}
+extern "C" int rna_scan_to_rays_tf(rna_engine* e, const rna_laser_scan_tf* scans_host, int n_scans, const float* ranges_host,
+                                   size_t n_ranges_total, rna_ray* rays_host, int max_rays, int* n_rays) {
+  return scan_to_rays_host_t(e, scans_host, n_scans, ranges_host, n_ranges_total, rays_host, max_rays, n_rays);
 }
 
 // RangeMapUpdater::bufferIncomingMsg (mc/src/range_map_updater.cpp:38-76): two tf::transformPoint calls per sonar
@@ -221,6 +292,31 @@ extern "C" int rna_range_to_rays(const rna_range_reading* readings, int n, rna_r
     rays[k].sy = s * 0.0 + c * 0.0 + m.y;
     rays[k].ex = c * r - s * 0.0 + m.x;
     rays[k].ey = s * r + c * 0.0 + m.y;
+    rays[k].clear_end = (m.range < m.max_range) ? 0 : 1;
+    rays[k]._pad = 0;
+  }
+  return RNA_OK;
+}
+
+// ... and for the sensor's full pose: tf::Transform(q, t) * point in double, x and y kept (Matrix3x3::setRotation, rows 0 / 1)
+extern "C" int rna_range_to_rays_tf(const rna_range_reading_tf* readings, int n, rna_ray* rays) {
+  if (n < 0 || (n > 0 && (!readings || !rays))) return RNA_EINVAL;
+  for (int k = 0; k < n; ++k) {
+    const rna_range_reading_tf& m = readings[k];
+    const double* q = m.q;
+    const double dd = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    const double s = 2.0 / dd;
+    const double xs = q[0] * s, ys = q[1] * s, zs = q[2] * s;
+    const double wx = q[3] * xs, wy = q[3] * ys, wz = q[3] * zs;
+    const double xx = q[0] * xs, xy = q[0] * ys, xz = q[0] * zs;
+    const double yy = q[1] * ys, yz = q[1] * zs, zz = q[2] * zs;
+    const double m00 = 1.0 - (yy + zz), m01 = xy - wz, m02 = xz + wy;
+    const double m10 = xy + wz, m11 = 1.0 - (xx + zz), m12 = yz - wx;
+    const double r = (double)m.range;
+    rays[k].sx = (m00 * 0.0 + m01 * 0.0 + m02 * 0.0) + m.t[0];
+    rays[k].sy = (m10 * 0.0 + m11 * 0.0 + m12 * 0.0) + m.t[1];
+    rays[k].ex = (m00 * r + m01 * 0.0 + m02 * 0.0) + m.t[0];
+    rays[k].ey = (m10 * r + m11 * 0.0 + m12 * 0.0) + m.t[1];
     rays[k].clear_end = (m.range < m.max_range) ? 0 : 1;
     rays[k]._pad = 0;
   }

@@ -333,8 +333,15 @@ class MapProvider {
     if (rna_range_to_rays(readings.data(), (int)readings.size(), rays.data()) != RNA_OK) throw std::invalid_argument("bufferRanges");
     range_buffer_.insert(range_buffer_.end(), rays.begin(), rays.end());
   }
-  // LaserMapUpdater::bufferIncomingMsg (laser_map_updater.cpp:37-75) for whole scans: decimation,
-  // projection and the tf transform run on the device (sensor pose planar and constant over the scan)
+  // ... and with the sensor's full tf pose (a tilted or raised mount)
+  void bufferRanges(const std::vector<rna_range_reading_tf>& readings) {
+    std::vector<rna_ray> rays(readings.size());
+    if (rna_range_to_rays_tf(readings.data(), (int)readings.size(), rays.data()) != RNA_OK) throw std::invalid_argument("bufferRanges");
+    range_buffer_.insert(range_buffer_.end(), rays.begin(), rays.end());
+  }
+  // LaserMapUpdater::bufferIncomingMsg (laser_map_updater.cpp:37-75) for whole scans: decimation, projection and the
+  // tf transform of every beam (interpolated between the scan's start and end) run on the device -- for planar sensor
+  // poses (x, y, yaw) and, below, for the full transforms tf reports
   void bufferScans(const std::vector<rna_laser_scan>& scans, const std::vector<float>& ranges) {
     size_t cap = 1;
     for (size_t k = 0; k < scans.size(); ++k) cap += (size_t)scans[k].n_ranges;
@@ -342,6 +349,15 @@ class MapProvider {
     int n = 0;
     grid_map::rna_check(rna_scan_to_rays(map_.engine(), scans.data(), (int)scans.size(), ranges.data(), ranges.size(), rays.data(),
                                          (int)cap, &n), map_.engine(), "LaserMapUpdater::bufferIncomingMsg");
+    buffer_.insert(buffer_.end(), rays.begin(), rays.begin() + n);
+  }
+  void bufferScans(const std::vector<rna_laser_scan_tf>& scans, const std::vector<float>& ranges) {
+    size_t cap = 1;
+    for (size_t k = 0; k < scans.size(); ++k) cap += (size_t)scans[k].n_ranges;
+    std::vector<rna_ray> rays(cap);
+    int n = 0;
+    grid_map::rna_check(rna_scan_to_rays_tf(map_.engine(), scans.data(), (int)scans.size(), ranges.data(), ranges.size(), rays.data(),
+                                            (int)cap, &n), map_.engine(), "LaserMapUpdater::bufferIncomingMsg");
     buffer_.insert(buffer_.end(), rays.begin(), rays.begin() + n);
   }
   // MapProvider::updateMap: drain the buffer through HIMM, then compose master (fused, dirty tiles)

@@ -121,6 +121,15 @@ class MapProvider {
     std::lock_guard<std::mutex> lock(mapMutex_);
     core_.bufferRanges(readings);
   }
+  // the same with the sensors' full tf transforms (tilted or raised mounts)
+  void bufferScans(const std::vector<rna_laser_scan_tf>& scans, const std::vector<float>& ranges) {
+    std::lock_guard<std::mutex> lock(mapMutex_);
+    core_.bufferScans(scans, ranges);
+  }
+  void bufferRanges(const std::vector<rna_range_reading_tf>& readings) {
+    std::lock_guard<std::mutex> lock(mapMutex_);
+    core_.bufferRanges(readings);
+  }
   // one pass of loopUpdateAndPublishMap's body (:151-175 of map_provider.cpp, 5 Hz): updateMap(), and publishMap()
   // ("global_map") once per publishRate_
   void spinUpdateOnce() {

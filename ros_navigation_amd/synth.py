@@ -137,3 +137,30 @@ def laser_scans(n_scans, n_beams, length_x, length_y, seed=6, angle_increment=No
         scans[k] = (np.float32(-0.5 * fan), np.float32(-0.5 * fan + inc * n_beams), inc, np.float32(0.1), np.float32(range_max),
                     n_beams, k * n_beams, x, y, yaw, xe, ye, yawe)
     return scans, ranges
+
+
+def laser_scans_tf(n_scans, n_beams, length_x, length_y, seed=7, angle_increment=None, range_max=6.0, tilt=0.35, planar=0.25, **kw):
+    """laser_scans() with the sensor's FULL pose (capi.SCAN_TF_DTYPE: tf's translation + quaternion x y z w at both ends of the
+    scan): mounts rolled / pitched by up to `tilt` rad and raised off the ground; a share `planar` of the scans keeps a pure
+    yaw (the planar entry point's case).  Moving scans also change roll and pitch a little while they sweep."""
+    from scipy.spatial.transform import Rotation
+    from .capi import SCAN_TF_DTYPE
+    base, ranges = laser_scans(n_scans, n_beams, length_x, length_y, seed=seed, angle_increment=angle_increment, range_max=range_max, **kw)
+    rng = np.random.default_rng(seed + 1000)
+    scans = np.zeros(n_scans, SCAN_TF_DTYPE)
+    for f in ("angle_min", "angle_max", "angle_increment", "range_min", "range_max", "n_ranges", "ranges_offset"):
+        scans[f] = base[f]
+    for k in range(n_scans):
+        flat = rng.random() < planar
+        roll, pitch = (0.0, 0.0) if flat else rng.uniform(-tilt, tilt, 2)
+        z = rng.uniform(0.1, 1.2)
+        moving = base["yaw_end"][k] != base["yaw"][k] or base["x_end"][k] != base["x"][k]
+        droll, dpitch, dz = (rng.uniform(-0.03, 0.03, 3) if (moving and not flat) else (0.0, 0.0, 0.0))
+        q0 = Rotation.from_euler("ZYX", [base["yaw"][k], pitch, roll]).as_quat()
+        q1 = Rotation.from_euler("ZYX", [base["yaw_end"][k], pitch + dpitch, roll + droll]).as_quat()
+        if rng.random() < 0.5:
+            q1 = -q1                 # the same rotation: tf's slerp has to take the short way round
+        scans["t"][k] = (base["x"][k], base["y"][k], z)
+        scans["t_end"][k] = (base["x_end"][k], base["y_end"][k], z + dz)
+        scans["q"][k], scans["q_end"][k] = q0, q1
+    return scans, ranges

@@ -149,6 +149,9 @@ def lib():
                                   C.POINTER(RrtResult)]
         L.og_rrt_plan.restype = None
         L.og_scan_to_rays.argtypes = [C.c_void_p, fp, C.c_void_p, C.c_int]
+        L.og_scan_to_rays_tf.argtypes = [C.c_void_p, fp, C.c_void_p, C.c_int]
+        L.og_range_to_ray_tf.argtypes = [C.c_float, C.c_float, d2, d2, C.c_void_p]
+        L.og_range_to_ray_tf.restype = None
         L.og_simplify_scan.argtypes = [C.c_int, C.c_float, i2, C.c_int, fp]
         L.og_to_occupancy_grid.argtypes = [C.POINTER(Geom), fp, C.c_float, C.c_float, C.c_void_p]
         L.og_to_occupancy_grid.restype = None
@@ -377,6 +380,35 @@ def scan_to_rays(scans, ranges):
         assert n <= cap
         out.append(rays[:n])
     return np.concatenate(out) if out else np.zeros(0, RAY_DTYPE)
+
+
+SCAN_TF_DTYPE = np.dtype([("angle_min", "<f4"), ("angle_max", "<f4"), ("angle_increment", "<f4"), ("range_min", "<f4"),
+                          ("range_max", "<f4"), ("n_ranges", "<i4"), ("ranges_offset", "<i8"), ("t", "<f8", (3,)), ("q", "<f8", (4,)),
+                          ("t_end", "<f8", (3,)), ("q_end", "<f8", (4,))])
+
+
+def scan_to_rays_tf(scans, ranges):
+    """the same for sensors with a full pose (og_scan_tf: tf's translation + quaternion at both ends of the scan)"""
+    scans = np.ascontiguousarray(scans, SCAN_TF_DTYPE)
+    ranges = np.ascontiguousarray(ranges, np.float32)
+    out = []
+    for k in range(len(scans)):
+        cap = int(scans["n_ranges"][k]) + 1
+        rays = np.zeros(cap, RAY_DTYPE)
+        n = lib().og_scan_to_rays_tf(scans[k:k + 1].ctypes.data, fptr(ranges), rays.ctypes.data, cap)
+        assert n <= cap
+        out.append(rays[:n])
+    return np.concatenate(out) if out else np.zeros(0, RAY_DTYPE)
+
+
+def range_to_rays_tf(readings):
+    rays = np.zeros(len(readings), RAY_DTYPE)
+    for k, m in enumerate(readings):
+        t = np.ascontiguousarray(m["t"], np.float64)
+        q = np.ascontiguousarray(m["q"], np.float64)
+        d2 = C.POINTER(C.c_double)
+        lib().og_range_to_ray_tf(float(m["range"]), float(m["max_range"]), t.ctypes.data_as(d2), q.ctypes.data_as(d2), rays[k:k + 1].ctypes.data)
+    return rays
 
 
 def simplify_scan(n, angle_increment):

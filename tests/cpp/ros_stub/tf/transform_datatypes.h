@@ -4,7 +4,11 @@
 #include <ros/time.h>
 namespace tf {
 struct Vector3 { double x() const; double y() const; double z() const; };
-struct Quaternion {};
+struct Quaternion {
+  Quaternion();
+  Quaternion(const double& x, const double& y, const double& z, const double& w);
+  const double& x() const; const double& y() const; const double& z() const; const double& w() const;
+};
 double getYaw(const Quaternion&);
 struct StampedTransform {
   Vector3 getOrigin() const;

@@ -44,7 +44,7 @@ def test_struct_layouts_match_header(capi):
       printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu ", sizeof(rna_geometry), sizeof(rna_ray), sizeof(rna_vfh_params),
              sizeof(rna_pose), sizeof(rna_vfh_out), sizeof(rna_astar_query), sizeof(rna_astar_result),
              sizeof(rna_rrt_query), sizeof(rna_rrt_result), (size_t)RNA_K_COUNT, sizeof(rna_laser_scan));
-      printf("%zu %zu\n", sizeof(rna_submap_info), sizeof(rna_range_reading));
+      printf("%zu %zu %zu %zu\n", sizeof(rna_submap_info), sizeof(rna_range_reading), sizeof(rna_laser_scan_tf), sizeof(rna_range_reading_tf));
       return 0;
     }"""
     exe = "/tmp/rna_layout_check"
@@ -53,7 +53,8 @@ def test_struct_layouts_match_header(capi):
     assert sizes == [C.sizeof(capi.Geometry), capi.RAY_DTYPE.itemsize, C.sizeof(capi.VfhParams),
                      capi.POSE_DTYPE.itemsize, capi.VFH_OUT_DTYPE.itemsize, capi.ASTAR_QUERY_DTYPE.itemsize,
                      capi.ASTAR_RESULT_DTYPE.itemsize, capi.RRT_QUERY_DTYPE.itemsize, capi.RRT_RESULT_DTYPE.itemsize,
-                     len(capi.KERNELS), capi.SCAN_DTYPE.itemsize, C.sizeof(capi.SubmapInfo), capi.RANGE_READING_DTYPE.itemsize]
+                     len(capi.KERNELS), capi.SCAN_DTYPE.itemsize, C.sizeof(capi.SubmapInfo), capi.RANGE_READING_DTYPE.itemsize,
+                     capi.SCAN_TF_DTYPE.itemsize, capi.RANGE_READING_TF_DTYPE.itemsize]
     assert src.count("extern \"C\"") == 1
 
 
@@ -137,6 +138,22 @@ def test_range_to_rays_host_entry_point(capi):
     m["x"], m["y"], m["yaw"] = rng.uniform(-20, 20, len(m)), rng.uniform(-20, 20, len(m)), rng.uniform(-7, 7, len(m))
     assert capi.range_to_rays(m).tobytes() == O.range_to_rays(m).tobytes()
     assert len(capi.range_to_rays(m[:0])) == 0
+    # the same sensors with their full pose: a mount pitched down by 30 degrees sees its 2 m reading 1.73 m ahead on the map
+    from scipy.spatial.transform import Rotation
+    t = np.zeros(3, capi.RANGE_READING_TF_DTYPE)
+    t[0] = (2.0, 4.0, (1.0, -1.0, 0.4), Rotation.from_euler("y", 30, degrees=True).as_quat())
+    t[1] = (4.0, 4.0, (0.0, 0.0, 0.2), Rotation.from_euler("z", 90, degrees=True).as_quat())
+    t[2] = (1.0, 4.0, (0.5, 0.5, 0.0), Rotation.from_euler("zyx", [40, 10, -5], degrees=True).as_quat())
+    r = capi.range_to_rays_tf(t)
+    assert (r["sx"][0], r["sy"][0]) == (1.0, -1.0) and abs(r["ex"][0] - (1.0 + 2.0 * np.cos(np.pi / 6))) < 1e-12 and abs(r["ey"][0] + 1.0) < 1e-12
+    assert r["clear_end"].tolist() == [0, 1, 0] and abs(r["ey"][1] - 4.0) < 1e-12 and abs(r["ex"][1]) < 1e-12
+    want = Rotation.from_quat(t["q"][2]).apply([1.0, 0.0, 0.0])[:2] + 0.5
+    assert np.allclose([r["ex"][2], r["ey"][2]], want, rtol=0, atol=1e-12)
+    t = np.zeros(3000, capi.RANGE_READING_TF_DTYPE)
+    t["range"], t["max_range"] = rng.uniform(0.0, 5.0, len(t)), rng.choice([3.0, 4.0], len(t))
+    t["t"] = rng.uniform(-20, 20, (len(t), 3))
+    t["q"] = Rotation.random(len(t), random_state=6).as_quat()
+    assert capi.range_to_rays_tf(t).tobytes() == O.range_to_rays_tf(t).tobytes()
 
 
 def test_product_never_imports_the_oracle():

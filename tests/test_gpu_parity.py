@@ -966,6 +966,47 @@ def test_scan_to_rays_matches_oracle_and_feeds_himm(R):
     e.close()
 
 
+def test_scan_to_rays_with_full_sensor_transforms_matches_oracle(R):
+    """SURVEY.md 8f row 3, non-planar mounts: the same ingestion with the transforms tf reports (translation + quaternion at the
+    scan's start and end) -- tilted, rolled and raised sensors, half of them moving while they sweep, end quaternions of either
+    sign.  Ray counts, order, origins and ifClearEnd flags are exact; end points are float32 values built from device
+    acos / sin (f64), compared at 1e-6 m and bit-exactly for the overwhelming majority.  Planar poses through this entry point
+    give the planar entry point's rays within the rounding of the two formulations."""
+    e = R.Engine(25.6, 25.6, 0.05)
+    g = O.make_geom(25.6, 25.6, 0.05)
+    for inc, beams in ((None, 1081), (np.float32(0.02), 200), (np.float32(0.0005), 4000)):
+        scans, ranges = R.synth.laser_scans_tf(24, beams, 25.6, 25.6, seed=beams + 3, angle_increment=inc)
+        tilted = np.abs(scans["q"][:, :2]).max(axis=1) > 1e-3
+        assert tilted.any() and (~tilted).any() and (scans["q_end"] != scans["q"]).any(axis=1).any()
+        want = O.scan_to_rays_tf(scans, ranges)
+        got = e.scan_to_rays_tf(scans, ranges)
+        assert len(got) == len(want) > 0
+        assert np.array_equal(got["sx"], want["sx"]) and np.array_equal(got["sy"], want["sy"])
+        assert np.array_equal(got["clear_end"], want["clear_end"])
+        assert np.allclose(got["ex"], want["ex"], rtol=0, atol=1e-6) and np.allclose(got["ey"], want["ey"], rtol=0, atol=1e-6)
+        exact = (got["ex"] == want["ex"]) & (got["ey"] == want["ey"])
+        assert exact.mean() > 0.99
+    # planar poses, both entry points
+    flat, ranges = R.synth.laser_scans(16, 720, 25.6, 25.6, seed=77)
+    tf = np.zeros(len(flat), R.capi.SCAN_TF_DTYPE)
+    for f in ("angle_min", "angle_max", "angle_increment", "range_min", "range_max", "n_ranges", "ranges_offset"):
+        tf[f] = flat[f]
+    for a, b, c, d in (("x", "y", "yaw", ""), ("x_end", "y_end", "yaw_end", "_end")):
+        tf["t" + d][:, 0], tf["t" + d][:, 1] = flat[a], flat[b]
+        tf["q" + d][:, 2], tf["q" + d][:, 3] = np.sin(flat[c] / 2), np.cos(flat[c] / 2)
+    a, b = e.scan_to_rays(flat, ranges), e.scan_to_rays_tf(tf, ranges)
+    assert len(a) == len(b) > 0 and np.array_equal(a["clear_end"], b["clear_end"]) and np.array_equal(a["sx"], b["sx"])
+    assert np.allclose(a["ex"], b["ex"], rtol=0, atol=2e-6) and np.allclose(a["ey"], b["ey"], rtol=0, atol=2e-6)
+    # the rays feed the HIMM update unchanged
+    ref = np.full(e.ncell, np.nan, np.float32)
+    O.himm_update(g, ref, b.view(O.RAY_DTYPE))
+    e.update_map(b, compose_mode=1)
+    assert same_f32(e.download(R.capi.LAYER_MASTER), ref)
+    with pytest.raises(R.RnaError):
+        e.scan_to_rays_tf(tf, ranges, max_rays=10)
+    e.close()
+
+
 def test_positions_on_the_far_edge_are_outside_not_out_of_bounds(R):
     """A position within rounding of the map's far edge can divide to index == size (see
     test_oracle_gridmap.test_index_from_position_never_returns_an_index_past_the_map).  rna_get_index, HIMM ray end
