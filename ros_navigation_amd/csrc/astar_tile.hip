@@ -868,6 +868,8 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   TSA_ACC(1, t_b, t_c);
   TSA_CNT(8, evals);
   TSA_CNT(11, hpass);
+  if (first) { TSA_CNT(18, 1); TSA_CNT(19, evals); TSA_CNT(20, __builtin_popcount(rowchg)); }   // first jobs: how many, their evaluations, the rows they changed
+  TSA_CNT(21, __builtin_popcount(rowchg));
   asm volatile("; TSA_MARK results_begin");
   // ---- 6. results: rows that changed, the edge-column copies, the goal ----
   asm volatile("" : "+v"(lane));
@@ -1466,7 +1468,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
 
   int my_evals = 0, my_jobs = 0;
 #ifdef RNA_TSA_STATS
-  unsigned long long tsa_acc[16] = {};
+  unsigned long long tsa_acc[24] = {};
   const unsigned long long t_life0 = wall_clock64();
   const unsigned long long c_life0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1619,6 +1621,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   tsa_acc[5] = wall_clock64() - t_life0;   // wave lifetime inside the search loop
   tsa_acc[12] = __builtin_amdgcn_s_memtime() - c_life0;   // the same in shader clock ticks
   if (lane == 0) for (int k = 0; k < 16; ++k) atomicAdd(&g_tsa_stat[k], tsa_acc[k]);
+  if (lane == 0) for (int k = 18; k < 24; ++k) atomicAdd(&g_tsa_stat[k], tsa_acc[k]);   // (16 / 17: per search, below)
   if (tid == 0) { atomicAdd(&g_tsa_stat[16], (unsigned long long)s_nalloc); atomicAdd(&g_tsa_stat[17], 1ull); }   // tiles this search touched; searches
 #endif
   // what the next search in this slot has to reset
@@ -1892,6 +1895,8 @@ void tsa_stats_dump() {
           jobs, 100.0 * (double)st[10] / jobs, st[0] * 0.01 / jobs, st[1] * 0.01 / jobs, st[2] * 0.01 / jobs, st[5] * 1e-5, busy * 1e-5,
           100.0 * busy / (double)st[5], st[4] * 1e-5, 100.0 * (double)st[4] / (double)st[5], st[8] / jobs, st[11] / jobs,
           100.0 * (double)st[12] / (double)std::max<unsigned long long>(1, st[5]));
+  fprintf(stderr, "[tsa stats] first jobs (a tile's first in a bucket: every row evaluated both ways) %.3f of all, %.1f row evaluations and %.1f changed rows each; rows changed per job %.1f; rows sent to the scan per job %.2f\n",
+          (double)st[18] / jobs, (double)st[19] / (double)std::max<unsigned long long>(1, st[18]), (double)st[20] / (double)std::max<unsigned long long>(1, st[18]), (double)st[21] / jobs, (double)st[14] / jobs);
 }
 #endif
 
