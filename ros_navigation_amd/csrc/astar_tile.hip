@@ -1564,6 +1564,9 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
         t = tt;
         first = r == 2;
       }
+#ifdef RNA_TSA_TAKE_SLEEP   /* developer build: extra latency (in units of 64 clocks) between taking a job and running it */
+      __builtin_amdgcn_s_sleep(RNA_TSA_TAKE_SLEEP);
+#endif
       TSA_T(t_p1);
       TSA_ACC(4, t_p0, t_p1);   // taking a job
       TSA_CNT(7, 1);
