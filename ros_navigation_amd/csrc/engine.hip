@@ -119,7 +119,8 @@ __global__ void __launch_bounds__(256) compose_nbr_tiles_kernel(uint8_t* __restr
   // A workgroup serves tiles in turn (grid-stride; at most 16 workgroups per CU are launched: one tile each on a 4096^2
   // map.  Fewer, longer workgroups -- 4 per CU, four tiles each -- are faster alone, 10 -> 8 us, and slower next to the
   // searches, 0.27 -> 0.38 ms per pass: there a kernel's time is its workgroups waiting for wave slots, and many short
-  // ones find them sooner).
+  // ones find them sooner.  RNA_COMPOSE_WGS_PER_CU = 2 / 4 / 8 / 12 / 16 in the loop: 0.44 / 0.37 / 0.30 / 0.29 / 0.29 ms,
+  // profiles/r04_sweep_compose_wgs_per_cu.txt).
   __shared__ uint8_t blk[(TILE + 2) * (TILE + 2)];  // [jj][ii], ii fastest; out of map = blocked
   for (int tt = blockIdx.x; tt < tiles_i * tiles_j; tt += gridDim.x) {
   const int ti = tt % tiles_i, tj = tt / tiles_i;
@@ -784,7 +785,8 @@ extern "C" int rna_compose_master(rna_engine* e, int mode) {
     // the usual case of the replan loop: dirty tiles only, masks valid before -- one launch, and the two flag arrays
     // swap roles (what this compose consumed = rna_last_dirty_tiles; the other one, cleared by the launch, is marked next)
     KernelTimer kt(e, RNA_K_COMPOSE);
-    hipLaunchKernelGGL(compose_nbr_tiles_kernel, dim3(std::min(e->tiles_i * e->tiles_j, 16 * e->cu_count)), dim3(256), 0, e->stream, e->nbr,
+    static const int wgs_per_cu = [] { const char* v = getenv("RNA_COMPOSE_WGS_PER_CU"); const int n = v ? atoi(v) : 0; return n > 0 ? n : 16; }();   // developer knob
+    hipLaunchKernelGGL(compose_nbr_tiles_kernel, dim3(std::min(e->tiles_i * e->tiles_j, wgs_per_cu * e->cu_count)), dim3(256), 0, e->stream, e->nbr,
                        e->layer[RNA_LAYER_MASTER], e->layer[RNA_LAYER_LASER], e->dirty_tiles, e->last_dirty, e->geom.size[0],
                        e->geom.size[1], e->tiles_i, e->tiles_j);
     RNA_HIP(e, hipGetLastError());
