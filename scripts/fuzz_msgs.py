@@ -79,6 +79,20 @@ while time.time() < t_end:
         sys.exit(1)
     nrays += len(want)
     inexact += int(((got["ex"] != want["ex"]) | (got["ey"] != want["ey"])).sum())
+    # the same with full sensor transforms (tilted / rolled / raised mounts, end quaternions of either sign)
+    scans_tf, ranges_tf = R.synth.laser_scans_tf(ns, beams, lx, ly, seed=int(rng.integers(0, 1 << 30)), angle_increment=inc,
+                                                 tilt=float(rng.choice([0.05, 0.35, 1.2])), planar=float(rng.choice([0.0, 0.25, 1.0])))
+    ranges_tf[rng.random(len(ranges_tf)) < 0.05] = np.float32(rng.choice([np.nan, np.inf, 0.0, -1.0]))
+    want = O.scan_to_rays_tf(scans_tf, ranges_tf)
+    got = e.scan_to_rays_tf(scans_tf, ranges_tf)
+    ok = (len(got) == len(want) and np.array_equal(got["sx"], want["sx"]) and np.array_equal(got["sy"], want["sy"]) and
+          np.array_equal(got["clear_end"], want["clear_end"]) and np.allclose(got["ex"], want["ex"], rtol=0, atol=1e-6) and
+          np.allclose(got["ey"], want["ey"], rtol=0, atol=1e-6))
+    if not ok:
+        print("MISMATCH scan_to_rays_tf", here, dict(ns=ns, beams=beams, inc=float(inc)), len(got), len(want))
+        sys.exit(1)
+    nrays += len(want)
+    inexact += int(((got["ex"] != want["ex"]) | (got["ey"] != want["ey"])).sum())
     cases += 1
     e.close()
 print("msgs fuzz ok: %d maps, %d cells converted, %d rays from scans (%d end points differ by a float32 ulp) in %.0f s, seed %d"
