@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- replan cycles/sec (HIMM + VFH+ + A*) on a 4096 x 4096 grid, BASELINE.json's metric.
 
-One "step" = one TURN of the A* pipeline (--pipeline map updates, default 13), i.e. 13 passes of
+One "step" = one TURN of the A* pipeline (--pipeline map updates, default 16), i.e. 16 passes of
     HIMM ray batch (64 robot origins x 1563 rays) on the laser layer + fused compose-master
     -> VFH+ step for 256 robot poses -> grid A* for 256 (start, goal) queries
-all resident in HBM: 13 x 256 = 3328 replan cycles per step.  The searches of 13 consecutive passes are in
+all resident in HBM: 16 x 256 = 4096 replan cycles per step.  The searches of 16 consecutive passes are in
 flight at once (each on its own pipeline stage), so a single pass is not a unit whose time can be
-measured by itself: a step hands every stage one batch, and the driver's 20 steps then time 260
+measured by itself: a step hands every stage one batch, and the driver's 20 steps then time 320
 passes of steady state instead of 20 passes through a pipeline that is empty at both ends.
 A "replan cycle" is one (pose -> VFH command, start/goal -> A* path) pair served against the map
 that has received its HIMM batch; the ray batch is amortised over the 256 cycles of its pass
@@ -33,6 +33,7 @@ import time
 
 # pipelined A* batches run on several HIP streams; give the runtime enough hardware queues
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+DEFAULT_PIPELINE = 16   # A* batches in flight (the engine's maximum; the committed counter files under profiles/ belong to it)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -57,11 +58,12 @@ def parse():
     ap.add_argument("--bucket-width", type=int, default=0)
     ap.add_argument("--queue-capacity", type=int, default=0)
     ap.add_argument("--max-path", type=int, default=32768)
-    ap.add_argument("--pipeline", type=int, default=13,
+    ap.add_argument("--pipeline", type=int, default=DEFAULT_PIPELINE,
                     help="A* batches in flight (rna_astar_set_pipeline_depth).  Four search workgroups share a CU, so ~900 queries "
-                         "run at once and the batches' tails differ (measured 10: 56.3k, 12: 75.9k, 13: 78.8k, 14: 80.5k cycles/s; "
-                         "from 15 on the streams outnumber the hardware queues a process gets and the rate collapses to 31k, "
-                         "so the default keeps one queue spare).  Every launch is stretched by the ones it overlaps with, and "
+                         "run at once and the batches' tails differ (round 4, default steps / the driver's 20: 13: 148.9k / 146.5k, "
+                         "16: 151.1k / 147.9k cycles/s -- profiles/r04_sweep_depth_13_16.txt; 16 is the engine's maximum and needs "
+                         "GPU_MAX_HW_QUEUES=8, set above: with the runtime's default of 4 queues the rate collapses).  "
+                         "Every launch is stretched by the ones it overlaps with, and "
                          "the roofline line divides by that per-launch duration")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
@@ -221,7 +223,7 @@ def valu_issue(args, world, wall_per_pass):
     the committed SQ counter pass of this workload's first query set, over the pass wall time and the SIMDs the searches
     may use.  None unless the counters were taken on this configuration."""
     try:
-        if (args.grid, args.queries, args.pipeline) != (4096, 256, 13) or world != 1 or args.tiled:
+        if (args.grid, args.queries, args.pipeline) != (4096, 256, DEFAULT_PIPELINE) or world != 1 or args.tiled:
             return None
         valu = salu = None
         for line in open(SQ_COUNTERS):
@@ -246,7 +248,7 @@ def work_inflation(args, world, settled_per_launch):
     under the bench's load.  Reported so that the next reader can track the inflation without reading DESIGN.md."""
     import re
     try:
-        if (args.grid, args.queries, args.pipeline) != (4096, 256, 13) or world != 1 or args.tiled:
+        if (args.grid, args.queries, args.pipeline) != (4096, 256, DEFAULT_PIPELINE) or world != 1 or args.tiled:
             return None
         valu = salu = settled = None
         for line in open(SQ_COUNTERS):

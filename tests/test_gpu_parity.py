@@ -487,7 +487,7 @@ def test_astar_searches_that_outgrow_their_pages_are_retried(R):
 
 
 def test_bench_configuration_answers_an_unreachable_goal(R):
-    """The default bench configuration (4096 x 4096, 256 queries per batch, thirteen stages) does not fit HBM with a page
+    """The bench's configuration (4096 x 4096, 256 queries per batch, thirteen stages here, sixteen in bench.py) does not fit HBM with a page
     per tile and query: the engine runs it with half a map's worth of pages per query.  A goal that cannot be reached
     floods its whole component -- more tiles than that -- and the reference answers "no path" (status 1), it does not
     fail: the search ends its first pass with status 5 internally, the host sees the count when the stage's stream is
@@ -604,8 +604,8 @@ def test_astar_pipelined_batches_with_map_updates_in_between(R):
 def test_bench_loop_at_full_size_matches_oracle_every_step(R):
     """bench.py's timed loop as it runs, at BASELINE's size: 4096 x 4096 map, per step a 100 032-ray HIMM batch (four
     batches in rotation) + fused compose -> VFH+ for 256 poses (four pose sets, the robots' VFH state carried from step
-    to step) -> 256 grid-A* queries (four query sets) through the asynchronous device entry points at the bench's own
-    pipeline depth (13 batches in flight on CU-masked streams), nothing waited for in between, for 27 steps: every stage
+    to step) -> 256 grid-A* queries (four query sets) through the asynchronous device entry points at a pipeline depth
+    like the bench's (13 batches in flight on CU-masked streams; bench.py: 16), nothing waited for in between, for 27 steps: every stage
     is used three times, so the lazy reset of the pages a stage's previous search handed out runs twice per stage under
     the load it has in the bench.  Every step's map, VFH+ commands and histograms and the statuses of all its A* queries,
     and the costs / paths of a rotating seventh of them (every query of the four sets at least once over the run; all
