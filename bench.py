@@ -33,7 +33,10 @@ import time
 
 # pipelined A* batches run on several HIP streams; give the runtime enough hardware queues
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-DEFAULT_PIPELINE = 16   # A* batches in flight (the engine's maximum; the committed counter files under profiles/ belong to it)
+DEFAULT_PIPELINE = 16   # A* batches in flight on one GPU (the committed counter files under profiles/ belong to it)
+# ... and next to an RCCL communicator, whose streams take hardware queues of their own: the rate falls off from 21 stages on
+# without one and from 18 on with one (profiles/r04_sweep_depth_rccl.txt); 14 and 16 measure the same there
+DEFAULT_PIPELINE_RCCL = 14
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -58,8 +61,9 @@ def parse():
     ap.add_argument("--bucket-width", type=int, default=0)
     ap.add_argument("--queue-capacity", type=int, default=0)
     ap.add_argument("--max-path", type=int, default=32768)
-    ap.add_argument("--pipeline", type=int, default=DEFAULT_PIPELINE,
-                    help="A* batches in flight (rna_astar_set_pipeline_depth).  Four search workgroups share a CU, so ~900 queries "
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="A* batches in flight (rna_astar_set_pipeline_depth); 0 = 16 on one GPU, 14 next to an RCCL communicator.  "
+                         "Four search workgroups share a CU, so ~900 queries "
                          "run at once and the batches' tails differ (round 4, default steps / the driver's 20: 13: 148.9k / 146.5k, "
                          "16: 151.1k / 147.9k cycles/s -- profiles/r04_sweep_depth_13_16.txt; 16 is the engine's maximum and needs "
                          "GPU_MAX_HW_QUEUES=8, set above: with the runtime's default of 4 queues the rate collapses).  "
@@ -313,6 +317,8 @@ def main():
         raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
+    if args.pipeline <= 0:
+        args.pipeline = DEFAULT_PIPELINE if (world == 1 and os.environ.get("RNA_BENCH_FORCE_DIST") != "1") else DEFAULT_PIPELINE_RCCL
     # developer switch: RNA_BENCH_FORCE_DIST=1 initialises RCCL and runs the barriers with a single rank too (how many
     # hardware queues are left for the search streams once a communicator exists can then be measured on a one-GPU box)
     use_dist = world > 1 or os.environ.get("RNA_BENCH_FORCE_DIST") == "1"
