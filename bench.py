@@ -71,6 +71,10 @@ def parse():
                          "the roofline line divides by that per-launch duration")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--check-paths", action="store_true",
+                    help="after the timed region: the LAST batch of one more turn of the pipeline (searched while the turn's other "
+                         "batches are in flight) is handed to the CPU oracle -- status, cost, length and every cell of every path "
+                         "of its queries against the map that batch saw (`config.paths_checked`; a mismatch ends the run)")
     ap.add_argument("--tiled-full-gather", action="store_true", help="--tiled: all-gather whole windows instead of dirty tiles")
     ap.add_argument("--tiled", action="store_true",
                     help="SURVEY 8e mode 2 / BASELINE config 5: ONE map tiled 2 x N/2 over the GPUs (windowed HIMM, halo "
@@ -100,6 +104,52 @@ def visible_gpus():
         if v is not None:
             n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
     return n
+
+
+def pin_to_gpu_numa_node(local_rank):
+    """Confine this process (and every thread it starts later: the engine's launch thread, torch's, RCCL's proxy) to the
+    host cores of the NUMA node its GPU hangs on -- BEFORE torch or HIP are loaded.  Eight ranks share one host at N = 8:
+    un-pinned, a rank's launch thread and its GPU may sit on different sockets and every doorbell / pinned-memory flag
+    crosses the inter-socket link.  The GPU of rank r is the r-th compute node of the KFD topology (HIP's order), narrowed
+    by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES when they are plain indices; its NUMA node is read from the DRM device
+    behind the node's render minor.  RNA_BENCH_CPUS=n (developer / test switch) keeps only the first n of those cores.
+    Returns what was done for `config.host_affinity`; never fails (an unreadable topology leaves the affinity alone)."""
+    import glob
+    info = {"numa_node": None, "cpus": len(os.sched_getaffinity(0)), "pinned": False}
+    try:
+        cpus = set(os.sched_getaffinity(0))
+        if os.environ.get("RNA_BENCH_NO_PIN") != "1":
+            gpus = []
+            for path in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"), key=lambda p: int(p.split("/")[-2])):
+                with open(path) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    gpus.append(int(props.get("drm_render_minor", "-1")))
+            for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+                v = os.environ.get(var)
+                if v is not None and all(x.strip().isdigit() for x in v.split(",") if x.strip()):
+                    gpus = [gpus[int(x)] for x in v.split(",") if x.strip() and int(x) < len(gpus)]
+            if 0 <= local_rank < len(gpus) and gpus[local_rank] >= 0:
+                with open("/sys/class/drm/renderD%d/device/numa_node" % gpus[local_rank]) as f:
+                    node = int(f.read().strip())
+                info["numa_node"] = node
+                if node >= 0:
+                    with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+                        want = set()
+                        for part in f.read().strip().split(","):
+                            a, _, b = part.partition("-")
+                            want.update(range(int(a), int(b or a) + 1))
+                    if cpus & want:
+                        cpus &= want
+                        info["pinned"] = True
+        keep = int(os.environ.get("RNA_BENCH_CPUS", "0"))
+        if keep > 0:
+            cpus = set(sorted(cpus)[:keep])
+        os.sched_setaffinity(0, cpus)
+        info["cpus"] = len(cpus)
+    except Exception as ex:   # noqa: BLE001 -- an optimisation, never a reason to fail the bench
+        info["error"] = repr(ex)
+    return info
 
 
 def spawn_ranks(args):
@@ -132,6 +182,29 @@ def spawn_ranks(args):
     raise SystemExit(rc)
 
 
+def check_paths(master, queries, res, paths, rows, cols):
+    """The checker leg of --check-paths: one batch of the loop against the oracle (the CPU restatement of the search contract,
+    tests/_oracle.py -> oracle/astar.c) on the map that batch saw.  Not part of any timed region."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    from concurrent.futures import ThreadPoolExecutor
+    _, nbr = O.astar_masks(master, rows, cols)
+    cores = max(1, len(os.sched_getaffinity(0)))
+
+    def one(k):
+        ores, opath, _ = O.astar_query(nbr, rows, cols, queries["start"][k], queries["goal"][k], path_cap=rows * cols)
+        if ores.status != 0:
+            return int(res[k, 0] == 1), 0
+        ok = res[k, 0] == 0 and res[k, 1] == ores.path_len and res[k, 2] == ores.cost and np.array_equal(paths[k, :ores.path_len], opath)
+        return int(ok), 1
+    with ThreadPoolExecutor(min(cores, 32)) as ex:
+        got = list(ex.map(one, range(len(queries))))
+    return {"queries": len(queries), "matched": sum(g[0] for g in got), "paths_found": sum(g[1] for g in got),
+            "against": "oracle/astar.c on the master layer as the batch's mask snapshot saw it (the last pass of a full turn of the "
+                       "pipeline, i.e. searched next to the turn's other batches)"}
+
+
 def cpu_baseline(args, R, master, rays, poses, queries, rows, cols, length):
     """Oracle (CPU restatement of the reference path) on a bounded sample: 1 thread, then one thread per host core."""
     import numpy as np
@@ -153,14 +226,35 @@ def cpu_baseline(args, R, master, rays, poses, queries, rows, cols, length):
     t_vfh = (time.perf_counter() - t0) / n_vfh
     _, nbr = O.astar_masks(mast, rows, cols)
     gw = np.empty(rows * cols, np.int32)
-    t_a, n_a, settled = 0.0, 0, 0
+    t_a, n_a, settled, settled_goal = 0.0, 0, 0, 0
     while n_a < len(queries) and (n_a < 2 or t_a < args.cpu_seconds):
         q = queries[n_a]
         t0 = time.perf_counter()
         res, _, _ = O.astar_query(nbr, rows, cols, q["start"], q["goal"], path_cap=rows * cols, g_work=gw)
         t_a += time.perf_counter() - t0
         settled += res.settled
+        settled_goal += O.astar_last_settled_at_goal() if res.status == 0 else res.settled
         n_a += 1
+    # the one reference translation unit that compiles here (move_control's own vfh.cpp -> oracle/_ref, built by oracle/Makefile
+    # where /root/reference exists and shipped to the GPU box as a binary): its Update_VFH timed beside the port's, on the
+    # port's own ranges (getRangesFromSubmap is in steerer.cpp, which needs ROS and cannot be compiled)
+    vfh_ref_us = vfh_port_us = None
+    try:
+        if O.ref() is not None:
+            rngs = [O.ranges_array(O.ranges_from_submap(g, mast, poses[k]["x"], poses[k]["y"], poses[k]["yaw"])[1]) for k in range(n_vfh)]
+            for cls in (O.RefVfh, O.OracleVfh):
+                inst = [cls() for _ in range(n_vfh)]
+                t0 = time.perf_counter()
+                for k in range(n_vfh):
+                    p = poses[k]
+                    if cls is O.RefVfh:
+                        O.ref().refvfh_set_clock(1000.0)   # (the shim's clock is one per process: every instance was created at 1000.0)
+                    inst[k].update(rngs[k], int(p["current_speed"]), float(p["goal_direction"]), float(p["goal_distance"]),
+                                   float(p["goal_tolerance"]), float(p["dt"]))
+                us = (time.perf_counter() - t0) / n_vfh * 1e6
+                vfh_ref_us, vfh_port_us = (us, vfh_port_us) if cls is O.RefVfh else (vfh_ref_us, us)
+    except Exception:   # noqa: BLE001 -- a side figure: the baseline stands without it
+        vfh_ref_us = vfh_port_us = None
     per_cycle_1 = t_himm / len(queries) + t_vfh + t_a / n_a
     # (ii) one thread per host core over independent A* queries (ctypes releases the GIL inside the C oracle)
     cores = max(1, len(os.sched_getaffinity(0)))
@@ -181,11 +275,18 @@ def cpu_baseline(args, R, master, rays, poses, queries, rows, cols, length):
     per_cycle = t_himm / len(queries) + t_vfh + t_mt
     return {"value": 1.0 / per_cycle, "unit": "replan cycles/s", "cores": cores, "kind": "port",
             "value_1core": 1.0 / per_cycle_1,
+            # Update_VFH alone (ranges given), per pose on one core: the reference's own vfh.cpp (oracle/_ref) and the port
+            "vfh_reference_us": vfh_ref_us, "vfh_port_update_us": vfh_port_us,
+            # E both ways on the single-thread sample: the contract settles the whole f == f* plateau (canonical ties), an A*
+            # that stops when the goal comes off the heap closes fewer cells
+            "settled_cells_contract": settled / n_a, "settled_cells_stop_at_goal": settled_goal / n_a,
             "sample": "oracle (C, -O2) on the first of the %d rotating input sets: full %d-ray HIMM batch + compose (1 thread, "
                       "%.3f s, amortised over %d cycles), %d VFH+ poses (%.1f us each on one core), A*: first %d queries on 1 "
-                      "thread (%.3f s each, %.0f cells settled each) and first %d queries on %d threads (%.4f s per query wall)"
+                      "thread (%.3f s each, %.0f cells settled each) and first %d queries on %d threads (%.4f s per query wall; "
+                      "the oracle refills a %d MB g[] per query -- oracle/astar.c -- so the many-thread figure is bound by "
+                      "the host's memory bandwidth, not by its cores)"
                       % (ROTATE, len(rays), t_himm, len(queries), n_vfh, t_vfh * 1e6, n_a, t_a / n_a, settled / n_a, n_mt,
-                         cores, t_mt)}
+                         cores, t_mt, rows * cols * 4 >> 20)}
 
 
 # the kernels timed as the "himm_raster" slot (himm.hip: rays binned to 64 x 64 tiles, then rasterised per tile in LDS);
@@ -295,6 +396,8 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    share_gpu = os.environ.get("RNA_BENCH_SHARE_GPU") == "1"
+    host_affinity = pin_to_gpu_numa_node(0 if share_gpu else int(os.environ.get("LOCAL_RANK", "0")))   # before torch / HIP start their threads
     import numpy as np
     import torch
     from ros_navigation_amd import capi as _capi
@@ -474,6 +577,16 @@ def main():
     e.profile(False)
     check_results("in the profiled turn after the timed region")
     xfer[0], xfer[1] = xfer_timed
+    paths_checked = None
+    if args.check_paths and layout is None:
+        # the profiled turn's last pass: no map update has followed it, so the master layer is the map its snapshot saw
+        b_last, k_last = (step_no[0] - 1) % n_out, (step_no[0] - 1) % ROTATE
+        paths_checked = check_paths(e.download(R.capi.LAYER_MASTER), query_sets[k_last],
+                                    d_results[b_last].cpu().numpy().reshape(nq, 6),
+                                    d_paths[b_last].cpu().numpy().reshape(nq, args.max_path), n, n)
+        if paths_checked["matched"] != paths_checked["queries"]:
+            raise SystemExit("--check-paths: %d of %d queries of the checked batch differ from the oracle"
+                             % (paths_checked["queries"] - paths_checked["matched"], paths_checked["queries"]))
 
     # E per query set (settled cells, from the pages still resident after a launch), on the map as the timed region left it
     settled_sets = []
@@ -531,7 +644,7 @@ def main():
                        "astar_queries_checked": total, "astar_queries_answered": answered, "astar_paths_found": found,
                        "astar_bucket_width": args.bucket_width or 96000, "astar_pipeline_depth": args.pipeline,
                        "astar_allocated": dict(zip(("pipeline_depth", "pages_per_query", "max_queries"), e.astar_effective_config())),
-                       "timed_seconds": t_max,
+                       "timed_seconds": t_max, "paths_checked": paths_checked, "host_affinity": host_affinity,
                        "shards": [r[:2] for r in shard_rows], "cycles_by_rank": [r[2] for r in shard_rows],
                        "launcher": ({"spawned_by_bench": True, "parent_pid": int(os.environ["RNA_BENCH_PARENT"].split(":")[0]),
                                      "parent_is_my_parent": int(os.environ["RNA_BENCH_PARENT"].split(":")[0]) == os.getppid(),
@@ -565,7 +678,11 @@ def main():
                             "halo_bytes_per_pass_rank0": xfer[0] / passes,
                             "gather_bytes_per_pass_rank0": xfer[1] / passes}
         if not args.no_cpu and world == 1:   # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args, R, master, ray_sets[0], pose_sets[0], query_sets[0], n, n, length)
+            out["cpu_baseline"] = cb = cpu_baseline(args, R, master, ray_sets[0], pose_sets[0], query_sets[0], n, n, length)
+            # the numerator both ways: E of the contract (plateau settled) and of an A* that stops at the goal (sample ratio)
+            ratio = cb["settled_cells_stop_at_goal"] / max(1.0, cb["settled_cells_contract"])
+            out["roofline"]["settled_ratio_stop_at_goal"] = ratio
+            out["roofline"]["frac_wall_stop_at_goal_basis"] = out["roofline"]["frac_wall"] * ratio
         else:
             out["cpu_baseline"] = None
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -100,8 +100,15 @@ static hnode heap_pop(hnode* a, size_t* n) {
   return top;
 }
 
+/* measurement aid (bench.py's cpu_baseline leg): how many cells the calling thread's last og_astar_query had closed when
+ * the goal came off the heap -- the count of an A* that stops there (SURVEY.md 7's wording) instead of settling the whole
+ * f == f* plateau as the contract does (the plateau is what makes the canonical path independent of the heap's tie order) */
+static __thread int32_t og_last_settled_at_goal;
+int32_t og_astar_last_settled_at_goal(void) { return og_last_settled_at_goal; }
+
 void og_astar_query(const uint8_t* nbr, int rows, int cols, int start_lin, int goal_lin,
                     int32_t* g, int32_t* path, int path_cap, og_astar_result* res) {
+  og_last_settled_at_goal = 0;
   size_t ncell = (size_t)rows * cols;
   res->status = 2; res->path_len = 0; res->cost = OG_ASTAR_INF; res->settled = 0;
   if (start_lin < 0 || goal_lin < 0 || (size_t)start_lin >= ncell || (size_t)goal_lin >= ncell) return;
@@ -121,7 +128,7 @@ void og_astar_query(const uint8_t* nbr, int rows, int cols, int start_lin, int g
     hnode u = heap_pop(heap, &hn);
     if (u.g != g[u.cell]) continue; /* stale */
     settled++;
-    if (u.cell == goal_lin && fstar == OG_ASTAR_INF) fstar = u.g; /* keep settling ties f == f* */
+    if (u.cell == goal_lin && fstar == OG_ASTAR_INF) { fstar = u.g; og_last_settled_at_goal = settled; } /* keep settling ties f == f* */
     const int ui = u.cell % rows, uj = u.cell / rows;
     const uint8_t m = nbr[u.cell];
     for (int k = 0; k < 8; ++k) {

@@ -177,6 +177,9 @@ typedef struct {
 void og_astar_query(const uint8_t* nbr, int rows, int cols, int start_lin, int goal_lin,
                     int32_t* g_work, int32_t* path, int path_cap, og_astar_result* res);
 
+/* cells the calling thread's last og_astar_query had closed when the goal came off the heap (a measurement aid) */
+int32_t og_astar_last_settled_at_goal(void);
+
 /* the same contract in map space for a moved (circular-buffer) map: start/goal/path are buffer linear
  * indices, adjacency and tie-breaking use unwrapped indices; g_work is left in unwrapped order */
 void og_astar_query_on_map(const og_geom* g, const float* master, int start_lin, int goal_lin, int32_t* g_work,

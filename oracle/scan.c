@@ -64,7 +64,12 @@ static double q_dot(const double* a, const double* b) { return a[0] * b[0] + a[1
 static void q_slerp(const double* a, const double* b, double t, double* out) {
   const double sl = sqrt(q_dot(a, a) * q_dot(b, b));
   const double dt = q_dot(a, b);
-  const double theta = (dt < 0 ? acos(-dt / sl) * 2.0 : acos(dt / sl) * 2.0) / 2.0;
+  /* tfAcos (tf/LinearMath/Scalar.h): the argument clamped to [-1, 1] -- rounding puts it at 1 + ulp for nearly equal
+   * orientations, where acos() itself returns NaN */
+  double ca = (dt < 0 ? -dt : dt) / sl;
+  if (ca < -1.0) ca = -1.0;
+  if (ca > 1.0) ca = 1.0;
+  const double theta = (acos(ca) * 2.0) / 2.0;
   if (theta != 0.0) {
     const double d = 1.0 / sin(theta);
     const double s0 = sin((1.0 - t) * theta);

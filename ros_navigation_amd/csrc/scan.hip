@@ -46,7 +46,11 @@ __device__ __forceinline__ void beam_to_map(const rna_laser_scan_tf& sc, double 
   {
     const double sl = sqrt(quat_dot(q0, q0) * quat_dot(q1, q1));
     const double dt = quat_dot(q0, q1);
-    const double theta = (dt < 0 ? acos(-dt / sl) * 2.0 : acos(dt / sl) * 2.0) / 2.0;   // angleShortestPath(q) / 2
+    // tfAcos (tf/LinearMath/Scalar.h) clamps its argument to [-1, 1]: for two orientations a few 1e-9 rad apart the
+    // quotient rounds to 1 + ulp in a fifth of the cases, and an unclamped acos made every beam of the scan NaN
+    double ca = (dt < 0 ? -dt : dt) / sl;
+    ca = ca < -1.0 ? -1.0 : (ca > 1.0 ? 1.0 : ca);
+    const double theta = (acos(ca) * 2.0) / 2.0;   // angleShortestPath(q) / 2
     if (theta != 0.0) {
       const double d = 1.0 / sin(theta);
       const double s0 = sin((1.0 - ratio) * theta);

@@ -342,6 +342,13 @@ def astar_query(nbr, rows, cols, start, goal, path_cap=None, g_work=None):
     return res, path[:n].copy(), g_work
 
 
+def astar_last_settled_at_goal():
+    """cells the calling thread's last astar_query had closed when the goal came off the heap (stop-at-goal A*)"""
+    f = lib().og_astar_last_settled_at_goal
+    f.restype = C.c_int32
+    return int(f())
+
+
 def astar_query_on_map(g, master, start, goal, path_cap=None):
     """grid A* in map space on a (possibly moved) map; start/goal/path are buffer linear indices"""
     n = g.size[0] * g.size[1]

@@ -9,6 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 # one step = one turn of the pipeline: 3 stages -> 3 passes of [HIMM batch, 32 VFH+ poses, 32 A* queries] per step
 SMALL = ["--grid", "512", "--queries", "32", "--steps", "5", "--warmup", "2", "--pipeline", "3", "--ray-poses", "8", "--rays-per-pose", "200"]
 PASSES = 5 * 3
@@ -62,11 +63,12 @@ def test_bench_line_contract_on_a_small_grid_through_the_spawn_path_with_rccl():
 # The 8-GPU bench runs once, unattended, at the end of a round: its two launch modes are rehearsed here at world size 8
 # with all ranks sharing the test box's GPU (RCCL refuses two ranks on one device, so the barrier and the max over ranks
 # go through gloo -- the RCCL leg of the same code runs in the test above), on a 1024 x 1024 grid.
-WORLD8 = ["--grid", "1024", "--queries", "32", "--steps", "3", "--warmup", "1", "--pipeline", "3", "--ray-poses", "8", "--rays-per-pose", "200",
+WORLD8 = ["--grid", "1024", "--queries", "32", "--steps", "3", "--warmup", "1", "--ray-poses", "8", "--rays-per-pose", "200",
           "--gpus", "8", "--no-cpu"]
 
 
-def run_world8(extra):
+def run_world8(extra, pipeline=3):
+    extra = extra + (["--pipeline", str(pipeline)] if pipeline else [])
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + WORLD8 + extra, capture_output=True, text=True,
                          timeout=900, cwd=ROOT, env=dict(os.environ, RNA_BENCH_SHARE_GPU="1"))
     assert out.returncode == 0, out.stderr[-3000:]
@@ -75,9 +77,9 @@ def run_world8(extra):
     return json.loads(lines[0])
 
 
-def check_world8_common(d):
+def check_world8_common(d, depth=3):
     cfg = d["config"]
-    passes = 3 * 3
+    passes = 3 * depth
     assert d["n_gpus"] == 8 and d["cpu_baseline"] is None and d["scaling"] == "weak"
     la = cfg["launcher"]
     assert la["spawned_by_bench"] and la["parent_is_my_parent"] and la["parent_hip_free"]      # 8 ranks, started by a HIP-free parent
@@ -89,12 +91,19 @@ def check_world8_common(d):
     assert abs(d["value"] - total / cfg["timed_seconds"]) < 1e-6 * d["value"]
     assert abs(d["ms_per_step"] * 3e-3 - cfg["timed_seconds"]) < 1e-9
     assert cfg["astar_queries_answered"] == cfg["astar_queries_checked"] and cfg["astar_paths_found"] > 0
+    assert cfg["astar_pipeline_depth"] == depth == cfg["astar_allocated"]["pipeline_depth"] and cfg["passes_per_step"] == depth
+    # every rank confined itself to host cores before it loaded torch / HIP (the GPU's NUMA node where the topology names one)
+    assert cfg["host_affinity"]["cpus"] >= 1 and "error" not in cfg["host_affinity"], cfg["host_affinity"]
 
 
 def test_world8_rehearsal_query_sharded():
-    """SURVEY 8e mode 1 as the driver launches it at N = 8 (`bench.py --gpus 8`): replicated maps, sharded cycles"""
-    d = run_world8([])
-    check_world8_common(d)
+    """SURVEY 8e mode 1 as the driver launches it at N = 8 (`bench.py --gpus 8`, NO --pipeline): replicated maps, sharded
+    cycles, and the pipeline depth the bench takes by itself next to a communicator (DEFAULT_PIPELINE_RCCL, not the one-GPU
+    default) -- the configuration of the driver's run is the one rehearsed"""
+    import bench
+    d = run_world8([], pipeline=0)
+    check_world8_common(d, depth=bench.DEFAULT_PIPELINE_RCCL)
+    assert bench.DEFAULT_PIPELINE_RCCL != bench.DEFAULT_PIPELINE
     assert "query-sharded x8" in d["config"]["parallelism"] and "tiled" not in d
 
 
@@ -137,15 +146,35 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
 
 
+_default_runs = {}
+
+
+def default_bench(cpus=0):
+    """the default bench (full size, 12 steps, --check-paths), run once per setting and shared by the tests below"""
+    if cpus not in _default_runs:
+        env = dict(os.environ, **({"RNA_BENCH_CPUS": str(cpus)} if cpus else {}))
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--no-cpu"] + ([] if cpus else ["--check-paths"]),
+                             capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        _default_runs[cpus] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    return _default_runs[cpus]
+
+
+def test_default_bench_holds_its_rate_on_four_host_cores():
+    """Eight ranks share one host at N = 8 (SURVEY 8e mode 1): a rank must not need more than its share of the cores.  The
+    default bench with the process confined to FOUR host cores (RNA_BENCH_CPUS=4: main thread, the engine's launch
+    thread, the runtime's helpers) keeps >= 95 % of the unconfined rate on the same box."""
+    free, four = default_bench(), default_bench(cpus=4)
+    assert four["config"]["host_affinity"]["cpus"] == 4, four["config"]["host_affinity"]
+    assert four["value"] >= 0.95 * free["value"], (four["value"], free["value"])
+
+
 def test_default_bench_keeps_the_engine_stream_alive():
     """The full-size loop, shortened: the search streams' CU mask has to leave the short engine-stream kernels (map
     update, VFH+, field reset) somewhere to run -- when four search workgroups per CU took every register of every CU,
     himm_prep took 3-6 ms instead of 0.3 ms per step and the step rate hung on the engine stream (22 k cycles/s).  Loose
     bounds: a guard against that cliff and against the hardware-queue cliff of too many pipeline stages, not a benchmark."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--no-cpu"], capture_output=True, text=True,
-                         timeout=900, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    d = default_bench()
     k = d["kernel_ms_per_pass"]
     assert k["himm_prep"] < 1.0 and k["vfh_step"] < 0.6 and k["compose_master"] < 0.6, k
     # the engine stream's chain (astar_search / astar_reset / astar_init run on the stages' own streams, vfh_step on the VFH+ stream)
@@ -157,6 +186,12 @@ def test_default_bench_keeps_the_engine_stream_alive():
     # (this kernel runs at 125 k+); RNA_TEST_BENCH_FLOOR overrides it on a shared or throttled box
     assert d["value"] > float(os.environ.get("RNA_TEST_BENCH_FLOOR", "50000")), d["value"]
     assert d["config"]["astar_allocated"]["pipeline_depth"] == d["config"]["astar_pipeline_depth"]
+    # parity AT the headline configuration (--check-paths): one whole batch of the loop -- searched next to the other batches of
+    # a full turn of the default pipeline -- path for path against the oracle
+    import bench
+    assert d["config"]["astar_pipeline_depth"] == bench.DEFAULT_PIPELINE
+    pc = d["config"]["paths_checked"]
+    assert pc["queries"] == 256 and pc["matched"] == 256 and pc["paths_found"] > 200, pc
 
 
 def test_bench_under_torchrun_as_the_driver_launches_it():

@@ -604,14 +604,20 @@ def test_astar_pipelined_batches_with_map_updates_in_between(R):
 def test_bench_loop_at_full_size_matches_oracle_every_step(R):
     """bench.py's timed loop as it runs, at BASELINE's size: 4096 x 4096 map, per step a 100 032-ray HIMM batch (four
     batches in rotation) + fused compose -> VFH+ for 256 poses (four pose sets, the robots' VFH state carried from step
-    to step) -> 256 grid-A* queries (four query sets) through the asynchronous device entry points at a pipeline depth
-    like the bench's (13 batches in flight on CU-masked streams; bench.py: 16), nothing waited for in between, for 27 steps: every stage
+    to step) -> 256 grid-A* queries (four query sets) through the asynchronous device entry points at THE BENCH'S OWN pipeline
+    depth (bench.DEFAULT_PIPELINE batches in flight on CU-masked streams: the page budget per stage, and with it the load on
+    the retry path, is the headline run's), nothing waited for in between, for 3 x depth steps: every stage
     is used three times, so the lazy reset of the pages a stage's previous search handed out runs twice per stage under
     the load it has in the bench.  Every step's map, VFH+ commands and histograms and the statuses of all its A* queries,
-    and the costs / paths of a rotating seventh of them (every query of the four sets at least once over the run; all
-    256 of a batch at once: test_astar_config3_every_bench_query_matches_oracle), against the oracle fed with the same sequence."""
+    and the costs / paths of a rotating twelfth of them (every query of the four sets at least once over the run; all
+    256 of a batch at once: test_astar_config3_every_bench_query_matches_oracle and bench.py --check-paths), against the
+    oracle fed with the same sequence."""
+    import bench
     hip = _Hip()
-    n, nq, steps, rot, depth, max_len = 4096, 256, 27, 4, 13, 32768
+    n, nq, rot, depth, max_len = 4096, 256, 4, bench.DEFAULT_PIPELINE, 32768
+    steps = 3 * depth
+    part = steps // rot          # visits of one query set; each checks every part-th query
+    assert steps % rot == 0 and depth >= 13
     L = n * 0.05
     e = R.Engine(L, L, 0.05)
     g = O.make_geom(L, L, 0.05)
@@ -658,13 +664,13 @@ def test_bench_loop_at_full_size_matches_oracle_every_step(R):
         # every query answered (found / no path) ...
         assert set(np.unique(res[:, 0]).tolist()) <= {0, 1}, (s, np.unique(res[:, 0]))
         answered += int((res[:, 0] == 0).sum())
-        # ... and a rotating seventh of them (37 of 256; steps s, s + 4, ... visit the same query set, so the 6-7 visits of a set
-        # cover all of it) path for path against the oracle on the map as it is at this step: 27 x 256 oracle searches of
-        # 0.1 s each were 690 CPU-seconds -- most of the suite's time on a box with few host cores
+        # ... and a rotating `part`-th of them (steps s, s + 4, ... visit the same query set, so the visits of a set
+        # cover all of it) path for path against the oracle on the map as it is at this step: every query of every step would
+        # be steps x 256 oracle searches of 0.1 s each -- most of the suite's time on a box with few host cores
         _, nbr = O.astar_masks(ref, n, n)
         q = query_sets[k]
         visit = s // rot
-        picks = [i for i in range(nq) if i % 7 == visit % 7]
+        picks = [i for i in range(nq) if i % part == visit % part]
         covered[k].update(picks)
 
         def one(j):
@@ -678,7 +684,8 @@ def test_bench_loop_at_full_size_matches_oracle_every_step(R):
         found += sum(oracle_pool(one, len(picks)))
         checked += len(picks)
     assert found > checked * 0.9 and answered > steps * nq * 0.9
-    assert all(len(c) == nq for c in covered[:3]) and len(covered[3]) >= nq * 6 // 7      # (27 steps: sets 0-2 are visited 7 times, set 3 six times)
+    assert all(len(c) == nq for c in covered)      # every query of the four sets, on the map of one of its visits
+    assert tuple(e.astar_effective_config())[0] == depth
     assert same_f32(e.download(R.capi.LAYER_MASTER), ref) and same_f32(e.download(R.capi.LAYER_LASER), ref)
     for t in outs:
         for p_ in t:
@@ -1004,6 +1011,23 @@ def test_scan_to_rays_with_full_sensor_transforms_matches_oracle(R):
     assert same_f32(e.download(R.capi.LAYER_MASTER), ref)
     with pytest.raises(R.RnaError):
         e.scan_to_rays_tf(tf, ranges, max_rays=10)
+    e.close()
+
+
+def test_scan_with_tf_jitter_between_start_and_end_keeps_every_beam(R):
+    """Round 4's advisor finding: end orientation 1e-10 .. 1e-7 rad from the start one (a robot standing still under tf jitter)
+    -- the slerp's acos argument rounds to 1 + ulp; clamped as tfAcos does, every beam stays finite and equals the oracle's."""
+    from test_oracle_scan import _jittered_scans
+    e = R.Engine(25.6, 25.6, 0.05)
+    scans, still, ranges = _jittered_scans()
+    got, want = e.scan_to_rays_tf(scans, ranges), O.scan_to_rays_tf(scans, ranges)
+    const = e.scan_to_rays_tf(still, ranges)
+    assert len(got) == len(want) == len(const) > 1000
+    for f in ("sx", "sy", "ex", "ey"):
+        assert np.isfinite(got[f]).all()
+    assert np.array_equal(got["sx"], want["sx"]) and np.array_equal(got["clear_end"], want["clear_end"])
+    assert np.allclose(got["ex"], want["ex"], rtol=0, atol=1e-6) and np.allclose(got["ey"], want["ey"], rtol=0, atol=1e-6)
+    assert np.allclose(got["ex"], const["ex"], rtol=0, atol=1e-5) and np.allclose(got["ey"], const["ey"], rtol=0, atol=1e-5)
     e.close()
 
 

@@ -128,3 +128,35 @@ def test_full_transform_restatement_against_scipy_slerp():
               Rotation.from_euler("y", 0.4).as_quat(), (1.0, 2.0, 0.5), Rotation.from_euler("y", 0.4).as_quat())
     ray = O.scan_to_rays_tf(one, np.array([3.0], np.float32))
     assert len(ray) == 1 and abs(ray["ex"][0] - (1.0 + 3.0 * np.cos(0.4))) < 1e-6 and abs(ray["ey"][0] - 2.0) < 1e-6
+
+
+def _jittered_scans(n=40, beams=181):
+    """scans whose end orientation is the start orientation turned by 1e-10 .. 1e-7 rad (tf jitter of a robot standing still)"""
+    from scipy.spatial.transform import Rotation
+    from ros_navigation_amd import synth
+    scans, ranges = synth.laser_scans_tf(n, beams, 25.6, 25.6, seed=5, angle_increment=np.float32(0.02), moving=0.0)
+    rng = np.random.default_rng(9)
+    still = scans.copy()
+    for k in range(n):
+        still["t_end"][k] = still["t"][k]
+        still["q_end"][k] = still["q"][k]
+        scans["t_end"][k] = scans["t"][k]
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        eps = 10.0 ** rng.uniform(-10, -7)
+        scans["q_end"][k] = (Rotation.from_quat(scans["q"][k]) * Rotation.from_rotvec(eps * axis)).as_quat()
+    return scans, still, ranges
+
+
+def test_nearly_equal_start_and_end_orientations_do_not_lose_the_scan():
+    """tf's slerp takes its angle through tfAcos, which clamps to [-1, 1] (tf/LinearMath/Scalar.h): with the end orientation
+    1e-10 .. 1e-7 rad from the start one, dot / sqrt(len2 len2) rounds to 1 + ulp for a fifth of the scans; unclamped, acos
+    returned NaN and every beam of such a scan was dropped by the ray filter (round 4's advisor finding)."""
+    scans, still, ranges = _jittered_scans()
+    assert (scans["q_end"] != scans["q"]).any(axis=1).all()
+    got, want = O.scan_to_rays_tf(scans, ranges), O.scan_to_rays_tf(still, ranges)
+    assert len(got) == len(want) > 1000
+    for f in ("sx", "sy", "ex", "ey"):
+        assert np.isfinite(got[f]).all()
+    assert np.array_equal(got["sx"], want["sx"]) and np.array_equal(got["clear_end"], want["clear_end"])
+    assert np.allclose(got["ex"], want["ex"], rtol=0, atol=1e-5) and np.allclose(got["ey"], want["ey"], rtol=0, atol=1e-5)
