@@ -118,6 +118,7 @@ def pin_to_gpu_numa_node(local_rank):
     info = {"numa_node": None, "cpus": len(os.sched_getaffinity(0)), "pinned": False}
     try:
         cpus = set(os.sched_getaffinity(0))
+        before = set(cpus)
         if os.environ.get("RNA_BENCH_NO_PIN") != "1":
             gpus = []
             for path in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"), key=lambda p: int(p.split("/")[-2])):
@@ -145,10 +146,12 @@ def pin_to_gpu_numa_node(local_rank):
         keep = int(os.environ.get("RNA_BENCH_CPUS", "0"))
         if keep > 0:
             cpus = set(sorted(cpus)[:keep])
-        os.sched_setaffinity(0, cpus)
-        info["cpus"] = len(cpus)
+        if cpus != before:
+            os.sched_setaffinity(0, cpus)    # (refused with EPERM inside some sandboxes: reported, not fatal)
+        info["cpus"] = len(os.sched_getaffinity(0))
     except Exception as ex:   # noqa: BLE001 -- an optimisation, never a reason to fail the bench
         info["error"] = repr(ex)
+        info["pinned"] = False
     return info
 
 

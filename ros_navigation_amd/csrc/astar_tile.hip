@@ -55,6 +55,12 @@ constexpr int MASK_STRIDE = TILE_WORDS + 32 + 128;  // snapshot bytes per tile: 
 #ifndef RNA_TSA_HPASS
 #define RNA_TSA_HPASS (RNA_TSA_SUPER == 2 ? 4 : (RNA_TSA_SUPER ? 8 : 16))  // one-cell passes first (mode 2: 3 / 4 / 5 -> 144.1 / 144.0 / 143.6 k; mode 0: 8 / 16 -> 55.8 / 56.7 k in round 2)
 #endif
+#ifndef RNA_TSA_FRESH
+#define RNA_TSA_FRESH 0   // 1: the wake tests at the end of a job read the neighbours' edges again instead of using the halo as loaded.
+                          // Measured (profiles/r05_ab_fresh_wake_tests.txt): the jobs that find nothing fall as the model says
+                          // (non-sticky ones to 7 % of all jobs), the bench from 154.3 k to 152.7 k cycles/s -- three more loads and
+                          // their addresses in every working job cost more than the cheap jobs they save.  Off.
+#endif
 #ifndef RNA_TSA_REDBLACK
 #define RNA_TSA_REDBLACK 1   // rounds alternate between the two checkerboard colours of the tiles
 #endif
@@ -66,7 +72,8 @@ constexpr int TSA_MAX_TILE_WORDS = 2048;   // active-tile bitset words -> up to 
 constexpr int COST_S = 1000, COST_D = 1414;
 constexpr int INF = 0x7fffffff;
 constexpr int KU = 0x40000000;             // field word u = KU - g; 0 = unreached
-constexpr int SCR_WORDS = 84 + 192 + 48 + 64;   // per-wave LDS scratch: column transposition (68 + a zero tail of 16), the halo rows and
+constexpr int SCR_CNT = 84 + 192 + 48 + 64;     // two counters behind the scratch proper: rows written, jobs (kept in LDS: a register each across the job loop was one too many)
+constexpr int SCR_WORDS = SCR_CNT + 2;          // per-wave LDS scratch: column transposition (68 + a zero tail of 16), the halo rows and
                                            // columns as loaded (3 x 64), this tile's edge columns at the end of the job (16 + 16 + 16),
                                            // the masks of the tile's edge-column cells as loaded (64)
 
@@ -434,15 +441,38 @@ __device__ __forceinline__ unsigned long long tsa_row_fixpoint(int& g, int& pp, 
 #define TSA_PP(b) TSA_CAT(pp, b)
 #define TSA_MKW(b) TSA_CAT(TSA_MK_, b)   // the mask word that holds row b's byte, at bit 8 * (b & 3)
 template <class Sched>
-__device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane_in, const int t, const TsaCtx& C,
-                                       const bool first, const unsigned bucket_end, const int key_base, const int key_shift, int* spare TSA_ACC_PARAM) {
+__device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lane_in, const int t_in, const TsaCtx& C,
+                                       const int first_in, const unsigned bucket_end, const int key_base, const int key_shift, int* spare TSA_ACC_PARAM) {
+  // STICKY TILES (round 5).  A tile that is woken while its job runs used to be queued again by its wavefront (class 0)
+  // and, as a rule, taken again at once by the same wavefront: a push, a pop, a claim, the sixteen rows, the masks and the
+  // sixteen pass-on values loaded and formed again -- for a third of all jobs (scripts/sim_async.c: 36 % of the jobs are
+  // such re-runs, half of them find nothing).  Now the wavefront KEEPS the tile: when a wake-up is pending at the end of
+  // the job (Sched::finish) it goes round the loop below with the rows and the masks still in
+  // registers and pulls only the halo again (`sticky`).  The schedule is the one the queue would have produced (class 0 is
+  // taken first), so jobs, results and exactness are unchanged; what goes is ~430 instructions and the queue round trip.
+  // (loop-carried flags as 32-bit scalars behind an opaque copy: as `bool` they become lane-mask phis, every selection on them
+  // a v_cndmask, and the scalar row sets that depend on `first` end up in VGPRs -- "illegal VGPR to SGPR copy")
+  int first_w = first_in, sticky_w = 0;
+  int g0, g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15;
+  unsigned mk0 = 0u, mk1 = 0u, mk2 = 0u, mk3 = 0u, fbits_ld = 0u;   // byte b of mk* of this lane = neighbour mask of cell (lane, b); bit b of fbits: the cell is free
+  unsigned pg = 0u;
+  for (;;) {   // one turn per job of this tile
+  {
+  // (the tile number behind an opaque copy per turn, like the lane id below: what is derived from it -- the tile's bit masks
+  // for the scheduler's words, its number as a vector value for the page list -- is otherwise hoisted out of this loop as
+  // loop-invariant VGPRs and spilled to scratch, whose reloads inside the job wait for every store in flight)
+  int t = t_in;
+  asm volatile("" : "+s"(t));
+  const int tiles_i = C.tiles_i, tiles_j = C.tiles_j, gi = C.gi, gj = C.gj;
+  const int ti = t % tiles_i, tj = t / tiles_i;
+  const int i0 = ti * TI, j0 = tj * TJ;
+  first_w = __builtin_amdgcn_readfirstlane(first_w);
+  sticky_w = __builtin_amdgcn_readfirstlane(sticky_w);
+  const bool first = first_w != 0, sticky = sticky_w != 0;
   // an opaque copy of the lane id per job (and one more for the results phase): everything derived from it is then
   // recomputed here instead of being hoisted out of the job loop, kept alive across the sweeps and spilled to scratch
   int lane = lane_in;
   asm volatile("" : "+v"(lane));
-  const int tiles_i = C.tiles_i, tiles_j = C.tiles_j, gi = C.gi, gj = C.gj;
-  const int ti = t % tiles_i, tj = t / tiles_i;
-  const int i0 = ti * TI, j0 = tj * TJ;
   TSA_T(t_a);
   asm volatile("; TSA_MARK job_begin");
   // ---- 1. page table look-up of the eight neighbouring tiles (lane k < 8: direction k; 0 = none or outside) and of
@@ -465,22 +495,24 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       nb_t = lane < 8 ? tt : -1;
     }
   }
-  unsigned pg = (unsigned)__builtin_amdgcn_readlane((int)nb_pg, 8);
+  pg = (unsigned)__builtin_amdgcn_readlane((int)nb_pg, 8);
+#if RNA_TSA_FRESH
+  if (lane < 8) scr[lane] = nb_pg;   // for the end of the job: the wake tests read the neighbours' edges again (TSA_FRESH)
+#endif
   // ---- 2. everything the job reads, issued before the first wait ----
-  int g0, g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15;
-  {
-    const unsigned* own = C.pages + (pg << 10);
-#define TSA_LOAD(b) TSA_G(b) = (int)ld_l2(&own[(b) * TI + lane]);
-    TSA_R16(TSA_LOAD)
-#undef TSA_LOAD
-  }
   // (the tile's snapshot through a scalar base and 32-bit lane offsets of known range: as `base + lane * 16` and
   // `(ushort*)(base + 1056)[lane]` the second address was a 64-bit multiply-add per lane)
   const uint8_t* const snap = C.nbr_tm + (size_t)t * MASK_STRIDE;
   const unsigned ulane_ld = (unsigned)lane & 63u;
-  const uint4 mv = *reinterpret_cast<const uint4*>(snap + (ulane_ld << 4));
-  const unsigned mk0 = mv.x, mk1 = mv.y, mk2 = mv.z, mk3 = mv.w;   // byte b of this lane = neighbour mask of cell (lane, b)
-  const unsigned fbits_ld = *reinterpret_cast<const unsigned short*>(snap + TILE_WORDS + 32 + (ulane_ld << 1));
+  if (!sticky) {   // (a sticky turn still holds the rows as it stored them, and the masks)
+    const unsigned* own = C.pages + (pg << 10);
+#define TSA_LOAD(b) TSA_G(b) = (int)ld_l2(&own[(b) * TI + lane]);
+    TSA_R16(TSA_LOAD)
+#undef TSA_LOAD
+    const uint4 mv = *reinterpret_cast<const uint4*>(snap + (ulane_ld << 4));
+    mk0 = mv.x; mk1 = mv.y; mk2 = mv.z; mk3 = mv.w;
+    fbits_ld = *reinterpret_cast<const unsigned short*>(snap + TILE_WORDS + 32 + (ulane_ld << 1));
+  }
   // X: the two halo columns and the four corners.  Lanes 0..17 hold the left one top-down (lane 0 = corner (-1,-1),
   // lanes 1..16 = rows 0..15, lane 17 = corner (-1,16)), lanes 32..49 the right one.
   const int xl = lane & 31;
@@ -508,12 +540,12 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   // "unreached" cell never passes anything on.  The heuristic of a row is recomputed where it is needed (one scalar
   // |dj| and four vector instructions) instead of living in 16 registers: the kernel has to fit 64 VGPRs so that eight
   // wavefronts share a SIMD.
-  const int best_in = sch.best();
+  const int best_in = __builtin_amdgcn_readfirstlane(sch.best());   // (wave-uniform: the sticky turn branches on the bound it gives)
   // pass on iff f < lim = min(end of the bucket, best + 1), in unsigned 32 bits: `bucket_end` arrives clamped to 2^31,
   // best + 1 <= 2^31 (as 64-bit integers these few scalar values cost vector compares and four spilled registers)
   const unsigned best1 = (unsigned)best_in + 1u;
   const unsigned lim_u = bucket_end < best1 ? bucket_end : best1;
-  const int thr = KU - (int)(lim_u > (unsigned)INF ? (unsigned)INF : lim_u) + 1;
+  const int thr = __builtin_amdgcn_readfirstlane(KU - (int)(lim_u > (unsigned)INF ? (unsigned)INF : lim_u) + 1);   // (wave-uniform by construction: the sticky turn branches on it)
 #if RNA_TSA_SUPER >= 2
   const bool scan_ok = lim_u < TSA_SCAN_LIM;   // the keys of tsa_row_fixpoint fit
 #endif
@@ -619,11 +651,13 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     // rows' pass-on values are formed.
     const unsigned long long upT = __builtin_amdgcn_ballot_w64(cT > g0), upB = __builtin_amdgcn_ballot_w64(cB > g15);
     const unsigned long long imask = __builtin_amdgcn_ballot_w64(cX > gcol);
-    if (!(upT | upB | imask) && !planted && !first) { TSA_CNT(10, 1); TSA_T(t_n); TSA_ACC(15, t_a, t_n); return 0; }   // the wake-up brought nothing better
+    if (!(upT | upB | imask) && !planted && !first) { TSA_CNT(10, 1); if (sticky) TSA_CNT(23, 1); TSA_T(t_n); TSA_ACC(15, t_a, t_n); goto tsa_job_done; }   // the wake-up brought nothing better
     asm volatile("; TSA_MARK noop_decided");
+#if !RNA_TSA_FRESH
     scr[84 + lane] = (unsigned)top;        // kept for the end of the job: does a changed edge row beat what the
     scr[84 + 64 + lane] = (unsigned)bot;   // neighbour already has?
     scr[84 + 128 + lane] = (unsigned)X;
+#endif
     scr[84 + 192 + 48 + lane] = eb;
     const unsigned cl = (unsigned)(imask >> 1) & 0xffffu, cr = (unsigned)(imask >> 33) & 0xffffu;   // rows whose cell in lane 0 / lane 63 improves
     const unsigned crow = cl | cr | planted;
@@ -658,7 +692,9 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
 #undef TSA_REPLANT
       }
     }
-    // what each cell may pass on in this bucket: sixteen rows, no branches
+    // what each cell may pass on in this bucket: sixteen rows, no branches (also on a sticky turn: kept across the turns, the
+    // sixteen values were live through the page look-ups and the halo step, and the kernel spilled into scratch -- whose
+    // loads wait for every store in flight; a turn that finds nothing has left before this point anyway)
 #define TSA_APPLY_PP(b) TSA_PP(b) = TSA_G(b) >= TSA_HT(b) ? TSA_G(b) : 0;
     TSA_R16(TSA_APPLY_PP)
 #undef TSA_APPLY_PP
@@ -873,6 +909,29 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
   asm volatile("; TSA_MARK results_begin");
   // ---- 6. results: rows that changed, the edge-column copies, the goal ----
   asm volatile("" : "+v"(lane));
+  // FRESH WAKE TESTS (round 5).  A changed edge cell wakes the tile beyond it only if it beats what that tile holds -- and
+  // what it holds is read again HERE, at the end of the job, not taken from the halo the job loaded when it started: the
+  // sweeps in between are most of the job's time, the neighbour (where the front came from, as a rule) has often caught up
+  // meanwhile, and the wake-up would cost a whole job that finds nothing (scripts/sim_async.c, SIM_FRESH: 17 % fewer
+  // jobs, no-op share 37 -> 23 %).  Values only get better, so a newer snapshot can only suppress wake-ups that would have
+  // found nothing; one that is read while the neighbour is still storing errs towards waking, as before.  The three loads
+  // are issued before this job's stores and used after them; pages come from the look-up at the job's start (a neighbour
+  // that had none then reads page 0, "unreached", and is woken as before).
+#if RNA_TSA_FRESH
+  int topf, botf, Xf = 0;
+  {
+    const unsigned pgN = scr[1], pgS = scr[6];
+    const int xl = lane & 31;
+    const bool xr = lane >= 32;
+    const int xz = (xl > 0 ? 1 : 0) + (xl > TJ ? 1 : 0);
+    const int xdir = 3 * xz - (xz >> 1) + (xr ? 2 - (xz & 1) : 0);
+    const unsigned pgX = scr[xdir];
+    const int xrow = xl == 0 ? TJ - 1 : (xl <= TJ ? xl - 1 : 0);
+    topf = (int)ld_l2(&C.pages[(pgN << 10) + (TJ - 1) * TI + lane]);
+    botf = (int)ld_l2(&C.pages[(pgS << 10) + lane]);
+    if (xl <= TJ + 1) Xf = (int)ld_l2(&C.paux[pgX * AUX_WORDS + (xr ? 0 : 16) + xrow]);
+  }
+#endif
   if (rowchg) {
     if (pg == 0u) {   // first change of this tile: it gets a page (this job is the tile's only writer)
       int p = 0;
@@ -882,7 +941,7 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
         else { C.owner[p] = (unsigned)t; __hip_atomic_store(&C.tmap[t], (unsigned)p, __ATOMIC_RELAXED, RNA_TSA_SCOPE); }
       }
       pg = (unsigned)__builtin_amdgcn_readfirstlane(p);
-      if (pg == 0u) return 0;
+      if (pg == 0u) return;   // (the search is being abandoned: status 5)
     }
     unsigned* own = C.pages + (pg << 10);
     unsigned* ax = C.paux + pg * AUX_WORDS + (lane ? 16 : 0);
@@ -978,7 +1037,11 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
     bool wakeN = q0 != 0ull, wakeS = q15 != 0ull;
     int kfN = 0, kfS = 0, kfW = 0, kfE = 0;
     if (wakeN) {
+#if !RNA_TSA_FRESH
       const int topv = (int)scr[84 + lane];
+#else
+      const int topv = topf;
+#endif
       const int c_ = __builtin_amdgcn_inverse_ballot_w64(q0) ? g0 : 0;
       const int cw_ = c_ & __builtin_amdgcn_sbfe((int)mk0, 0, 1), cn_ = c_ & __builtin_amdgcn_sbfe((int)mk0, 1, 1), ce_ = c_ & __builtin_amdgcn_sbfe((int)mk0, 2, 1);
       // (the shifted values are formed for ALL lanes first: inside a short-circuit `||` the wave shift would run with the
@@ -990,7 +1053,11 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       if (wakeN) kfN = wave_max_i32(imp_ ? un_ - TSA_H(-1) : (int)0x80000000);
     }
     if (wakeS) {
+#if !RNA_TSA_FRESH
       const int botv = (int)scr[84 + 64 + lane];
+#else
+      const int botv = botf;
+#endif
       const int c_ = __builtin_amdgcn_inverse_ballot_w64(q15) ? g15 : 0;
       const int cw_ = c_ & __builtin_amdgcn_sbfe((int)mk3, 24 + 5, 1), cs_ = c_ & __builtin_amdgcn_sbfe((int)mk3, 24 + 6, 1), ce_ = c_ & __builtin_amdgcn_sbfe((int)mk3, 24 + 7, 1);
       const int from_w_ = lane_m1(ce_) + nD, from_e_ = lane_p1(cw_) + nD;
@@ -1015,7 +1082,11 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       const int xl_ = lane & 31;
       const bool xr_ = lane >= 32;
       const int v_ = (xl_ >= 1 && xl_ <= TJ) ? (int)scr[276 + (lane & 32) + xl_ - 1] : 0;
+#if !RNA_TSA_FRESH
       const int xv = (int)scr[84 + 128 + lane];
+#else
+      const int xv = Xf;
+#endif
       const unsigned eb_ = scr[84 + 192 + 48 + lane];   // the edge cell's mask, as loaded (lanes 1..16 / 33..48)
       // straight: k3 / k4; towards the row above: k0 / k2; towards the row below: k5 / k7
       const int vs_ = v_ & -(int)((eb_ >> (xr_ ? 4 : 3)) & 1u), vu_ = v_ & -(int)((eb_ >> (xr_ ? 2 : 0)) & 1u), vd_ = v_ & -(int)((eb_ >> (xr_ ? 7 : 5)) & 1u);
@@ -1052,13 +1123,28 @@ __device__ __forceinline__ int tsa_job(Sched& sch, unsigned* scr, const int lane
       TSA_CNT(13, 1);
     }
   }
-#undef TSA_ROW_CHANGED
-#undef TSA_H
   asm volatile("; TSA_MARK job_end");
   TSA_T(t_d);
   TSA_ACC(2, t_c, t_d);
   TSA_ACC(6, t_w0, t_d);   // wake tests + queueing
-  return __builtin_popcount(rowchg);   // rows written
+  if (lane_in == 0) { atomicAdd(&scr[SCR_CNT], (unsigned)__builtin_popcount(rowchg)); atomicAdd(&scr[SCR_CNT + 1], 1u); }   // rows written, jobs (this wavefront's own words; adds that return nothing)
+  }
+tsa_job_done:
+  // the job's stores are performed before the tile can be taken again (or is pulled again by this wavefront)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    int t_f = t_in;   // (opaque once more: the masks finish() forms from the tile number are not to be hoisted to the top of the job)
+    asm volatile("" : "+s"(t_f));
+    const int again = sch.finish(t_f, lane_in, spare);   // 0: the tile is released, 1: a wake-up came in while it ran, 2: ... and it is due as a first job
+    if (!again) break;
+    first_w = again >> 1;
+    sticky_w = 1;
+    TSA_CNT(7, 1);    // (a sticky turn counts as a job of its own in the developer build's figures)
+    TSA_CNT(22, 1);
+  }
+  }   // next turn on the same tile
+#undef TSA_ROW_CHANGED
+#undef TSA_H
 }
 
 // ---- scheduler of the one-workgroup-per-query kernel: an open list of tiles in LDS ----
@@ -1111,6 +1197,8 @@ struct TsaLocalSched {
   unsigned* qc_;
   int* count_;   // entries in the queue + tiles of the open set nobody has taken yet (a hint for idle wavefronts)
   int* spill_;   // no free node: wake-ups were parked in `far` and this bucket runs again
+  unsigned* open_;   // tiles due as first jobs of this bucket
+  int* open_left_;   // ... how many of them nobody has taken yet
   __device__ __forceinline__ int best() const { return __hip_atomic_load(best_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   __device__ __forceinline__ void improve_best(int g) { atomicMin(best_, g); }
   __device__ __forceinline__ void overflow() { *state_ = 4; }
@@ -1187,6 +1275,36 @@ struct TsaLocalSched {
     }
     const unsigned long long okm = __builtin_amdgcn_ballot_w64(idx >= 0);
     if (okm && lane == __builtin_ctzll(okm)) atomicAdd(count_, __builtin_popcountll(okm));
+  }
+  // End of a job of tile t (all lanes call; the job's stores have been performed).  A wake-up that came in while the tile
+  // ran leaves the tile with this wavefront: D is cleared, R stays, and the caller goes round its job loop once more
+  // (returns 1; 2 when the tile is also due as a FIRST job of this bucket -- whoever wanted to take it from the open set
+  // found it running, put the bit back and set D).  Otherwise the tile is released; a wake-up that slipped in between
+  // the look and the release is queued as before (class 0).
+  // D of a running tile is only ever SET by others (an entry is only claimed while R is clear), so the look cannot miss.
+  __device__ __forceinline__ int finish(int t, int lane, int* spare) {
+    const unsigned sh = 2u * ((unsigned)t & 15u);
+    int r = 0;
+    if (lane == 0) {
+#ifdef RNA_TSA_NO_STICKY   /* developer build: the round-4 behaviour (release, queue again) in this round's code */
+      if (false) {
+#else
+      if ((lds_ld(&st2_[t >> 4]) >> sh) & 1u) {
+#endif
+        atomicAnd(&st2_[t >> 4], ~(1u << sh));
+        r = 1;
+        if (lds_ldi(open_left_) > 0 && ((atomicAnd(&open_[t >> 5], ~(1u << (t & 31))) >> (t & 31)) & 1u)) {
+          atomicSub(open_left_, 1);
+          atomicSub(count_, 1);
+          r = 2;
+        }
+      } else if ((atomicAnd(&st2_[t >> 4], ~(2u << sh)) >> sh) & 1u) {
+        r = 3;
+      }
+    }
+    r = __builtin_amdgcn_readfirstlane(r);
+    if (r == 3) { push((unsigned)t, 0u, lane, spare); r = 0; }
+    return r;
   }
   // take the top entry of the lowest class that has one: its tile, POP_EMPTY if the queue is empty.  The node becomes
   // the wavefront's spare one (*spare; the one it held goes back to the pool).
@@ -1427,6 +1545,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   for (int w = tid; w < TSA_BMW; w += TSA_THREADS) s_bm[w] = 0xffffffffu;
   for (int w = tid; w < TSA_QC; w += TSA_THREADS) s_qc[w] = 0xffffffffu;
   if (lane >= 48) s_scr[wv][68 + lane - 48] = 0u;   // the zero tail of the wave's scratch
+  if (lane < 2) s_scr[wv][SCR_CNT + lane] = 0u;     // ... and its two counters
   // a start or a goal without a single traversable neighbour: blocked or walled in; nothing has been written yet, so
   // no page is in use
   {
@@ -1466,17 +1585,16 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   if (tid == 0) s_open[C.ts >> 5] = 1u << (C.ts & 31);   // the start tile's first job plants g(start) = 0
   __syncthreads();
 
-  int my_evals = 0, my_jobs = 0;
 #ifdef RNA_TSA_STATS
   unsigned long long tsa_acc[24] = {};
   const unsigned long long t_life0 = wall_clock64();
   const unsigned long long c_life0 = __builtin_amdgcn_s_memtime();
 #endif
-  TsaLocalSched sch{&s_best, &s_state, s_st2, s_far, s_node, s_head, s_bm, s_qc, &s_count, &s_spill};
+  TsaLocalSched sch{&s_best, &s_state, s_st2, s_far, s_node, s_head, s_bm, s_qc, &s_count, &s_spill, s_open, &s_open_left};
   int spare = -1;   // a queue node this wavefront owns (the one its last job's entry sat in): its next wake-up uses it
 
   for (;;) {   // one pass per f-bucket (or per re-run of a bucket whose queue overflowed)
-    const int bucket = lds_ldi(&s_bucket);
+    const int bucket = __builtin_amdgcn_readfirstlane(lds_ldi(&s_bucket));
     const long long bucket_end = ((long long)bucket + 1) * A.bucket_width;
     const unsigned bucket_end_u = bucket_end > 0x80000000LL ? 0x80000000u : (unsigned)bucket_end;   // (everything >= 2^31 is "beyond any f")
     const long long key_base_ll = (long long)KU - (long long)bucket * A.bucket_width;   // KU - (f at the bucket's start)
@@ -1493,7 +1611,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
         idle = false;
       }
       int t = -1;
-      bool first = false;
+      int first = 0;   // (a 32-bit scalar, not a lane-mask bool: see tsa_job)
       // ---- 1. a tile of the open set (runs as "first") ----
       const int open_left = lds_ldi(&s_open_left);   // (a hint: read once per turn)
       if (!open_blocked && open_left > 0) {
@@ -1529,7 +1647,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
         if (r == 0) continue;
         if (r == 2) { open_blocked = true; continue; }   // take an entry meanwhile
         t = tt;
-        first = true;
+        first = 1;
       } else {
         // ---- 2. the queued tile with the lowest key ----
         open_blocked = false;
@@ -1562,7 +1680,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
         r = __builtin_amdgcn_readfirstlane(r);
         if (r <= 0) continue;
         t = tt;
-        first = r == 2;
+        first = r >> 1;
       }
 #ifdef RNA_TSA_TAKE_SLEEP   /* developer build: extra latency (in units of 64 clocks) between taking a job and running it */
       __builtin_amdgcn_s_sleep(RNA_TSA_TAKE_SLEEP);
@@ -1570,22 +1688,14 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
       TSA_T(t_p1);
       TSA_ACC(4, t_p0, t_p1);   // taking a job
       TSA_CNT(7, 1);
-      my_jobs += 1;
 #if defined(RNA_TSA_JOBPRIO)
       __builtin_amdgcn_s_setprio(RNA_TSA_JOBPRIO);        // developer build: issue priority of a wavefront inside a job ...
 #endif
-      my_evals += tsa_job(sch, s_scr[wv], lane, t, C, first, bucket_end_u, key_base, key_shift, &spare TSA_ACC_ARG);
+      tsa_job(sch, s_scr[wv], lane, t, C, first, bucket_end_u, key_base, key_shift, &spare TSA_ACC_ARG);
 #if defined(RNA_TSA_JOBPRIO)
       __builtin_amdgcn_s_setprio(RNA_TSA_IDLEPRIO);       // ... and while it takes the next one / polls
 #endif
-      // the job's stores are performed before the tile can be taken again (it may have been woken while it ran)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      {
-        const unsigned sh = 2u * ((unsigned)t & 15u);
-        int again = 0;
-        if (lane == 0) again = (int)((atomicAnd(&s_st2[t >> 4], ~(2u << sh)) >> sh) & 1u);
-        if (__builtin_amdgcn_readfirstlane(again)) sch.push((unsigned)t, 0u, lane, &spare);   // class 0: as soon as possible
-      }
+      // (the tile has been released by the job itself -- or kept for further turns while wake-ups kept coming: Sched::finish)
     }
     // ---- the bucket is at its fixed point (or the search is being abandoned) ----
     __syncthreads();
@@ -1618,7 +1728,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     __syncthreads();
     if (s_state != 0) break;
   }
-  if (lane == 0) { atomicAdd(&s_expanded, my_evals * TI); atomicAdd(&s_jobs_done, my_jobs); }   // cells written
+  if (lane == 0) { atomicAdd(&s_expanded, (int)s_scr[wv][SCR_CNT] * TI); atomicAdd(&s_jobs_done, (int)s_scr[wv][SCR_CNT + 1]); }   // cells written, jobs
   __syncthreads();
 #ifdef RNA_TSA_STATS
   tsa_acc[5] = wall_clock64() - t_life0;   // wave lifetime inside the search loop
@@ -1898,6 +2008,8 @@ void tsa_stats_dump() {
           jobs, 100.0 * (double)st[10] / jobs, st[0] * 0.01 / jobs, st[1] * 0.01 / jobs, st[2] * 0.01 / jobs, st[5] * 1e-5, busy * 1e-5,
           100.0 * busy / (double)st[5], st[4] * 1e-5, 100.0 * (double)st[4] / (double)st[5], st[8] / jobs, st[11] / jobs,
           100.0 * (double)st[12] / (double)std::max<unsigned long long>(1, st[5]));
+  fprintf(stderr, "[tsa stats] sticky turns (the wavefront kept a tile that was woken while it ran) %.3f of all jobs, of which %.3f find nothing\n",
+          (double)st[22] / jobs, (double)st[23] / (double)std::max<unsigned long long>(1, st[22]));
   fprintf(stderr, "[tsa stats] first jobs (a tile's first in a bucket: every row evaluated both ways) %.3f of all, %.1f row evaluations and %.1f changed rows each; rows changed per job %.1f; rows sent to the scan per job %.2f\n",
           (double)st[18] / jobs, (double)st[19] / (double)std::max<unsigned long long>(1, st[18]), (double)st[20] / (double)std::max<unsigned long long>(1, st[18]), (double)st[21] / jobs, (double)st[14] / jobs);
 }

@@ -46,9 +46,27 @@ def test_eight_search_wavefronts_fit_a_simd():
     tile = resources("astar_tile.hip")
     search = next(v for k, v in tile.items() if "tsa_search_kernelILi8ELb0E" in k)     # the pipelined instantiation: 8 wavefronts per workgroup
     single = next(v for k, v in tile.items() if "tsa_search_kernelILi16ELb0E" in k)    # one batch at a time: 16
-    assert alloc(single["VGPRs"]) * 8 <= VGPRS_PER_SIMD and single["ScratchSize"] <= 16, single
+    assert alloc(single["VGPRs"]) * 8 <= VGPRS_PER_SIMD and single["ScratchSize"] <= 32, single
     assert alloc(search["VGPRs"]) * 8 <= VGPRS_PER_SIMD, search        # 8 wavefronts per SIMD = 4 workgroups of 8 per CU
-    assert search["ScratchSize"] <= 16, search                          # nothing spilled inside the tile job (one kernel-level value may be)
+    assert search["ScratchSize"] <= 32, search                          # a few kernel-level values may live in scratch ...
+    # ... but nothing is spilled or reloaded INSIDE the tile job (between its first and last marker in the assembly): a scratch
+    # reload there waits for every store of the job that is still in flight.  Round 5's first sticky-tile build had four (tile
+    # numbers and bit masks hoisted out of the new job loop as loop invariants) and ran 11 % slower than the kernel it replaced.
+    asm = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+                          os.path.join(CSRC, "astar_tile.hip"), "-o", "-"], capture_output=True, text=True, timeout=600)
+    assert asm.returncode == 0, asm.stderr[-2000:]
+    lines = asm.stdout.split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3rna17tsa_search_kernelILi8ELb0EEEvNS_9TsaLaunchE:"))
+    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    inside, in_job = [], False
+    for l in lines[start:end]:
+        if "TSA_MARK job_begin" in l:
+            in_job = True
+        elif "TSA_MARK job_end" in l:
+            in_job = False
+        elif in_job and l.strip().startswith("scratch_"):
+            inside.append(l.strip())
+    assert not inside, inside
     bench_lds = search["LDS"] + 4 * 4 * ((64 * 256 + 31) // 32)         # + the tile bit sets (pending / running pairs, open, far) of a 4096 x 4096 map (64 x 256 tiles)
     assert 4 * bench_lds <= LDS_PER_CU, bench_lds
     largest_lds = search["LDS"] + 4 * 4 * 2048                          # the largest supported map (65536 tiles): at least two per CU
