@@ -4,6 +4,7 @@
 //   MapProvider::composeMasterMapFromLayerdMap  mc/src/map_provider.cpp:216-223
 //   GridMap::move                          gmc/src/GridMap.cpp:346-412
 #include "engine.hpp"
+#include "compose_dev.hpp"
 
 #include <cmath>
 #include <cstdlib>
@@ -39,9 +40,7 @@ __global__ void compose_dirty_tiles_kernel(float* __restrict__ master, const flo
   }
 }
 
-// GlobalPlanner::ifBlocked predicate (mc/include/move_control/map_global_planner.h:47-50):
-// blocked iff the master value is finite-or-inf (not NaN) and > 0.
-__device__ __forceinline__ bool cell_blocked(float v) { return !(v != v) && v > 0.0f; }
+// (cell_blocked -- GlobalPlanner::ifBlocked's predicate -- lives in compose_dev.hpp)
 
 // Per-cell 8-bit traversable-neighbour mask (DESIGN.md "Grid A* contract"): bit k <-> neighbour
 // (di,dj) in the order (-1,-1),(0,-1),(1,-1),(-1,0),(1,0),(-1,1),(0,1),(1,1); a diagonal needs the
@@ -122,57 +121,8 @@ __global__ void __launch_bounds__(256) compose_nbr_tiles_kernel(uint8_t* __restr
   // ones find them sooner.  RNA_COMPOSE_WGS_PER_CU = 2 / 4 / 8 / 12 / 16 in the loop: 0.44 / 0.37 / 0.30 / 0.29 / 0.29 ms,
   // profiles/r04_sweep_compose_wgs_per_cu.txt).
   __shared__ uint8_t blk[(TILE + 2) * (TILE + 2)];  // [jj][ii], ii fastest; out of map = blocked
-  for (int tt = blockIdx.x; tt < tiles_i * tiles_j; tt += gridDim.x) {
-  const int ti = tt % tiles_i, tj = tt / tiles_i;
-  const unsigned char* dflag = reinterpret_cast<const unsigned char*>(dirty);
-  unsigned dmask = 0u;   // bit (dj + 1) * 3 + (di + 1): that neighbouring tile is dirty
-  for (int dj = -1; dj <= 1; ++dj)
-    for (int di = -1; di <= 1; ++di) {
-      const int a = ti + di, b = tj + dj;
-      if (a < 0 || b < 0 || a >= tiles_i || b >= tiles_j) continue;
-      if (dflag[b * tiles_i + a]) dmask |= 1u << ((dj + 1) * 3 + di + 1);
-    }
-  if (threadIdx.x == 0) reinterpret_cast<volatile unsigned char*>(next_dirty)[tj * tiles_i + ti] = 0;
-  if (!dmask) continue;   // (uniform across the workgroup)
-  const bool own = (dmask >> 4) & 1u;
-  __syncthreads();        // the previous tile's block has been read
-  const int i0 = ti * TILE - 1, j0 = tj * TILE - 1;
-  for (int k = threadIdx.x; k < (TILE + 2) * (TILE + 2); k += blockDim.x) {
-    const int ii = k % (TILE + 2), jj = k / (TILE + 2);
-    const int i = i0 + ii, j = j0 + jj;
-    uint8_t b = 1;
-    if (i >= 0 && j >= 0 && i < rows && j < cols) {
-      const int di = ii == 0 ? 0 : (ii == TILE + 1 ? 2 : 1), dj = jj == 0 ? 0 : (jj == TILE + 1 ? 2 : 1);
-      const size_t lin = (size_t)j * rows + i;
-      const bool from_laser = (dmask >> (dj * 3 + di)) & 1u;
-      const float v = from_laser ? laser[lin] : master[lin];
-      if (own && di == 1 && dj == 1) master[lin] = v;   // the compose itself
-      b = cell_blocked(v) ? 1 : 0;
-    }
-    blk[k] = b;
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < TILE * TILE; k += blockDim.x) {
-    const int li = k & (TILE - 1), lj = k >> 6;
-    const int i = ti * TILE + li, j = tj * TILE + lj;
-    if (i >= rows || j >= cols) continue;
-    const uint8_t* c = &blk[(lj + 1) * (TILE + 2) + (li + 1)];
-    constexpr int S = TILE + 2;
-    unsigned m = 0;
-    if (!c[0]) {
-      const bool up = !c[-1], dn = !c[1], lf = !c[-S], rt = !c[S];
-      if (lf && up && !c[-S - 1]) m |= 1u;        // (-1,-1)
-      if (lf) m |= 2u;                            // ( 0,-1)
-      if (lf && dn && !c[-S + 1]) m |= 4u;        // ( 1,-1)
-      if (up) m |= 8u;                            // (-1, 0)
-      if (dn) m |= 16u;                           // ( 1, 0)
-      if (rt && up && !c[S - 1]) m |= 32u;        // (-1, 1)
-      if (rt) m |= 64u;                           // ( 0, 1)
-      if (rt && dn && !c[S + 1]) m |= 128u;       // ( 1, 1)
-    }
-    nbr[(size_t)j * rows + i] = (uint8_t)m;
-  }
-  }   // next tile
+  for (int tt = blockIdx.x; tt < tiles_i * tiles_j; tt += gridDim.x)
+    compose_nbr_tile(blk, tt, nbr, master, laser, dirty, next_dirty, rows, cols, tiles_i, tiles_j);
 }
 
 // GridMap::clearRows / clearCols on every layer (gmc/src/GridMap.cpp:590-606)
@@ -713,7 +663,18 @@ int side_stream(rna_engine* e, hipStream_t* out) {
   if (!e->vfh_stream) {
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    RNA_HIP(e, hipStreamCreateWithPriority(&e->vfh_stream, hipStreamNonBlocking, prio_hi));
+    // developer knob RNA_SIDE_CU_MASK=n: the side stream (VFH+, mask snapshots, launch orders) may only use the first n CUs of
+    // the mask order, like RNA_ENGINE_CU_MASK for the engine stream
+    int only = 0;
+    if (const char* m = getenv("RNA_SIDE_CU_MASK")) only = atoi(m);
+    if (only > 0 && only < e->cu_count) {
+      uint32_t mask[16] = {};
+      const int words = (e->cu_count + 31) / 32 < 16 ? (e->cu_count + 31) / 32 : 16;
+      for (int c = 0; c < only && c < 512; ++c) mask[c >> 5] |= 1u << (c & 31);
+      RNA_HIP(e, hipExtStreamCreateWithCUMask(&e->vfh_stream, (uint32_t)words, mask));
+    } else {
+      RNA_HIP(e, hipStreamCreateWithPriority(&e->vfh_stream, hipStreamNonBlocking, prio_hi));
+    }
     RNA_HIP(e, hipEventCreateWithFlags(&e->ev_vfh_go, hipEventDisableTiming));
     RNA_HIP(e, hipEventCreateWithFlags(&e->ev_vfh_done, hipEventDisableTiming));
   }
@@ -744,9 +705,10 @@ int sync_all(rna_engine* e) {
 }
 
 int profile_flush(rna_engine* e) {
-  if (e->pending_events == 0) return RNA_OK;
+  if (e->pending_events == 0 && !(e->profiling == 1 && e->himm.fused_ticks)) return RNA_OK;
   int src = sync_all(e);
   if (src != RNA_OK) return src;
+  if ((src = himm_profile_drain(e)) != RNA_OK) return src;
   for (auto& slot : e->prof) {
     for (auto& pr : slot.pending) {
       float ms = 0;

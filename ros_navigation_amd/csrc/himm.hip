@@ -25,6 +25,7 @@
 // 61 MB the batch needs (rays from one origin re-touch the same lines hundreds of times).  Per tile it is at most
 // one read and one write of 16 KB.
 #include "engine.hpp"
+#include "compose_dev.hpp"
 
 #include <algorithm>
 
@@ -94,24 +95,25 @@ __global__ void himm_init_slots_kernel(HimmSlot* __restrict__ slots, int n_slots
   if (i == 0) *total = 0;
 }
 
-__global__ void himm_prep_kernel(Geom g, const rna_ray* __restrict__ rays, int n, int4* __restrict__ desc,
-                                 int* __restrict__ ncells, int* __restrict__ next, HimmSlot* __restrict__ slots,
-                                 int slot_mask, unsigned* __restrict__ mark_bitmap, int4 win) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n) return;
+// one ray: clipping, cell count, mark registration; returns the cell count and leaves the clipped ends in `d`
+__device__ __forceinline__ int himm_prep_ray(const Geom& g, const rna_ray* __restrict__ rays, int r, int4* __restrict__ desc,
+                                             int* __restrict__ ncells, int* __restrict__ next, HimmSlot* __restrict__ slots,
+                                             int slot_mask, unsigned* __restrict__ mark_bitmap, int4 win, int4& d) {
   const rna_ray ray = rays[r];
   int s[2], t[2];
   int nc = 0;
+  d = make_int4(0, 0, 0, 0);
   if (!ray_well_formed(g, ray)) {
     ncells[r] = 0;
     next[r] = -1;
-    return;
+    return 0;
   }
   if (index_limited_to_map(g, ray.sx, ray.sy, ray.ex, ray.ey, s) &&
       index_limited_to_map(g, ray.ex, ray.ey, ray.sx, ray.sy, t)) {
     const int dx = abs(t[0] - s[0]), dy = abs(t[1] - s[1]);
     nc = (dx >= dy ? dx : dy) + 1;
-    desc[r] = make_int4(s[0], s[1], t[0], t[1]);
+    d = make_int4(s[0], s[1], t[0], t[1]);
+    desc[r] = d;
   }
   ncells[r] = nc;
   next[r] = -1;
@@ -131,6 +133,16 @@ __global__ void himm_prep_kernel(Geom g, const rna_ray* __restrict__ rays, int n
       atomicOr(&mark_bitmap[cell >> 5], 1u << (cell & 31));
     }
   }
+  return nc;
+}
+
+__global__ void himm_prep_kernel(Geom g, const rna_ray* __restrict__ rays, int n, int4* __restrict__ desc,
+                                 int* __restrict__ ncells, int* __restrict__ next, HimmSlot* __restrict__ slots,
+                                 int slot_mask, unsigned* __restrict__ mark_bitmap, int4 win) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  int4 d;
+  (void)himm_prep_ray(g, rays, r, desc, ncells, next, slots, slot_mask, mark_bitmap, win, d);
 }
 
 __device__ void sift_down(int* a, int start, int end) {
@@ -144,31 +156,31 @@ __device__ void sift_down(int* a, int start, int end) {
   }
 }
 
-__global__ void __launch_bounds__(1024) himm_collect_kernel(HimmSlot* __restrict__ slots, int n_slots, const int* __restrict__ next,
-                                    int* __restrict__ seqs, unsigned* __restrict__ before,
-                                    unsigned* __restrict__ after, int* __restrict__ total) {
-  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+// one hash slot per thread, a workgroup's worth of slots at a time (all threads of the workgroup call: three barriers inside);
+// s_wave: one int per wavefront of the workgroup, s_base: one int
+__device__ __forceinline__ void himm_collect_slot(int h, HimmSlot* __restrict__ slots, int n_slots, const int* __restrict__ next,
+                                                  int* __restrict__ seqs, unsigned* __restrict__ before,
+                                                  unsigned* __restrict__ after, int* __restrict__ total, int* s_wave, int* s_base) {
   HimmSlot sl = h < n_slots ? slots[h] : HimmSlot{-1, -1, 0, 0};
   const bool live = sl.cell >= 0;
   // One atomic per WORKGROUP on the shared running total: returning atomics on one L2 address take ~12 ns each, and the
   // compiler's one-per-wavefront aggregation still left 4096 of them -- 49 of the kernel's 51 us.
   int off = 0;
   {
-    __shared__ int s_wave[16];
-    __shared__ int s_base;
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int wv = threadIdx.x >> 6, nwv = (blockDim.x + 63) >> 6;
     int incl = live ? sl.len : 0;
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    __syncthreads();   // (the previous chunk's offsets have been read)
     if (lane == 63) s_wave[wv] = incl;
     __syncthreads();
     if (threadIdx.x == 0) {
       int run = 0;
       for (int w = 0; w < nwv; ++w) { const int t = s_wave[w]; s_wave[w] = run; run += t; }
-      s_base = run > 0 ? atomicAdd(total, run) : 0;
+      *s_base = run > 0 ? atomicAdd(total, run) : 0;
     }
     __syncthreads();
-    off = s_base + s_wave[wv] + incl - (live ? sl.len : 0);
+    off = *s_base + s_wave[wv] + incl - (live ? sl.len : 0);
   }
   if (!live) return;
   slots[h].offset = off;
@@ -193,6 +205,14 @@ __global__ void __launch_bounds__(1024) himm_collect_kernel(HimmSlot* __restrict
     }
   }
   for (int i = 0; i < len; ++i) { before[off + i] = 0; after[off + i] = 0; }
+}
+
+__global__ void __launch_bounds__(1024) himm_collect_kernel(HimmSlot* __restrict__ slots, int n_slots, const int* __restrict__ next,
+                                    int* __restrict__ seqs, unsigned* __restrict__ before,
+                                    unsigned* __restrict__ after, int* __restrict__ total) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  himm_collect_slot(blockIdx.x * blockDim.x + threadIdx.x, slots, n_slots, next, seqs, before, after, total, s_wave, &s_base);
 }
 
 // ---- rays -> tiles ------------------------------------------------------------------------------------------------
@@ -270,23 +290,22 @@ __global__ void himm_bin_count_kernel(const int4* __restrict__ desc, const int* 
 // list of the tiles that hold at least one ray: the rasteriser's workgroups take (tile, half) jobs from that list with a
 // ticket instead of one workgroup per half tile of the map -- of the 8192 half tiles of a 4096^2 map a 100 k-ray batch
 // touches ~1500, and next to the search workgroups that fill every CU each EMPTY workgroup still had to wait for a slot.
-__global__ void __launch_bounds__(1024) himm_bin_scan_kernel(int* __restrict__ tile_count, int ntile, int* __restrict__ tile_off,
-                                                             int* __restrict__ tile_cursor, int4* __restrict__ active,
-                                                             int* __restrict__ n_active, int* __restrict__ ticket) {
-  __shared__ int s_part[1024];
-  __shared__ int s_act[1024];    // tiles with many rays: their jobs go first (the longest jobs must not be the last ones started)
-  __shared__ int s_act2[1024];   // the other tiles with rays
+template <int NT>   // threads of the (one) workgroup that runs it; LDS: three arrays of NT ints
+__device__ __forceinline__ void himm_bin_scan(int* __restrict__ tile_count, int ntile, int* __restrict__ tile_off,
+                                              int* __restrict__ tile_cursor, int4* __restrict__ active,
+                                              int* __restrict__ n_active, int* __restrict__ ticket, int* s_part, int* s_act, int* s_act2) {
+  // s_act: tiles with many rays -- their jobs go first (the longest jobs must not be the last ones started); s_act2: the other tiles with rays
   constexpr int HEAVY = 512;     // rays: more than one round of a rasteriser workgroup
-  const int per = (ntile + 1023) / 1024;
-  const int lo = threadIdx.x * per, hi = min(ntile, lo + per);
+  const int per = (ntile + NT - 1) / NT;
+  const int lo = min(ntile, (int)threadIdx.x * per), hi = min(ntile, lo + per);
   int sum = 0, nact = 0, nact2 = 0;
   for (int t = lo; t < hi; ++t) { const int c = tile_count[t]; sum += c; nact += c >= HEAVY; nact2 += c > 0 && c < HEAVY; }
   s_part[threadIdx.x] = sum;
   s_act[threadIdx.x] = nact;
   s_act2[threadIdx.x] = nact2;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const bool in = threadIdx.x >= o;
+  for (int o = 1; o < NT; o <<= 1) {
+    const bool in = (int)threadIdx.x >= o;
     const int v = in ? s_part[threadIdx.x - o] : 0, a = in ? s_act[threadIdx.x - o] : 0, a2 = in ? s_act2[threadIdx.x - o] : 0;
     __syncthreads();
     s_part[threadIdx.x] += v;
@@ -294,7 +313,7 @@ __global__ void __launch_bounds__(1024) himm_bin_scan_kernel(int* __restrict__ t
     s_act2[threadIdx.x] += a2;
     __syncthreads();
   }
-  const int n_heavy = s_act[1023];
+  const int n_heavy = s_act[NT - 1];
   int run = s_part[threadIdx.x] - sum, arun = s_act[threadIdx.x] - nact, arun2 = n_heavy + s_act2[threadIdx.x] - nact2;
   for (int t = lo; t < hi; ++t) {
     const int c = tile_count[t];
@@ -304,7 +323,16 @@ __global__ void __launch_bounds__(1024) himm_bin_scan_kernel(int* __restrict__ t
     else if (c > 0) active[arun2++] = make_int4(t, run - c, c, 0);
     tile_count[t] = 0;   // (counts: zero again for the next batch)
   }
-  if (threadIdx.x == 1023) { tile_off[ntile] = s_part[1023]; *n_active = s_act[1023] + s_act2[1023]; *ticket = 0; }
+  if (threadIdx.x == NT - 1) { tile_off[ntile] = s_part[NT - 1]; *n_active = s_act[NT - 1] + s_act2[NT - 1]; *ticket = 0; }
+}
+
+__global__ void __launch_bounds__(1024) himm_bin_scan_kernel(int* __restrict__ tile_count, int ntile, int* __restrict__ tile_off,
+                                                             int* __restrict__ tile_cursor, int4* __restrict__ active,
+                                                             int* __restrict__ n_active, int* __restrict__ ticket) {
+  __shared__ int s_part[1024];
+  __shared__ int s_act[1024];
+  __shared__ int s_act2[1024];
+  himm_bin_scan<1024>(tile_count, ntile, tile_off, tile_cursor, active, n_active, ticket, s_part, s_act, s_act2);
 }
 
 __global__ void himm_bin_fill_kernel(const int4* __restrict__ desc, const int* __restrict__ ncells, int n, int tiles_i,
@@ -369,7 +397,21 @@ constexpr int HIMM_TR_ROWS = RNA_HIMM_TR_ROWS;
 #define RNA_HIMM_TR_THREADS 512
 #endif
 constexpr int HIMM_TR_THREADS = RNA_HIMM_TR_THREADS;   // (a power of two: the lane -> ray permutation of the rasteriser relies on it) // 8 wavefronts: two per SIMD next to the four of a resident search workgroup
-__global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int rows, int cols, int tiles_i, const int4* __restrict__ desc,
+// LDS of a rasteriser workgroup
+struct RasterLds {
+  unsigned cnt[HIMM_TR_ROWS * 64];   // clears per cell of this job's rows, index (j - j0) * 64 + (i & 63)
+  unsigned mark[HIMM_TR_ROWS * 2];   // mark bits of those cells: word lc >> 5, bit lc & 31
+  unsigned short mrank[HIMM_TR_ROWS * 2];   // marked cells in the words before this one
+  int moff[HIMM_MTAB];     // per marked cell (by rank): offset of its marks in seqs / before / after, -1: not a single-mark cell
+  int mseq[HIMM_MTAB];     // ... the ray sequence number of its one mark
+  unsigned mcnt[2 * HIMM_MTAB];   // ... clears before / after that mark
+  int touched, job;
+  int4 rec;
+};
+
+// the (tile, half) jobs of a batch, taken by the calling workgroup (HIMM_TR_THREADS threads): `first_job` first, then by
+// ticket (`grid` = workgroups that take part)
+__device__ __forceinline__ void himm_raster_jobs(RasterLds& L, const int first_job, const int grid, int rows, int cols, int tiles_i, const int4* __restrict__ desc,
                                                                const int* __restrict__ ncells,
                                                                const int* __restrict__ tile_off, const int* __restrict__ pairs,
                                                                const int4* __restrict__ active, const int* __restrict__ n_active,
@@ -378,14 +420,7 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
                                                                const HimmSlot* __restrict__ slots, int slot_mask,
                                                                const int* __restrict__ seqs, unsigned* __restrict__ before,
                                                                unsigned* __restrict__ after, unsigned* __restrict__ dirty_tiles, int4 win) {
-  __shared__ unsigned s_cnt[HIMM_TR_ROWS * 64];   // clears per cell of this job's rows, index (j - j0) * 64 + (i & 63)
-  __shared__ unsigned s_mark[HIMM_TR_ROWS * 2];   // mark bits of those cells: word lc >> 5, bit lc & 31
-  __shared__ unsigned short s_mrank[HIMM_TR_ROWS * 2];   // marked cells in the words before this one
-  __shared__ int s_moff[HIMM_MTAB];     // per marked cell (by rank): offset of its marks in seqs / before / after, -1: not a single-mark cell
-  __shared__ int s_mseq[HIMM_MTAB];     // ... the ray sequence number of its one mark
-  __shared__ unsigned s_mcnt[2 * HIMM_MTAB];   // ... clears before / after that mark
-  __shared__ int s_touched, s_job;
-  __shared__ int4 s_rec;
+
   constexpr int JPT = 64 / HIMM_TR_ROWS, NW = HIMM_TR_ROWS * 2;   // jobs per 64 x 64 tile; words of mark bits per job
   const int njobs = JPT * *n_active;
   // Which ray of a round a lane takes (-1: none).  A round is up to HIMM_TR_THREADS rays; a shorter one is dealt to the
@@ -407,7 +442,7 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
   // NEXT job are fetched by thread 0 while this job runs; the barriers only order LDS (s_waitcnt lgkmcnt(0) + s_barrier:
   // __syncthreads() would drain the global loads in flight at every barrier), so each step's loads are issued before the
   // previous step's LDS work; and the cells to rewrite are loaded all at once.
-  int job = (int)blockIdx.x;
+  int job = first_job;
   int4 rec = job < njobs ? active[job / JPT] : make_int4(0, 0, 0, 0);   // tile, its first (tile, ray) pair, its pairs (> 0)
   for (;;) {
   if (job >= njobs) break;
@@ -434,40 +469,40 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
         for (int b = 0; b < 32 && ib + b < rows; ++b) bits |= ((mark_bitmap[(cell + b) >> 5] >> ((cell + b) & 31)) & 1u) << b;
     }
   }
-  for (int c = threadIdx.x; c < HIMM_TR_ROWS * 64; c += HIMM_TR_THREADS) s_cnt[c] = 0u;
-  for (int c = threadIdx.x; c < 2 * HIMM_MTAB; c += HIMM_TR_THREADS) s_mcnt[c] = 0u;
-  for (int c = threadIdx.x; c < HIMM_MTAB; c += HIMM_TR_THREADS) s_moff[c] = -1;
-  if (threadIdx.x == 0) s_touched = 0;
+  for (int c = threadIdx.x; c < HIMM_TR_ROWS * 64; c += HIMM_TR_THREADS) L.cnt[c] = 0u;
+  for (int c = threadIdx.x; c < 2 * HIMM_MTAB; c += HIMM_TR_THREADS) L.mcnt[c] = 0u;
+  for (int c = threadIdx.x; c < HIMM_MTAB; c += HIMM_TR_THREADS) L.moff[c] = -1;
+  if (threadIdx.x == 0) L.touched = 0;
   // round trip 2: the ray itself (used after the marked cells have been looked up)
   int4 d0 = make_int4(0, 0, 0, 0);
   int nc0 = 0;
   if (r0 >= 0) { d0 = desc[r0]; nc0 = ncells[r0]; }
-  if (threadIdx.x < NW) s_mark[threadIdx.x] = bits;
+  if (threadIdx.x < NW) L.mark[threadIdx.x] = bits;
   himm_lds_barrier();
   HST(t_1);
   if (threadIdx.x < 64) {   // marked cells in the words before this one: a prefix sum across the first wavefront (NW / 64 words per lane)
     constexpr int PER = NW / 64;
     int mine_n = 0;
-    for (int k = 0; k < PER; ++k) mine_n += __popc(s_mark[threadIdx.x * PER + k]);
+    for (int k = 0; k < PER; ++k) mine_n += __popc(L.mark[threadIdx.x * PER + k]);
     int incl = mine_n;
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if ((int)threadIdx.x >= o) incl += v; }
     int run = incl - mine_n;
-    for (int k = 0; k < PER; ++k) { s_mrank[threadIdx.x * PER + k] = (unsigned short)run; run += __popc(s_mark[threadIdx.x * PER + k]); }
+    for (int k = 0; k < PER; ++k) { L.mrank[threadIdx.x * PER + k] = (unsigned short)run; run += __popc(L.mark[threadIdx.x * PER + k]); }
   }
   himm_lds_barrier();
   // one hash probe per marked cell of the half tile (also round trip 2): the slot is one 16-byte load, and a cell with
   // a single mark has that mark's ray in `head`
   for (int w = threadIdx.x >> 5, b = threadIdx.x & 31; w < NW; w += HIMM_TR_THREADS / 32) {
-    if (!((s_mark[w] >> b) & 1u)) continue;
+    if (!((L.mark[w] >> b) & 1u)) continue;
     const int lc = (w << 5) + b;
-    s_cnt[lc] = 0x80000000u;   // "marked": seen by the walk in the value its add returns (zeroed before the first barrier)
-    const int rank = s_mrank[w] + __popc(s_mark[w] & ((1u << b) - 1u));
+    L.cnt[lc] = 0x80000000u;   // "marked": seen by the walk in the value its add returns (zeroed before the first barrier)
+    const int rank = L.mrank[w] + __popc(L.mark[w] & ((1u << b) - 1u));
     if (rank >= HIMM_MTAB) continue;
     const int cell = (j0 + (lc >> 6)) * rows + i0 + (lc & 63);
     unsigned h = hash_cell((unsigned)cell) & (unsigned)slot_mask;
     int4 sl = *reinterpret_cast<const int4*>(&slots[h]);   // cell, head, len, offset
     while (sl.x != cell) { h = (h + 1) & (unsigned)slot_mask; sl = *reinterpret_cast<const int4*>(&slots[h]); }
-    if (sl.z == 1) { s_moff[rank] = sl.w; s_mseq[rank] = sl.y; }
+    if (sl.z == 1) { L.moff[rank] = sl.w; L.mseq[rank] = sl.y; }
   }
   HST(t_2);
   himm_lds_barrier();
@@ -529,20 +564,20 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
     // One LDS operation per cell: the counter of a MARKED cell carries bit 31 (set by the prologue), and the add returns
     // the old value -- which is looked at one step later, when the next cell's add is already on its way (with a read of
     // the mark bits in front of every add a step was two dependent LDS round trips, ~300 cycles; 8.7 of a job's 14.5 us).
-    // A marked cell's clear belongs to an interval between that cell's marks, not to s_cnt (whose value for such a cell
+    // A marked cell's clear belongs to an interval between that cell's marks, not to L.cnt (whose value for such a cell
     // is never used).
     auto marked_clear = [&](int c) {
-      const unsigned mw = s_mark[c >> 5];
-      const int rank = s_mrank[c >> 5] + __popc(mw & ((1u << (c & 31)) - 1u));
-      const int off = rank < HIMM_MTAB ? s_moff[rank] : -1;
+      const unsigned mw = L.mark[c >> 5];
+      const int rank = L.mrank[c >> 5] + __popc(mw & ((1u << (c & 31)) - 1u));
+      const int off = rank < HIMM_MTAB ? L.moff[rank] : -1;
       // the clear belongs to the interval before the first mark with seq >= r
-      if (off >= 0) atomicAdd(&s_mcnt[2 * rank + (s_mseq[rank] < r ? 1 : 0)], 1u);
+      if (off >= 0) atomicAdd(&L.mcnt[2 * rank + (L.mseq[rank] < r ? 1 : 0)], 1u);
       else himm_count_marked_clear((j0 + (c >> 6)) * rows + i0 + (c & 63), r, slots, slot_mask, seqs, before, after);
     };
     unsigned old_prev = 0u;
     int lc_prev = 0;
     for (int k = k_lo; k <= k_hi; ++k) {
-      const unsigned old = atomicAdd(&s_cnt[lc], 1u);
+      const unsigned old = atomicAdd(&L.cnt[lc], 1u);
       if (old_prev >> 31) marked_clear(lc_prev);
       old_prev = old;
       lc_prev = lc;
@@ -553,24 +588,24 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
     if (old_prev >> 31) marked_clear(lc_prev);
   }
   HST(t_4);
-  if (touched) s_touched = 1;
+  if (touched) L.touched = 1;
   // the next job: its ticket has long arrived; its record is loaded now, next to the cells this job rewrites
   int4 rec_next = make_int4(0, 0, 0, 0);
   int job_next = 0;
   if (threadIdx.x == 0) {
-    job_next = (int)gridDim.x + next_ticket;
+    job_next = grid + next_ticket;
     if (job_next < njobs) rec_next = active[job_next / JPT];
   }
   himm_lds_barrier();
   HST(t_5);
-  if (s_touched) {
+  if (L.touched) {
     // flags exist for the laser layer only ("laser differs from master here")
     if (threadIdx.x == 0 && dirty_tiles) reinterpret_cast<volatile unsigned char*>(dirty_tiles)[t] = 1;
     for (int c = threadIdx.x; c < HIMM_MTAB; c += HIMM_TR_THREADS)
-      if (s_moff[c] >= 0) {
-        const unsigned kb = s_mcnt[2 * c], ka = s_mcnt[2 * c + 1];
-        if (kb) atomicAdd(&before[s_moff[c]], kb);
-        if (ka) atomicAdd(&after[s_moff[c]], ka);
+      if (L.moff[c] >= 0) {
+        const unsigned kb = L.mcnt[2 * c], ka = L.mcnt[2 * c + 1];
+        if (kb) atomicAdd(&before[L.moff[c]], kb);
+        if (ka) atomicAdd(&after[L.moff[c]], ka);
       }
     // apply: lanes run along i (contiguous in the column-major layer); only cells that were counted are touched.  All of
     // a thread's cells are loaded before the first is used (one memory round trip, not one per cell).
@@ -579,7 +614,7 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
     float vv[PER_T];
 #pragma unroll
     for (int u = 0; u < PER_T; ++u) {
-      kk[u] = s_cnt[threadIdx.x + u * HIMM_TR_THREADS];
+      kk[u] = L.cnt[threadIdx.x + u * HIMM_TR_THREADS];
       if (kk[u] >> 31) kk[u] = 0u;   // a marked cell: rewritten by himm_apply from its interval counters
     }
 #pragma unroll
@@ -596,21 +631,35 @@ __global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int r
     }
   }
   HST(t_6);
-  if (threadIdx.x == 0) { s_job = job_next; s_rec = rec_next; }
+  if (threadIdx.x == 0) { L.job = job_next; L.rec = rec_next; }
   himm_lds_barrier();   // this job's LDS has been read; the next job is known
   HST(t_7);
   HACC(0, t_0, t_1); HACC(1, t_1, t_2); HACC(2, t_2, t_3); HACC(3, t_3, t_4); HACC(4, t_4, t_5); HACC(5, t_5, t_6); HACC(6, t_6, t_7);
   HCNT(7, 1); HCNT(8, np);
-  job = s_job;
-  rec = s_rec;
+  job = L.job;
+  rec = L.rec;
   }   // next job
 }
 
-__global__ void himm_apply_kernel(int rows, HimmSlot* __restrict__ slots, int n_slots, int* __restrict__ total,
-                                  const unsigned* __restrict__ before, const unsigned* __restrict__ after,
-                                  float* __restrict__ layer, unsigned* __restrict__ mark_bitmap,
-                                  unsigned* __restrict__ dirty_tiles, int tiles_i) {
-  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(HIMM_TR_THREADS) himm_tile_raster_kernel(int rows, int cols, int tiles_i, const int4* __restrict__ desc,
+                                                               const int* __restrict__ ncells,
+                                                               const int* __restrict__ tile_off, const int* __restrict__ pairs,
+                                                               const int4* __restrict__ active, const int* __restrict__ n_active,
+                                                               int* __restrict__ ticket,
+                                                               float* __restrict__ layer, const unsigned* __restrict__ mark_bitmap,
+                                                               const HimmSlot* __restrict__ slots, int slot_mask,
+                                                               const int* __restrict__ seqs, unsigned* __restrict__ before,
+                                                               unsigned* __restrict__ after, unsigned* __restrict__ dirty_tiles, int4 win) {
+  __shared__ RasterLds L;
+  himm_raster_jobs(L, (int)blockIdx.x, (int)gridDim.x, rows, cols, tiles_i, desc, ncells, tile_off, pairs, active, n_active, ticket, layer, mark_bitmap,
+                   slots, slot_mask, seqs, before, after, dirty_tiles, win);
+}
+
+// one hash slot: the ordered replay on its marked cell; leaves bitmap and table empty for the next batch
+__device__ __forceinline__ void himm_apply_slot(int h, int rows, HimmSlot* __restrict__ slots, int n_slots, int* __restrict__ total,
+                                                const unsigned* __restrict__ before, const unsigned* __restrict__ after,
+                                                float* __restrict__ layer, unsigned* __restrict__ mark_bitmap,
+                                                unsigned* __restrict__ dirty_tiles, int tiles_i) {
   if (h == 0) *total = 0;   // (himm_collect, the only user, has finished)
   if (h >= n_slots) return;
   const HimmSlot sl = slots[h];
@@ -628,6 +677,126 @@ __global__ void himm_apply_kernel(int rows, HimmSlot* __restrict__ slots, int n_
   const int tile = (j >> 6) * tiles_i + (i >> 6);
   // (most of the ~50 marked cells of a tile find the flag set already: a cached read instead of a store each)
   if (dirty_tiles && reinterpret_cast<volatile unsigned char*>(dirty_tiles)[tile] != 1) reinterpret_cast<volatile unsigned char*>(dirty_tiles)[tile] = 1;
+}
+
+__global__ void himm_apply_kernel(int rows, HimmSlot* __restrict__ slots, int n_slots, int* __restrict__ total,
+                                  const unsigned* __restrict__ before, const unsigned* __restrict__ after,
+                                  float* __restrict__ layer, unsigned* __restrict__ mark_bitmap,
+                                  unsigned* __restrict__ dirty_tiles, int tiles_i) {
+  himm_apply_slot(blockIdx.x * blockDim.x + threadIdx.x, rows, slots, n_slots, total, before, after, layer, mark_bitmap, dirty_tiles, tiles_i);
+}
+
+
+// ---- the whole map update as ONE kernel (round 5) -------------------------------------------------------------------------
+// MapProvider::updateMap (mc/src/map_provider.cpp:190-223) used to be ten dependent launches: prep, collect, bin count / scan /
+// fill, raster, apply, compose + masks.  Alone they take 0.18 ms; in the replan loop, next to sixteen streams of searches,
+// 1.15 ms -- every launch of the chain pays ~70 us of dispatch latency whatever it does (the one-workgroup bin scan: 8 us alone,
+// 67 us in the loop; profiles/r04_engine_timeline.txt), and their workgroups land on the searches' CUs whenever one frees up.
+// Here the same device code runs as the phases of one persistent kernel: a fixed, small number of workgroups (all resident
+// at once), grid-stride or ticket loops inside a phase, a device-wide barrier between phases.  Results are those of the chain
+// (same functions, same order of the order-sensitive steps).
+// The barrier: one counter per phase in device memory, never reset -- the launch's target is the running total of arrivals
+// (`target`, kept by the host); release / acquire fences at agent scope on both sides, so what other workgroups (other XCDs)
+// wrote before it is read after it.  A workgroup that waits longer than five seconds traps: a launch whose workgroups cannot all
+// be resident fails loudly instead of hanging the GPU.
+struct HimmFused {
+  Geom g;
+  const rna_ray* rays;
+  int n;
+  int4* desc; int* ncells; int* next; HimmSlot* slots; int n_slots; unsigned* mark_bitmap; int4 win;
+  int* seqs; unsigned* before; unsigned* after; int* total;
+  int tiles_i, tiles_j; int* tile_count; int* tile_off; int* tile_cursor; int4* active; int* n_active; int* ticket; int* pairs;
+  float* layer; unsigned* dirty_tiles;
+  int do_compose; uint8_t* nbr; float* master; const float* laser; const unsigned* cdirty; unsigned* next_dirty;
+  unsigned* bar; unsigned target;   // target: what the counters of the barriers EVERY launch passes read when all have arrived ...
+  unsigned target_compose;          // ... and the one only launches with a compose phase pass
+  unsigned long long* phase_ticks;   // (may be null) 100 MHz ticks per phase, summed over launches, + a launch count
+};
+constexpr int HIMM_FUSED_PHASES = 6;
+
+__device__ __forceinline__ void himm_grid_barrier(unsigned* counter, unsigned target) {
+  __threadfence();     // this thread's writes are visible device-wide before its workgroup arrives
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > 500000000ull) __builtin_trap();   // 5 s of the 100 MHz clock
+    }
+  }
+  __syncthreads();
+  __threadfence();     // nothing cached before the barrier is read after it
+  __builtin_amdgcn_s_dcache_inv();
+}
+
+union HimmFusedLds {
+  RasterLds raster;
+  int scan[3 * HIMM_TR_THREADS];
+  uint8_t blk[COMPOSE_BLK_BYTES];
+  int collect[20];
+};
+
+__global__ void __launch_bounds__(HIMM_TR_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) himm_fused_kernel(const HimmFused A) {   // (64 VGPRs: four workgroups per CU)
+  constexpr int NT = HIMM_TR_THREADS;
+  __shared__ HimmFusedLds U;
+  const int G = (int)gridDim.x, tid = (int)threadIdx.x;
+  const int ntile = A.tiles_i * A.tiles_j;
+  unsigned long long t_prev = 0;
+  const bool timed = A.phase_ticks != nullptr && blockIdx.x == 0 && tid == 0;
+  if (timed) t_prev = wall_clock64();
+  int phase = 0;
+  auto end_phase = [&](bool barrier) {
+    if (barrier) himm_grid_barrier(A.bar + phase, phase == 4 ? A.target_compose : A.target);
+    if (timed) { const unsigned long long t = wall_clock64(); atomicAdd(&A.phase_ticks[phase], t - t_prev); t_prev = t; }
+    ++phase;
+  };
+  // phase 0: clip the rays, register the marks, count the rays per 64 x 64 tile (himm_prep + himm_bin_count)
+  for (int base = (int)blockIdx.x * NT; base < A.n; base += G * NT) {
+    const int r = base + tid;
+    int4 d = make_int4(0, 0, 0, 0);
+    int nc = 0;
+    if (r < A.n) nc = himm_prep_ray(A.g, A.rays, r, A.desc, A.ncells, A.next, A.slots, A.n_slots - 1, A.mark_bitmap, A.win, d);
+    const RayWalk w(d, nc);
+    w.for_each_tile_lockstep(A.tiles_i, [&](bool act, int t) { (void)wave_tile_add(A.tile_count, act, t); });
+  }
+  end_phase(true);
+  // phase 1: the marks of every marked cell in ray order (himm_collect); workgroup 0 first turns the tile counts into offsets and
+  // the list of tiles with rays (himm_bin_scan)
+  if (blockIdx.x == 0) {
+    himm_bin_scan<NT>(A.tile_count, ntile, A.tile_off, A.tile_cursor, A.active, A.n_active, A.ticket, U.scan, U.scan + NT, U.scan + 2 * NT);
+    __syncthreads();
+  }
+  for (int base = (int)blockIdx.x * NT; base < A.n_slots; base += G * NT)
+    himm_collect_slot(base + tid, A.slots, A.n_slots, A.next, A.seqs, A.before, A.after, A.total, U.collect, U.collect + 16);
+  end_phase(true);
+  // phase 2: the (tile, ray) pairs, grouped by tile (himm_bin_fill)
+  for (int base = (int)blockIdx.x * NT; base < A.n; base += G * NT) {
+    const int r = base + tid;
+    const int nc = r < A.n ? A.ncells[r] : 0;
+    const RayWalk w(nc ? A.desc[r] : make_int4(0, 0, 0, 0), nc);
+    w.for_each_tile_lockstep(A.tiles_i, [&](bool act, int t) {
+      const int slot = wave_tile_add(A.tile_cursor, act, t);
+      if (act) A.pairs[A.tile_off[t] + slot] = r;
+    });
+  }
+  end_phase(true);
+  // phase 3: clears counted per cell in LDS, every touched line of the layer read once and written once (himm_tile_raster)
+  __syncthreads();
+  himm_raster_jobs(U.raster, (int)blockIdx.x, G, A.g.size[0], A.g.size[1], A.tiles_i, A.desc, A.ncells, A.tile_off, A.pairs, A.active, A.n_active,
+                   A.ticket, A.layer, A.mark_bitmap, A.slots, A.n_slots - 1, A.seqs, A.before, A.after, A.dirty_tiles, A.win);
+  end_phase(true);
+  // phase 4: the ordered replay on the marked cells (himm_apply)
+  for (int h = (int)blockIdx.x * NT + tid; h < A.n_slots; h += G * NT)
+    himm_apply_slot(h, A.g.size[0], A.slots, A.n_slots, A.total, A.before, A.after, A.layer, A.mark_bitmap, A.dirty_tiles, A.tiles_i);
+  if (!A.do_compose) { end_phase(false); if (timed) atomicAdd(&A.phase_ticks[HIMM_FUSED_PHASES], 1ull); return; }
+  end_phase(true);
+  // phase 5: master = laser on the dirty tiles and the neighbour masks of those tiles and their ring (compose_nbr_tiles_kernel)
+  __syncthreads();
+  for (int tt = (int)blockIdx.x; tt < ntile; tt += G)
+    compose_nbr_tile(U.blk, tt, A.nbr, A.master, A.laser, A.cdirty, A.next_dirty, A.g.size[0], A.g.size[1], A.tiles_i, A.tiles_j);
+  end_phase(false);
+  if (timed) { atomicAdd(&A.phase_ticks[HIMM_FUSED_PHASES], 1ull); atomicAdd(&A.phase_ticks[HIMM_FUSED_PHASES + 1], 1ull); }
 }
 
 // (tile, ray) pairs of a batch.  Worst case: a ray is registered with at most two tiles per 64-cell tile column it crosses,
@@ -664,6 +833,12 @@ int ensure_scratch(rna_engine* e, int n) {
     const size_t bins = himm_bins_active_at((size_t)e->tiles_i * e->tiles_j) + (size_t)4 * e->tiles_i * e->tiles_j;
     if ((rc = dev_alloc(e, &s.tile_bins, bins)) != RNA_OK) return rc;
     RNA_HIP(e, hipMemsetAsync(s.tile_bins, 0, bins * sizeof(int), e->stream));
+    // the fused kernel's phase barriers (counters that only ever grow) and its phase timers
+    if ((rc = dev_alloc(e, &s.fused_bar, (size_t)16)) != RNA_OK) return rc;
+    RNA_HIP(e, hipMemsetAsync(s.fused_bar, 0, 16 * sizeof(unsigned), e->stream));
+    if ((rc = dev_alloc(e, &s.fused_ticks, (size_t)16)) != RNA_OK) return rc;
+    RNA_HIP(e, hipMemsetAsync(s.fused_ticks, 0, 16 * sizeof(unsigned long long), e->stream));
+    s.fused_target = s.fused_target_compose = 0;
   }
   if (n <= s.cap_rays) return RNA_OK;
   int cap = 1024;
@@ -692,7 +867,56 @@ int ensure_scratch(rna_engine* e, int n) {
   return RNA_OK;
 }
 
+// How many workgroups the fused kernel gets.  All of them have to be resident at once (they meet at barriers), and several
+// engines may share a GPU (ranks of a test, the 8-rank rehearsals): few enough that any number of such kernels fits the chip
+// next to each other -- 64 workgroups of 8 wavefronts are a sixteenth of the chip's wave slots.  RNA_HIMM_FUSED_WGS overrides it
+// (developer knob); 0 switches the fused kernel off (the chain of separate launches).
+static int himm_fused_wgs(const rna_engine* e) {
+  static const int env = [] { const char* v = getenv("RNA_HIMM_FUSED_WGS"); return v ? atoi(v) : -1; }();
+  if (env >= 0) return std::min(env, 1024);
+  return std::min(64, e->cu_count);
+}
+
+// HIMM batch (+ compose when `do_compose`) as one launch of himm_fused_kernel; the caller has checked that the batch qualifies
+static int himm_fused_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n, bool do_compose) {
+  HimmScratch& s = e->himm;
+  const Geom g = e->geom;
+  int n_slots = 1024;
+  while (n_slots < 2 * n) n_slots <<= 1;
+  if (n_slots > s.n_slots) n_slots = s.n_slots;
+  const int ntile = e->tiles_i * e->tiles_j;
+  const int G = himm_fused_wgs(e);
+  HimmFused A;
+  A.g = g; A.rays = rays_dev; A.n = n;
+  A.desc = s.desc; A.ncells = s.ncells; A.next = s.next; A.slots = s.slots; A.n_slots = n_slots; A.mark_bitmap = s.mark_bitmap;
+  A.win = s.win[1] > 0 ? make_int4(s.win[0], s.win[1], s.win[2], s.win[3]) : make_int4(0, g.size[0], 0, g.size[1]);
+  A.seqs = s.seqs; A.before = s.before; A.after = s.after; A.total = s.total;
+  A.tiles_i = e->tiles_i; A.tiles_j = e->tiles_j;
+  A.tile_count = s.tile_bins; A.tile_off = s.tile_bins + ntile; A.tile_cursor = s.tile_bins + 2 * ntile + 1;
+  A.n_active = s.tile_bins + 3 * ntile + 1; A.ticket = s.tile_bins + 3 * ntile + 2;
+  A.active = reinterpret_cast<int4*>(s.tile_bins + himm_bins_active_at((size_t)ntile));
+  A.pairs = s.pairs;
+  A.layer = e->layer[layer];
+  A.dirty_tiles = layer == RNA_LAYER_LASER ? e->dirty_tiles : nullptr;
+  A.do_compose = do_compose ? 1 : 0;
+  A.nbr = e->nbr; A.master = e->layer[RNA_LAYER_MASTER]; A.laser = e->layer[RNA_LAYER_LASER];
+  A.cdirty = e->dirty_tiles; A.next_dirty = e->last_dirty;
+  s.fused_target += (unsigned)G;
+  if (do_compose) s.fused_target_compose += (unsigned)G;
+  A.bar = s.fused_bar; A.target = s.fused_target; A.target_compose = s.fused_target_compose;
+  A.phase_ticks = e->profiling == 1 ? s.fused_ticks : nullptr;
+  hipLaunchKernelGGL(himm_fused_kernel, dim3(G), dim3(HIMM_TR_THREADS), 0, e->stream, A);
+  RNA_HIP(e, hipGetLastError());
+  if (do_compose) std::swap(e->dirty_tiles, e->last_dirty);   // (as rna_compose_master's one-launch case does)
+  if (layer == RNA_LAYER_MASTER) { e->nbr_all_dirty = true; e->master_diverged = true; }
+  return RNA_OK;
+}
+
+// the batch can go through the fused kernel: the pair buffer holds the worst case (no read-back in the middle of the chain)
+static bool himm_fused_ok(const rna_engine* e) { return himm_fused_wgs(e) > 0 && !e->himm.pairs_checked; }
+
 int himm_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n) {
+  if (himm_fused_ok(e)) return himm_fused_launch(e, layer, rays_dev, n, false);
   HimmScratch& s = e->himm;
   const Geom g = e->geom;
   // hash sized to the batch: a power of two >= 2n keeps probe sequences short
@@ -756,6 +980,26 @@ int himm_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n) {
 }  // namespace
 
 namespace rna {
+// the fused kernel's phase timers -> the profile slots of the kernels whose work the phases do (called by profile_flush, all
+// streams idle): prep + collect + bin scan | bin count is in phase 0 with prep, fill + raster | apply | compose
+int himm_profile_drain(rna_engine* e) {
+  HimmScratch& s = e->himm;
+  if (!s.fused_ticks) return RNA_OK;
+  unsigned long long t[16];
+  RNA_HIP(e, hipMemcpy(t, s.fused_ticks, sizeof(t), hipMemcpyDeviceToHost));
+  if (t[HIMM_FUSED_PHASES] == 0) return RNA_OK;
+  RNA_HIP(e, hipMemset(s.fused_ticks, 0, sizeof(t)));
+  const double ms = 1e-5;   // a tick of the 100 MHz clock
+  e->prof[RNA_K_HIMM_PREP].total_ms += (double)(t[0] + t[1]) * ms;
+  e->prof[RNA_K_HIMM_RASTER].total_ms += (double)(t[2] + t[3]) * ms;
+  e->prof[RNA_K_HIMM_APPLY].total_ms += (double)t[4] * ms;
+  e->prof[RNA_K_COMPOSE].total_ms += (double)t[5] * ms;
+  e->prof[RNA_K_HIMM_PREP].launches += (int64_t)t[HIMM_FUSED_PHASES];
+  e->prof[RNA_K_HIMM_RASTER].launches += (int64_t)t[HIMM_FUSED_PHASES];
+  e->prof[RNA_K_HIMM_APPLY].launches += (int64_t)t[HIMM_FUSED_PHASES];
+  e->prof[RNA_K_COMPOSE].launches += (int64_t)t[HIMM_FUSED_PHASES + 1];
+  return RNA_OK;
+}
 int himm_release(rna_engine* e) {
   HimmScratch& s = e->himm;
 #ifdef RNA_HIMM_STATS
@@ -771,7 +1015,7 @@ int himm_release(rna_engine* e) {
 #endif
   dev_free(&s.rays_dev); dev_free(&s.desc); dev_free(&s.ncells); dev_free(&s.next); dev_free(&s.slots);
   dev_free(&s.seqs); dev_free(&s.before); dev_free(&s.after); dev_free(&s.total); dev_free(&s.mark_bitmap);
-  dev_free(&s.pairs); dev_free(&s.tile_bins);
+  dev_free(&s.pairs); dev_free(&s.tile_bins); dev_free(&s.fused_bar); dev_free(&s.fused_ticks);
   if (s.pairs_total_host) { (void)hipHostFree(s.pairs_total_host); s.pairs_total_host = nullptr; }
   s.pairs_cap = 0;
   s.cap_rays = 0;
@@ -818,6 +1062,17 @@ extern "C" int rna_himm_update(rna_engine* e, int layer, const rna_ray* rays_hos
 }
 
 extern "C" int rna_update_map_device(rna_engine* e, const rna_ray* rays_device, int n, int compose_mode) {
+  if (!e || n < 0 || (n > 0 && !rays_device) || (compose_mode != 0 && compose_mode != 1)) return RNA_EINVAL;
+  // the usual case of the replan loop -- dirty tiles only, an unmoved map, masks valid before the update (what
+  // rna_compose_master serves with one launch) -- is ONE launch for the ray batch and the compose together
+  const bool moved = e->geom.start[0] != 0 || e->geom.start[1] != 0;
+  static const bool fused_compose = [] { const char* v = getenv("RNA_HIMM_FUSED_COMPOSE"); return !v || atoi(v) != 0; }();   // developer knob: 0 = the compose stays a launch of its own
+  if (fused_compose && n > 0 && compose_mode == 0 && !e->laser_all_dirty && !e->master_diverged && !moved && !e->nbr_all_dirty) {
+    RNA_ENTER(e);   // (joins the side work: the compose phase writes what VFH+ and the mask snapshots read)
+    int rc = ensure_scratch(e, n);
+    if (rc != RNA_OK) return rc;
+    if (himm_fused_ok(e)) return himm_fused_launch(e, RNA_LAYER_LASER, rays_device, n, true);
+  }
   int rc = rna_himm_update_device(e, RNA_LAYER_LASER, rays_device, n);
   if (rc != RNA_OK) return rc;
   return rna_compose_master(e, compose_mode);

@@ -30,7 +30,7 @@ namespace {
 constexpr int VFH_THREADS = 128;
 constexpr int MAX_W = 64;
 constexpr int MAX_NQ = (MAX_W / 2 + 1) * MAX_W;   // 2112
-constexpr int MAX_NW = (MAX_NQ + 31) / 32;        // 66
+[[maybe_unused]] [[maybe_unused]] constexpr int MAX_NW = (MAX_NQ + 31) / 32;        // 66 (the kernel sizes its LDS by the actual window) (the kernel sizes its LDS by the actual window)
 constexpr int MAX_H = 128;
 constexpr int VFH_OCC_CAP = 1024;
 
@@ -76,8 +76,13 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
                 const double* __restrict__ ext_ranges, rna_vfh_out* __restrict__ out,
                 float* __restrict__ origin_out, float* __restrict__ hist_out) {
   __shared__ unsigned long long rng[361];
-  __shared__ float mag[MAX_NQ];
-  __shared__ unsigned nz[MAX_NW];
+  // cell magnitudes and their non-zero bits: sized by the launch for THIS window (NQ floats, then NW words).  As static arrays
+  // for the largest window the header allows (64 x 33 cells: 8.7 KB) a workgroup took 16 KB of LDS and ten fitted a CU; with
+  // the Steerer's 30 x 30 window it takes 9.5 KB and all sixteen that the CU's wave slots hold are resident (config 2's
+  // batches of thousands of poses run in waves of resident workgroups: 16 384 poses 147 -> see profiles/r05_vfh_probe.txt)
+  extern __shared__ float vfh_dyn[];
+  float* const mag = vfh_dyn;
+  unsigned* const nz = reinterpret_cast<unsigned*>(vfh_dyn + ((K.NQ + 31) & ~31));
   __shared__ float s_hist[MAX_H];
   __shared__ unsigned s_phi_right, s_phi_left;
   __shared__ int s_emergency, s_nocc;
@@ -649,7 +654,9 @@ int launch_step(rna_engine* e, const rna_pose* poses_dev, const double* ranges_d
   }
   {
     KernelTimer kt(e, RNA_K_VFH_STEP, st);
-    hipLaunchKernelGGL(vfh_step_kernel, dim3(n), dim3(VFH_THREADS), 0, st, make_k(e), e->geom,
+    const VfhK K = make_k(e);
+    const size_t lds = (size_t)(((K.NQ + 31) & ~31) + K.NW) * sizeof(float);   // mag | nz
+    hipLaunchKernelGGL(vfh_step_kernel, dim3(n), dim3(VFH_THREADS), lds, st, K, e->geom,
                        e->layer[RNA_LAYER_MASTER], poses_dev, ranges_dev, out_dev, origin_dev, hist_dev);
     RNA_HIP(e, hipGetLastError());
   }
