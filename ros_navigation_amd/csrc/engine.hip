@@ -705,10 +705,9 @@ int sync_all(rna_engine* e) {
 }
 
 int profile_flush(rna_engine* e) {
-  if (e->pending_events == 0 && !(e->profiling == 1 && e->himm.fused_ticks)) return RNA_OK;
+  if (e->pending_events == 0) return RNA_OK;
   int src = sync_all(e);
   if (src != RNA_OK) return src;
-  if ((src = himm_profile_drain(e)) != RNA_OK) return src;
   for (auto& slot : e->prof) {
     for (auto& pr : slot.pending) {
       float ms = 0;

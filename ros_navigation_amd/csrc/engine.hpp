@@ -36,9 +36,6 @@ struct HimmScratch {
   int* pairs_total_host = nullptr;   // pinned: the count of the batch being launched (pairs_checked only)
   int* tile_bins = nullptr;      // [3][ntile]: pair count, offset and fill cursor per tile
   int win[4] = {0, 0, 0, 0};     // owner window [i0, i1) x [j0, j1) in buffer indices; i1 == 0: whole map
-  unsigned* fused_bar = nullptr; // himm_fused_kernel: one arrival counter per phase barrier (they only grow) ...
-  unsigned fused_target = 0, fused_target_compose = 0;   // ... and what they read when every workgroup of the latest launch has arrived (the barrier in front of the compose phase counts on its own)
-  unsigned long long* fused_ticks = nullptr;   // its phase timers (profiling)
 };
 
 struct VfhDevice {
@@ -240,7 +237,6 @@ int astar_settle(rna_engine* e);
 
 // module entry points used across translation units
 int himm_release(rna_engine* e);
-int himm_profile_drain(rna_engine* e);   // the fused map-update kernel's phase timers -> profile slots
 int vfh_release(rna_engine* e);
 int astar_release(rna_engine* e);
 int map_prepare_nbr(rna_engine* e);   // make e->nbr consistent with the master layer

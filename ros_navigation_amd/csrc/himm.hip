@@ -21,11 +21,15 @@
 //              k clears are clear^k, whatever their order -- then every touched line of the layer is read once,
 //              coalesced, and written once; clears of marked cells go to the interval counters instead),
 //          himm_apply (1 thread/hash slot: ordered replay on marked cells).
+// Round 5 ran the whole chain (and the compose) as the phases of ONE persistent kernel with device-wide barriers: exact, and
+// slower in the replan loop (95-130 k against 146 k cycles/s, profiles/r05_fused_map_update_*.txt) -- next to the searches every
+// phase took as long as the kernel it replaced (their time there is memory latency under load, not launch overhead), the compose
+// phase serialised the update with the side work, and a barrier whose workgroups cannot all be resident can only trap.  Removed;
+// the kernels' bodies stayed the device functions it was built from.
 // Round 1 rasterised ray by ray with a 4-byte compare-and-swap per cell straight on HBM: 295 MB of traffic for the
 // 61 MB the batch needs (rays from one origin re-touch the same lines hundreds of times).  Per tile it is at most
 // one read and one write of 16 KB.
 #include "engine.hpp"
-#include "compose_dev.hpp"
 
 #include <algorithm>
 
@@ -687,118 +691,6 @@ __global__ void himm_apply_kernel(int rows, HimmSlot* __restrict__ slots, int n_
 }
 
 
-// ---- the whole map update as ONE kernel (round 5) -------------------------------------------------------------------------
-// MapProvider::updateMap (mc/src/map_provider.cpp:190-223) used to be ten dependent launches: prep, collect, bin count / scan /
-// fill, raster, apply, compose + masks.  Alone they take 0.18 ms; in the replan loop, next to sixteen streams of searches,
-// 1.15 ms -- every launch of the chain pays ~70 us of dispatch latency whatever it does (the one-workgroup bin scan: 8 us alone,
-// 67 us in the loop; profiles/r04_engine_timeline.txt), and their workgroups land on the searches' CUs whenever one frees up.
-// Here the same device code runs as the phases of one persistent kernel: a fixed, small number of workgroups (all resident
-// at once), grid-stride or ticket loops inside a phase, a device-wide barrier between phases.  Results are those of the chain
-// (same functions, same order of the order-sensitive steps).
-// The barrier: one counter per phase in device memory, never reset -- the launch's target is the running total of arrivals
-// (`target`, kept by the host); release / acquire fences at agent scope on both sides, so what other workgroups (other XCDs)
-// wrote before it is read after it.  A workgroup that waits longer than five seconds traps: a launch whose workgroups cannot all
-// be resident fails loudly instead of hanging the GPU.
-struct HimmFused {
-  Geom g;
-  const rna_ray* rays;
-  int n;
-  int4* desc; int* ncells; int* next; HimmSlot* slots; int n_slots; unsigned* mark_bitmap; int4 win;
-  int* seqs; unsigned* before; unsigned* after; int* total;
-  int tiles_i, tiles_j; int* tile_count; int* tile_off; int* tile_cursor; int4* active; int* n_active; int* ticket; int* pairs;
-  float* layer; unsigned* dirty_tiles;
-  int do_compose; uint8_t* nbr; float* master; const float* laser; const unsigned* cdirty; unsigned* next_dirty;
-  unsigned* bar; unsigned target;   // target: what the counters of the barriers EVERY launch passes read when all have arrived ...
-  unsigned target_compose;          // ... and the one only launches with a compose phase pass
-  unsigned long long* phase_ticks;   // (may be null) 100 MHz ticks per phase, summed over launches, + a launch count
-};
-constexpr int HIMM_FUSED_PHASES = 6;
-
-__device__ __forceinline__ void himm_grid_barrier(unsigned* counter, unsigned target) {
-  __threadfence();     // this thread's writes are visible device-wide before its workgroup arrives
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long t0 = wall_clock64();
-    while ((int)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-      __builtin_amdgcn_s_sleep(4);
-      if (wall_clock64() - t0 > 500000000ull) __builtin_trap();   // 5 s of the 100 MHz clock
-    }
-  }
-  __syncthreads();
-  __threadfence();     // nothing cached before the barrier is read after it
-  __builtin_amdgcn_s_dcache_inv();
-}
-
-union HimmFusedLds {
-  RasterLds raster;
-  int scan[3 * HIMM_TR_THREADS];
-  uint8_t blk[COMPOSE_BLK_BYTES];
-  int collect[20];
-};
-
-__global__ void __launch_bounds__(HIMM_TR_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) himm_fused_kernel(const HimmFused A) {   // (64 VGPRs: four workgroups per CU)
-  constexpr int NT = HIMM_TR_THREADS;
-  __shared__ HimmFusedLds U;
-  const int G = (int)gridDim.x, tid = (int)threadIdx.x;
-  const int ntile = A.tiles_i * A.tiles_j;
-  unsigned long long t_prev = 0;
-  const bool timed = A.phase_ticks != nullptr && blockIdx.x == 0 && tid == 0;
-  if (timed) t_prev = wall_clock64();
-  int phase = 0;
-  auto end_phase = [&](bool barrier) {
-    if (barrier) himm_grid_barrier(A.bar + phase, phase == 4 ? A.target_compose : A.target);
-    if (timed) { const unsigned long long t = wall_clock64(); atomicAdd(&A.phase_ticks[phase], t - t_prev); t_prev = t; }
-    ++phase;
-  };
-  // phase 0: clip the rays, register the marks, count the rays per 64 x 64 tile (himm_prep + himm_bin_count)
-  for (int base = (int)blockIdx.x * NT; base < A.n; base += G * NT) {
-    const int r = base + tid;
-    int4 d = make_int4(0, 0, 0, 0);
-    int nc = 0;
-    if (r < A.n) nc = himm_prep_ray(A.g, A.rays, r, A.desc, A.ncells, A.next, A.slots, A.n_slots - 1, A.mark_bitmap, A.win, d);
-    const RayWalk w(d, nc);
-    w.for_each_tile_lockstep(A.tiles_i, [&](bool act, int t) { (void)wave_tile_add(A.tile_count, act, t); });
-  }
-  end_phase(true);
-  // phase 1: the marks of every marked cell in ray order (himm_collect); workgroup 0 first turns the tile counts into offsets and
-  // the list of tiles with rays (himm_bin_scan)
-  if (blockIdx.x == 0) {
-    himm_bin_scan<NT>(A.tile_count, ntile, A.tile_off, A.tile_cursor, A.active, A.n_active, A.ticket, U.scan, U.scan + NT, U.scan + 2 * NT);
-    __syncthreads();
-  }
-  for (int base = (int)blockIdx.x * NT; base < A.n_slots; base += G * NT)
-    himm_collect_slot(base + tid, A.slots, A.n_slots, A.next, A.seqs, A.before, A.after, A.total, U.collect, U.collect + 16);
-  end_phase(true);
-  // phase 2: the (tile, ray) pairs, grouped by tile (himm_bin_fill)
-  for (int base = (int)blockIdx.x * NT; base < A.n; base += G * NT) {
-    const int r = base + tid;
-    const int nc = r < A.n ? A.ncells[r] : 0;
-    const RayWalk w(nc ? A.desc[r] : make_int4(0, 0, 0, 0), nc);
-    w.for_each_tile_lockstep(A.tiles_i, [&](bool act, int t) {
-      const int slot = wave_tile_add(A.tile_cursor, act, t);
-      if (act) A.pairs[A.tile_off[t] + slot] = r;
-    });
-  }
-  end_phase(true);
-  // phase 3: clears counted per cell in LDS, every touched line of the layer read once and written once (himm_tile_raster)
-  __syncthreads();
-  himm_raster_jobs(U.raster, (int)blockIdx.x, G, A.g.size[0], A.g.size[1], A.tiles_i, A.desc, A.ncells, A.tile_off, A.pairs, A.active, A.n_active,
-                   A.ticket, A.layer, A.mark_bitmap, A.slots, A.n_slots - 1, A.seqs, A.before, A.after, A.dirty_tiles, A.win);
-  end_phase(true);
-  // phase 4: the ordered replay on the marked cells (himm_apply)
-  for (int h = (int)blockIdx.x * NT + tid; h < A.n_slots; h += G * NT)
-    himm_apply_slot(h, A.g.size[0], A.slots, A.n_slots, A.total, A.before, A.after, A.layer, A.mark_bitmap, A.dirty_tiles, A.tiles_i);
-  if (!A.do_compose) { end_phase(false); if (timed) atomicAdd(&A.phase_ticks[HIMM_FUSED_PHASES], 1ull); return; }
-  end_phase(true);
-  // phase 5: master = laser on the dirty tiles and the neighbour masks of those tiles and their ring (compose_nbr_tiles_kernel)
-  __syncthreads();
-  for (int tt = (int)blockIdx.x; tt < ntile; tt += G)
-    compose_nbr_tile(U.blk, tt, A.nbr, A.master, A.laser, A.cdirty, A.next_dirty, A.g.size[0], A.g.size[1], A.tiles_i, A.tiles_j);
-  end_phase(false);
-  if (timed) { atomicAdd(&A.phase_ticks[HIMM_FUSED_PHASES], 1ull); atomicAdd(&A.phase_ticks[HIMM_FUSED_PHASES + 1], 1ull); }
-}
-
 // (tile, ray) pairs of a batch.  Worst case: a ray is registered with at most two tiles per 64-cell tile column it crosses,
 // i.e. 2 * ceil(max(rows, cols) / 64) + 2 pairs -- 130 ints per ray on a 4096^2 map although the bench's rays make 2.3.
 // While that is small (<= 256 MB) it is simply allocated: nothing to check, nothing to wait for.  Beyond (a million
@@ -833,12 +725,6 @@ int ensure_scratch(rna_engine* e, int n) {
     const size_t bins = himm_bins_active_at((size_t)e->tiles_i * e->tiles_j) + (size_t)4 * e->tiles_i * e->tiles_j;
     if ((rc = dev_alloc(e, &s.tile_bins, bins)) != RNA_OK) return rc;
     RNA_HIP(e, hipMemsetAsync(s.tile_bins, 0, bins * sizeof(int), e->stream));
-    // the fused kernel's phase barriers (counters that only ever grow) and its phase timers
-    if ((rc = dev_alloc(e, &s.fused_bar, (size_t)16)) != RNA_OK) return rc;
-    RNA_HIP(e, hipMemsetAsync(s.fused_bar, 0, 16 * sizeof(unsigned), e->stream));
-    if ((rc = dev_alloc(e, &s.fused_ticks, (size_t)16)) != RNA_OK) return rc;
-    RNA_HIP(e, hipMemsetAsync(s.fused_ticks, 0, 16 * sizeof(unsigned long long), e->stream));
-    s.fused_target = s.fused_target_compose = 0;
   }
   if (n <= s.cap_rays) return RNA_OK;
   int cap = 1024;
@@ -867,56 +753,7 @@ int ensure_scratch(rna_engine* e, int n) {
   return RNA_OK;
 }
 
-// How many workgroups the fused kernel gets.  All of them have to be resident at once (they meet at barriers), and several
-// engines may share a GPU (ranks of a test, the 8-rank rehearsals): few enough that any number of such kernels fits the chip
-// next to each other -- 64 workgroups of 8 wavefronts are a sixteenth of the chip's wave slots.  RNA_HIMM_FUSED_WGS overrides it
-// (developer knob); 0 switches the fused kernel off (the chain of separate launches).
-static int himm_fused_wgs(const rna_engine* e) {
-  static const int env = [] { const char* v = getenv("RNA_HIMM_FUSED_WGS"); return v ? atoi(v) : -1; }();
-  if (env >= 0) return std::min(env, 1024);
-  return std::min(64, e->cu_count);
-}
-
-// HIMM batch (+ compose when `do_compose`) as one launch of himm_fused_kernel; the caller has checked that the batch qualifies
-static int himm_fused_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n, bool do_compose) {
-  HimmScratch& s = e->himm;
-  const Geom g = e->geom;
-  int n_slots = 1024;
-  while (n_slots < 2 * n) n_slots <<= 1;
-  if (n_slots > s.n_slots) n_slots = s.n_slots;
-  const int ntile = e->tiles_i * e->tiles_j;
-  const int G = himm_fused_wgs(e);
-  HimmFused A;
-  A.g = g; A.rays = rays_dev; A.n = n;
-  A.desc = s.desc; A.ncells = s.ncells; A.next = s.next; A.slots = s.slots; A.n_slots = n_slots; A.mark_bitmap = s.mark_bitmap;
-  A.win = s.win[1] > 0 ? make_int4(s.win[0], s.win[1], s.win[2], s.win[3]) : make_int4(0, g.size[0], 0, g.size[1]);
-  A.seqs = s.seqs; A.before = s.before; A.after = s.after; A.total = s.total;
-  A.tiles_i = e->tiles_i; A.tiles_j = e->tiles_j;
-  A.tile_count = s.tile_bins; A.tile_off = s.tile_bins + ntile; A.tile_cursor = s.tile_bins + 2 * ntile + 1;
-  A.n_active = s.tile_bins + 3 * ntile + 1; A.ticket = s.tile_bins + 3 * ntile + 2;
-  A.active = reinterpret_cast<int4*>(s.tile_bins + himm_bins_active_at((size_t)ntile));
-  A.pairs = s.pairs;
-  A.layer = e->layer[layer];
-  A.dirty_tiles = layer == RNA_LAYER_LASER ? e->dirty_tiles : nullptr;
-  A.do_compose = do_compose ? 1 : 0;
-  A.nbr = e->nbr; A.master = e->layer[RNA_LAYER_MASTER]; A.laser = e->layer[RNA_LAYER_LASER];
-  A.cdirty = e->dirty_tiles; A.next_dirty = e->last_dirty;
-  s.fused_target += (unsigned)G;
-  if (do_compose) s.fused_target_compose += (unsigned)G;
-  A.bar = s.fused_bar; A.target = s.fused_target; A.target_compose = s.fused_target_compose;
-  A.phase_ticks = e->profiling == 1 ? s.fused_ticks : nullptr;
-  hipLaunchKernelGGL(himm_fused_kernel, dim3(G), dim3(HIMM_TR_THREADS), 0, e->stream, A);
-  RNA_HIP(e, hipGetLastError());
-  if (do_compose) std::swap(e->dirty_tiles, e->last_dirty);   // (as rna_compose_master's one-launch case does)
-  if (layer == RNA_LAYER_MASTER) { e->nbr_all_dirty = true; e->master_diverged = true; }
-  return RNA_OK;
-}
-
-// the batch can go through the fused kernel: the pair buffer holds the worst case (no read-back in the middle of the chain)
-static bool himm_fused_ok(const rna_engine* e) { return himm_fused_wgs(e) > 0 && !e->himm.pairs_checked; }
-
 int himm_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n) {
-  if (himm_fused_ok(e)) return himm_fused_launch(e, layer, rays_dev, n, false);
   HimmScratch& s = e->himm;
   const Geom g = e->geom;
   // hash sized to the batch: a power of two >= 2n keeps probe sequences short
@@ -980,26 +817,6 @@ int himm_launch(rna_engine* e, int layer, const rna_ray* rays_dev, int n) {
 }  // namespace
 
 namespace rna {
-// the fused kernel's phase timers -> the profile slots of the kernels whose work the phases do (called by profile_flush, all
-// streams idle): prep + collect + bin scan | bin count is in phase 0 with prep, fill + raster | apply | compose
-int himm_profile_drain(rna_engine* e) {
-  HimmScratch& s = e->himm;
-  if (!s.fused_ticks) return RNA_OK;
-  unsigned long long t[16];
-  RNA_HIP(e, hipMemcpy(t, s.fused_ticks, sizeof(t), hipMemcpyDeviceToHost));
-  if (t[HIMM_FUSED_PHASES] == 0) return RNA_OK;
-  RNA_HIP(e, hipMemset(s.fused_ticks, 0, sizeof(t)));
-  const double ms = 1e-5;   // a tick of the 100 MHz clock
-  e->prof[RNA_K_HIMM_PREP].total_ms += (double)(t[0] + t[1]) * ms;
-  e->prof[RNA_K_HIMM_RASTER].total_ms += (double)(t[2] + t[3]) * ms;
-  e->prof[RNA_K_HIMM_APPLY].total_ms += (double)t[4] * ms;
-  e->prof[RNA_K_COMPOSE].total_ms += (double)t[5] * ms;
-  e->prof[RNA_K_HIMM_PREP].launches += (int64_t)t[HIMM_FUSED_PHASES];
-  e->prof[RNA_K_HIMM_RASTER].launches += (int64_t)t[HIMM_FUSED_PHASES];
-  e->prof[RNA_K_HIMM_APPLY].launches += (int64_t)t[HIMM_FUSED_PHASES];
-  e->prof[RNA_K_COMPOSE].launches += (int64_t)t[HIMM_FUSED_PHASES + 1];
-  return RNA_OK;
-}
 int himm_release(rna_engine* e) {
   HimmScratch& s = e->himm;
 #ifdef RNA_HIMM_STATS
@@ -1015,7 +832,7 @@ int himm_release(rna_engine* e) {
 #endif
   dev_free(&s.rays_dev); dev_free(&s.desc); dev_free(&s.ncells); dev_free(&s.next); dev_free(&s.slots);
   dev_free(&s.seqs); dev_free(&s.before); dev_free(&s.after); dev_free(&s.total); dev_free(&s.mark_bitmap);
-  dev_free(&s.pairs); dev_free(&s.tile_bins); dev_free(&s.fused_bar); dev_free(&s.fused_ticks);
+  dev_free(&s.pairs); dev_free(&s.tile_bins);
   if (s.pairs_total_host) { (void)hipHostFree(s.pairs_total_host); s.pairs_total_host = nullptr; }
   s.pairs_cap = 0;
   s.cap_rays = 0;
@@ -1062,17 +879,6 @@ extern "C" int rna_himm_update(rna_engine* e, int layer, const rna_ray* rays_hos
 }
 
 extern "C" int rna_update_map_device(rna_engine* e, const rna_ray* rays_device, int n, int compose_mode) {
-  if (!e || n < 0 || (n > 0 && !rays_device) || (compose_mode != 0 && compose_mode != 1)) return RNA_EINVAL;
-  // the usual case of the replan loop -- dirty tiles only, an unmoved map, masks valid before the update (what
-  // rna_compose_master serves with one launch) -- is ONE launch for the ray batch and the compose together
-  const bool moved = e->geom.start[0] != 0 || e->geom.start[1] != 0;
-  static const bool fused_compose = [] { const char* v = getenv("RNA_HIMM_FUSED_COMPOSE"); return !v || atoi(v) != 0; }();   // developer knob: 0 = the compose stays a launch of its own
-  if (fused_compose && n > 0 && compose_mode == 0 && !e->laser_all_dirty && !e->master_diverged && !moved && !e->nbr_all_dirty) {
-    RNA_ENTER(e);   // (joins the side work: the compose phase writes what VFH+ and the mask snapshots read)
-    int rc = ensure_scratch(e, n);
-    if (rc != RNA_OK) return rc;
-    if (himm_fused_ok(e)) return himm_fused_launch(e, RNA_LAYER_LASER, rays_device, n, true);
-  }
   int rc = rna_himm_update_device(e, RNA_LAYER_LASER, rays_device, n);
   if (rc != RNA_OK) return rc;
   return rna_compose_master(e, compose_mode);
