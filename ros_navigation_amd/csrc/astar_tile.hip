@@ -1392,7 +1392,13 @@ __device__ __forceinline__ void tsa_backtrace_wave(const TsaLaunch& A, const Tsa
   const int off = di + dj * BW;
   int len = 0;
   bool ok = true, done = false;
+#ifdef RNA_TSA_STATS
+  unsigned long long bt_loads = 0, bt_load_ticks = 0;
+#endif
   while (ok && !done) {
+#ifdef RNA_TSA_STATS
+    const unsigned long long t_l0 = wall_clock64();
+#endif
     // ---- tile of the current cell + halo ring + masks -> LDS ----
     const int ti = ci >> 6, tj = cj >> 4;
     const int t = tj * tiles_i + ti;
@@ -1430,6 +1436,9 @@ __device__ __forceinline__ void tsa_backtrace_wave(const TsaLaunch& A, const Tsa
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+#ifdef RNA_TSA_STATS
+    bt_loads += 1; bt_load_ticks += wall_clock64() - t_l0;
+#endif
     // ---- walk inside the tile ----
     int il = ci & (TI - 1), jl = cj & (TJ - 1);
     unsigned uc = s_tile[(jl + 1) * BW + il + 1];
@@ -1444,12 +1453,15 @@ __device__ __forceinline__ void tsa_backtrace_wave(const TsaLaunch& A, const Tsa
       const unsigned long long m = __ballot(hit);
       if (!m) { ok = false; break; }
       const int src = __ffsll((long long)m) - 1;
-      uc = (unsigned)__shfl((int)un, src);
+      uc = (unsigned)__builtin_amdgcn_readlane((int)un, src);   // (src is wave-uniform: a v_readlane, not a trip through the LDS crossbar)
       const int sdi = kdi_of(src), sdj = kdj_of(src);
       ci += sdi; cj += sdj; il += sdi; jl += sdj;
       if (il < 0 || jl < 0 || il >= TI || jl >= TJ) break;   // left the tile: load that one
     }
   }
+#ifdef RNA_TSA_STATS
+  if (lane == 0) { atomicAdd(&g_tsa_stat[27], bt_loads); atomicAdd(&g_tsa_stat[28], bt_load_ticks); atomicAdd(&g_tsa_stat[29], (unsigned long long)len); }
+#endif
   if (!ok) {
     if (lane == 0) A.results[q] = rna_astar_result{1, 0, INF, r.expanded, r.rounds, r.buckets};
     return;
@@ -1507,6 +1519,9 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
 #endif
   if (__builtin_amdgcn_readfirstlane(s_rank) < A.prio_first) __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef RNA_TSA_STATS
+  const unsigned long long t_kernel0 = wall_clock64();
+#endif
   const int rows = A.rows, cols = A.cols, tiles_i = A.tiles_i, tiles_j = A.tiles_j;
   rna_astar_query qu = A.queries[q];   // buffer linear indices; the search itself runs in map space
   const int ncell = rows * cols;
@@ -1754,7 +1769,21 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   __syncthreads();
   if (wv != 0) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // The walk is ONE chain of dependent instructions (a step: two LDS reads, a ballot, a lane read, a handful of scalar
+  // instructions), run by one wavefront while its workgroup's LDS and query slot stay taken: at the priority of the seven
+  // search wavefronts it shares its SIMD with, a step took 0.88 us and a path of 2 000 cells 2 ms -- 18 % of the workgroup's
+  // residence (profiles/r05_search_job_stats.txt).  At the highest issue priority it gets its instructions in when it asks.
+#ifndef RNA_TSA_BT_PRIO
+#define RNA_TSA_BT_PRIO 3
+#endif
+  __builtin_amdgcn_s_setprio(RNA_TSA_BT_PRIO);
+#ifdef RNA_TSA_STATS
+  const unsigned long long t_bt0 = wall_clock64();
+#endif
   tsa_backtrace_wave(A, S, sl, q, r, lane, s_node, reinterpret_cast<unsigned char*>(s_node + BW * (TJ + 2)));
+#ifdef RNA_TSA_STATS
+  if (lane == 0) { atomicAdd(&g_tsa_stat[24], wall_clock64() - t_bt0); atomicAdd(&g_tsa_stat[25], 1ull); atomicAdd(&g_tsa_stat[26], wall_clock64() - t_kernel0); }
+#endif
 }
 
 // |{n : g(n) + h(n) <= f*}| per query from the pages still resident in HBM (measurement utility)
@@ -2008,6 +2037,12 @@ void tsa_stats_dump() {
           jobs, 100.0 * (double)st[10] / jobs, st[0] * 0.01 / jobs, st[1] * 0.01 / jobs, st[2] * 0.01 / jobs, st[5] * 1e-5, busy * 1e-5,
           100.0 * busy / (double)st[5], st[4] * 1e-5, 100.0 * (double)st[4] / (double)st[5], st[8] / jobs, st[11] / jobs,
           100.0 * (double)st[12] / (double)std::max<unsigned long long>(1, st[5]));
+  if (st[25]) fprintf(stderr, "[tsa stats] backtrace (one wavefront, the workgroup's LDS held meanwhile): %.1f us per found path, %.1f %% of the workgroup's residence (%.2f ms from its first instruction to the end of the backtrace, found paths only)\n",
+                      st[24] * 0.01 / (double)st[25], 100.0 * (double)st[24] / (double)std::max<unsigned long long>(1, st[26]), st[26] * 1e-5 / (double)st[25]);
+  if (st[25]) fprintf(stderr, "[tsa stats] backtrace: %.0f cells and %.1f tile loads per path (%.1f cells per load), a tile load %.2f us (%.0f %% of the backtrace), a step %.3f us\n",
+                      (double)st[29] / (double)st[25], (double)st[27] / (double)st[25], (double)st[29] / (double)std::max<unsigned long long>(1, st[27]),
+                      st[28] * 0.01 / (double)std::max<unsigned long long>(1, st[27]), 100.0 * (double)st[28] / (double)std::max<unsigned long long>(1, st[24]),
+                      (double)(st[24] - st[28]) * 0.01 / (double)std::max<unsigned long long>(1, st[29]));
   fprintf(stderr, "[tsa stats] sticky turns (the wavefront kept a tile that was woken while it ran) %.3f of all jobs, of which %.3f find nothing\n",
           (double)st[22] / jobs, (double)st[23] / (double)std::max<unsigned long long>(1, st[22]));
   fprintf(stderr, "[tsa stats] first jobs (a tile's first in a bucket: every row evaluated both ways) %.3f of all, %.1f row evaluations and %.1f changed rows each; rows changed per job %.1f; rows sent to the scan per job %.2f\n",
