@@ -561,11 +561,13 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
     for _ in range(args.steps):
         step()
     e.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    host_cores_used = (time.process_time() - cpu0) / max(elapsed, 1e-9)   # CPU seconds of ALL the process's threads per wall second
     barrier()
     prof = e.profile_get()
     e.profile(False)
@@ -648,6 +650,8 @@ def main():
                        "astar_bucket_width": args.bucket_width or 96000, "astar_pipeline_depth": args.pipeline,
                        "astar_allocated": dict(zip(("pipeline_depth", "pages_per_query", "max_queries"), e.astar_effective_config())),
                        "timed_seconds": t_max, "paths_checked": paths_checked, "host_affinity": host_affinity,
+                       # what a rank asks of the host in the timed region (eight ranks share one at N = 8): cores' worth of CPU time
+                       "host_cores_used": host_cores_used,
                        "shards": [r[:2] for r in shard_rows], "cycles_by_rank": [r[2] for r in shard_rows],
                        "launcher": ({"spawned_by_bench": True, "parent_pid": int(os.environ["RNA_BENCH_PARENT"].split(":")[0]),
                                      "parent_is_my_parent": int(os.environ["RNA_BENCH_PARENT"].split(":")[0]) == os.getppid(),

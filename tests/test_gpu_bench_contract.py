@@ -164,13 +164,13 @@ def test_default_bench_holds_its_rate_on_four_host_cores():
     """Eight ranks share one host at N = 8 (SURVEY 8e mode 1): a rank must not need more than its share of the cores.  The
     default bench with the process confined to FOUR host cores (RNA_BENCH_CPUS=4: main thread, the engine's launch
     thread, the runtime's helpers) keeps >= 95 % of the unconfined rate on the same box."""
-    try:
-        os.sched_setaffinity(0, os.sched_getaffinity(0))
-        probe = subprocess.run([sys.executable, "-c", "import os; os.sched_setaffinity(0, set(sorted(os.sched_getaffinity(0))[:4]))"], capture_output=True)
-        if probe.returncode != 0:
-            pytest.skip("this box does not let a process change its CPU affinity: " + probe.stderr.decode()[-200:])
-    except OSError as ex:
-        pytest.skip("this box does not let a process change its CPU affinity: %r" % ex)
+    # (some sandboxes refuse sched_setaffinity: the bench then reports the refusal in config.host_affinity and runs unpinned --
+    # nothing to compare; asked of the bench's own function in a fresh process, exactly as a rank would call it)
+    probe = subprocess.run([sys.executable, "-c", "import json, bench; print(json.dumps(bench.pin_to_gpu_numa_node(0)))"],
+                           capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, RNA_BENCH_CPUS="4"))
+    info = json.loads(probe.stdout.strip().splitlines()[-1]) if probe.returncode == 0 and probe.stdout.strip() else {"error": probe.stderr[-300:]}
+    if info.get("cpus") != 4:
+        pytest.skip("this box does not let a process confine itself to four cores: %r" % (info,))
     free, four = default_bench(), default_bench(cpus=4)
     assert four["config"]["host_affinity"]["cpus"] == 4, four["config"]["host_affinity"]
     assert four["value"] >= 0.95 * free["value"], (four["value"], free["value"])
@@ -199,6 +199,10 @@ def test_default_bench_keeps_the_engine_stream_alive():
     assert d["config"]["astar_pipeline_depth"] == bench.DEFAULT_PIPELINE
     pc = d["config"]["paths_checked"]
     assert pc["queries"] == 256 and pc["matched"] == 256 and pc["paths_found"] > 200, pc
+    # eight ranks share one host at N = 8: what ONE rank asks of it in the timed region -- CPU seconds of all its threads (main
+    # thread, the engine's launch thread, the runtime's helpers) per wall second -- has to stay well below an eighth of any host
+    # the driver would use (independent of whether the sandbox lets a process pin itself, see the four-core test above)
+    assert 0.0 < d["config"]["host_cores_used"] < 4.0, d["config"]["host_cores_used"]
 
 
 def test_bench_under_torchrun_as_the_driver_launches_it():
