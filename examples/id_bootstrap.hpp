@@ -4,10 +4,12 @@
 //
 // A file left behind by an earlier job must never be taken for this job's (the id inside names a communicator that no
 // longer exists: ncclCommInitRank would wait for ever).  Every file therefore carries a SESSION token and a reader only
-// accepts the token of its own job:
-//   * the launcher passes one (argv / RNA_TILED_SESSION), fresh per job; or
-//   * by default the token is (parent pid, parent start time): the ranks of a job are children of one launcher, and an
-//     earlier launcher had another pid or another start time.
+// accepts the token of its own job.  The launcher passes one, fresh per job (argv / RNA_TILED_SESSION); a job of MORE THAN
+// ONE rank must (examples/tiled_host.cpp refuses to start without it).  The default -- (parent pid, parent start time) --
+// only tells jobs of DIFFERENT launchers apart: two jobs started one after the other by the same long-lived shell, pytest
+// process or job script share it, a rank > 0 of the second job that starts before its rank 0 has re-published would
+// accept the first job's id, and ncclCommInitRank would hang -- so the default serves single-rank runs only, where nobody
+// reads the file.
 // The writer publishes with write-to-temporary + rename(), so a reader never sees half a file.
 #pragma once
 

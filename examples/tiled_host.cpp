@@ -88,6 +88,10 @@ int main(int argc, char** argv) {
   const char* id_file = argv[3];
   const int n = argc > 4 ? std::atoi(argv[4]) : 2048, rounds = argc > 5 ? std::atoi(argv[5]) : 3;
   const char* session = argc > 6 ? argv[6] : std::getenv("RNA_TILED_SESSION");
+  if (world > 1 && !(session && *session)) {   // (id_bootstrap.hpp: the default token cannot tell two jobs of one launcher apart)
+    std::fprintf(stderr, "tiled_host: a job of %d ranks needs a session token that is fresh per job (7th argument or RNA_TILED_SESSION), the same for all its ranks\n", world);
+    return 2;
+  }
   // The engine pipelines A* batches over CU-masked streams (rna_astar_set_pipeline_depth): each wants a hardware queue
   // of its own, and HIP multiplexes all streams over GPU_MAX_HW_QUEUES (default 4) of them.  Must be in the environment
   // before the first HIP call (INTEGRATION.md "Runtime notes").

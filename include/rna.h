@@ -28,7 +28,8 @@ extern "C" {
 /* 2: rna_laser_scan carries the end pose (80 bytes), rna_astar_result.expanded / .rounds changed meaning (cells written,
  *    tile jobs per wavefront), statuses 4 / 5, profile slot astar_reset, default bucket width 96000.  A host checks
  *    rna_abi_version() == RNA_ABI_VERSION after loading the library (capi.py and move_control_amd.hpp do). */
-/* 3: rna_synchronize_map, rna_hw_queue_advice (round 4); no existing signature changed. */
+/* 3: rna_synchronize_map, rna_hw_queue_advice (round 4); no existing signature changed.
+ * 4: rna_scan_to_rays_tf[_device], rna_range_to_rays_tf (sensors with a full tf transform; round 4); no existing signature changed. */
 #define RNA_ABI_VERSION 4
 
 typedef enum {
@@ -270,9 +271,11 @@ int rna_astar_configure(rna_engine* e, int max_queries, int queue_capacity, int 
  * value in force is too small for `depth` the call still succeeds -- searches then share queues and overlap less --
  * and rna_last_error() holds the one-line advice of rna_hw_queue_advice(). */
 int rna_astar_set_pipeline_depth(rna_engine* e, int depth);
-/* Host-only (no engine, no GPU): 0 and an empty string when GPU_MAX_HW_QUEUES, as this process's environment has it,
+/* Host-only (no engine, no GPU): 0 and an empty string when GPU_MAX_HW_QUEUES -- the value librna.so found (or set) WHEN IT
+ * WAS LOADED, which is what the HIP runtime latches at its first call; later changes of the environment do not count --
  * leaves the stages of `pipeline_depth` a hardware queue each (depth <= 2, or >= 8 queues); 1 and one line of advice in
- * buf otherwise. */
+ * buf when it is too small; 2 and one line when the library set the variable itself but the process had already opened
+ * the GPU by then (the setting probably came too late: export it before the first HIP call, e.g. before importing torch). */
 int rna_hw_queue_advice(int pipeline_depth, char* buf, size_t cap);
 /* The tile kernel keeps a search's distance field in 4 KiB pages (64 x 16 cells) handed out on first touch.  By
  * default every query may take one page per tile of the map (it can never run out; HBM is only touched where a

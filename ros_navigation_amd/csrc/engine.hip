@@ -7,6 +7,7 @@
 #include "compose_dev.hpp"
 
 #include <cmath>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -622,22 +623,54 @@ extern "C" int rna_synchronize_map(rna_engine* e) {
 
 // GPU_MAX_HW_QUEUES is read by the HIP runtime at its first call: set it when the library is loaded (a host links or
 // dlopens librna.so before it touches the GPU) unless the host has chosen a value itself.  Priority 101: before the
-// constructors that register this library's code objects with the runtime.
+// constructors that register this library's code objects with the runtime.  What the constructor found is kept for
+// rna_hw_queue_advice: the value as it was then (not as the environment reads later), whether this library had to set it,
+// and whether the process had ALREADY opened the GPU by then (/dev/kfd among its file descriptors: the runtime has latched
+// its settings and a value set now comes too late -- a host that initialises HIP, e.g. through torch.cuda, before it
+// loads librna.so must export the variable itself).  (setenv from a constructor is not thread-safe against other threads'
+// getenv: a host that dlopens the library from a threaded process should set the variable itself, then nothing is written.)
+static int g_hwq_at_load = 0;            // GPU_MAX_HW_QUEUES after the constructor ran (0: unset)
+static bool g_hwq_set_by_us = false, g_gpu_open_at_load = false;
+static bool process_has_kfd_open() {
+  char link[64], target[256];
+  for (int fd = 0; fd < 4096; ++fd) {
+    snprintf(link, sizeof(link), "/proc/self/fd/%d", fd);
+    const ssize_t n = readlink(link, target, sizeof(target) - 1);
+    if (n <= 0) continue;
+    target[n] = 0;
+    if (strcmp(target, "/dev/kfd") == 0) return true;
+  }
+  return false;
+}
 __attribute__((constructor(101))) static void rna_default_hw_queues() {
-  if (!getenv("RNA_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  g_gpu_open_at_load = process_has_kfd_open();
+  if (!getenv("RNA_KEEP_HW_QUEUES") && !getenv("GPU_MAX_HW_QUEUES")) {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    g_hwq_set_by_us = true;
+  }
+  const char* v = getenv("GPU_MAX_HW_QUEUES");
+  g_hwq_at_load = v ? atoi(v) : 0;
 }
 
 extern "C" int rna_hw_queue_advice(int pipeline_depth, char* buf, size_t cap) {
   if (buf && cap) buf[0] = 0;
   if (pipeline_depth <= 2) return 0;
-  const char* v = getenv("GPU_MAX_HW_QUEUES");
-  const int have = v ? atoi(v) : 4;   // the runtime's default
-  if (have >= 8) return 0;
-  if (buf && cap)
-    snprintf(buf, cap, "A* pipeline depth %d needs GPU_MAX_HW_QUEUES >= 8 in the environment before the first HIP call (%s%s): "
-             "the stages' streams share %d hardware queues and their searches overlap less", pipeline_depth,
-             v ? "it is " : "unset, the runtime's default is 4", v ? v : "", have);
-  return 1;
+  const int have = g_hwq_at_load > 0 ? g_hwq_at_load : 4;   // (unset: the runtime's default)
+  if (have < 8) {
+    if (buf && cap)
+      snprintf(buf, cap, "A* pipeline depth %d needs GPU_MAX_HW_QUEUES >= 8 in the environment before the first HIP call (%s%d): "
+               "the stages' streams share %d hardware queues and their searches overlap less", pipeline_depth,
+               g_hwq_at_load > 0 ? "it was " : "unset, the runtime's default is ", have, have);
+    return 1;
+  }
+  if (g_hwq_set_by_us && g_gpu_open_at_load) {
+    if (buf && cap)
+      snprintf(buf, cap, "librna.so set GPU_MAX_HW_QUEUES=8 when it was loaded, but this process had opened the GPU before that: the HIP "
+               "runtime has probably latched its default of 4 hardware queues, and a pipeline of %d A* stages shares them.  Export "
+               "GPU_MAX_HW_QUEUES=8 before the first HIP call (e.g. before importing torch)", pipeline_depth);
+    return 2;
+  }
+  return 0;
 }
 
 extern "C" int rna_get_index(const rna_engine* e, double x, double y, int32_t index[2]) {

@@ -168,29 +168,34 @@ def test_hw_queue_advice_text_and_the_load_time_default(capi):
     """Library-side guard for the hardware queues of a pipelined engine: librna.so sets GPU_MAX_HW_QUEUES=8 when it is
     loaded with the variable unset (in time for any host that loads it before touching the GPU), leaves a host's own
     value alone, and rna_hw_queue_advice says in one line when the value in force is too small for a pipeline depth --
-    the text rna_astar_set_pipeline_depth leaves in rna_last_error."""
+    the text rna_astar_set_pipeline_depth leaves in rna_last_error.  The advice speaks of the value the library FOUND WHEN IT
+    WAS LOADED (what the HIP runtime latches at its first call), not of what the environment reads at the time of the call
+    (round 4's advisor finding), and it says so when the process had opened the GPU before the library set the variable."""
     import sys
-    L = capi.lib()
-    buf = C.create_string_buffer(400)
-    old = os.environ.get("GPU_MAX_HW_QUEUES")
-    try:
-        os.environ["GPU_MAX_HW_QUEUES"] = "8"
-        assert L.rna_hw_queue_advice(13, buf, 400) == 0 and buf.value == b""
-        os.environ["GPU_MAX_HW_QUEUES"] = "4"
-        assert L.rna_hw_queue_advice(13, buf, 400) == 1
-        text = buf.value.decode()
-        assert "depth 13" in text and "GPU_MAX_HW_QUEUES >= 8" in text and "it is 4" in text and "before the first HIP call" in text
-        assert "\n" not in text
-        assert L.rna_hw_queue_advice(2, buf, 400) == 0 and buf.value == b""      # two stages fit the default four queues
-        del os.environ["GPU_MAX_HW_QUEUES"]
-        assert L.rna_hw_queue_advice(4, buf, 400) == 1 and "unset" in buf.value.decode()
-        assert L.rna_hw_queue_advice(4, None, 0) == 1                               # no buffer: just the answer
-        assert L.rna_hw_queue_advice(4, buf, 8) == 1 and len(buf.value) <= 7       # truncated, terminated
-    finally:
-        if old is None:
-            os.environ.pop("GPU_MAX_HW_QUEUES", None)
-        else:
-            os.environ["GPU_MAX_HW_QUEUES"] = old
+    base = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "RNA_KEEP_HW_QUEUES")}
+
+    def advice(depth, env, cap=400, pre=""):
+        prog = ("import ctypes, os\n%s\nL = ctypes.CDLL(%r)\nos.environ['GPU_MAX_HW_QUEUES'] = '1'\n"     # (a later change of the environment must not matter)
+                "buf = ctypes.create_string_buffer(400)\nL.rna_hw_queue_advice.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]\n"
+                "rc = L.rna_hw_queue_advice(%d, buf if %d else None, %d)\nprint(rc); print(buf.value.decode())" % (pre, capi.LIB_PATH, depth, cap, cap))
+        out = subprocess.check_output([sys.executable, "-c", prog], env=env, text=True).split("\n")
+        return int(out[0]), out[1]
+
+    assert advice(13, dict(base, GPU_MAX_HW_QUEUES="8")) == (0, "")
+    assert advice(13, base) == (0, "")                                   # unset: the library set 8 itself, nobody had opened the GPU
+    rc, text = advice(13, dict(base, GPU_MAX_HW_QUEUES="4"))
+    assert rc == 1 and "depth 13" in text and "GPU_MAX_HW_QUEUES >= 8" in text and "it was 4" in text and "before the first HIP call" in text
+    assert advice(2, dict(base, GPU_MAX_HW_QUEUES="4")) == (0, "")      # two stages fit the default four queues
+    rc, text = advice(4, dict(base, RNA_KEEP_HW_QUEUES="1"))
+    assert rc == 1 and "unset" in text
+    assert advice(4, dict(base, RNA_KEEP_HW_QUEUES="1"), cap=0)[0] == 1      # no buffer: just the answer
+    rc, text = advice(4, dict(base, RNA_KEEP_HW_QUEUES="1"), cap=8)
+    assert rc == 1 and len(text) <= 7                                          # truncated, terminated
+    if os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK | os.W_OK):
+        # the process has the GPU open before the library is loaded: the library's own setting may have come too late
+        rc, text = advice(13, base, pre="fd = os.open('/dev/kfd', os.O_RDWR)")
+        assert rc == 2 and "had opened the GPU before" in text and "\n" not in text
+        assert advice(13, dict(base, GPU_MAX_HW_QUEUES="8"), pre="fd = os.open('/dev/kfd', os.O_RDWR)") == (0, "")   # the host's own setting: fine
     prog = ("import ctypes, sys; ctypes.CDLL(%r); g = ctypes.CDLL(None).getenv; g.restype = ctypes.c_char_p; "
             "print(g(b'GPU_MAX_HW_QUEUES'))" % capi.LIB_PATH)
     env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "RNA_KEEP_HW_QUEUES")}

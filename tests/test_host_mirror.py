@@ -106,6 +106,16 @@ def test_rccl_tiled_host_compiles_against_rocm_rccl():
     assert os.path.exists(_build.cpp("tiled_host"))
 
 
+def test_tiled_host_refuses_a_multi_rank_job_without_a_session_token(tmp_path):
+    """round 4's advisor finding: the default token (parent pid, parent start time) is the same for two jobs that one
+    long-lived launcher starts one after the other -- a rank > 0 could accept the earlier job's ncclUniqueId and hang in
+    ncclCommInitRank.  A job of more than one rank therefore has to name its session; checked before any HIP call."""
+    exe = _build.cpp("tiled_host")
+    env = {k: v for k, v in os.environ.items() if k != "RNA_TILED_SESSION"}
+    out = subprocess.run([exe, "1", "2", str(tmp_path / "id")], capture_output=True, text=True, timeout=60, env=env)
+    assert out.returncode == 2 and "session token" in out.stderr, out.stderr[-500:]
+
+
 def test_cmake_configures_the_targets():
     import shutil
     import tempfile
