@@ -211,6 +211,10 @@ typedef struct {
 void og_rrt_plan(const og_geom* g, const float* master, const double start[2], const double target[2],
                  double close_tol, unsigned seed, int max_samples, double* path_xy, int path_cap,
                  og_rrt_result* res);
+/* the same with the steering step's formulation chosen (oracle/rrt.c): 0 = the reference's atan2 / cos / sin, 1 = normalised offset */
+void og_rrt_plan_steer(const og_geom* g, const float* master, const double start[2], const double target[2],
+                       double close_tol, unsigned seed, int max_samples, int steer, double* path_xy, int path_cap,
+                       og_rrt_result* res);
 
 /* ---- laser ingestion: LaserScan -> RangeSamples (scan.c; laser_map_updater.cpp:37-143) ---- */
 typedef struct {

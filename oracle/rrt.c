@@ -60,9 +60,16 @@ int og_if_blocked(const og_geom* g, const float* master, const double p[2]) {
 
 typedef struct { double pos[2]; int parent; } rrt_node;
 
-void og_rrt_plan(const og_geom* g, const float* master, const double start[2], const double target[2],
-                 double close_tol, unsigned seed, int max_samples, double* path_xy, int path_cap,
-                 og_rrt_result* res) {
+/* steer: how the new node is placed one stride from the nearest one towards the sample (rrt_planner.cpp:44-49)
+ *   0  as the reference writes it: a = atan2(dy, dx); near + stride * (cos(a), sin(a))         [this libc's libm]
+ *   1  the same point without the three libm calls: near + stride * (dx, dy) / sqrt(dx^2 + dy^2)  [IEEE operations only]
+ * The two agree to the last bit or two of the offset; the sum with the node's coordinate then rounds differently for a few
+ * per cent of the nodes, by one ulp.  The HIP kernel uses 1 (no device libm reproduces glibc's atan2 / cos / sin bit for bit
+ * anyway); the GPU parity tests compare it with steer = 1 BIT FOR BIT, and tests/test_oracle_misc.py measures how rarely
+ * the one-ulp difference between 0 and 1 changes a tree (a later nearest-node or blocked-disc decision at a last-bit tie). */
+void og_rrt_plan_steer(const og_geom* g, const float* master, const double start[2], const double target[2],
+                       double close_tol, unsigned seed, int max_samples, int steer, double* path_xy, int path_cap,
+                       og_rrt_result* res) {
   const int iteratorNum = 2000;             /* rrt_planner.cpp:6 */
   const double strideStep = 0.4;            /* rrt_planner.h:23 */
   const int targetTendency = (int)0.5;      /* rrt_planner.h:24,32 : int <- 0.5 == 0 */
@@ -115,9 +122,16 @@ void og_rrt_plan(const og_geom* g, const float* master, const double start[2], c
       if (hypot(np[0] - rnd[0], np[1] - rnd[1]) < strideStep) {
         nw[0] = rnd[0]; nw[1] = rnd[1];
       } else {
-        double a = atan2(rnd[1] - np[1], rnd[0] - np[0]);
-        nw[0] = np[0] + strideStep * cos(a);
-        nw[1] = np[1] + strideStep * sin(a);
+        if (steer == 0) {
+          double a = atan2(rnd[1] - np[1], rnd[0] - np[0]);
+          nw[0] = np[0] + strideStep * cos(a);
+          nw[1] = np[1] + strideStep * sin(a);
+        } else {
+          const double sdx = rnd[0] - np[0], sdy = rnd[1] - np[1];
+          const double sh = sqrt(sdx * sdx + sdy * sdy);
+          nw[0] = np[0] + strideStep * (sdx / sh);
+          nw[1] = np[1] + strideStep * (sdy / sh);
+        }
       }
       if (!og_if_blocked(g, master, nw)) {
         node.pos[0] = nw[0]; node.pos[1] = nw[1]; node.parent = near;
@@ -142,4 +156,11 @@ void og_rrt_plan(const og_geom* g, const float* master, const double start[2], c
   }
   res->path_len = len;
   free(tree);
+}
+
+/* the reference's formulation */
+void og_rrt_plan(const og_geom* g, const float* master, const double start[2], const double target[2],
+                 double close_tol, unsigned seed, int max_samples, double* path_xy, int path_cap,
+                 og_rrt_result* res) {
+  og_rrt_plan_steer(g, master, start, target, close_tol, seed, max_samples, 0, path_xy, path_cap, res);
 }

@@ -491,7 +491,7 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
     const int nti = ti + ki - 1, ntj = tj + kj - 1;
     if (lane < 9 && nti >= 0 && ntj >= 0 && nti < tiles_i && ntj < tiles_j) {
       const int tt = (int)__umul24((unsigned)ntj, (unsigned)tiles_i) + nti;   // (ntj >= 0 here; at most 2^20 tiles)
-      nb_pg = C.page_of(tt);
+      nb_pg = C.page_of(tt);   // (a sticky turn looks them up again: kept in LDS across the turns and looked up only where there was none, the bench measured the same -- profiles/r05_ab_sticky_pages.txt)
       nb_t = lane < 8 ? tt : -1;
     }
   }

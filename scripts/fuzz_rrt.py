@@ -63,7 +63,9 @@ def engine_for(info, g, master, ref):
 
 
 def oracle_plan(g, ref, q, k, budget=None):
-    return O.rrt_plan(g, ref, tuple(q["start"][k]), tuple(q["target"][k]), tol=float(q["close_tolerance"][k]),
+    # (steer=1: the oracle in the kernel's formulation of the steering step -- way points then agree bit for bit; the
+    # reference's atan2 / cos / sin formulation differs from it in the last bits only, tests/test_oracle_misc.py)
+    return O.rrt_plan(g, ref, tuple(q["start"][k]), tuple(q["target"][k]), tol=float(q["close_tolerance"][k]), steer=1,
                       seed=int(q["seed"][k]), max_samples=int(q["max_samples"][k]) if budget is None else budget)
 
 

@@ -148,6 +148,9 @@ def lib():
         L.og_rrt_plan.argtypes = [C.POINTER(Geom), fp, d2, d2, C.c_double, C.c_uint, C.c_int, d2, C.c_int,
                                   C.POINTER(RrtResult)]
         L.og_rrt_plan.restype = None
+        L.og_rrt_plan_steer.argtypes = [C.POINTER(Geom), fp, d2, d2, C.c_double, C.c_uint, C.c_int, C.c_int, d2, C.c_int,
+                                        C.POINTER(RrtResult)]
+        L.og_rrt_plan_steer.restype = None
         L.og_scan_to_rays.argtypes = [C.c_void_p, fp, C.c_void_p, C.c_int]
         L.og_scan_to_rays_tf.argtypes = [C.c_void_p, fp, C.c_void_p, C.c_int]
         L.og_range_to_ray_tf.argtypes = [C.c_float, C.c_float, d2, d2, C.c_void_p]
@@ -362,11 +365,12 @@ def astar_query_on_map(g, master, start, goal, path_cap=None):
     return res, path[:k].copy()
 
 
-def rrt_plan(g, master, start, target, tol=0.2, seed=1, max_samples=200000, cap=2048):
+def rrt_plan(g, master, start, target, tol=0.2, seed=1, max_samples=200000, cap=2048, steer=0):
+    """steer: 0 = the reference's atan2 / cos / sin (glibc), 1 = the normalised-offset form the HIP kernel uses (oracle/rrt.c)"""
     path = np.zeros(2 * cap, np.float64)
     res = RrtResult()
-    lib().og_rrt_plan(C.byref(g), fptr(master), d2(*start), d2(*target), tol, seed, max_samples,
-                      path.ctypes.data_as(C.POINTER(C.c_double)), cap, C.byref(res))
+    lib().og_rrt_plan_steer(C.byref(g), fptr(master), d2(*start), d2(*target), tol, seed, max_samples, steer,
+                            path.ctypes.data_as(C.POINTER(C.c_double)), cap, C.byref(res))
     return res, path[:2 * min(res.path_len, cap)].reshape(-1, 2).copy()
 
 

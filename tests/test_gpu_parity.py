@@ -793,11 +793,11 @@ def test_rrt_matches_oracle(R):
     assert (res["status"] == -1).sum() >= 3 and (res["status"] == 1).sum() >= 3
     for k in range(len(q)):
         ores, opath = O.rrt_plan(g, master, tuple(q["start"][k]), tuple(q["target"][k]), tol=0.2,
-                                 seed=int(q["seed"][k]), max_samples=int(q["max_samples"][k]))
+                                 seed=int(q["seed"][k]), max_samples=int(q["max_samples"][k]), steer=1)
         assert (res["status"][k], res["path_len"][k], res["tree_size"][k], res["samples"][k]) == \
                (ores.status, ores.path_len, ores.tree_size, ores.samples), k
         n = ores.path_len
-        assert np.allclose(paths[k, :n], opath, rtol=0, atol=1e-9), k
+        assert np.array_equal(paths[k, :n], opath), k      # bit for bit: the oracle in the kernel's steering formulation (oracle/rrt.c)
     e.close()
 
 
@@ -1154,7 +1154,9 @@ def test_astar_config3_every_bench_query_matches_oracle(R):
 def test_rrt_config4_one_gpu_share_matches_oracle(R):
     """Config 4: 2048 x 2048, 30 % rectangles (seed 3), one GPU's share of the 4096 trees = 512 queries (the reference's
     2000 extendTree iterations, rrt_planner.cpp:6, each bounded to the batch's 100 000 samples in total): status, tree
-    size, sample count and path length exact, way points at 1e-9 m."""
+    size, sample count, path length and every way point bit for bit -- against the oracle with the steering step in the kernel's
+    formulation (near + 0.4 (dx, dy) / sqrt(dx^2 + dy^2) instead of atan2 / cos / sin; oracle/rrt.c `steer`, and
+    tests/test_oracle_misc.py for how rarely the two formulations part)."""
     n = 2048
     L = n * 0.05
     e = R.Engine(L, L, 0.05)
@@ -1166,10 +1168,10 @@ def test_rrt_config4_one_gpu_share_matches_oracle(R):
 
     def one(k):
         ores, opath = O.rrt_plan(g, master, tuple(q["start"][k]), tuple(q["target"][k]), tol=0.2,
-                                 seed=int(q["seed"][k]), max_samples=int(q["max_samples"][k]))
+                                 seed=int(q["seed"][k]), max_samples=int(q["max_samples"][k]), steer=1)
         assert (res["status"][k], res["tree_size"][k], res["samples"][k], res["path_len"][k]) == \
                (ores.status, ores.tree_size, ores.samples, ores.path_len), k
-        assert np.allclose(paths[k, :ores.path_len], opath, rtol=0, atol=1e-9), k
+        assert np.array_equal(paths[k, :ores.path_len], opath), k      # bit for bit (steer = 1: the kernel's formulation of the steering step)
         return ores.status
     st = oracle_pool(one, len(q))
     assert 0 in st                       # some trees reach their target within the budget
@@ -1240,7 +1242,7 @@ def test_vfh_config2_full_batch_matches_oracle(R):
 
 def test_rrt_config4_sample_matches_oracle(R):
     """Config 4's map (2048 x 2048, 30 % rectangles, seed 3): a sample of its queries against the oracle --
-    status, tree size, sample count exact; way points at 1e-9 m."""
+    status, tree size, sample count and way points exact (oracle with steer = 1, see the share test above)."""
     n = 2048
     L = n * 0.05
     e = R.Engine(L, L, 0.05)
@@ -1251,10 +1253,10 @@ def test_rrt_config4_sample_matches_oracle(R):
     res, paths = e.rrt(q)
     for k in range(len(q)):
         ores, opath = O.rrt_plan(g, master, tuple(q["start"][k]), tuple(q["target"][k]), tol=0.2,
-                                 seed=int(q["seed"][k]), max_samples=int(q["max_samples"][k]))
+                                 seed=int(q["seed"][k]), max_samples=int(q["max_samples"][k]), steer=1)
         assert (res["status"][k], res["tree_size"][k], res["samples"][k], res["path_len"][k]) == \
                (ores.status, ores.tree_size, ores.samples, ores.path_len), k
-        assert np.allclose(paths[k, :ores.path_len], opath, rtol=0, atol=1e-9), k
+        assert np.array_equal(paths[k, :ores.path_len], opath), k      # bit for bit (steer = 1: the kernel's formulation of the steering step)
     e.close()
 
 

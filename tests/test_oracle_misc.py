@@ -216,3 +216,36 @@ def test_oracle_himm_drops_malformed_rays():
     mixed = np.concatenate([bad[:2], good[:1], bad[2:4], good[1:], bad[4:]])
     O.himm_update(g, b, mixed)
     assert np.array_equal(a, b) and (a != 40.0).any()
+
+
+def test_rrt_steering_formulations_part_only_in_the_last_bits():
+    """oracle/rrt.c restates extendTree's steering step twice: as the reference writes it (a = atan2(dy, dx); near + 0.4 (cos a,
+    sin a), this libc's libm) and as the HIP kernel computes it (near + 0.4 (dx, dy) / sqrt(dx^2 + dy^2): IEEE operations only --
+    no device libm reproduces glibc's atan2 / cos / sin bit for bit, and the three calls held the kernel at 127 VGPRs).  The
+    GPU tests compare the kernel with the second one bit for bit; this test measures what separates the two formulations:
+    on 120 queries of a 512 x 512 map every tree has the same size, sample count, status and path length, and no way point
+    differs by more than 1e-12 m (measured: 5.3e-15).  A one-ulp difference CAN flip a later nearest-node or blocked-disc
+    decision at a last-bit tie (round 4's advisor finding; scripts/fuzz_rrt.py counts such cases: 4 in 1.9e5 queries) -- the
+    bound below is what a regression would have to break."""
+    import ctypes as C
+    from ros_navigation_amd import synth
+    n = 512
+    L = n * 0.05
+    g = O.make_geom(L, L, 0.05)
+    master = synth.obstacles_rect(n, n, density=0.15, seed=3, side=(4, 24))
+
+    def getpos(i, j):
+        p = (C.c_double * 2)()
+        O.lib().og_position_from_index(C.byref(g), (C.c_int * 2)(i, j), p)
+        return (p[0], p[1])
+    q = synth.rrt_queries(120, master, n, n, getpos, seed=5, max_samples=20000)
+    same = 0
+    worst = 0.0
+    for k in range(len(q)):
+        a, pa = O.rrt_plan(g, master, tuple(q["start"][k]), tuple(q["target"][k]), seed=int(q["seed"][k]), max_samples=20000, steer=0)
+        b, pb = O.rrt_plan(g, master, tuple(q["start"][k]), tuple(q["target"][k]), seed=int(q["seed"][k]), max_samples=20000, steer=1)
+        if (a.status, a.tree_size, a.samples, a.path_len) == (b.status, b.tree_size, b.samples, b.path_len):
+            same += 1
+            if len(pa):
+                worst = max(worst, float(np.abs(pa - pb).max()))
+    assert same >= len(q) - 1 and worst < 1e-12, (same, worst)
