@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/
 ASTAR_BYTES_PER_SETTLED = 44   # 8 neighbour occupancy reads x 4 B + 12 B g/parent/flag RMW
 VFH_BYTES_PER_POSE = 4 * 31 * 31 + 2 * 72 * 4 + 32
 ROTATE = int(os.environ.get("RNA_BENCH_ROTATE", "4"))   # distinct ray batches / pose sets / query sets the steps cycle through (developer override)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
 
 
 def parse():
@@ -314,14 +314,14 @@ def pmc_traffic(kernel, args, world):
         ks = [find(name) for name in ([kernel] if isinstance(kernel, str) else kernel)]   # a slot's chain: one launch each
         lo = sum(k["fetch_size_kb_avg"] + k["write_size_kb_avg"] for k in ks) * 1024.0
         hi = sum(2.0 * k["fetch_size_kb_avg"] + k["write_size_kb_avg"] for k in ks) * 1024.0
-        return [lo, hi], "profiles/r04_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " \
+        return [lo, hi], "profiles/r05_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " \
                          "[(FETCH+WRITE), (2*FETCH+WRITE)] x 1024 B per launch"
     except Exception:
         return None, "no PMC summary committed for this kernel"
 
 
-SQ_COUNTERS = os.path.join(ROOT, "profiles", "r04_search_sq_counters.txt")
-JOB_STATS = os.path.join(ROOT, "profiles", "r04_search_job_stats.txt")
+SQ_COUNTERS = os.path.join(ROOT, "profiles", "r05_search_sq_counters.txt")
+JOB_STATS = os.path.join(ROOT, "profiles", "r05_search_job_stats.txt")
 VALU_PEAK_PER_NS_SIMD = 0.58      # profiles/r03_ubench_valu.txt: eight wavefronts per SIMD issue 0.54-0.59 dependent VALU instructions per ns
 SEARCH_SIMDS = (256 - 32) * 4     # the search streams' CU mask leaves 32 of the 256 CUs to the engine stream
 
@@ -343,7 +343,7 @@ def valu_issue(args, world, wall_per_pass):
         per_ns_simd = valu / (wall_per_pass * 1e9) / SEARCH_SIMDS
         return {"bound": "valu issue", "achieved": per_ns_simd, "peak": VALU_PEAK_PER_NS_SIMD, "unit": "wavefront VALU instructions / ns / SIMD",
                 "frac": per_ns_simd / VALU_PEAK_PER_NS_SIMD, "valu_per_batch": valu, "salu_per_batch": salu,
-                "source": "profiles/r04_search_sq_counters.txt (one batch alone), profiles/r03_ubench_valu.txt (the SIMD's issue rate); "
+                "source": "profiles/r05_search_sq_counters.txt (one batch alone), profiles/r03_ubench_valu.txt (the SIMD's issue rate); "
                           "224 CUs x 4 SIMDs"}
     except Exception:
         return None
@@ -368,14 +368,26 @@ def work_inflation(args, world, settled_per_launch):
                 settled = float(f[1])
         out = {"instructions_per_settled_cell": (valu + salu) / settled, "valu_per_settled_cell": valu / settled,
                "salu_per_settled_cell": salu / settled,
-               "source": "profiles/r04_search_sq_counters.txt: SQ_INSTS_VALU + SQ_INSTS_SALU of one 256-query batch alone (the first query set on the "
+               "source": "profiles/r05_search_sq_counters.txt: SQ_INSTS_VALU + SQ_INSTS_SALU of one 256-query batch alone (the first query set on the "
                          "untouched bench map) / the cells the oracle settles for that batch"}
         text = open(JOB_STATS).read()
         m = re.search(r"jobs per touched tile ([0-9.]+), jobs that find nothing ([0-9.]+) of all", text)
         if m:
             out["jobs_per_touched_tile"] = float(m.group(1))
             out["noop_job_frac"] = float(m.group(2))
-            out["source"] += "; profiles/r04_search_job_stats.txt (phase timers and job counts of the stats build under the bench's load)"
+        m = re.search(r"sticky turns .*? ([0-9.]+) of all jobs, of which ([0-9.]+) find nothing", text)
+        if m:   # (a sticky turn -- the wavefront keeps a tile that was woken while it ran -- counts as a job in these figures)
+            out["sticky_turn_frac"] = float(m.group(1))
+            out["sticky_turn_noop_frac"] = float(m.group(2))
+        m = re.search(r"in jobs [0-9.]+ wave-ms \(([0-9.]+)%\), taking jobs [0-9.]+ wave-ms \(([0-9.]+)%\)", text)
+        if m:
+            out["wavefront_lifetime_in_jobs_frac"] = float(m.group(1)) / 100.0
+            out["wavefront_lifetime_taking_jobs_frac"] = float(m.group(2)) / 100.0
+        m = re.search(r"backtrace .*?: ([0-9.]+) us per found path, ([0-9.]+) % of the workgroup's residence", text)
+        if m:
+            out["backtrace_us_per_path"] = float(m.group(1))
+            out["backtrace_frac_of_residence"] = float(m.group(2)) / 100.0
+            out["source"] += "; profiles/r05_search_job_stats.txt (phase timers and job counts of the stats build under the bench's load)"
         return out
     except Exception:
         return None
