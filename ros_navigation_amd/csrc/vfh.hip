@@ -109,6 +109,12 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
     st_max_speed_picked = K.max_speed_picked[b];
     st_blocked_radius = K.blocked_radius[b];
   }
+  // (round 5: every load whose address is known here goes out here -- the kernel is a chain of phases, each of which used to
+  // start with a trip to L2 of its own: the robot's last speed before the cell magnitudes, its last binary histogram inside
+  // the histogram step)
+  const int last_speed = K.last_chosen_speed[b];
+  float st_last_binary = 0.0f;
+  if (tid < K.H) st_last_binary = K.last_binary[(size_t)b * K.H + tid];
 
   // ---------------- ranges (steerer.cpp:147-191) ----------------
   for (int i = tid; i < 361; i += VFH_THREADS)
@@ -146,17 +152,33 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
         atomicMin(&rng[fl * 2], bits);
         atomicMin(&rng[ce * 2], bits);
       };
-      for (int lin = tid; lin < sr * sc; lin += VFH_THREADS) {
-        const int i = lin % sr, j = lin / sr;
-        const int u[2] = {tl_u[0] + i, tl_u[1] + j};
-        int bi[2];
-        buffer_index(g, u, bi);
-        const float value = master[(size_t)bi[1] * g.size[0] + bi[0]];
-        if (value != value) continue;
-        if (value <= 3) continue;
-        const int k = atomicAdd(&s_nocc, 1);
-        if (k < VFH_OCC_CAP) occ[k] = lin;
-        else obstacle(lin);   // a submap with more obstacle cells than the list holds: the rest in place
+      // eight cells per thread and trip, all eight reads issued before the first is looked at: the 31 x 31 window is ONE trip
+      // to L2 instead of eight one after the other (the loop's `continue`s kept the compiler from batching them: 5 of the
+      // phase's 6-8 us)
+      const int ncell_sm = sr * sc;
+      for (int base = 0; base < ncell_sm; base += 8 * VFH_THREADS) {
+        float val[8];
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+          const int lin = base + k8 * VFH_THREADS + tid;
+          val[k8] = 0.0f;
+          if (lin < ncell_sm) {
+            const int i = lin % sr, j = lin / sr;
+            const int u[2] = {tl_u[0] + i, tl_u[1] + j};
+            int bi[2];
+            buffer_index(g, u, bi);
+            val[k8] = master[(size_t)bi[1] * g.size[0] + bi[0]];
+          }
+        }
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+          const int lin = base + k8 * VFH_THREADS + tid;
+          const float value = val[k8];
+          if (lin >= ncell_sm || value != value || value <= 3) continue;
+          const int k = atomicAdd(&s_nocc, 1);
+          if (k < VFH_OCC_CAP) occ[k] = lin;
+          else obstacle(lin);   // a submap with more obstacle cells than the list holds: the rest in place
+        }
       }
       __syncthreads();
       const int nocc = s_nocc < VFH_OCC_CAP ? s_nocc : VFH_OCC_CAP;
@@ -170,26 +192,39 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
   const float desired_angle = pose.goal_direction;
   const float dist_to_goal = pose.goal_distance;
   const float goal_tol = pose.goal_tolerance;
-  const int last_speed = K.last_chosen_speed[b];
   int speed = pose.current_speed < 0 ? 0 : pose.current_speed;
   if (speed < last_speed) speed = last_speed;
   const int tspeed = speed > K.max_speed ? K.max_speed : speed;  // table index (reference: OOB read)
+  const float bcr_tspeed = K.bcr[tspeed];   // (for the tail: on its way while the histograms are built)
 
   // ---------------- Calculate_Cells_Mag (vfh.cpp:986-1049) ----------------
   const float r_safe = K.robot_radius + (float)k_safety_dist(K.sd0, K.sd1, speed);
-  for (int q = tid; q < K.NQ; q += VFH_THREADS) {
-    float m = 0.0f;
-    if (q < K.NQF) {
-      const float cd = K.cell_dist[q];
-      const double range = __longlong_as_double((long long)rng[K.range_idx[q]]);
-      if ((cd + K.cell_width / 2.0) > range) {
-        const int x = q % K.W, y = q / K.W;
-        if (cd < r_safe && !(x == K.CX && y == K.CY)) s_emergency = 1;
-        m = K.cell_base_mag[q];
-      }
+  for (int q0 = 0; q0 < K.NQ; q0 += 4 * VFH_THREADS) {   // (four cells per thread and trip, the table reads first)
+    float cd4[4], bm4[4];
+    int ri4[4];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int q = q0 + k4 * VFH_THREADS + tid;
+      cd4[k4] = 0.0f; bm4[k4] = 0.0f; ri4[k4] = 0;
+      if (q < K.NQF) { cd4[k4] = K.cell_dist[q]; ri4[k4] = K.range_idx[q]; bm4[k4] = K.cell_base_mag[q]; }
     }
-    mag[q] = m;
-    if (m != 0.0f) atomicOr(&nz[q >> 5], 1u << (q & 31));
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int q = q0 + k4 * VFH_THREADS + tid;
+      if (q >= K.NQ) continue;
+      float m = 0.0f;
+      if (q < K.NQF) {
+        const float cd = cd4[k4];
+        const double range = __longlong_as_double((long long)rng[ri4[k4]]);
+        if ((cd + K.cell_width / 2.0) > range) {
+          const int x = q % K.W, y = q / K.W;
+          if (cd < r_safe && !(x == K.CX && y == K.CY)) s_emergency = 1;
+          m = bm4[k4];
+        }
+      }
+      mag[q] = m;
+      if (m != 0.0f) atomicOr(&nz[q >> 5], 1u << (q & 31));
+    }
   }
   __syncthreads();
   VFH_STAMP();
@@ -209,12 +244,19 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
     if (tid < K.H) {
       const unsigned* mb = K.memb + ((size_t)speed_index * K.H + tid) * K.NW;
       float sum = 0.0f;
-      for (int w = 0; w < K.NW; ++w) {
-        unsigned bits = mb[w] & nz[w];
-        while (bits) {  // ascending q == the reference's (y outer, x inner) order
-          const int bit = __ffs(bits) - 1;
-          bits &= bits - 1;
-          sum += mag[w * 32 + bit];
+      for (int w0 = 0; w0 < K.NW; w0 += 8) {   // (the sector's membership words eight at a time: one trip to L2 per eight)
+        unsigned mbw[8];
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) mbw[k8] = w0 + k8 < K.NW ? mb[w0 + k8] : 0u;
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+          const int w = w0 + k8;
+          unsigned bits = w < K.NW ? (mbw[k8] & nz[w]) : 0u;
+          while (bits) {  // ascending q == the reference's (y outer, x inner) order
+            const int bit = __ffs(bits) - 1;
+            bits &= bits - 1;
+            sum += mag[w * 32 + bit];
+          }
         }
       }
       origin[tid] = sum;
@@ -224,7 +266,7 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
       float h;
       if (sum > hi) h = 1.0f;
       else if (sum < lo) h = 0.0f;
-      else h = last_binary[tid];
+      else h = st_last_binary;
       last_binary[tid] = h;
       s_hist[tid] = h;
     }
@@ -287,7 +329,7 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
       max_speed_for_picked = 0;
       last_picked = picked;
     } else {
-      blocked_radius = K.bcr[tspeed];
+      blocked_radius = bcr_tspeed;
       // ---------------- Select_Direction (vfh.cpp:755-870) ----------------
       // The reference walks the ring of sectors once from the first blocked sector of the front half, opens a valley
       // at every 1 -> 0 step, closes it at the next 0 -> 1 step, and weighs the valley's candidate angles as they come;
