@@ -61,6 +61,9 @@ constexpr int MASK_STRIDE = TILE_WORDS + 32 + 128;  // snapshot bytes per tile: 
                           // (non-sticky ones to 7 % of all jobs), the bench from 154.3 k to 152.7 k cycles/s -- three more loads and
                           // their addresses in every working job cost more than the cheap jobs they save.  Off.
 #endif
+#ifndef RNA_TSA_IDLE_SLEEP
+#define RNA_TSA_IDLE_SLEEP 4   // an idle wavefront looks at the entry counter every 64 x this many clocks (1 / 4 / 12: profiles/r05_ab_idle_sleep.txt)
+#endif
 #ifndef RNA_TSA_REDBLACK
 #define RNA_TSA_REDBLACK 1   // rounds alternate between the two checkerboard colours of the tiles
 #endif
@@ -1621,7 +1624,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
       if (lds_ldi(&s_state) >= 4) break;
       if (idle) {
         if (lds_ldi(&s_idle) == WAVES) break;          // every wavefront idle: nothing queued, nothing running
-        if (lds_ldi(&s_count) <= 0) { __builtin_amdgcn_s_sleep(4); continue; }
+        if (lds_ldi(&s_count) <= 0) { __builtin_amdgcn_s_sleep(RNA_TSA_IDLE_SLEEP); continue; }
         if (lane == 0) atomicSub(&s_idle, 1);
         idle = false;
       }
