@@ -15,6 +15,11 @@
  *            4: the protocol of tsa_search_kernel: every wake-up adds a (key, tile) entry unless the tile is running (then
  *               its own wavefront queues it again with the lowest key when it ends); a free wavefront takes the entry
  *               with the lowest key and drops it if the tile has nothing pending (its wake-ups were consumed already)
+ *   round 5: SIM_FIRSTROWS (a tile's first job in a bucket evaluates only the rows that hold a cell the new bound releases --
+ *   the rule the kernel's RNA_TSA_FIRST_ROWS implements), SIM_FIRSTWAKE (... and its wake tests take released cells only: no
+ *   difference), SIM_AGAINKEY (a tile woken while it ran is queued with its waker's key instead of the lowest); the last lines
+ *   count the re-runs of tiles woken while they ran and how often a wavefront's next tile is the one it just finished -- the
+ *   figures behind the kernel's sticky tiles.
  *   job cost model (microseconds, from the RNA_TSA_STATS phase timers under load): load+halo 3.8, rows 0.2 each,
  *   horizontal passes 0.065 each, results 2.6; a job that finds nothing in its halo 3.8.
  */
@@ -94,9 +99,21 @@ static void job(int t, int first, jobres* r) {
       }
       if (v < cur[b][a]) { cur[b][a] = v; hz |= 1u << b; if (b + 1 < TJ) fa |= 1u << (b + 1); if (b > 0) fb |= 1u << (b - 1); }
     }
-  const unsigned all = (1u << TJ) - 1;
-  if (first) { hz = fa = fb = all; }
-  if (!(hz | fa | fb)) {
+  const unsigned all = (1u << TJ) - 1; int first_noskip = 0;
+  if (first && getenv("SIM_FIRSTROWS")) {
+    /* only the rows that hold a cell the new bound releases: it passes on now and f >= the bucket's start */
+    for (int b = 0; b < TJ; ++b)
+      for (int a = 0; a < TI; ++a) {
+        const int i = i0 + a, j = j0 + b;
+        if (i >= rows || j >= cols) continue;
+        const int v = cur[b][a];
+        if (v >= INF) continue;
+        const long long f = (long long)v + octile(i, j);
+        if (f < lim && f >= bend - bucket_w) { hz |= 1u << b; if (b + 1 < TJ) fa |= 1u << (b + 1); if (b > 0) fb |= 1u << (b - 1); }
+      }
+    first_noskip = 1;
+  } else if (first) { hz = fa = fb = all; }
+  if (!(hz | fa | fb) && !first) {
     r->noop = 1; r->cost = C_LOAD;
     for (int b = 0; b < TJ; ++b) for (int a = 0; a < TI; ++a) r->val[b * TI + a] = cur[b][a];
     return;
@@ -160,7 +177,7 @@ static void job(int t, int first, jobres* r) {
     }
     dir ^= 1;
   }
-  static uint8_t chg[16][64];
+  static uint8_t chg[16][64]; static uint8_t rel[16][64]; const int firstw = getenv("SIM_FIRSTWAKE") != NULL;
   r->first = first;
   for (int b = 0; b < TJ; ++b)
     for (int a = 0; a < TI; ++a) { r->ppv[b * TI + a] = pp[b][a]; r->chgv[b * TI + a] = 0; }
@@ -169,8 +186,9 @@ static void job(int t, int first, jobres* r) {
       const int i = i0 + a, j = j0 + b;
       const int v = cur[b][a];
       r->val[b * TI + a] = v;
-      chg[b][a] = 0;
+      chg[b][a] = 0; rel[b][a] = 0;
       if (i >= rows || j >= cols || v >= INF) continue;
+      { const long long f_ = (long long)v + octile(i, j); rel[b][a] = (uint8_t)(first && f_ < lim && f_ >= bend - bucket_w); }
       const int ch = v < old[b][a];
       chg[b][a] = (uint8_t)ch;
       r->chgv[b * TI + a] = (uint8_t)ch;
@@ -193,7 +211,7 @@ static void job(int t, int first, jobres* r) {
   for (int side = 0; side < 2; ++side) {
     const int b = side ? TJ - 1 : 0;
     for (int a = 0; a < TI; ++a) {
-      if (!PASSES(b, a) || !(chg[b][a] || first)) continue;
+      if (!PASSES(b, a) || !(chg[b][a] || (firstw ? rel[b][a] : first))) continue;
       for (int k = (side ? 5 : 0); k < (side ? 8 : 3); ++k) {
         if (!((mk[b][a] >> k) & 1)) continue;
         const int na = a + di[k];
@@ -203,9 +221,9 @@ static void job(int t, int first, jobres* r) {
       }
     }
   }
-  int trig = first;
+  int trig = firstw ? 0 : first;
   for (int b = 0; b < TJ && !trig; ++b)
-    if ((chg[b][0] && PASSES(b, 0)) || (chg[b][TI - 1] && PASSES(b, TI - 1))) trig = 1;
+    if (((chg[b][0] || rel[b][0]) && PASSES(b, 0)) || ((chg[b][TI - 1] || rel[b][TI - 1]) && PASSES(b, TI - 1))) trig = 1;
   if (trig)
     for (int side = 0; side < 2; ++side) {
       const int a = side ? TI - 1 : 0, da = side ? 1 : -1;
@@ -229,7 +247,7 @@ static void job(int t, int first, jobres* r) {
 
 /* SIM_FRESH: the wake tests of a job evaluated when it ENDS against what the neighbours hold THEN (the kernel would
    re-read their edge rows / columns after its stores), instead of against the halo it loaded when it started */
-static int fresh = 0;
+static int fresh = 0; static long n_again=0, n_again_noop=0, n_sticky=0, n_nbr=0; static int last_t[64]; static uint8_t *isagain;
 static void wake_fresh(jobres* r) {
   static const int di[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dj[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
   const int t = r->t, ti = t % tiles_i, tj = t / tiles_i, i0 = ti * TI, j0 = tj * TJ;
@@ -309,7 +327,9 @@ static void epush(int t, long long key) {
   if (nent > maxent) maxent = nent;
 }
 static long long cls_of(long long key) { if (kshift < 0) return key; const long long lo = bend - bucket_w; return key < lo ? 0 : (key - lo) >> kshift; }
+static int againkey=0; static long long *akey;
 static void wake4(int t, long long key) {
+  if (running[t]) { if (!Dbit[t] || key < akey[t]) akey[t] = key; }
   if (nodup && !running[t]) {
     /* nodup 1: a pending tile keeps its first entry; 2: a duplicate only when the key class gets lower */
     if (Dbit[t]) { if (nodup == 2 && cls_of(key) < qcls[t]) { qcls[t] = cls_of(key); epush(t, key); } return; }
@@ -402,7 +422,7 @@ int main(int argc, char** argv) {
   g = malloc(sizeof(int32_t) * (size_t)rows * cols);
   first_f = calloc(ntile, 1); queued = calloc(ntile, 1); running = calloc(ntile, 1); dirty = calloc(ntile, 1); farflag = calloc(ntile, 1);
   popkey = calloc(ntile, sizeof(long long));
-  ents = malloc(sizeof(entry) * (1 << 22)); Dbit = calloc(ntile, 1); qcls = calloc(ntile, sizeof(long long));
+  ents = malloc(sizeof(entry) * (1 << 22)); isagain=calloc(ntile,1); akey=calloc(ntile,sizeof(long long)); if(getenv("SIM_AGAINKEY")) againkey=1; for(int w=0;w<64;++w) last_t[w]=-1; Dbit = calloc(ntile, 1); qcls = calloc(ntile, sizeof(long long));
   qkey = malloc(sizeof(long long) * ntile); dkey = malloc(sizeof(long long) * ntile);
   qlist = malloc(sizeof(int) * (ntile + 8192));
   jobres* slot = malloc(sizeof(jobres) * (W > 4096 ? W : 4096));
@@ -495,6 +515,8 @@ int main(int argc, char** argv) {
             lim = bend < (long long)best + 1 ? bend : (long long)best + 1;
             const int fst = first_f[t]; first_f[t] = 0;
             job(t, fst, &slot[w]);
+            if (isagain[t]) { isagain[t]=0; n_again_noop += slot[w].noop; }
+            if (last_t[w]==t) n_sticky++; else if (last_t[w]>=0) { int d=abs(last_t[w]%tiles_i - t%tiles_i), e=abs(last_t[w]/tiles_i - t/tiles_i); if (d<=1&&e<=1) n_nbr++; } last_t[w]=t;
             running[t] = 1; dirty[t] = 0;
             busy[w] = 1; tend[w] = now + C_POP * (1 + spent) + slot[w].cost;
             st.jobs++; st.noop += slot[w].noop; st.row_evals += slot[w].rowsn; st.hextra += slot[w].hp;
@@ -528,7 +550,7 @@ int main(int argc, char** argv) {
         running[r->t] = 0;
         if (r->far) farflag[r->t] = 1;
         if (policy == 4) {
-          if (Dbit[r->t]) epush(r->t, 0);
+          if (Dbit[r->t]) { epush(r->t, againkey ? akey[r->t] : 0); n_again++; isagain[r->t]=1; }
           for (int d = 0; d < 8; ++d) if (r->wake[d] >= 0) wake4(r->wake[d], r->wkey[d]);
           continue;
         }
@@ -564,6 +586,7 @@ int main(int argc, char** argv) {
          tot.busy * 1e-3 / nq, sum_makespan * 1e-3 / nq, max_makespan * 1e-3, 100.0 * tot.busy / (sum_makespan * W), bad);
   printf("  most entries queued at once: %d (most in one key class: %d)\n", policy == 4 ? maxent : maxlive, clsmax);
   if (ringcap) printf("  pushes that found every class from theirs on full: %ld\n", ringspill);
+  printf("  again re-queues %ld (%.3f of jobs), of which no-op %.3f; next job same tile %.3f of jobs, a neighbour tile %.3f\n", n_again, (double)n_again/tot.jobs, (double)n_again_noop/(n_again?n_again:1), (double)n_sticky/tot.jobs, (double)n_nbr/tot.jobs);
   if (policy == 4) printf("  entries pushed per job %.2f, stale entries dropped per job %.2f\n", (double)pushes / tot.jobs, (double)stale_pops / tot.jobs);
   return bad ? 1 : 0;
 }

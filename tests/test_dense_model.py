@@ -72,7 +72,8 @@ def test_open_list_schedule_model_matches_the_oracle(sim_async, tmp_path, rows, 
     assert (rec[:, 2] < 0x7fffffff).sum() >= 8
     for policy in ("0", "1", "2", "3", "4"):
         for bucket, waves in ((2828, 3), (24000, 8), (96000, 8), (400000, 16)):
-            for env in ({}, {"SIM_KSHIFT": "2"}, {"SIM_DIRTYKEY": "2", "SIM_KSHIFT": "10"}):
+            for env in ({}, {"SIM_KSHIFT": "2"}, {"SIM_DIRTYKEY": "2", "SIM_KSHIFT": "10"}) + (
+                    ({"SIM_FIRSTROWS": "1", "SIM_KSHIFT": "9"}, {"SIM_FIRSTROWS": "1", "SIM_FIRSTWAKE": "1"}) if policy == "4" else ()):   # (round 5: the first-job rule of RNA_TSA_FIRST_ROWS)
                 out = subprocess.run([sim_async, wl, str(bucket), "16", policy, str(waves)], capture_output=True, text=True,
                                      env=dict(os.environ, **env), timeout=300)
                 assert out.returncode == 0 and "mismatches 0" in out.stdout, (policy, bucket, waves, env, out.stdout[-400:], out.stderr[-400:])
