@@ -2070,7 +2070,7 @@ void tsa_stats_dump() {
                       (double)(st[24] - st[28]) * 0.01 / (double)std::max<unsigned long long>(1, st[29]));
   fprintf(stderr, "[tsa stats] sticky turns (the wavefront kept a tile that was woken while it ran) %.3f of all jobs, of which %.3f find nothing\n",
           (double)st[22] / jobs, (double)st[23] / (double)std::max<unsigned long long>(1, st[22]));
-  fprintf(stderr, "[tsa stats] first jobs (a tile's first in a bucket: every row evaluated both ways) %.3f of all, %.1f row evaluations and %.1f changed rows each; rows changed per job %.1f; rows sent to the scan per job %.2f\n",
+  fprintf(stderr, "[tsa stats] first jobs (a tile's first in a bucket: the rows a new bound releases, and what they flag) %.3f of all, %.1f row evaluations and %.1f changed rows each; rows changed per job %.1f; rows sent to the scan per job %.2f\n",
           (double)st[18] / jobs, (double)st[19] / (double)std::max<unsigned long long>(1, st[18]), (double)st[20] / (double)std::max<unsigned long long>(1, st[18]), (double)st[21] / jobs, (double)st[14] / jobs);
 }
 #endif
