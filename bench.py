@@ -119,6 +119,7 @@ def pin_to_gpu_numa_node(local_rank):
     try:
         cpus = set(os.sched_getaffinity(0))
         before = set(cpus)
+        _AFFINITY_AT_START[:] = sorted(before)
         if os.environ.get("RNA_BENCH_NO_PIN") != "1":
             gpus = []
             for path in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"), key=lambda p: int(p.split("/")[-2])):
@@ -153,6 +154,9 @@ def pin_to_gpu_numa_node(local_rank):
         info["error"] = repr(ex)
         info["pinned"] = False
     return info
+
+
+_AFFINITY_AT_START = []   # the cores the process started with (the CPU baseline leg goes back to them: it is timed on all host cores)
 
 
 def spawn_ranks(args):
@@ -259,7 +263,13 @@ def cpu_baseline(args, R, master, rays, poses, queries, rows, cols, length):
     except Exception:   # noqa: BLE001 -- a side figure: the baseline stands without it
         vfh_ref_us = vfh_port_us = None
     per_cycle_1 = t_himm / len(queries) + t_vfh + t_a / n_a
-    # (ii) one thread per host core over independent A* queries (ctypes releases the GIL inside the C oracle)
+    # (ii) one thread per host core over independent A* queries (ctypes releases the GIL inside the C oracle) -- on ALL the cores
+    # the process started with, not only those of the GPU's NUMA node the timed region was pinned to
+    if _AFFINITY_AT_START:
+        try:
+            os.sched_setaffinity(0, set(_AFFINITY_AT_START))
+        except OSError:
+            pass
     cores = max(1, len(os.sched_getaffinity(0)))
     from concurrent.futures import ThreadPoolExecutor
     n_mt = min(len(queries), max(cores, int(round(cores * args.cpu_seconds / max(t_a / n_a, 1e-6)))))
