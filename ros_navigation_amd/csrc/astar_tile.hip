@@ -733,7 +733,9 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
   // wake-ups) releases the same cells again: evaluated once more, harmless.
   if (first) {
     unsigned rel = 0u;
-#define TSA_RELEASED(b) if (__builtin_amdgcn_ballot_w64(TSA_PP(b) != 0 && TSA_G(b) <= TSA_HC(b, key_base)) != 0ull) rel |= 1u << (b);
+    // (pp is the cell's value or 0, and h + key_base > 0: `pp != 0 && pp <= h + key_base` is ONE unsigned comparison -- as two
+    // conditions the compiler built an exec-masked block per row, 17 instructions)
+#define TSA_RELEASED(b) if (__builtin_amdgcn_ballot_w64((unsigned)(TSA_PP(b) - 1) < (unsigned)TSA_HC(b, key_base)) != 0ull) rel |= 1u << (b);
     TSA_R16(TSA_RELEASED)
 #undef TSA_RELEASED
     nd |= (rel | (rel << 1)) & 0xffffu;
