@@ -362,7 +362,8 @@ __device__ __forceinline__ unsigned long long tsa_row_fixpoint(int& g, int& pp, 
     const unsigned c = __builtin_amdgcn_mbcnt_hi((unsigned)(blk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)blk, 0u)) << TSA_SCAN_SHIFT;
     const unsigned t = tsa_prefix_max(c + (pp != 0 ? (unsigned)(pp + off) : 0u)) - c;
     const int cand = (int)t - off;
-    best = (t != 0u && cand + COST_S >= lane_m1(ht_, INF)) ? cand : 0;
+    const int ht_before = lane_m1(ht_, INF);   // (formed for ALL lanes, outside any condition: a wave shift inside a short-circuit `&&` runs with the other lanes switched off)
+    best = ((t != 0u) & (cand + COST_S >= ht_before)) ? cand : 0;
   }
 #ifndef RNA_TSA_SCAN_BOTH
   if (__builtin_amdgcn_ballot_w64(((lane_p1(pp) - COST_S) & open_) > g))
@@ -377,7 +378,8 @@ __device__ __forceinline__ unsigned long long tsa_row_fixpoint(int& g, int& pp, 
     const unsigned t_rev = tsa_prefix_max(c + (unsigned)__builtin_amdgcn_ds_bpermute(rl << 2, (int)key)) - c;
     const unsigned t = (unsigned)__builtin_amdgcn_ds_bpermute(rl << 2, (int)t_rev);
     const int cand = (int)t - off;
-    best = max(best, (t != 0u && cand + COST_S >= lane_p1(ht_, INF)) ? cand : 0);
+    const int ht_before = lane_p1(ht_, INF);
+    best = max(best, ((t != 0u) & (cand + COST_S >= ht_before)) ? cand : 0);
   }
   g = max(g, best & open_);
   pp = g >= ht_ ? g : 0;
@@ -1476,7 +1478,7 @@ __device__ __forceinline__ void tsa_backtrace_wave(const TsaLaunch& A, const Tsa
       if (len > ncell || uc == 0u) { ok = false; break; }
       const unsigned mc = s_mask[il * 16 + jl];
       const unsigned un = s_tile[(jl + 1) * BW + il + 1 + off];
-      const bool hit = lane < 8 && ((mc >> k) & 1u) && un != 0u && un == uc + (unsigned)wk;   // g(n) + w == g(c)
+      const bool hit = (lane < 8) & (((mc >> k) & 1u) != 0u) & (un != 0u) & (un == uc + (unsigned)wk);   // g(n) + w == g(c)  (no short circuits: one chain of compares, no exec-masked blocks in the walk)
       const unsigned long long m = __ballot(hit);
       if (!m) { ok = false; break; }
       const int src = __ffsll((long long)m) - 1;
