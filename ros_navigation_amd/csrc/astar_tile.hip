@@ -1481,7 +1481,9 @@ __device__ __forceinline__ void tsa_backtrace_wave(const TsaLaunch& A, const Tsa
       const bool hit = (lane < 8) & (((mc >> k) & 1u) != 0u) & (un != 0u) & (un == uc + (unsigned)wk);   // g(n) + w == g(c)  (no short circuits: one chain of compares, no exec-masked blocks in the walk)
       const unsigned long long m = __ballot(hit);
       if (!m) { ok = false; break; }
-      const int src = __ffsll((long long)m) - 1;
+      // (only lanes 0..7 can hit: a 32-bit bit search.  As __ffsll the index was carried as a 64-bit scalar pair whose upper half the
+      // compiler took from a register it reused inside the loop -- the -DRNA_TSA_STATS build walked in circles until `len > ncell`)
+      const int src = __builtin_ctz((unsigned)m);
       uc = (unsigned)__builtin_amdgcn_readlane((int)un, src);   // (src is wave-uniform: a v_readlane, not a trip through the LDS crossbar)
       const int sdi = kdi_of(src), sdj = kdj_of(src);
       ci += sdi; cj += sdj; il += sdi; jl += sdj;
