@@ -71,8 +71,10 @@ def parse():
                          "the roofline line divides by that per-launch duration")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-check-paths", action="store_true", help="skip the path check that is the default on one GPU")
     ap.add_argument("--check-paths", action="store_true",
-                    help="after the timed region: the LAST batch of one more turn of the pipeline (searched while the turn's other "
+                    help="(default at --gpus 1, so that the driver's own record is path-certified; about 2 s on the box's host "
+                         "cores, outside the timed region) after the timed region: the LAST batch of one more turn of the pipeline (searched while the turn's other "
                          "batches are in flight) is handed to the CPU oracle -- status, cost, length and every cell of every path "
                          "of its queries against the map that batch saw (`config.paths_checked`; a mismatch ends the run)")
     ap.add_argument("--tiled-full-gather", action="store_true", help="--tiled: all-gather whole windows instead of dirty tiles")
@@ -331,7 +333,6 @@ def pmc_traffic(kernel, args, world):
 
 
 SQ_COUNTERS = os.path.join(ROOT, "profiles", "r05_search_sq_counters.txt")
-JOB_STATS = os.path.join(ROOT, "profiles", "r05_search_job_stats.txt")
 VALU_PEAK_PER_NS_SIMD = 0.58      # profiles/r03_ubench_valu.txt: eight wavefronts per SIMD issue 0.54-0.59 dependent VALU instructions per ns
 SEARCH_SIMDS = (256 - 32) * 4     # the search streams' CU mask leaves 32 of the 256 CUs to the engine stream
 
@@ -353,54 +354,80 @@ def valu_issue(args, world, wall_per_pass):
         per_ns_simd = valu / (wall_per_pass * 1e9) / SEARCH_SIMDS
         return {"bound": "valu issue", "achieved": per_ns_simd, "peak": VALU_PEAK_PER_NS_SIMD, "unit": "wavefront VALU instructions / ns / SIMD",
                 "frac": per_ns_simd / VALU_PEAK_PER_NS_SIMD, "valu_per_batch": valu, "salu_per_batch": salu,
-                "source": "profiles/r05_search_sq_counters.txt (one batch alone), profiles/r03_ubench_valu.txt (the SIMD's issue rate); "
-                          "224 CUs x 4 SIMDs"}
+                "source": "%s (one batch alone), profiles/r03_ubench_valu.txt (the SIMD's issue rate); "
+                          "224 CUs x 4 SIMDs" % os.path.relpath(SQ_COUNTERS, ROOT), "provenance": profile_provenance(SQ_COUNTERS)}
     except Exception:
         return None
 
 
-def work_inflation(args, world, settled_per_launch):
-    """How much work the search kernel does per cell the oracle settles (the committed counter / timer files of THIS
-    configuration; None otherwise): wavefront instructions per settled cell from the SQ counter pass of one batch, tile
-    jobs per touched tile and the share of jobs that find nothing better in their halo from the -DRNA_TSA_STATS build
-    under the bench's load.  Reported so that the next reader can track the inflation without reading DESIGN.md."""
+def kernel_source_sha():
+    """sha256[:12] of the search kernel's source: the profile files under profiles/ carry the value they were taken at, so a
+    line that quotes them says by itself whether they describe the kernel that ran (`stale`)."""
+    import hashlib
+    with open(os.path.join(ROOT, "ros_navigation_amd", "csrc", "astar_tile.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:12]
+
+
+def profile_provenance(path):
+    """{"file", "kernel_source_sha", "stale"} of a committed profile file: the sha is read from a `kernel_source_sha` line / key in
+    the file (scripts/profile_r06.sh writes it), None for files of earlier rounds."""
     import re
+    sha = None
     try:
-        if (args.grid, args.queries, args.pipeline) != (4096, 256, DEFAULT_PIPELINE) or world != 1 or args.tiled:
-            return None
-        valu = salu = settled = None
-        for line in open(SQ_COUNTERS):
-            f = line.split()
-            if len(f) >= 3 and f[0] in ("SQ_INSTS_VALU", "SQ_INSTS_SALU"):
-                v = float(f[-1].split("=")[-1])
-                valu, salu = (v, salu) if f[0] == "SQ_INSTS_VALU" else (valu, v)
-            if len(f) >= 2 and f[0] == "SETTLED_CELLS_OF_THE_BATCH":
-                settled = float(f[1])
-        out = {"instructions_per_settled_cell": (valu + salu) / settled, "valu_per_settled_cell": valu / settled,
-               "salu_per_settled_cell": salu / settled,
-               "source": "profiles/r05_search_sq_counters.txt: SQ_INSTS_VALU + SQ_INSTS_SALU of one 256-query batch alone (the first query set on the "
-                         "untouched bench map) / the cells the oracle settles for that batch"}
-        text = open(JOB_STATS).read()
-        m = re.search(r"jobs per touched tile ([0-9.]+), jobs that find nothing ([0-9.]+) of all", text)
-        if m:
-            out["jobs_per_touched_tile"] = float(m.group(1))
-            out["noop_job_frac"] = float(m.group(2))
-        m = re.search(r"sticky turns .*? ([0-9.]+) of all jobs, of which ([0-9.]+) find nothing", text)
-        if m:   # (a sticky turn -- the wavefront keeps a tile that was woken while it ran -- counts as a job in these figures)
-            out["sticky_turn_frac"] = float(m.group(1))
-            out["sticky_turn_noop_frac"] = float(m.group(2))
-        m = re.search(r"in jobs [0-9.]+ wave-ms \(([0-9.]+)%\), taking jobs [0-9.]+ wave-ms \(([0-9.]+)%\)", text)
-        if m:
-            out["wavefront_lifetime_in_jobs_frac"] = float(m.group(1)) / 100.0
-            out["wavefront_lifetime_taking_jobs_frac"] = float(m.group(2)) / 100.0
-        m = re.search(r"backtrace .*?: ([0-9.]+) us per found path, ([0-9.]+) % of the workgroup's residence", text)
-        if m:
-            out["backtrace_us_per_path"] = float(m.group(1))
-            out["backtrace_frac_of_residence"] = float(m.group(2)) / 100.0
-            out["source"] += "; profiles/r05_search_job_stats.txt (phase timers and job counts of the stats build under the bench's load)"
-        return out
+        m = re.search(r"kernel_source_sha\W+([0-9a-f]{12})", open(path).read())
+        sha = m.group(1) if m else None
+    except OSError:
+        pass
+    return {"file": os.path.relpath(path, ROOT), "kernel_source_sha": sha, "stale": sha != kernel_source_sha()}
+
+
+def work_inflation(args, world, settled_per_launch, counters, passes):
+    """How much work the search kernel does per cell the oracle settles.  The job figures are OBSERVED IN THIS RUN: the search
+    kernels count their jobs (rna_astar_job_counters, seven atomic adds per search) and the timed region's totals are read after
+    it -- tile jobs per touched tile, the share of jobs that find nothing better in their halo, sticky turns, rows written.
+    (Rounds 4-5 parsed these from the committed output of a -DRNA_TSA_STATS build, whose wall-clock timers slow the kernel down
+    by a factor of 2-3 and are not quoted any more.)  Instructions per settled cell still come from a committed SQ counter pass of
+    one batch alone (counters need rocprofv3), with the kernel source hash it was taken at."""
+    out = {}
+    try:
+        c = counters
+        if c and c["searches"] > 0 and c["jobs"] > 0:
+            out.update({
+                "observed_in": "the timed region of this run (rna_astar_job_counters)",
+                "searches": c["searches"], "tile_jobs": c["jobs"],
+                "tiles_touched_per_search": c["tiles_touched"] / c["searches"],
+                "jobs_per_search": c["jobs"] / c["searches"],
+                "jobs_per_touched_tile": c["jobs"] / max(1, c["tiles_touched"]),
+                "noop_job_frac": c["jobs_noop"] / c["jobs"],
+                "sticky_turn_frac": c["sticky_turns"] / c["jobs"],
+                "rows_written_per_job": c["rows_written"] / c["jobs"],
+                "buckets_per_search": c["buckets"] / c["searches"],
+                # (a -DRNA_TSA_IDLE developer build reports wavefront life / idle ticks in the last two counters instead)
+                "idle_frac_developer_build": (c["reserved"] / max(1, c["buckets"])) if c.get("reserved") else None,
+                # a tile holds 1024 cells: jobs per tile's worth of settled cells (the verdict's "revisit factor")
+                "jobs_per_1024_settled_cells": c["jobs"] / max(1.0, settled_per_launch * passes / 1024.0),
+                "cells_written_per_settled_cell": 64.0 * c["rows_written"] / max(1.0, settled_per_launch * passes)})
+        if (args.grid, args.queries, args.pipeline) == (4096, 256, DEFAULT_PIPELINE) and world == 1 and not args.tiled:
+            valu = salu = settled = None
+            for line in open(SQ_COUNTERS):
+                f = line.split()
+                if len(f) >= 3 and f[0] in ("SQ_INSTS_VALU", "SQ_INSTS_SALU"):
+                    v = float(f[-1].split("=")[-1])
+                    valu, salu = (v, salu) if f[0] == "SQ_INSTS_VALU" else (valu, v)
+                if len(f) >= 2 and f[0] == "SETTLED_CELLS_OF_THE_BATCH":
+                    settled = float(f[1])
+            out.update({"instructions_per_settled_cell": (valu + salu) / settled, "valu_per_settled_cell": valu / settled,
+                        "salu_per_settled_cell": salu / settled,
+                        "instructions_source": "SQ_INSTS_VALU + SQ_INSTS_SALU of one 256-query batch alone (the first query set on the untouched "
+                                               "bench map) / the cells the oracle settles for that batch",
+                        "instructions_provenance": profile_provenance(SQ_COUNTERS)})
+            if out.get("tile_jobs"):
+                jobs_per_batch = out["tile_jobs"] / passes
+                out["valu_per_job"] = valu / jobs_per_batch
+                out["salu_per_job"] = salu / jobs_per_batch
+        return out or None
     except Exception:
-        return None
+        return out or None
 
 
 def main():
@@ -580,6 +607,7 @@ def main():
     e.profile(2)
     e.profile_reset()
     xfer[0] = xfer[1] = 0
+    e.astar_job_counters(reset=True)   # (waits for the warm-up's searches; the timed region's jobs are read after it)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -593,6 +621,7 @@ def main():
     barrier()
     prof = e.profile_get()
     e.profile(False)
+    job_counters = e.astar_job_counters(reset=True)
     found, answered, total = check_results("in the timed region")
     xfer_timed = list(xfer)
     e.profile(1)
@@ -605,7 +634,7 @@ def main():
     check_results("in the profiled turn after the timed region")
     xfer[0], xfer[1] = xfer_timed
     paths_checked = None
-    if args.check_paths and layout is None:
+    if (args.check_paths or (world == 1 and not args.no_check_paths)) and layout is None:
         # the profiled turn's last pass: no map update has followed it, so the master layer is the map its snapshot saw
         b_last, k_last = (step_no[0] - 1) % n_out, (step_no[0] - 1) % ROTATE
         paths_checked = check_paths(e.download(R.capi.LAYER_MASTER), query_sets[k_last],
@@ -684,6 +713,7 @@ def main():
                                        "windows), A* query-sharded x%d" % (layout.ti, layout.tj, halo, world))},
             "roofline": {"bound": "hbm", "kernel": "tsa_search_kernel (astar_search)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_provenance": profile_provenance(PMC_SUMMARY),
                          "algorithmic_bytes_per_launch": alg_bytes, "settled_cells_per_launch": settled_per_launch,
                          "settled_cells_by_query_set": settled_sets,
                          "avg_launch_ms": ms_search, "launches": prof["astar_search"][1],
@@ -694,7 +724,7 @@ def main():
                          "frac_wall": alg_bytes / wall_per_pass / 1e9 / HBM_PEAK_GBS,
                          # the kernel's real bound (not HBM): see valu_issue()
                          "valu_issue": valu_issue(args, world, wall_per_pass),
-                         "work_inflation": work_inflation(args, world, settled_per_launch)},
+                         "work_inflation": work_inflation(args, world, settled_per_launch, job_counters, passes)},
             "roofline_rows": [row("himm_raster", HIMM_RASTER_CHAIN, himm_alg),
                               row("vfh_step", "vfh_step_kernel", float(nq * VFH_BYTES_PER_POSE))],
             # every kernel slot bracketed by events, in ONE turn of the pipeline run after the timed region (the brackets

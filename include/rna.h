@@ -249,7 +249,8 @@ typedef struct {
   int32_t path_len;    /* cells, start..goal inclusive */
   int32_t cost;        /* 1000/1414 integer cost of the path */
   int32_t expanded;    /* cells the device wrote (64 per row of a tile a job changed; >= the oracle's settled count) */
-  int32_t rounds;      /* tile jobs per wavefront of the query's workgroup (rounds 1-2: barrier-separated rounds of jobs) */
+  int32_t rounds;      /* tile jobs per wavefront of the query's workgroup: every job, also the ones that find nothing better in their
+                          halo, and every sticky turn (rounds 1-2: barrier-separated rounds of jobs) */
   int32_t buckets;     /* f-buckets visited */
 } rna_astar_result;
 /* max_queries: queries searched concurrently (one g-field each; larger batches are processed in
@@ -296,6 +297,15 @@ int rna_astar_batch_device(rna_engine* e, const rna_astar_query* queries_device,
  * oracle's settled count; measurement/test utility, not part of the timed path.  -1 for a query whose field is gone
  * (it outgrew its share of pages and was searched again in a second pass whose retry slot has been reused since). */
 int rna_astar_settled_counts(rna_engine* e, int32_t* counts_host, int n);
+/* What the grid-A* search kernels counted since the engine's search state was allocated (or since the last call with
+ * reset != 0), summed over all searches of all batches; waits for the batches in flight.  counters_host[8]:
+ *   [0] searches, [1] tiles that got a page (a search's "touched tiles"), [2] tile jobs -- every job, sticky turns included --,
+ *   [3] of them jobs that found nothing better in their halo and left before the sweeps, [4] sticky turns (a wavefront kept a
+ *   tile that was woken while its job ran), [5] rows of 64 cells written, [6] f-buckets, [7] reserved (0).
+ * Measurement utility (bench.py's roofline.work_inflation: jobs per touched tile and the no-op share, observed in the timed
+ * run itself); the kernel's cost is seven atomic adds per SEARCH.  No reference counterpart (the reference has no grid search:
+ * move_control/src/astar_planner.cpp:63-96 is the waypoint graph). */
+int rna_astar_job_counters(rna_engine* e, uint64_t* counters_host, int reset);
 /* per-cell traversable-neighbour mask derived from the master layer (rows*cols uint8) */
 int rna_astar_download_nbr_mask(rna_engine* e, uint8_t* host, size_t n_cells);
 

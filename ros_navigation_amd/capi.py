@@ -33,7 +33,7 @@ SYMBOLS = [
     "rna_layers_unpack_tiles_device",
     "rna_vfh_default_params", "rna_vfh_init", "rna_vfh_reset", "rna_vfh_hist_size", "rna_vfh_step_batch",
     "rna_vfh_step_batch_device", "rna_vfh_update_batch",
-    "rna_astar_configure", "rna_astar_set_pipeline_depth", "rna_astar_set_page_cap", "rna_astar_effective_config", "rna_astar_batch", "rna_astar_batch_device", "rna_astar_settled_counts",
+    "rna_astar_configure", "rna_astar_set_pipeline_depth", "rna_astar_set_page_cap", "rna_astar_effective_config", "rna_astar_batch", "rna_astar_batch_device", "rna_astar_settled_counts", "rna_astar_job_counters",
     "rna_astar_download_nbr_mask",
     "rna_graph_astar_batch", "rna_rrt_batch", "rna_rrt_batch_device",
     "rna_to_occupancy_grid", "rna_to_occupancy_grid_device", "rna_from_occupancy_grid", "rna_vfh_hist_msg_batch",
@@ -177,6 +177,8 @@ def lib():
     L.rna_astar_batch_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
     L.rna_astar_download_nbr_mask.argtypes = [vp, vp, C.c_size_t]
     L.rna_astar_settled_counts.argtypes = [vp, vp, C.c_int]
+    if hasattr(L, "rna_astar_job_counters"):   # (absent only in an older build named by the developer switch RNA_LIB of bench.py's A/B runs)
+        L.rna_astar_job_counters.argtypes = [vp, vp, C.c_int]
     L.rna_graph_astar_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, vp]
     L.rna_rrt_batch.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
     L.rna_rrt_batch_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
@@ -587,6 +589,14 @@ class Engine:
         out = np.zeros(n, np.int32)
         self._check(self._L.rna_astar_settled_counts(self.h, _ptr(out), n))
         return out
+
+    def astar_job_counters(self, reset=False):
+        """What the search kernels counted since the last reset (rna_astar_job_counters): a dict of totals over all searches."""
+        out = np.zeros(8, np.uint64)
+        if not hasattr(self._L, "rna_astar_job_counters"):
+            return None
+        self._check(self._L.rna_astar_job_counters(self.h, _ptr(out), 1 if reset else 0))
+        return dict(zip(("searches", "tiles_touched", "jobs", "jobs_noop", "sticky_turns", "rows_written", "buckets", "reserved"), (int(v) for v in out)))
 
     def nbr_mask(self):
         a = np.empty(self.ncell, np.uint8)

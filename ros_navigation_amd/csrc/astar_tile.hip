@@ -78,10 +78,12 @@ constexpr int TSA_MAX_TILE_WORDS = 2048;   // active-tile bitset words -> up to 
 constexpr int COST_S = 1000, COST_D = 1414;
 constexpr int INF = 0x7fffffff;
 constexpr int KU = 0x40000000;             // field word u = KU - g; 0 = unreached
-constexpr int SCR_CNT = 84 + 192 + 48 + 64;     // two counters behind the scratch proper: rows written, jobs (kept in LDS: a register each across the job loop was one too many)
-constexpr int SCR_WORDS = SCR_CNT + 2;          // per-wave LDS scratch: column transposition (68 + a zero tail of 16), the halo rows and
+constexpr int SCR_CNT = 84 + 192 + 48 + 64;     // four counters behind the scratch proper: rows written, jobs that got past the halo step, all turns
+                                                // (jobs and sticky turns), sticky turns (kept in LDS: a register each across the job loop was one too many)
+constexpr int SCR_WORDS = SCR_CNT + 4;          // per-wave LDS scratch: column transposition (68 + a zero tail of 16), the halo rows and
                                            // columns as loaded (3 x 64), this tile's edge columns at the end of the job (16 + 16 + 16),
                                            // the masks of the tile's edge-column cells as loaded (64)
+static_assert(SCR_WORDS % 4 == 0 && 276 % 4 == 0, "a wavefront's scratch starts on 16 bytes and so do the edge columns in it (ds_write_b128)");
 
 __device__ __forceinline__ int tsa_octile(int i, int j, int gi, int gj) {
   const int dx = abs(i - gi), dy = abs(j - gj);
@@ -659,7 +661,10 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
     // rows' pass-on values are formed.
     const unsigned long long upT = __builtin_amdgcn_ballot_w64(cT > g0), upB = __builtin_amdgcn_ballot_w64(cB > g15);
     const unsigned long long imask = __builtin_amdgcn_ballot_w64(cX > gcol);
-    if (!(upT | upB | imask) && !planted && !first) { TSA_CNT(10, 1); if (sticky) TSA_CNT(23, 1); TSA_T(t_n); TSA_ACC(15, t_a, t_n); goto tsa_job_done; }   // the wake-up brought nothing better
+    if (!(upT | upB | imask) && !planted && !first) {   // the wake-up brought nothing better
+      TSA_CNT(10, 1); if (sticky) TSA_CNT(23, 1); TSA_T(t_n); TSA_ACC(15, t_a, t_n);
+      goto tsa_job_done;   // (counted in Sched::finish like every turn; the jobs that get past this point are counted at the end of the job)
+    }
     asm volatile("; TSA_MARK noop_decided");
 #if !RNA_TSA_FRESH
     scr[84 + lane] = (unsigned)top;        // kept for the end of the job: does a changed edge row beat what the
@@ -1156,7 +1161,7 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
   TSA_T(t_d);
   TSA_ACC(2, t_c, t_d);
   TSA_ACC(6, t_w0, t_d);   // wake tests + queueing
-  if (lane_in == 0) { atomicAdd(&scr[SCR_CNT], (unsigned)__builtin_popcount(rowchg)); atomicAdd(&scr[SCR_CNT + 1], 1u); }   // rows written, jobs (this wavefront's own words; adds that return nothing)
+  if (lane_in == 0) { atomicAdd(&scr[SCR_CNT], (unsigned)__builtin_popcount(rowchg)); atomicAdd(&scr[SCR_CNT + 1], 1u); }   // rows written, jobs that got past the halo step (this wavefront's own words; adds that return nothing)
   }
 tsa_job_done:
   // the job's stores are performed before the tile can be taken again (or is pulled again by this wavefront)
@@ -1164,7 +1169,7 @@ tsa_job_done:
   {
     int t_f = t_in;   // (opaque once more: the masks finish() forms from the tile number are not to be hoisted to the top of the job)
     asm volatile("" : "+s"(t_f));
-    const int again = sch.finish(t_f, lane_in, spare);   // 0: the tile is released, 1: a wake-up came in while it ran, 2: ... and it is due as a first job
+    const int again = sch.finish(t_f, lane_in, spare, scr + SCR_CNT);   // 0: the tile is released, 1: a wake-up came in while it ran, 2: ... and it is due as a first job
     if (!again) break;
     first_w = again >> 1;
     sticky_w = 1;
@@ -1311,16 +1316,20 @@ struct TsaLocalSched {
   // found it running, put the bit back and set D).  Otherwise the tile is released; a wake-up that slipped in between
   // the look and the release is queued as before (class 0).
   // D of a running tile is only ever SET by others (an entry is only claimed while R is clear), so the look cannot miss.
-  __device__ __forceinline__ int finish(int t, int lane, int* spare) {
+  // `cnt`: the wavefront's own counters in LDS -- [2] every turn that ends here (jobs of both kinds and sticky turns), [3] the
+  // turns after which the tile stays (inside the lane-0 block that is there anyway: two LDS adds that return nothing).
+  __device__ __forceinline__ int finish(int t, int lane, int* spare, unsigned* cnt) {
     const unsigned sh = 2u * ((unsigned)t & 15u);
     int r = 0;
     if (lane == 0) {
+      atomicAdd(&cnt[2], 1u);
 #ifdef RNA_TSA_NO_STICKY   /* developer build: the round-4 behaviour (release, queue again) in this round's code */
       if (false) {
 #else
       if ((lds_ld(&st2_[t >> 4]) >> sh) & 1u) {
 #endif
         atomicAnd(&st2_[t >> 4], ~(1u << sh));
+        atomicAdd(&cnt[3], 1u);
         r = 1;
         if (lds_ldi(open_left_) > 0 && ((atomicAnd(&open_[t >> 5], ~(1u << (t & 31))) >> (t & 31)) & 1u)) {
           atomicSub(open_left_, 1);
@@ -1393,6 +1402,7 @@ struct TsaLaunch {
   int32_t* rev_all;
   int rev_cap;
   rna_astar_result* results;
+  unsigned long long* counters;   // (device memory, may be null) [8]: searches, tiles that got a page, jobs, jobs that found nothing, sticky turns, rows written, buckets
 };
 constexpr int TSA_FOUND = -1000;        // provisional status inside the search kernel: found, path not traced yet
 
@@ -1516,13 +1526,13 @@ __device__ __forceinline__ void tsa_backtrace_wave(const TsaLaunch& A, const Tsa
 template <int WAVES, bool RETRY>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(RNA_TSA_WAVES_PER_EU, RNA_TSA_WAVES_PER_EU))) tsa_search_kernel(const TsaLaunch A) {
   constexpr int TSA_THREADS = WAVES * 64;
-  __shared__ unsigned s_scr[WAVES][SCR_WORDS];
+  __shared__ __attribute__((aligned(16))) unsigned s_scr[WAVES][SCR_WORDS];
   extern __shared__ unsigned s_dyn[];   // sized by the launch: st2 (2 x nt_words) | open (nt_words) | far (nt_words)
   __shared__ __attribute__((aligned(16))) unsigned s_node[TSA_NP];
   __shared__ __attribute__((aligned(16))) unsigned s_head[TSA_NCLS];
   __shared__ unsigned s_bm[TSA_BMW];
   __shared__ unsigned s_qc[TSA_QC];
-  __shared__ int s_best, s_state, s_bucket, s_bucket0, s_jobs_done, s_expanded, s_nalloc, s_any;
+  __shared__ int s_best, s_state, s_bucket, s_bucket0, s_jobs_done, s_jobs_noop, s_jobs_sticky, s_expanded, s_nalloc, s_any;
   __shared__ int s_count, s_spill, s_idle, s_open_left, s_open_pos;
 
   // Workgroups take their query when they START (a ticket), not by blockIdx: the hardware deals workgroup
@@ -1591,7 +1601,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   for (int w = tid; w < TSA_BMW; w += TSA_THREADS) s_bm[w] = 0xffffffffu;
   for (int w = tid; w < TSA_QC; w += TSA_THREADS) s_qc[w] = 0xffffffffu;
   if (lane >= 48) s_scr[wv][68 + lane - 48] = 0u;   // the zero tail of the wave's scratch
-  if (lane < 2) s_scr[wv][SCR_CNT + lane] = 0u;     // ... and its two counters
+  if (lane < 4) s_scr[wv][SCR_CNT + lane] = 0u;     // ... and its four counters
   // a start or a goal without a single traversable neighbour: blocked or walled in; nothing has been written yet, so
   // no page is in use
   {
@@ -1621,7 +1631,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   int key_shift = 0;
   while (((long long)A.bucket_width >> key_shift) > TSA_NCLS - 1) ++key_shift;
   if (tid == 0) {
-    s_best = INF; s_state = 0; s_jobs_done = 0; s_expanded = 0; s_nalloc = 0;
+    s_best = INF; s_state = 0; s_jobs_done = 0; s_jobs_noop = 0; s_jobs_sticky = 0; s_expanded = 0; s_nalloc = 0;
     s_bucket = tsa_octile(si, sj, gi, gj) / A.bucket_width;
     s_bucket0 = s_bucket;
     s_spill = 0; s_idle = 0; s_open_pos = 0;
@@ -1636,6 +1646,12 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   const unsigned long long t_life0 = wall_clock64();
   const unsigned long long c_life0 = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef RNA_TSA_IDLE
+  // developer build: what share of a search wavefront's life has nothing to take (shader-clock ticks; counters [6] / [7] of
+  // rna_astar_job_counters then hold life and idle ticks summed over the wavefronts instead of buckets / 0)
+  unsigned long long idle_ticks = 0ull;
+  const unsigned long long t_wave0 = __builtin_amdgcn_s_memtime();
+#endif
   TsaLocalSched sch{&s_best, &s_state, s_st2, s_far, s_node, s_head, s_bm, s_qc, &s_count, &s_spill, s_open, &s_open_left};
   int spare = -1;   // a queue node this wavefront owns (the one its last job's entry sat in): its next wake-up uses it
 
@@ -1647,6 +1663,9 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     const int key_base = key_base_ll < -(long long)INF ? -INF : (int)key_base_ll;
     bool idle = false;   // this wavefront is counted in s_idle
     bool open_blocked = false;
+#ifdef RNA_TSA_IDLE
+    unsigned long long t_idle0 = 0ull;
+#endif
     for (;;) {
       TSA_T(t_p0);
       if (lds_ldi(&s_state) >= 4) break;
@@ -1655,6 +1674,9 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
         if (lds_ldi(&s_count) <= 0) { __builtin_amdgcn_s_sleep(RNA_TSA_IDLE_SLEEP); continue; }
         if (lane == 0) atomicSub(&s_idle, 1);
         idle = false;
+#ifdef RNA_TSA_IDLE
+        idle_ticks += __builtin_amdgcn_s_memtime() - t_idle0;
+#endif
       }
       int t = -1;
       int first = 0;   // (a 32-bit scalar, not a lane-mask bool: see tsa_job)
@@ -1702,6 +1724,9 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
           if (open_left > 0) { __builtin_amdgcn_s_sleep(2); continue; }   // (the open tile that was running)
           if (lane == 0) atomicAdd(&s_idle, 1);
           idle = true;
+#ifdef RNA_TSA_IDLE
+          t_idle0 = __builtin_amdgcn_s_memtime();
+#endif
           continue;
         }
         const int tt = (int)(e & 0xffffu);
@@ -1745,6 +1770,9 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     }
     // ---- the bucket is at its fixed point (or the search is being abandoned) ----
     __syncthreads();
+#ifdef RNA_TSA_IDLE
+    if (idle) idle_ticks += __builtin_amdgcn_s_memtime() - t_idle0;   // (the wait for the last wavefront of the bucket included)
+#endif
     if (s_state >= 4) break;
     int tid_r = threadIdx.x;
     asm volatile("" : "+v"(tid_r));
@@ -1774,8 +1802,30 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     __syncthreads();
     if (s_state != 0) break;
   }
-  if (lane == 0) { atomicAdd(&s_expanded, (int)s_scr[wv][SCR_CNT] * TI); atomicAdd(&s_jobs_done, (int)s_scr[wv][SCR_CNT + 1]); }   // cells written, jobs
+#ifdef RNA_TSA_IDLE
+  if (lane == 0 && A.counters) {
+    atomicAdd(&A.counters[8], __builtin_amdgcn_s_memtime() - t_wave0);
+    atomicAdd(&A.counters[9], idle_ticks);
+  }
+#endif
+  if (lane == 0) {   // cells written; jobs (those that changed something, those that found nothing), sticky turns among them
+    atomicAdd(&s_expanded, (int)s_scr[wv][SCR_CNT] * TI);
+    atomicAdd(&s_jobs_done, (int)s_scr[wv][SCR_CNT + 2]);
+    atomicAdd(&s_jobs_noop, (int)(s_scr[wv][SCR_CNT + 2] - s_scr[wv][SCR_CNT + 1]));
+    atomicAdd(&s_jobs_sticky, (int)s_scr[wv][SCR_CNT + 3]);
+  }
   __syncthreads();
+  // the launch's job counters (rna_astar_job_counters: what the bench reports as jobs per touched tile / no-op share,
+  // observed in the run itself): six adds per SEARCH
+  if (tid == 0 && A.counters) {
+    atomicAdd(&A.counters[0], 1ull);
+    atomicAdd(&A.counters[1], (unsigned long long)s_nalloc);
+    atomicAdd(&A.counters[2], (unsigned long long)s_jobs_done);
+    atomicAdd(&A.counters[3], (unsigned long long)s_jobs_noop);
+    atomicAdd(&A.counters[4], (unsigned long long)s_jobs_sticky);
+    atomicAdd(&A.counters[5], (unsigned long long)(s_expanded / TI));
+    atomicAdd(&A.counters[6], (unsigned long long)(s_bucket - s_bucket0 + 1));
+  }
 #ifdef RNA_TSA_STATS
   tsa_acc[5] = wall_clock64() - t_life0;   // wave lifetime inside the search loop
   tsa_acc[12] = __builtin_amdgcn_s_memtime() - c_life0;   // the same in shader clock ticks
@@ -1785,7 +1835,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
 #endif
   // what the next search in this slot has to reset
   if (tid == 0) S.nalloc[sl] = s_nalloc < C.cap ? s_nalloc : C.cap;
-  // (`rounds` reports tile jobs per wavefront: there are no rounds any more)
+  // (`rounds` reports tile jobs per wavefront -- every job, also the ones that found nothing in their halo: there are no rounds any more)
   const int state = s_state;
   const rna_astar_result r{state == 1 ? TSA_FOUND : (state >= 4 ? state : 1), 0, state == 1 ? s_best : INF, s_expanded,
                            (s_jobs_done + WAVES - 1) / WAVES, s_bucket - s_bucket0 + 1};
@@ -2022,6 +2072,7 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     A.queries = q_dev; A.S = S; A.bucket_width = a.bucket_width; A.paths = paths_dev; A.max_path_len = max_len;
     A.rev_all = a.rev[slot]; A.rev_cap = a.rev_cap; A.results = res_dev;
     A.retry = 0; A.n = n; A.S2 = S;
+    A.counters = a.job_counters;
     A.prio_first = a.depth > 1 ? RNA_TSA_PRIO_FIRST : 0;
     if (const char* pf = getenv("RNA_TSA_PRIO_FIRST")) A.prio_first = atoi(pf);   // developer knob
     size_t lds_dyn = 4 * nt_bytes;

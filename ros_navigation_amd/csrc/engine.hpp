@@ -106,6 +106,7 @@ struct AstarDevice {
   size_t last_lds[MAX_DEPTH] = {};
   alignas(8) unsigned char last_launch[MAX_DEPTH][384] = {};   // TsaLaunch of the stage's last batch
   unsigned long long launches = 0;
+  unsigned long long* job_counters = nullptr;   // device, [8]: what the search kernels count per search (rna_astar_job_counters)
   int last_slot = 0;
   size_t field_stride = 0;         // words per query field incl. padding
   rna_astar_query* queries_dev = nullptr;
