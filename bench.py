@@ -403,7 +403,8 @@ def work_inflation(args, world, settled_per_launch, counters, passes):
                 "rows_written_per_job": c["rows_written"] / c["jobs"],
                 "buckets_per_search": c["buckets"] / c["searches"],
                 # (a -DRNA_TSA_IDLE developer build reports wavefront life / idle ticks in the last two counters instead)
-                "idle_frac_developer_build": (c["reserved"] / max(1, c["buckets"])) if c.get("reserved") else None,
+                "bucket_reruns_per_search": c["bucket_reruns"] / c["searches"],
+                "idle_frac_developer_build": (c["bucket_reruns"] / max(1, c["buckets"])) if os.environ.get("RNA_LIB", "").startswith("librna_idle") else None,
                 # a tile holds 1024 cells: jobs per tile's worth of settled cells (the verdict's "revisit factor")
                 "jobs_per_1024_settled_cells": c["jobs"] / max(1.0, settled_per_launch * passes / 1024.0),
                 "cells_written_per_settled_cell": 64.0 * c["rows_written"] / max(1.0, settled_per_launch * passes)})

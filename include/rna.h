@@ -301,7 +301,7 @@ int rna_astar_settled_counts(rna_engine* e, int32_t* counts_host, int n);
  * reset != 0), summed over all searches of all batches; waits for the batches in flight.  counters_host[8]:
  *   [0] searches, [1] tiles that got a page (a search's "touched tiles"), [2] tile jobs -- every job, sticky turns included --,
  *   [3] of them jobs that found nothing better in their halo and left before the sweeps, [4] sticky turns (a wavefront kept a
- *   tile that was woken while its job ran), [5] rows of 64 cells written, [6] f-buckets, [7] reserved (0).
+ *   tile that was woken while its job ran), [5] rows of 64 cells written, [6] f-buckets, [7] buckets that were run again because the open list ran out of nodes.
  * Measurement utility (bench.py's roofline.work_inflation: jobs per touched tile and the no-op share, observed in the timed
  * run itself); the kernel's cost is seven atomic adds per SEARCH.  No reference counterpart (the reference has no grid search:
  * move_control/src/astar_planner.cpp:63-96 is the waypoint graph). */

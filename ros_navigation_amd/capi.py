@@ -596,7 +596,7 @@ class Engine:
         if not hasattr(self._L, "rna_astar_job_counters"):
             return None
         self._check(self._L.rna_astar_job_counters(self.h, _ptr(out), 1 if reset else 0))
-        return dict(zip(("searches", "tiles_touched", "jobs", "jobs_noop", "sticky_turns", "rows_written", "buckets", "reserved"), (int(v) for v in out)))
+        return dict(zip(("searches", "tiles_touched", "jobs", "jobs_noop", "sticky_turns", "rows_written", "buckets", "bucket_reruns"), (int(v) for v in out)))
 
     def nbr_mask(self):
         a = np.empty(self.ncell, np.uint8)

@@ -105,8 +105,6 @@ static int alloc_stages_impl(rna_engine* e) {
     for (int d = 0; d < AstarDevice::MAX_DEPTH; ++d) a.retry_flag[d] = 0;
   }
   a.launches = 0;
-  if ((rc = dev_alloc(e, &a.job_counters, (size_t)16)) != RNA_OK) { astar_release(e); return rc; }
-  RNA_HIP(e, hipMemsetAsync(a.job_counters, 0, 16 * sizeof(unsigned long long), e->stream));
   if ((rc = dev_alloc(e, &a.queries_dev, (size_t)a.max_queries)) != RNA_OK) { astar_release(e); return rc; }
   if ((rc = dev_alloc(e, &a.results_dev, (size_t)a.max_queries)) != RNA_OK) { astar_release(e); return rc; }
   return RNA_OK;
@@ -305,7 +303,7 @@ int astar_release(rna_engine* e) {
   a.ring_n = 0;
   if (a.retry_flag) { (void)hipHostFree(a.retry_flag); a.retry_flag = nullptr; }
   for (int d = 0; d < AstarDevice::MAX_DEPTH; ++d) a.retry_armed[d] = false;
-  dev_free(&a.queries_dev); dev_free(&a.results_dev); dev_free(&a.paths_dev); dev_free(&a.job_counters);
+  dev_free(&a.queries_dev); dev_free(&a.results_dev); dev_free(&a.paths_dev);
   a.paths_cap = 0;
   a.last_queries = nullptr; a.last_results = nullptr; a.last_n = 0;
   return RNA_OK;
@@ -434,15 +432,13 @@ extern "C" int rna_astar_download_nbr_mask(rna_engine* e, uint8_t* host, size_t 
 extern "C" int rna_astar_job_counters(rna_engine* e, uint64_t* counters_host, int reset) {
   if (!e || !counters_host) return RNA_EINVAL;
   AstarDevice& a = e->astar;
-  if (!a.job_counters) return fail(e, RNA_ESTATE, "no A* batch has run yet");
+  if (!a.g[0]) return fail(e, RNA_ESTATE, "no A* batch has run yet");
   RNA_ENTER(e);
-  const int rc = sync_all(e);
+  int rc = sync_all(e);
   if (rc != RNA_OK) return rc;
-  uint64_t all[16];
-  RNA_HIP(e, hipMemcpyAsync(all, a.job_counters, sizeof(all), hipMemcpyDeviceToHost, e->stream));
-  if (reset) RNA_HIP(e, hipMemsetAsync(a.job_counters, 0, sizeof(all), e->stream));
-  RNA_HIP(e, hipStreamSynchronize(e->stream));
-  memcpy(counters_host, all, 8 * sizeof(uint64_t));
+  unsigned long long all[16];
+  if ((rc = tsa_counters_read(e, all, reset != 0)) != RNA_OK) return rc;
+  for (int k = 0; k < 8; ++k) counters_host[k] = all[k];
 #ifdef RNA_TSA_IDLE   /* developer build: wavefront life / idle ticks (shader clock) in the reserved word and the bucket count's */
   counters_host[6] = all[8];
   counters_host[7] = all[9];

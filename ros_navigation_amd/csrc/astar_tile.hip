@@ -198,6 +198,14 @@ struct TsaStage {
   int cap;              // pages per query
 };
 __host__ __device__ inline size_t tsa_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+// What the search kernels count about themselves (rna_astar_job_counters): sixteen 64-bit words per stage view, in the second
+// half of the 256-byte block in front of the view's page counts (its first half: the ticket, and in a retry view the queries the
+// retry slots served).  [0] searches, [1] tiles that got a page, [2] jobs (every turn), [3] jobs that found nothing, [4] sticky
+// turns, [5] rows written, [6] buckets, [7] buckets run again because the queue ran out of nodes; [8] / [9] wavefront life / idle ticks in a -DRNA_TSA_IDLE developer build.
+constexpr int TSA_COUNTER_WORDS = 16;
+__host__ __device__ inline unsigned long long* tsa_counters_of(const TsaStage& S) {
+  return reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(S.nalloc) - TSA_COUNTER_WORDS * sizeof(unsigned long long));
+}
 
 // snapshot of the neighbour masks, taken at launch so that a later map update cannot disturb a search in flight.
 // Per tile (MAP-space, unwrapped indices): byte a*16 + b = mask of cell (a, b) -- the 16 rows of a lane are one
@@ -298,6 +306,7 @@ __device__ unsigned long long g_tsa_stat[32];
 // Per-query context of a tile job (wave-uniform).
 struct TsaCtx {
   int rows, cols, tiles_i, tiles_j;
+  unsigned tiles_magic;       // floor(2^32 / tiles_i) + 1 (0 when tiles_i == 1): t / tiles_i == umulhi(t, tiles_magic) for t < 2^16
   unsigned* pages;            // this query's pages: local page p at pages + (p << 10); page 0 stays "unreached"
   unsigned* paux;             // this query's edge-column copies, AUX_WORDS per page
   unsigned* tmap;             // this query's tile -> local page table
@@ -398,6 +407,15 @@ __device__ __forceinline__ unsigned long long tsa_row_fixpoint(int& g, int& pp, 
 // The 16 rows are 2 x 16 NAMED scalars (g0..g15: the field, pp0..pp15: what a cell may pass on in this bucket) and
 // every per-row step is a macro pasted 16 times: with `int g[16]` and unrolled loops the optimiser turns the rows into
 // one <16 x i32> value and copies all 16 registers at every row update (and spills them as a block).
+// Code layout.  The search kernel is 74 KB of code and a tile job walks most of it; the instruction cache is 64 KB for two
+// CUs, whose 64 wavefronts are at different places of the job at any time.  Blocks that are executed rarely (a row's scan: 9 % of
+// the row evaluations, 32 copies of 400 bytes; the first job of a bucket; the start and the goal tile; overflow) carry a branch
+// weight, so that the block placement moves them behind the hot path instead of leaving them inside the row sequence.
+#ifndef RNA_TSA_NO_LAYOUT_HINTS
+#define TSA_UNLIKELY(c) __builtin_expect(!!(c), 0)
+#else
+#define TSA_UNLIKELY(c) (c)
+#endif
 #define TSA_CAT_(a, b) a##b
 #define TSA_CAT(a, b) TSA_CAT_(a, b)
 #define TSA_R16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
@@ -474,7 +492,11 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
   int t = t_in;
   asm volatile("" : "+s"(t));
   const int tiles_i = C.tiles_i, tiles_j = C.tiles_j, gi = C.gi, gj = C.gj;
-  const int ti = t % tiles_i, tj = t / tiles_i;
+  // tile number -> (ti, tj): a multiplication by floor(2^32 / tiles_i) + 1, exact for t < 2^16 and tiles_i <= 2^16 (the error term
+  // t * e / 2^32 with e <= tiles_i stays below one tiles_i-th); the compiler's division by a run-time value was 18 scalar
+  // instructions at the top of every turn
+  const int tj = C.tiles_magic ? (int)__umulhi((unsigned)t, C.tiles_magic) : t;
+  const int ti = t - tj * tiles_i;
   const int i0 = ti * TI, j0 = tj * TJ;
   first_w = __builtin_amdgcn_readfirstlane(first_w);
   sticky_w = __builtin_amdgcn_readfirstlane(sticky_w);
@@ -642,7 +664,7 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
       cX = (xcell && eb != 0u) ? cX : 0;
     }
     unsigned planted = 0u;
-    if (t == C.ts) {   // the start cell: g = 0, whatever its mask says (a blocked start still answers start == goal)
+    if (TSA_UNLIKELY(t == C.ts)) {   // the start cell: g = 0, whatever its mask says (a blocked start still answers start == goal)
       // (the row as a one-bit set tested with a shift: compared as `b == C.sb` the sixteen conditions were hoisted out of
       // the job loop as sixteen lane masks, 32 spilled SGPRs)
       unsigned srow = 1u << C.sb;
@@ -738,7 +760,7 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
   // flagged by the halo step as in any job.  Exact on the model (scripts/sim_async.c: first jobs with released rows only, cost
   // and settled count of every query the oracle's, at 96 000 and 24 000 per bucket).  A bucket that is run again (parked
   // wake-ups) releases the same cells again: evaluated once more, harmless.
-  if (first) {
+  if (TSA_UNLIKELY(first)) {
     unsigned rel = 0u;
     // (pp is the cell's value or 0, and h + key_base > 0: `pp != 0 && pp <= h + key_base` is ONE unsigned comparison -- as two
     // conditions the compiler built an exec-masked block per row, 17 instructions)
@@ -800,7 +822,7 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
 #if RNA_TSA_SUPER == 2
 #define TSA_HP_OUT_OF_PASSES
 #define TSA_SUPER(b, AGVAR)                                                                                      \
-  if (left_ == 0u) {   /* the one-cell passes ran out while the row was still moving: the rest in one scan */     \
+  if (TSA_UNLIKELY(left_ == 0u)) {   /* the one-cell passes ran out while the row was still moving: the rest in one scan */     \
     if (scan_ok) {                                                                                               \
       TSA_CNT(14, 1);                                                                                            \
       up_ |= tsa_row_fixpoint(TSA_G(b), TSA_PP(b), open_, ht_, thr, lane);                                       \
@@ -967,7 +989,7 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
   }
 #endif
   if (rowchg) {
-    if (pg == 0u) {   // first change of this tile: it gets a page (this job is the tile's only writer)
+    if (TSA_UNLIKELY(pg == 0u)) {   // first change of this tile: it gets a page (this job is the tile's only writer)
       int p = 0;
       if (lane == 0) {
         p = atomicAdd(C.nalloc, 1) + 1;
@@ -979,7 +1001,7 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
     }
     unsigned* own = C.pages + (pg << 10);
     unsigned* ax = C.paux + pg * AUX_WORDS + (lane ? 16 : 0);
-    const bool edge_lane = lane == 0 || lane == TI - 1;
+    const bool edge_lane = __builtin_amdgcn_inverse_ballot_w64(0x8000000000000001ull);   // lanes 0 and 63 (as `lane == 0 || lane == 63` the compiler nests two exec-masked blocks)
     // A reached cell whose g is about to leave the 30-bit range of the field word: a value written by this job is at
     // most lim + 1414 (its source passed on, i.e. g + h < lim), so the rows are only looked at when the bound is that far out.
     const bool ovf_possible = lim_u > (unsigned)(KU - 5 * COST_D);
@@ -990,7 +1012,7 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
 #define TSA_STORE(b) if ((rowchg >> (b)) & 1u) own[(b) * TI + ulane] = (unsigned)TSA_G(b);
     TSA_R16(TSA_STORE)
 #undef TSA_STORE
-    if (ovf_possible) {
+    if (TSA_UNLIKELY(ovf_possible)) {
       unsigned rowchg_o = rowchg;
       asm volatile("" : "+s"(rowchg_o));
 #define TSA_OVF(b) if ((rowchg_o >> (b)) & 1u) ovfm |= __builtin_amdgcn_ballot_w64((unsigned)(TSA_G(b) - 1) < (unsigned)(4 * COST_D - 1));
@@ -1008,7 +1030,7 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
       a4[3] = make_uint4((unsigned)g12, (unsigned)g13, (unsigned)g14, (unsigned)g15);
     }
     if (ovfm && lane == 0) sch.overflow();   // path costs beyond 2^30 - 5656: the search is abandoned (status 4)
-    if (t == C.tg) {
+    if (TSA_UNLIKELY(t == C.tg)) {
       unsigned rowchg_g = rowchg & (1u << C.gb);   // (the goal's row, if it changed: see srow above)
       asm volatile("" : "+s"(rowchg_g));
 #define TSA_GOAL(b)                                                                               \
@@ -1033,7 +1055,7 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
     asm volatile("" : "+s"(look));
     if (look && best1 > bucket_end && !sch.is_far(t)) {
       unsigned long long farm = 0ull;
-      if (best_in == INF) {
+      if (!TSA_UNLIKELY(best_in != INF)) {
         // no path known yet: every reached cell matters, so "held back" is all there is to test -- and what a cell may
         // pass on is its value or 0, i.e. a reached cell is held back iff g ^ pp != 0: two vector instructions per row,
         // no heuristic (this is the case of almost every job: the goal is reached in a search's last bucket)
@@ -1053,7 +1075,7 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
     }
     // (b) a first job: cells the previous bucket's bound held back may pass their values on now although they did not
     //     change -- every edge cell that may pass on takes part in the tests below
-    if (first) {
+    if (TSA_UNLIKELY(first)) {
       q0 |= __builtin_amdgcn_ballot_w64(pp0 != 0);
       q15 |= __builtin_amdgcn_ballot_w64(pp15 != 0);
       qany |= (1ull << 63) | 1ull;
@@ -1103,9 +1125,9 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
     // the same for the two edge columns and the four corners: lane 0 / 63 lay their 16 cells (what they may pass on)
     // out in LDS, the lanes that hold the halo column as loaded (lane = row + 1) compare.  Unchanged cells take part
     // too: they cannot beat a neighbour that has already seen them.
-    unsigned colw = 0u;   // bit 0 NW, 1 W, 2 SW, 3 NE, 4 E, 5 SE
+    unsigned colw = 0u;   // the six column / corner directions that wake, at their bits of `am`
     if ((qany & 1ull) || (qany >> 63) || (q0 & 1ull) || (q0 >> 63) || (q15 & 1ull) || (q15 >> 63)) {
-      if (lane == 0 || lane == TI - 1) {
+      if (__builtin_amdgcn_inverse_ballot_w64(0x8000000000000001ull)) {   // lanes 0 and 63
         uint4* cp = reinterpret_cast<uint4*>(&scr[276 + (lane ? 32 : 0)]);
         cp[0] = make_uint4((unsigned)pp0, (unsigned)pp1, (unsigned)pp2, (unsigned)pp3);
         cp[1] = make_uint4((unsigned)pp4, (unsigned)pp5, (unsigned)pp6, (unsigned)pp7);
@@ -1130,9 +1152,10 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
       const int ux_ = max3i(vs_ + nS, from_below_, from_above_);
       const bool imp = (xl_ <= TJ + 1) & (ux_ > xv);
       const unsigned long long im = __builtin_amdgcn_ballot_w64(imp);
+      // straight into the direction bits of `am` below (0 NW, 3 W, 5 SW from the low half; 2 NE, 4 E, 7 SE from the high half):
+      // through an intermediate bit set and sixteen selects this was 35 scalar instructions
       const unsigned lo = (unsigned)im, hi = (unsigned)(im >> 32);
-      colw = ((lo & 1u) ? 1u : 0u) | ((lo & 0x1fffeu) ? 2u : 0u) | ((lo & 0x20000u) ? 4u : 0u) |
-             ((hi & 1u) ? 8u : 0u) | ((hi & 0x20000u) ? 32u : 0u) | ((hi & 0x1fffeu) ? 16u : 0u);
+      colw = (lo & 1u) | ((lo >> 12) & 32u) | ((hi & 1u) << 2) | ((hi >> 10) & 128u) | ((lo & 0x1fffeu) ? 8u : 0u) | ((hi & 0x1fffeu) ? 16u : 0u);
       if (im) {   // one key per side: the corner tiles of a side share it
         const int hX_ = tsa_octile24(xr_ ? i0 + TI : i0 - 1, j0 + xl_ - 1, gi, gj);
         wave_halves_max_i32(imp ? ux_ - hX_ : (int)0x80000000, kfW, kfE);
@@ -1140,18 +1163,22 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
       __builtin_amdgcn_wave_barrier();
     }
     // directions: 0 NW, 1 N, 2 NE, 3 W, 4 E, 5 SW, 6 S, 7 SE
-    const unsigned am = ((colw & 1u) ? 1u : 0u) | (wakeN ? 2u : 0u) | ((colw & 8u) ? 4u : 0u) | ((colw & 2u) ? 8u : 0u) | ((colw & 16u) ? 16u : 0u) |
-                        ((colw & 4u) ? 32u : 0u) | (wakeS ? 64u : 0u) | ((colw & 32u) ? 128u : 0u);
-    const unsigned wm = am & (unsigned)__builtin_amdgcn_ballot_w64(lane < 8 && nb_t >= 0);
+    const unsigned am = colw | (wakeN ? 2u : 0u) | (wakeS ? 64u : 0u);
+    const unsigned wm = am & (unsigned)__builtin_amdgcn_ballot_w64(nb_t >= 0);   // (nb_t is -1 in every lane from 8 on)
     if (wm) {
       // this job's stores are in L2 before anybody is told to look at them (a woken tile's job loads with sc1 from L2)
+#ifndef RNA_TSA_UNSAFE_NOWAIT   /* (developer build that is NOT exact: what hiding the stores' round trip could be worth at most) */
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
       // lane k < 8 speaks for direction k: its tile, its key ((f - f at the bucket's start), quantised)
-      const int kf = lane == 1 ? kfN : (lane == 6 ? kfS : ((lane == 0 || lane == 3 || lane == 5) ? kfW : kfE));
+      // (four selects under constant lane masks: the nested comparisons became four levels of exec-masked blocks)
+      int kf = __builtin_amdgcn_inverse_ballot_w64(0x29ull) ? kfW : kfE;   // lanes 0, 3, 5: the western side
+      kf = __builtin_amdgcn_inverse_ballot_w64(0x02ull) ? kfN : kf;
+      kf = __builtin_amdgcn_inverse_ballot_w64(0x40ull) ? kfS : kf;
       int key = (key_base - kf) >> key_shift;
       key = key < 0 ? 0 : (key > TSA_NCLS - 1 ? TSA_NCLS - 1 : key);
       TSA_T(t_w1);
-      sch.wake8(lane < 8 && ((wm >> lane) & 1u), nb_t, (unsigned)key, lane, spare);
+      sch.wake8(__builtin_amdgcn_inverse_ballot_w64((unsigned long long)wm), nb_t, (unsigned)key, lane, spare);
       TSA_T(t_w2);
       TSA_ACC(3, t_w1, t_w2);   // queueing the wake-ups
       TSA_CNT(13, 1);
@@ -1165,7 +1192,9 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
   }
 tsa_job_done:
   // the job's stores are performed before the tile can be taken again (or is pulled again by this wavefront)
+#ifndef RNA_TSA_UNSAFE_NOWAIT
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   {
     int t_f = t_in;   // (opaque once more: the masks finish() forms from the tile number are not to be hoisted to the top of the job)
     asm volatile("" : "+s"(t_f));
@@ -1402,7 +1431,6 @@ struct TsaLaunch {
   int32_t* rev_all;
   int rev_cap;
   rna_astar_result* results;
-  unsigned long long* counters;   // (device memory, may be null) [8]: searches, tiles that got a page, jobs, jobs that found nothing, sticky turns, rows written, buckets
 };
 constexpr int TSA_FOUND = -1000;        // provisional status inside the search kernel: found, path not traced yet
 
@@ -1533,7 +1561,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   __shared__ unsigned s_bm[TSA_BMW];
   __shared__ unsigned s_qc[TSA_QC];
   __shared__ int s_best, s_state, s_bucket, s_bucket0, s_jobs_done, s_jobs_noop, s_jobs_sticky, s_expanded, s_nalloc, s_any;
-  __shared__ int s_count, s_spill, s_idle, s_open_left, s_open_pos;
+  __shared__ int s_count, s_spill, s_idle, s_open_left, s_open_pos, s_reruns;
 
   // Workgroups take their query when they START (a ticket), not by blockIdx: the hardware deals workgroup
   // indices round-robin to the XCDs, so a fixed mapping lets one XCD with several long searches hold back
@@ -1585,6 +1613,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
 
   TsaCtx C;
   C.rows = rows; C.cols = cols; C.tiles_i = tiles_i; C.tiles_j = tiles_j;
+  C.tiles_magic = tiles_i > 1 ? (unsigned)(0x100000000ull / (unsigned)tiles_i) + 1u : 0u;
   C.pages = S.pages + (((size_t)sl * ((size_t)S.cap + 1)) << 10);
   C.paux = S.paux + (size_t)sl * ((size_t)S.cap + 1) * AUX_WORDS;
   C.tmap = S.tmap + (size_t)sl * ntile;
@@ -1634,7 +1663,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     s_best = INF; s_state = 0; s_jobs_done = 0; s_jobs_noop = 0; s_jobs_sticky = 0; s_expanded = 0; s_nalloc = 0;
     s_bucket = tsa_octile(si, sj, gi, gj) / A.bucket_width;
     s_bucket0 = s_bucket;
-    s_spill = 0; s_idle = 0; s_open_pos = 0;
+    s_spill = 0; s_idle = 0; s_open_pos = 0; s_reruns = 0;
     s_count = 1; s_open_left = 1;
   }
   __syncthreads();
@@ -1781,6 +1810,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     if (tid_r == 0) {
       // every cell with f < (bucket + 1) * B has its exact g (unless wake-ups were parked: then this bucket runs again)
       if (!spilled && s_best != INF && (long long)s_best < bucket_end) s_state = 1;
+      if (spilled) s_reruns += 1;   // (the queue ran out of nodes: wake-ups were parked and the bucket runs again)
       s_any = 0; s_spill = 0; s_idle = 0; s_open_pos = 0;
     }
     __syncthreads();
@@ -1803,9 +1833,9 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     if (s_state != 0) break;
   }
 #ifdef RNA_TSA_IDLE
-  if (lane == 0 && A.counters) {
-    atomicAdd(&A.counters[8], __builtin_amdgcn_s_memtime() - t_wave0);
-    atomicAdd(&A.counters[9], idle_ticks);
+  if (lane == 0) {
+    atomicAdd(&tsa_counters_of(S)[8], __builtin_amdgcn_s_memtime() - t_wave0);
+    atomicAdd(&tsa_counters_of(S)[9], idle_ticks);
   }
 #endif
   if (lane == 0) {   // cells written; jobs (those that changed something, those that found nothing), sticky turns among them
@@ -1817,14 +1847,19 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   __syncthreads();
   // the launch's job counters (rna_astar_job_counters: what the bench reports as jobs per touched tile / no-op share,
   // observed in the run itself): six adds per SEARCH
-  if (tid == 0 && A.counters) {
-    atomicAdd(&A.counters[0], 1ull);
-    atomicAdd(&A.counters[1], (unsigned long long)s_nalloc);
-    atomicAdd(&A.counters[2], (unsigned long long)s_jobs_done);
-    atomicAdd(&A.counters[3], (unsigned long long)s_jobs_noop);
-    atomicAdd(&A.counters[4], (unsigned long long)s_jobs_sticky);
-    atomicAdd(&A.counters[5], (unsigned long long)(s_expanded / TI));
-    atomicAdd(&A.counters[6], (unsigned long long)(s_bucket - s_bucket0 + 1));
+  // (they live in the second half of the 256-byte block in front of the stage's page counts -- reached through S.nalloc, which
+  // the lines below need anyway: as a kernel argument of its own the pointer was two more SGPRs alive across every tile job,
+  // and the spills they caused cost the bench 1 %)
+  if (tid == 0) {
+    unsigned long long* const cnt = tsa_counters_of(S);
+    atomicAdd(&cnt[0], 1ull);
+    atomicAdd(&cnt[1], (unsigned long long)s_nalloc);
+    atomicAdd(&cnt[2], (unsigned long long)s_jobs_done);
+    atomicAdd(&cnt[3], (unsigned long long)s_jobs_noop);
+    atomicAdd(&cnt[4], (unsigned long long)s_jobs_sticky);
+    atomicAdd(&cnt[5], (unsigned long long)(s_expanded / TI));
+    atomicAdd(&cnt[6], (unsigned long long)(s_bucket - s_bucket0 + 1));
+    if (s_reruns) atomicAdd(&cnt[7], (unsigned long long)s_reruns);
   }
 #ifdef RNA_TSA_STATS
   tsa_acc[5] = wall_clock64() - t_life0;   // wave lifetime inside the search loop
@@ -2072,7 +2107,6 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
     A.queries = q_dev; A.S = S; A.bucket_width = a.bucket_width; A.paths = paths_dev; A.max_path_len = max_len;
     A.rev_all = a.rev[slot]; A.rev_cap = a.rev_cap; A.results = res_dev;
     A.retry = 0; A.n = n; A.S2 = S;
-    A.counters = a.job_counters;
     A.prio_first = a.depth > 1 ? RNA_TSA_PRIO_FIRST : 0;
     if (const char* pf = getenv("RNA_TSA_PRIO_FIRST")) A.prio_first = atoi(pf);   // developer knob
     size_t lds_dyn = 4 * nt_bytes;
@@ -2100,6 +2134,25 @@ int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t sea
   if (ring >= 0) {
     RNA_HIP(e, hipEventRecord(a.ring_free[ring], search_stream));
     a.ring_used[ring] = true;
+  }
+  return RNA_OK;
+}
+
+// the counters of every stage view that exists, summed into out[TSA_COUNTER_WORDS] (the caller has waited for the searches)
+int tsa_counters_read(rna_engine* e, unsigned long long* out, bool reset) {
+  AstarDevice& a = e->astar;
+  for (int k = 0; k < TSA_COUNTER_WORDS; ++k) out[k] = 0ull;
+  for (int d = 0; d < AstarDevice::MAX_DEPTH; ++d) {
+    for (int view = 0; view < 2; ++view) {
+      char* base = static_cast<char*>(view ? a.tsa_aux_retry[d] : a.tsa_aux[d]);
+      if (!base) continue;
+      unsigned long long w[TSA_COUNTER_WORDS];
+      char* cnt = base + 256 - sizeof(w);   // (nalloc starts at base + 256 in both views: tsa_stage_view / tsa_retry_view)
+      RNA_HIP(e, hipMemcpyAsync(w, cnt, sizeof(w), hipMemcpyDeviceToHost, e->stream));
+      if (reset) RNA_HIP(e, hipMemsetAsync(cnt, 0, sizeof(w), e->stream));
+      RNA_HIP(e, hipStreamSynchronize(e->stream));
+      for (int k = 0; k < TSA_COUNTER_WORDS; ++k) out[k] += w[k];
+    }
   }
   return RNA_OK;
 }

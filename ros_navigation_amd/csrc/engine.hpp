@@ -106,7 +106,6 @@ struct AstarDevice {
   size_t last_lds[MAX_DEPTH] = {};
   alignas(8) unsigned char last_launch[MAX_DEPTH][384] = {};   // TsaLaunch of the stage's last batch
   unsigned long long launches = 0;
-  unsigned long long* job_counters = nullptr;   // device, [8]: what the search kernels count per search (rna_astar_job_counters)
   int last_slot = 0;
   size_t field_stride = 0;         // words per query field incl. padding
   rna_astar_query* queries_dev = nullptr;
@@ -257,5 +256,6 @@ int tsa_retry_launch(rna_engine* e, int slot, hipStream_t search_stream, int cou
 int tsa_launch(rna_engine* e, int slot, hipStream_t init_stream, hipStream_t search_stream, hipEvent_t ev_init,
                const rna_astar_query* q_dev, int n, int32_t* paths_dev, int max_len, rna_astar_result* res_dev);
 int tsa_settled(rna_engine* e, int slot, const rna_astar_query* q, const rna_astar_result* r, int n, int32_t* d_counts);
+int tsa_counters_read(rna_engine* e, unsigned long long* out, bool reset);   // sums the job counters of every stage view into out[16]
 
 }  // namespace rna

@@ -18,7 +18,7 @@ import sys,json
 try:
     d=json.loads(sys.stdin.read()); k=d['kernel_ms_per_pass']; w=d['roofline'].get('work_inflation') or {}
     print('$l', round(d['value']), 'ms/pass %.3f' % d['config']['ms_per_pass'], 'search ms %.2f' % k['astar_search'], 'overlap %.1f' % d['roofline']['overlapped_launches'], 'engine ms/pass', round(sum(v for n,v in k.items() if not n.startswith('astar') and n != 'vfh_step'),3), 'host cores %.2f' % d['config']['host_cores_used'],
-          '| jobs/search %.0f jobs/tile %.2f noop %.3f sticky %.3f rows/job %.1f tiles %.0f idle %s' % tuple(w.get(x, 0) for x in ('jobs_per_search','jobs_per_touched_tile','noop_job_frac','sticky_turn_frac','rows_written_per_job','tiles_touched_per_search','idle_frac_developer_build')))
+          '| jobs/search %.0f jobs/tile %.2f noop %.3f sticky %.3f rows/job %.1f tiles %.0f reruns %.3f idle %s' % tuple(w.get(x, 0) for x in ('jobs_per_search','jobs_per_touched_tile','noop_job_frac','sticky_turn_frac','rows_written_per_job','tiles_touched_per_search','bucket_reruns_per_search','idle_frac_developer_build')))
 except Exception as ex:
     print('$l FAILED', ex)
 " >> $OUT
