@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/
 ASTAR_BYTES_PER_SETTLED = 44   # 8 neighbour occupancy reads x 4 B + 12 B g/parent/flag RMW
 VFH_BYTES_PER_POSE = 4 * 31 * 31 + 2 * 72 * 4 + 32
 ROTATE = int(os.environ.get("RNA_BENCH_ROTATE", "4"))   # distinct ray batches / pose sets / query sets the steps cycle through (developer override)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r06_pmc_summary.json")
 
 
 def parse():
@@ -326,13 +326,13 @@ def pmc_traffic(kernel, args, world):
         ks = [find(name) for name in ([kernel] if isinstance(kernel, str) else kernel)]   # a slot's chain: one launch each
         lo = sum(k["fetch_size_kb_avg"] + k["write_size_kb_avg"] for k in ks) * 1024.0
         hi = sum(2.0 * k["fetch_size_kb_avg"] + k["write_size_kb_avg"] for k in ks) * 1024.0
-        return [lo, hi], "profiles/r05_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " \
-                         "[(FETCH+WRITE), (2*FETCH+WRITE)] x 1024 B per launch"
+        return [lo, hi], "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; " \
+                         "[(FETCH+WRITE), (2*FETCH+WRITE)] x 1024 B per launch" % os.path.relpath(PMC_SUMMARY, ROOT)
     except Exception:
         return None, "no PMC summary committed for this kernel"
 
 
-SQ_COUNTERS = os.path.join(ROOT, "profiles", "r05_search_sq_counters.txt")
+SQ_COUNTERS = os.path.join(ROOT, "profiles", "r06_search_sq_counters.txt")
 VALU_PEAK_PER_NS_SIMD = 0.58      # profiles/r03_ubench_valu.txt: eight wavefronts per SIMD issue 0.54-0.59 dependent VALU instructions per ns
 SEARCH_SIMDS = (256 - 32) * 4     # the search streams' CU mask leaves 32 of the 256 CUs to the engine stream
 
@@ -699,7 +699,7 @@ def main():
                        "cycles_per_step": nq * args.pipeline, "passes_per_step": args.pipeline, "cycles_per_pass": nq,
                        "rays_per_pass": int(len(ray_sets[0])), "rotating_input_sets": ROTATE, "ms_per_pass": 1e3 * wall_per_pass,
                        "astar_queries_checked": total, "astar_queries_answered": answered, "astar_paths_found": found,
-                       "astar_bucket_width": args.bucket_width or 96000, "astar_pipeline_depth": args.pipeline,
+                       "astar_bucket_width": args.bucket_width or 128000, "astar_pipeline_depth": args.pipeline,
                        "astar_allocated": dict(zip(("pipeline_depth", "pages_per_query", "max_queries"), e.astar_effective_config())),
                        "timed_seconds": t_max, "paths_checked": paths_checked, "host_affinity": host_affinity,
                        # what a rank asks of the host in the timed region (eight ranks share one at N = 8): cores' worth of CPU time

@@ -256,7 +256,7 @@ typedef struct {
 /* max_queries: queries searched concurrently (one g-field each; larger batches are processed in
  * chunks); queue_capacity: ignored (the cell queues of the frontier kernel removed in round 3; the tile kernel's open
  * list has a fixed size in LDS and parks what does not fit); bucket_width: the f-range (cost units, >= 2828) inside
- * which free wavefronts take tiles by key before the search advances (default 96000); 0 = keep/default.
+ * which free wavefronts take tiles by key before the search advances (default 128000; 96000 until round 5); 0 = keep/default.
  * Maps of more than 65 536 tiles of 64 x 16 cells (8192 x 8192 cells) are refused with RNA_EINVAL. */
 int rna_astar_configure(rna_engine* e, int max_queries, int queue_capacity, int bucket_width);
 /* Pipelined batches: with depth d > 1 consecutive rna_astar_batch_device calls run their searches on d
@@ -265,7 +265,7 @@ int rna_astar_configure(rna_engine* e, int max_queries, int queue_capacity, int 
  * bare hipDeviceSynchronize(): searches that ran out of their share of pages are searched again by a second launch
  * the host issues when it sees their count, at the latest inside rna_synchronize().  The call returns after
  * enqueueing; while every stage is busy it blocks until one is free.  The caller must give calls that may be in
- * flight together distinct output buffers.  Default 4; up to 16.
+ * flight together distinct output buffers.  Default 4; up to 20 (16 until round 5).
  * Hardware queues: every stage's stream wants a hardware queue of its own, and the HIP runtime multiplexes all of a
  * process's streams over GPU_MAX_HW_QUEUES (default 4) of them, read from the environment at its first call.  librna.so
  * sets GPU_MAX_HW_QUEUES=8 when it is loaded and the variable is unset (RNA_KEEP_HW_QUEUES=1 turns that off); when the

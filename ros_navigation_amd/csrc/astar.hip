@@ -213,7 +213,11 @@ int launch_chunk(rna_engine* e, const rna_astar_query* q_dev, int n, int32_t* pa
       }
       if (best >= 0) { slot = best; break; }
       if (nowait) { slot = oldest; break; }
-      if (spin > 64) std::this_thread::sleep_for(std::chrono::microseconds(20));
+      // (no stage free: the host SLEEPS between looks -- with thirteen launches in flight a stage that frees up 50 us before
+      // the host notices costs nothing, and eight ranks of one node share the host's cores; round 5 yielded 64 times and then
+      // slept 20 us, which kept a core busy: config.host_cores_used 0.98)
+      static const int wait_us = getenv("RNA_ASTAR_WAIT_US") ? atoi(getenv("RNA_ASTAR_WAIT_US")) : 50;   // developer knob
+      if (spin >= 2 && wait_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(wait_us));
       else std::this_thread::yield();
     }
     // the ring entry this launch writes: the batch that read it 2 x depth launches ago is over and settled

@@ -62,11 +62,11 @@ struct VfhDevice {
 struct AstarDevice {
   int max_queries = 0;
   int queue_cap = 0;
-  int bucket_width = 96000;         // f-range of one bucket (96 cells); inside it free wavefronts take the tile with the lowest key (astar_tile.hip)
+  int bucket_width = 128000;        // f-range of one bucket (128 cells; round 6, on the bench: 72 / 96 / 128 / 160 / 200 / 256 k -> 159.8 / 160.8 / 162.2 / 159.7 / 158.5 / 159.3 k cycles/s, profiles/r06_sweep_bucket_width.txt); inside it free wavefronts take the tile with the lowest key (astar_tile.hip)
   int threads = 512;               // workgroup size of the search kernel (256 / 512 / 1024)
   // Pipelined batches: `depth` independent sets of search fields + queues, each with its own HIP
   // stream, so the tail of batch k (few long queries) overlaps the head of batch k+1.
-  static constexpr int MAX_DEPTH = 16;
+  static constexpr int MAX_DEPTH = 20;   // (a process's streams run out of hardware queues from 22 stages on: profiles/r04_sweep_depth_16_22_engine_max_24.txt)
   int depth = 4;
   int32_t* g[MAX_DEPTH] = {};      // frontier kernel: [max_queries][field_stride] search fields (g << 8) | mask;
                                    // tile kernel: the stage's page pool (pages, then pending bitmaps), see astar_tile.hip
