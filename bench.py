@@ -33,7 +33,10 @@ import time
 
 # pipelined A* batches run on several HIP streams; give the runtime enough hardware queues
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-DEFAULT_PIPELINE = 16   # A* batches in flight on one GPU (the committed counter files under profiles/ belong to it)
+DEFAULT_PIPELINE = 18   # A* batches in flight on one GPU (the committed counter files under profiles/ belong to it).  Round 6, default
+                        # bench / the driver's 20-step run: 16 -> 162.0 / 158.0 k, 18 -> 162.5 / 160.1 k, 20 -> 163.5 / 161.1 k cycles/s
+                        # (profiles/r06_sweep_depth.txt); from 22 on a process's streams run out of hardware queues (129 k), so
+                        # 18 it is: four stages away from the cliff
 # ... and next to an RCCL communicator, whose streams take hardware queues of their own: the rate falls off from 21 stages on
 # without one and from 18 on with one (profiles/r04_sweep_depth_rccl.txt); 14 and 16 measure the same there
 DEFAULT_PIPELINE_RCCL = 14
@@ -52,7 +55,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=54, help="timed steps; one step = one turn of the pipeline = --pipeline passes of "
-                                                           "[HIMM batch, VFH+ x queries, A* x queries] (default: 702 passes)")
+                                                           "[HIMM batch, VFH+ x queries, A* x queries] (default: 972 passes)")
     ap.add_argument("--warmup", type=int, default=2, help="untimed steps (turns of the pipeline)")
     ap.add_argument("--grid", type=int, default=4096)
     ap.add_argument("--queries", type=int, default=256, help="A* queries == VFH poses per step (cycles per step)")
@@ -62,10 +65,10 @@ def parse():
     ap.add_argument("--queue-capacity", type=int, default=0)
     ap.add_argument("--max-path", type=int, default=32768)
     ap.add_argument("--pipeline", type=int, default=0,
-                    help="A* batches in flight (rna_astar_set_pipeline_depth); 0 = 16 on one GPU, 14 next to an RCCL communicator.  "
+                    help="A* batches in flight (rna_astar_set_pipeline_depth); 0 = 18 on one GPU, 14 next to an RCCL communicator.  "
                          "Four search workgroups share a CU, so ~900 queries "
                          "run at once and the batches' tails differ (round 4, default steps / the driver's 20: 13: 148.9k / 146.5k, "
-                         "16: 151.1k / 147.9k cycles/s -- profiles/r04_sweep_depth_13_16.txt; 16 is the engine's maximum and needs "
+                         "16: 151.1k / 147.9k cycles/s -- profiles/r04_sweep_depth_13_16.txt; round 6: profiles/r06_sweep_depth.txt; 20 is the engine's maximum, and more than two stages need "
                          "GPU_MAX_HW_QUEUES=8, set above: with the runtime's default of 4 queues the rate collapses).  "
                          "Every launch is stretched by the ones it overlaps with, and "
                          "the roofline line divides by that per-launch duration")

@@ -338,7 +338,7 @@ extern "C" int rna_astar_set_pipeline_depth(rna_engine* e, int depth) {
     astar_release(e);
     e->astar.depth = depth;
   }
-  char advice[320];
+  char advice[448];   // (the longest advice line is about 330 characters)
   if (rna_hw_queue_advice(depth, advice, sizeof(advice))) e->err = advice;   // (still RNA_OK: correct, only slower)
   return RNA_OK;
 }

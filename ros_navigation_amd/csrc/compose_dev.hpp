@@ -1,4 +1,5 @@
-// compose_dev.hpp -- device code shared by engine.hip (compose_nbr_tiles_kernel) and himm.hip (the fused map-update kernel):
+// compose_dev.hpp -- device code of engine.hip's compose_nbr_tiles_kernel (a header of its own since round 5's fused map-update
+// kernel, which was measured slower and removed, shared it):
 // MapProvider::updateMap's compose step and the neighbour-mask refresh of ONE 64 x 64 tile.
 #pragma once
 #include "engine.hpp"

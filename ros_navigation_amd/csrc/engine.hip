@@ -7,6 +7,7 @@
 #include "compose_dev.hpp"
 
 #include <cmath>
+#include <dirent.h>
 #include <unistd.h>
 #include <cstdlib>
 #include <cstring>
@@ -632,15 +633,21 @@ extern "C" int rna_synchronize_map(rna_engine* e) {
 static int g_hwq_at_load = 0;            // GPU_MAX_HW_QUEUES after the constructor ran (0: unset)
 static bool g_hwq_set_by_us = false, g_gpu_open_at_load = false;
 static bool process_has_kfd_open() {
-  char link[64], target[256];
-  for (int fd = 0; fd < 4096; ++fd) {
-    snprintf(link, sizeof(link), "/proc/self/fd/%d", fd);
+  // (the descriptors the process HAS, whatever their numbers: round 5 probed 0..4095 with 4 096 readlink calls per dlopen)
+  DIR* d = opendir("/proc/self/fd");
+  if (!d) return false;
+  bool found = false;
+  char link[300], target[256];
+  while (const dirent* ent = readdir(d)) {
+    if (ent->d_name[0] == '.') continue;
+    snprintf(link, sizeof(link), "/proc/self/fd/%s", ent->d_name);
     const ssize_t n = readlink(link, target, sizeof(target) - 1);
     if (n <= 0) continue;
     target[n] = 0;
-    if (strcmp(target, "/dev/kfd") == 0) return true;
+    if (strcmp(target, "/dev/kfd") == 0) { found = true; break; }
   }
-  return false;
+  closedir(d);
+  return found;
 }
 __attribute__((constructor(101))) static void rna_default_hw_queues() {
   g_gpu_open_at_load = process_has_kfd_open();

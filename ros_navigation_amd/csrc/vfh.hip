@@ -30,7 +30,7 @@ namespace {
 constexpr int VFH_THREADS = 128;
 constexpr int MAX_W = 64;
 constexpr int MAX_NQ = (MAX_W / 2 + 1) * MAX_W;   // 2112
-[[maybe_unused]] [[maybe_unused]] constexpr int MAX_NW = (MAX_NQ + 31) / 32;        // 66 (the kernel sizes its LDS by the actual window) (the kernel sizes its LDS by the actual window)
+[[maybe_unused]] constexpr int MAX_NW = (MAX_NQ + 31) / 32;        // 66 (the kernel sizes its LDS by the actual window)
 constexpr int MAX_H = 128;
 constexpr int VFH_OCC_CAP = 1024;
 

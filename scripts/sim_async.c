@@ -20,6 +20,9 @@
  *   difference), SIM_AGAINKEY (a tile woken while it ran is queued with its waker's key instead of the lowest); the last lines
  *   count the re-runs of tiles woken while they ran and how often a wavefront's next tile is the one it just finished -- the
  *   figures behind the kernel's sticky tiles.
+ *   round 6: SIM_GKEY (keys are g instead of f = g + h: Dijkstra order inside a bucket), SIM_HW16=n (key = g + n/16 h), and a line
+ *   with the working jobs (those that get past the halo step), the rows they write and the cells reached over the cells settled --
+ *   the runs behind profiles/r06_sim_schedules.txt.
  *   job cost model (microseconds, from the RNA_TSA_STATS phase timers under load): load+halo 3.8, rows 0.2 each,
  *   horizontal passes 0.065 each, results 2.6; a job that finds nothing in its halo 3.8.
  */
@@ -30,6 +33,7 @@
 
 #define INF 0x3fffffff
 static int rows, cols, TI = 64, TJ = 16, tiles_i, tiles_j, bucket_w, extra_h = 16;
+static int gkey = 0, hw16 = 16;
 static uint8_t* nbr;
 static int32_t* g;
 static int gi, gj;
@@ -217,7 +221,7 @@ static void job(int t, int first, jobres* r) {
         const int na = a + di[k];
         if (na < 0 || na >= TI) continue;
         const int c = pp[b][a] + ((di[k] && dj[k]) ? 1414 : 1000);
-        if (c < gat(i0 + na, j0 + b + dj[k])) WAKE(ti, tj + dj[k], (long long)c + octile(i0 + na, j0 + b + dj[k]));
+        if (c < gat(i0 + na, j0 + b + dj[k])) WAKE(ti, tj + dj[k], (long long)c + (gkey ? 0 : (long long)octile(i0 + na, j0 + b + dj[k]) * hw16 / 16));
       }
     }
   }
@@ -233,7 +237,7 @@ static void job(int t, int first, jobres* r) {
           if (di[k] != da || !((mk[b][a] >> k) & 1)) continue;
           const int nb = b + dj[k];
           const int c = pp[b][a] + (dj[k] ? 1414 : 1000);
-          if (c < gat(i0 + a + da, j0 + nb)) WAKE(ti + da, tj + (nb < 0 ? -1 : (nb >= TJ ? 1 : 0)), (long long)c + octile(i0 + a + da, j0 + nb));
+          if (c < gat(i0 + a + da, j0 + nb)) WAKE(ti + da, tj + (nb < 0 ? -1 : (nb >= TJ ? 1 : 0)), (long long)c + (gkey ? 0 : (long long)octile(i0 + a + da, j0 + nb) * hw16 / 16));
         }
       }
     }
@@ -247,7 +251,7 @@ static void job(int t, int first, jobres* r) {
 
 /* SIM_FRESH: the wake tests of a job evaluated when it ENDS against what the neighbours hold THEN (the kernel would
    re-read their edge rows / columns after its stores), instead of against the halo it loaded when it started */
-static int fresh = 0; static long n_again=0, n_again_noop=0, n_sticky=0, n_nbr=0; static int last_t[64]; static uint8_t *isagain;
+static long n_work = 0, n_rows_written = 0, n_reached = 0; static int fresh = 0; static long n_again=0, n_again_noop=0, n_sticky=0, n_nbr=0; static int last_t[64]; static uint8_t *isagain;
 static void wake_fresh(jobres* r) {
   static const int di[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, dj[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
   const int t = r->t, ti = t % tiles_i, tj = t / tiles_i, i0 = ti * TI, j0 = tj * TJ;
@@ -270,7 +274,7 @@ static void wake_fresh(jobres* r) {
           const int wi = ti + (na < 0 ? -1 : (na >= TI ? 1 : 0)), wj = tj + (nb < 0 ? -1 : (nb >= TJ ? 1 : 0));
           if (wi < 0 || wj < 0 || wi >= tiles_i || wj >= tiles_j) continue;
           const int kk = (wj - tj + 1) * 3 + (wi - ti + 1), k8 = kk < 4 ? kk : kk - 1;
-          const long long f = (long long)c + octile(i0 + na, j0 + nb);
+          const long long f = (long long)c + (gkey ? 0 : octile(i0 + na, j0 + nb));
           r->wake[k8] = wj * tiles_i + wi;
           if (f < r->wkey[k8]) r->wkey[k8] = f;
         }
@@ -280,6 +284,7 @@ static void wake_fresh(jobres* r) {
 
 static void apply(const jobres* r) {
   const int t = r->t, i0 = (t % tiles_i) * TI, j0 = (t / tiles_i) * TJ;
+  if (!r->noop) { n_work++; for (int b = 0; b < TJ; ++b) { int c = 0; for (int a = 0; a < TI; ++a) c |= r->chgv[b * TI + a]; n_rows_written += c; } }
   for (int b = 0; b < TJ; ++b)
     for (int a = 0; a < TI; ++a)
       if (i0 + a < rows && j0 + b < cols) g[(size_t)(j0 + b) * rows + i0 + a] = r->val[b * TI + a];
@@ -320,13 +325,13 @@ static entry* ents; static int nent = 0, maxent = 0; static long stale_pops = 0,
 static uint8_t *Dbit;
 static void epush(int t, long long key) {
   long long k = key;
-  if (kshift >= 0) { const long long lo = bend - bucket_w; k = key < lo ? 0 : (key - lo) >> kshift; }
+  if (kshift >= 0) { const long long lo = gkey ? 0 : bend - bucket_w; k = key < lo ? 0 : (key - lo) >> kshift; }
   if (ringcap > 0) { while (k < ringnc - 1 && clsn[k] >= ringcap) k++; if (k > ringnc - 1) k = ringnc - 1; if (clsn[k] >= ringcap) ringspill++; }
   ents[nent].key = k; ents[nent].t = t; ents[nent].seq = eseq++; nent++; pushes++;
   if (k >= 0 && k < 4096) { if (++clsn[k] > clsmax) clsmax = clsn[k]; }
   if (nent > maxent) maxent = nent;
 }
-static long long cls_of(long long key) { if (kshift < 0) return key; const long long lo = bend - bucket_w; return key < lo ? 0 : (key - lo) >> kshift; }
+static long long cls_of(long long key) { if (kshift < 0) return key; const long long lo = gkey ? 0 : bend - bucket_w; return key < lo ? 0 : (key - lo) >> kshift; }
 static int againkey=0; static long long *akey;
 static void wake4(int t, long long key) {
   if (running[t]) { if (!Dbit[t] || key < akey[t]) akey[t] = key; }
@@ -406,7 +411,7 @@ int main(int argc, char** argv) {
   if (getenv("SIM_RINGNC")) ringnc = atoi(getenv("SIM_RINGNC"));
   if (getenv("SIM_RING")) ringmode = atoi(getenv("SIM_RING"));   /* 2: last in, first out */     /* policy 4: entries of one key class leave in the order they came (a ring per class) */
   if (getenv("SIM_NODUP")) nodup = atoi(getenv("SIM_NODUP"));
-  if (getenv("SIM_FRESH")) fresh = 1;
+  if (getenv("SIM_FRESH")) fresh = 1; if (getenv("SIM_GKEY")) gkey = 1; if (getenv("SIM_HW16")) hw16 = atoi(getenv("SIM_HW16"));
   if (getenv("SIM_EXCL")) excl4 = 1;   /* policy 4: a tile does not start while one of its four edge neighbours runs */
   if (getenv("SIM_NODEC")) nodec = 1;                            /* a queued tile keeps the key of its first wake-up */
   if (getenv("SIM_DIRTYKEY")) dirtykey = atoi(getenv("SIM_DIRTYKEY"));   /* key of a tile woken while it ran: 0 the waker's, 1 the key it was taken with, 2 lowest, 3 highest */
@@ -571,6 +576,7 @@ int main(int argc, char** argv) {
       for (int i = 0; i < rows; ++i) {
         int v = g[(size_t)j * rows + i];
         if (v < INF && best != INF && v + octile(i, j) <= best) E++;
+        if (v < INF) n_reached++;
       }
     const int ok = (best == want_cost || (best == INF && want_cost >= 0x7fffffff)) && E == want_E;
     if (!ok) { bad++; fprintf(stderr, "query %d MISMATCH cost %d want %d E %ld want %d\n", q, best, want_cost, E, want_E); }
@@ -584,6 +590,7 @@ int main(int argc, char** argv) {
   printf("policy %d W %d bucket %d subbins %d: E %ld jobs/query %.0f (%.1f%% no-op) rows/job %.1f hpass/job %.1f | busy %.2f wave-ms/query, makespan mean %.2f ms max %.2f ms, wave efficiency %.0f%%, mismatches %ld\n",
          policy, W, bucket_w, subbins, totE, (double)tot.jobs / nq, 100.0 * tot.noop / tot.jobs, (double)tot.row_evals / tot.jobs, (double)tot.hextra / tot.jobs,
          tot.busy * 1e-3 / nq, sum_makespan * 1e-3 / nq, max_makespan * 1e-3, 100.0 * tot.busy / (sum_makespan * W), bad);
+  printf("  working jobs/query %.0f, rows written per working job %.1f, cells reached / E %.3f\n", (double)n_work / nq, (double)n_rows_written / (n_work ? n_work : 1), (double)n_reached / totE);
   printf("  most entries queued at once: %d (most in one key class: %d)\n", policy == 4 ? maxent : maxlive, clsmax);
   if (ringcap) printf("  pushes that found every class from theirs on full: %ld\n", ringspill);
   printf("  again re-queues %ld (%.3f of jobs), of which no-op %.3f; next job same tile %.3f of jobs, a neighbour tile %.3f\n", n_again, (double)n_again/tot.jobs, (double)n_again_noop/(n_again?n_again:1), (double)n_sticky/tot.jobs, (double)n_nbr/tot.jobs);
