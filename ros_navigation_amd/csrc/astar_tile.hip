@@ -61,6 +61,13 @@ constexpr int MASK_STRIDE = TILE_WORDS + 32 + 128;  // snapshot bytes per tile: 
                           // (non-sticky ones to 7 % of all jobs), the bench from 154.3 k to 152.7 k cycles/s -- three more loads and
                           // their addresses in every working job cost more than the cheap jobs they save.  Off.
 #endif
+#ifndef RNA_TSA_CONFIRM
+#define RNA_TSA_CONFIRM 0   // 1: a side whose wake test (against the halo as loaded) says "wake" is looked at AGAIN before the wake-up goes
+                            // out: the neighbour's edge is read as it is NOW and the test repeated -- round 5's fresh wake tests, but only
+                            // where a wake-up is about to be queued.  Measured (profiles/r06_ab_confirm.txt): exact (A* parity tests, fuzz
+                            // seeds), jobs per search 2 709 -> 2 489, no-op share 33.6 -> 29.8 %, and the bench 162.8 -> 158.9 k cycles/s:
+                            // the second look runs in 61 % of the working jobs and costs more than the 220 cheap jobs it saves.  Off.
+#endif
 #ifndef RNA_TSA_IDLE_SLEEP
 #define RNA_TSA_IDLE_SLEEP 4   // an idle wavefront looks at the entry counter every 64 x this many clocks (1 / 4 / 12: profiles/r05_ab_idle_sleep.txt)
 #endif
@@ -528,8 +535,8 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
     }
   }
   pg = (unsigned)__builtin_amdgcn_readlane((int)nb_pg, 8);
-#if RNA_TSA_FRESH
-  if (lane < 8) scr[lane] = nb_pg;   // for the end of the job: the wake tests read the neighbours' edges again (TSA_FRESH)
+#if RNA_TSA_FRESH || RNA_TSA_CONFIRM
+  if (lane < 8) scr[lane] = nb_pg;   // for the end of the job: the wake tests read the neighbours' edges again (TSA_FRESH / TSA_CONFIRM)
 #endif
   // ---- 2. everything the job reads, issued before the first wait ----
   // (the tile's snapshot through a scalar base and 32-bit lane offsets of known range: as `base + lane * 16` and
@@ -552,14 +559,16 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
   int top, bot, X = 0, gcol = 0;
   unsigned eb = 0u;   // lanes 1..16 / 33..48: mask of the tile's own edge cell (0, xl-1) / (63, xl-1)
   {
-    const unsigned pgN = (unsigned)__shfl((int)nb_pg, 1), pgS = (unsigned)__shfl((int)nb_pg, 6);
+    // (ds_bpermute with the byte address of the source lane, not __shfl: that adds the wavefront's base lane -- zero here, but a
+    // vector value the compiler keeps across the whole kernel, i.e. one of the 64 registers, or a scratch reload at the top of a job)
+    const unsigned pgN = (unsigned)__builtin_amdgcn_ds_bpermute(1 << 2, (int)nb_pg), pgS = (unsigned)__builtin_amdgcn_ds_bpermute(6 << 2, (int)nb_pg);
     top = (int)ld_l2(&C.pages[(pgN << 10) + (TJ - 1) * TI + lane]);
     bot = (int)ld_l2(&C.pages[(pgS << 10) + lane]);
     // direction of the tile a halo-column lane reads: NW W SW = 0 3 5 on the left, NE E SE = 2 4 7 on the right
     // (arithmetic: as nested selections it became three levels of exec-mask branches)
     const int xz = (xl > 0 ? 1 : 0) + (xl > TJ ? 1 : 0);
     const int xdir = 3 * xz - (xz >> 1) + (xr ? 2 - (xz & 1) : 0);
-    const unsigned pgX = (unsigned)__shfl((int)nb_pg, xdir);
+    const unsigned pgX = (unsigned)__builtin_amdgcn_ds_bpermute(xdir << 2, (int)nb_pg);
     const int xrow = xl == 0 ? TJ - 1 : (xl <= TJ ? xl - 1 : 0);
     if (xl <= TJ + 1) X = (int)ld_l2(&C.paux[pgX * AUX_WORDS + (xr ? 0 : 16) + xrow]);   // a left tile's column 63 / a right tile's column 0
     if (xcell) eb = snap[TILE_WORDS + ((ulane_ld & 31u) - 1u) + (ulane_ld & 32u ? 16u : 0u)];   // (xl - 1 + (xr ? 16 : 0))
@@ -1090,8 +1099,18 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
     // u - h; one wave reduction per side).  Free wavefronts take the queued tile with the lowest key, so tiles are
     // relaxed roughly in the order A* would settle their cells (scripts/sim_async.c: 7 % fewer jobs than red-black
     // rounds and no wavefront waiting at a round barrier).
-    bool wakeN = q0 != 0ull, wakeS = q15 != 0ull;
+    bool wakeN, wakeS;
     int kfN = 0, kfS = 0, kfW = 0, kfE = 0;
+    unsigned colw, am, wm;
+#if RNA_TSA_CONFIRM
+    int confirm_w = 0;          // (a 32-bit scalar, like the job loop's flags)
+    bool col_any = (qany & 1ull) || (qany >> 63) || (q0 & 1ull) || (q0 >> 63) || (q15 & 1ull) || (q15 >> 63);
+    for (;;) {
+#else
+    const bool col_any = (qany & 1ull) || (qany >> 63) || (q0 & 1ull) || (q0 >> 63) || (q15 & 1ull) || (q15 >> 63);
+    {
+#endif
+    wakeN = q0 != 0ull; wakeS = q15 != 0ull;
     if (wakeN) {
 #if !RNA_TSA_FRESH
       const int topv = (int)scr[84 + lane];
@@ -1125,8 +1144,8 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
     // the same for the two edge columns and the four corners: lane 0 / 63 lay their 16 cells (what they may pass on)
     // out in LDS, the lanes that hold the halo column as loaded (lane = row + 1) compare.  Unchanged cells take part
     // too: they cannot beat a neighbour that has already seen them.
-    unsigned colw = 0u;   // the six column / corner directions that wake, at their bits of `am`
-    if ((qany & 1ull) || (qany >> 63) || (q0 & 1ull) || (q0 >> 63) || (q15 & 1ull) || (q15 >> 63)) {
+    colw = 0u;   // the six column / corner directions that wake, at their bits of `am`
+    if (col_any) {
       if (__builtin_amdgcn_inverse_ballot_w64(0x8000000000000001ull)) {   // lanes 0 and 63
         uint4* cp = reinterpret_cast<uint4*>(&scr[276 + (lane ? 32 : 0)]);
         cp[0] = make_uint4((unsigned)pp0, (unsigned)pp1, (unsigned)pp2, (unsigned)pp3);
@@ -1163,8 +1182,47 @@ __device__ __forceinline__ void tsa_job(Sched& sch, unsigned* scr, const int lan
       __builtin_amdgcn_wave_barrier();
     }
     // directions: 0 NW, 1 N, 2 NE, 3 W, 4 E, 5 SW, 6 S, 7 SE
-    const unsigned am = colw | (wakeN ? 2u : 0u) | (wakeS ? 64u : 0u);
-    const unsigned wm = am & (unsigned)__builtin_amdgcn_ballot_w64(nb_t >= 0);   // (nb_t is -1 in every lane from 8 on)
+    am = colw | (wakeN ? 2u : 0u) | (wakeS ? 64u : 0u);
+    wm = am & (unsigned)__builtin_amdgcn_ballot_w64(nb_t >= 0);   // (nb_t is -1 in every lane from 8 on)
+#if RNA_TSA_CONFIRM
+    // CONFIRM.  A wake-up costs the neighbour a whole job, and a third of all jobs find nothing: the neighbour has caught up
+    // by itself since this job loaded its halo (both were reached by the same front).  So the sides that are about to wake are
+    // looked at once more: the neighbour's edge as it is in memory NOW replaces the copy in the wavefront's scratch, and the
+    // tests above run again for those sides only.  Values only get better, a row that is being stored while it is read shows a
+    // mix of old and new words, and either way the test can only err towards waking.
+    confirm_w = __builtin_amdgcn_readfirstlane(confirm_w);
+    if (!wm || confirm_w) break;
+    confirm_w = 1;
+    // (scalar page bases and 32-bit lane offsets of known range: no 64-bit vector addresses -- the first version of this
+    // block spilled the zero the compiler keeps for extending indices, at the top of every job)
+    const unsigned ul_c = (unsigned)lane & 63u;
+    if (!(wm & 2u)) q0 = 0ull;
+    else {
+      const unsigned* pN = C.pages + ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)scr[1]) << 10);
+      scr[84 + lane] = ld_l2(&pN[(TJ - 1) * TI + ul_c]);
+    }
+    if (!(wm & 64u)) q15 = 0ull;
+    else {
+      const unsigned* pS = C.pages + ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)scr[6]) << 10);
+      scr[84 + 64 + lane] = ld_l2(&pS[ul_c]);
+    }
+    col_any = (wm & 0xbdu) != 0u;
+    if (col_any) {
+      const unsigned xl = ul_c & 31u;
+      const unsigned xr = ul_c >> 5;
+      const unsigned xz = (xl > 0u ? 1u : 0u) + (xl > (unsigned)TJ ? 1u : 0u);
+      const unsigned xdir = 3u * xz - (xz >> 1) + (xr ? 2u - (xz & 1u) : 0u);
+      const unsigned xrow = xl == 0u ? (unsigned)(TJ - 1) : (xl <= (unsigned)TJ ? xl - 1u : 0u);
+      if (xl <= (unsigned)(TJ + 1)) {
+        const unsigned pgX = scr[xdir] & 0xfffffu;   // (a page number: at most 65 536 per query; the mask tells the compiler the offset fits 32 bits)
+        scr[84 + 128 + lane] = ld_l2(&C.paux[pgX * AUX_WORDS + (xr ? 0u : 16u) + xrow]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    }   // once more, for the sides that claimed a wake-up
+#else
+    }
+#endif
     if (wm) {
       // this job's stores are in L2 before anybody is told to look at them (a woken tile's job loads with sc1 from L2)
 #ifndef RNA_TSA_UNSAFE_NOWAIT   /* (developer build that is NOT exact: what hiding the stores' round trip could be worth at most) */
