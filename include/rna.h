@@ -29,8 +29,10 @@ extern "C" {
  *    tile jobs per wavefront), statuses 4 / 5, profile slot astar_reset, default bucket width 96000.  A host checks
  *    rna_abi_version() == RNA_ABI_VERSION after loading the library (capi.py and move_control_amd.hpp do). */
 /* 3: rna_synchronize_map, rna_hw_queue_advice (round 4); no existing signature changed.
- * 4: rna_scan_to_rays_tf[_device], rna_range_to_rays_tf (sensors with a full tf transform; round 4); no existing signature changed. */
-#define RNA_ABI_VERSION 4
+ * 4: rna_scan_to_rays_tf[_device], rna_range_to_rays_tf (sensors with a full tf transform; round 4); no existing signature changed.
+ * 5: rna_astar_job_counters (round 6); the default bucket width of the grid search is 128000, a pipeline may have up to 20 stages,
+ *    rna_astar_result.rounds counts every job again (also the ones that find nothing); no existing signature changed. */
+#define RNA_ABI_VERSION 5
 
 typedef enum {
   RNA_OK = 0,

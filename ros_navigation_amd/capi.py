@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("RNA_LIB") or "librna.so")   # RNA_LIB: developer switch to an alternative build
 
 RNA_OK = 0
-ABI_VERSION = 4   # include/rna.h: RNA_ABI_VERSION
+ABI_VERSION = 5   # include/rna.h: RNA_ABI_VERSION
 STATUS = {0: "RNA_OK", -1: "RNA_EINVAL", -2: "RNA_ENOMEM", -3: "RNA_EHIP", -4: "RNA_ECAPACITY",
           -5: "RNA_ESTATE", -6: "RNA_ENODEVICE"}
 LAYER_MASTER, LAYER_LASER, LAYER_RANGE = 0, 1, 2
