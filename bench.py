@@ -553,6 +553,7 @@ def main():
     torch.cuda.synchronize()
 
     only_astar = os.environ.get("RNA_BENCH_ONLY_ASTAR") == "1"
+    host_t = [0.0, 0.0, 0.0, 0] if os.environ.get("RNA_BENCH_HOST_TIMING") == "1" and not args.tiled else None
     step_no = [0]
     xfer = [0, 0]          # bytes received: halo strips, gathered windows
 
@@ -562,6 +563,16 @@ def main():
         step_no[0] += 1
         if only_astar:   # developer switch RNA_BENCH_ONLY_ASTAR=1: the search capacity without the map update and VFH+ (NOT the metric)
             e.astar_device(d_queries[k].data_ptr(), nq, d_paths[b].data_ptr(), args.max_path, d_results[b].data_ptr())
+            return b
+        if host_t is not None:   # developer switch RNA_BENCH_HOST_TIMING=1: host seconds inside each of the pass's three calls
+            t_a = time.perf_counter()
+            e.update_map_device(d_rays[k].data_ptr(), len(ray_sets[k]), compose_mode=0)
+            t_b = time.perf_counter()
+            e.vfh_step_device(d_poses[k].data_ptr(), nq, d_vfh_out.data_ptr())
+            t_c = time.perf_counter()
+            e.astar_device(d_queries[k].data_ptr(), nq, d_paths[b].data_ptr(), args.max_path, d_results[b].data_ptr())
+            t_d = time.perf_counter()
+            host_t[0] += t_b - t_a; host_t[1] += t_c - t_b; host_t[2] += t_d - t_c; host_t[3] += 1
             return b
         e.update_map_device(d_rays[k].data_ptr(), len(ray_sets[k]), compose_mode=0)
         if layout is not None and world > 1:
@@ -612,6 +623,8 @@ def main():
     e.profile_reset()
     xfer[0] = xfer[1] = 0
     e.astar_job_counters(reset=True)   # (waits for the warm-up's searches; the timed region's jobs are read after it)
+    if host_t is not None:
+        host_t[:] = [0.0, 0.0, 0.0, 0]
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -626,6 +639,7 @@ def main():
     prof = e.profile_get()
     e.profile(False)
     job_counters = e.astar_job_counters(reset=True)
+    host_t_timed = list(host_t) if host_t is not None else None
     found, answered, total = check_results("in the timed region")
     xfer_timed = list(xfer)
     e.profile(1)
@@ -707,6 +721,9 @@ def main():
                        "timed_seconds": t_max, "paths_checked": paths_checked, "host_affinity": host_affinity,
                        # what a rank asks of the host in the timed region (eight ranks share one at N = 8): cores' worth of CPU time
                        "host_cores_used": host_cores_used,
+                       "host_us_per_pass_developer": ({"update_map": 1e6 * host_t_timed[0] / host_t_timed[3], "vfh_step": 1e6 * host_t_timed[1] / host_t_timed[3],
+                                                       "astar_batch (incl. the wait for a free stage)": 1e6 * host_t_timed[2] / host_t_timed[3]}
+                                                      if host_t_timed and host_t_timed[3] else None),
                        "shards": [r[:2] for r in shard_rows], "cycles_by_rank": [r[2] for r in shard_rows],
                        "launcher": ({"spawned_by_bench": True, "parent_pid": int(os.environ["RNA_BENCH_PARENT"].split(":")[0]),
                                      "parent_is_my_parent": int(os.environ["RNA_BENCH_PARENT"].split(":")[0]) == os.getppid(),

@@ -28,6 +28,48 @@ namespace {
 
 constexpr int COST_D = 1414;
 
+// developer switch RNA_HOST_TRACE=1: host microseconds inside the segments of a pipelined batch launch, printed when the search
+// state is released (where the host's share of a pass goes)
+struct HostTrace {
+  bool on = getenv("RNA_HOST_TRACE") != nullptr;
+  double us[8] = {};
+  long n = 0, queries = 0;
+  std::chrono::steady_clock::time_point t;
+  void start() { if (on) t = std::chrono::steady_clock::now(); }
+  void lap(int k) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    us[k] += std::chrono::duration<double, std::micro>(now - t).count();
+    t = now;
+  }
+  void dump() {
+    if (!on || n == 0) return;
+    fprintf(stderr, "[host trace] %ld pipelined launches, us each: wait for a free stage %.1f (%.2f hipEventQuery calls) | ring entry's old batch %.1f | "
+            "tsa_launch (events, snapshot, launch order, search, flag copy) %.1f | done event + bookkeeping %.1f\n", n, us[0] / n, (double)queries / n,
+            us[1] / n, us[2] / n, us[3] / n);
+    for (double& v : us) v = 0;
+    n = 0; queries = 0;
+  }
+};
+HostTrace g_trace;
+// (RNA_HOST_TRACE) a stage's cycle in GPU time: event A when the stage's stream reaches the new batch (it is idle: at enqueue),
+// C when the search and what follows it on the stream have ended; host clock: enqueue and "noticed free".  (With a third event
+// where the search's last wait ends -- inside tsa_launch, a temporary hook -- round 6 measured 4.46 ms from enqueue until the
+// search may start, 22.40 ms of search, 27.89 ms until the host has noticed: profiles/r06_host_trace.txt.)
+struct StageTrace {
+  hipEvent_t a[32] = {}, c[32] = {};
+  std::chrono::steady_clock::time_point t_enq[32];
+  bool armed[32] = {};
+  double gpu_ms = 0, host_busy_ms = 0;
+  long n = 0;
+};
+StageTrace g_stage;
+void stage_trace_dump() {
+  if (g_stage.n) fprintf(stderr, "[host trace] a stage's cycle, ms: from enqueue to the end of the search and what follows it on the stream %.2f (the search itself: roofline.avg_launch_ms) | "
+                         "host: enqueue -> noticed free %.2f (%ld cycles)\n", g_stage.gpu_ms / g_stage.n, g_stage.host_busy_ms / g_stage.n, g_stage.n);
+  g_stage.gpu_ms = g_stage.host_busy_ms = 0; g_stage.n = 0;
+}
+
 // allocation of the configuration ensure_config settled on; everything is released again on failure
 static int alloc_stages_impl(rna_engine* e) {
   AstarDevice& a = e->astar;
@@ -192,24 +234,48 @@ int launch_chunk(rna_engine* e, const rna_astar_query* q_dev, int n, int32_t* pa
   // is enqueued before the wait, so the search starts the moment a stage frees up -- enqueued blindly behind "the
   // oldest", as in round 2, a stage's stream sat idle 7 ms between two searches of 23 ms.
   int slot = 0;
+  g_trace.start();
   if (a.depth > 1) {
     static const bool nowait = getenv("RNA_ASTAR_NOWAIT") != nullptr;   // developer knob: the round-2 behaviour
+    // A stage known to be free is taken without asking anybody; otherwise the stages are asked in the order of their launches
+    // (they end roughly in that order), at most RNA_ASTAR_QUERIES_PER_LOOK (3) per look, and the first one found complete is
+    // taken.  (Round 6 measured this loop, RNA_HOST_TRACE=1: the host spends 1.38 ms of a 1.57 ms pass here -- not in the
+    // queries, which cost 5 us each, but because every stage IS taken: a stage's cycle is 4.5 ms from enqueue until its search
+    // may start (the pass's map-update chain, snapshot and launch order), 22.4 ms of search and 1 ms until the host has
+    // noticed; a completion flag written by the stream instead of the event changes nothing.)
+    static const int per_look = getenv("RNA_ASTAR_QUERIES_PER_LOOK") ? std::max(1, atoi(getenv("RNA_ASTAR_QUERIES_PER_LOOK"))) : 3;   // developer knob
     for (int spin = 0;; ++spin) {
       int best = -1, oldest = 0;
       for (int d = 0; d < a.depth; ++d) {
         if (a.stage_seq[d] < a.stage_seq[oldest]) oldest = d;
-        bool free_now = !a.busy[d];
-        if (!free_now) {
+        if (!a.busy[d] && (best < 0 || a.stage_seq[d] < a.stage_seq[best])) best = d;
+      }
+      if (best < 0) {
+        // the busy stages by age; every eighth look asks all of them (a batch with one very long search must not hide the others)
+        int order[AstarDevice::MAX_DEPTH], nb = 0;
+        for (int d = 0; d < a.depth; ++d) if (a.busy[d]) order[nb++] = d;
+        std::sort(order, order + nb, [&](int x, int y) { return a.stage_seq[x] < a.stage_seq[y]; });
+        const int ask = (spin & 7) == 7 ? nb : std::min(nb, per_look);
+        for (int k = 0; k < ask && best < 0; ++k) {
+          const int d = order[k];
+          g_trace.queries += 1;
           const hipError_t q = hipEventQuery(a.done[d]);
           if (q == hipSuccess) {
             int rc = RNA_OK;
-            if (stage_settled(e, d, &rc)) { a.busy[d] = false; free_now = true; }
+            if (stage_settled(e, d, &rc)) { a.busy[d] = false; best = d; }
+            if (g_trace.on && g_stage.armed[d] && best == d) {
+              float f = 0;
+              if (hipEventElapsedTime(&f, g_stage.a[d], g_stage.c[d]) == hipSuccess) {
+                g_stage.gpu_ms += f; g_stage.n += 1;
+                g_stage.host_busy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_stage.t_enq[d]).count();
+              }
+              g_stage.armed[d] = false;
+            }
             if (rc != RNA_OK) return rc;
           } else {
             (void)hipGetLastError();   // hipErrorNotReady is not an error
           }
         }
-        if (free_now && (best < 0 || a.stage_seq[d] < a.stage_seq[best])) best = d;
       }
       if (best >= 0) { slot = best; break; }
       if (nowait) { slot = oldest; break; }
@@ -220,6 +286,7 @@ int launch_chunk(rna_engine* e, const rna_astar_query* q_dev, int n, int32_t* pa
       if (spin >= 2 && wait_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(wait_us));
       else std::this_thread::yield();
     }
+    g_trace.lap(0);
     // the ring entry this launch writes: the batch that read it 2 x depth launches ago is over and settled
     const unsigned long long prev = a.launches + 1 >= (unsigned long long)a.ring_n ? a.launches + 1 - (unsigned long long)a.ring_n : 0;
     if (prev > 0)
@@ -231,6 +298,7 @@ int launch_chunk(rna_engine* e, const rna_astar_query* q_dev, int n, int32_t* pa
           a.busy[d] = false;
         }
   }
+  g_trace.lap(1);
   if (a.depth == 1 && a.retry_armed[0]) {   // one stream: the batch before this one has to be complete before its slots are reused
     RNA_HIP(e, hipStreamSynchronize(e->stream));
     int rc = RNA_OK;
@@ -239,10 +307,17 @@ int launch_chunk(rna_engine* e, const rna_astar_query* q_dev, int n, int32_t* pa
   }
   hipStream_t search_stream = a.depth > 1 ? a.side[slot] : e->stream;
   if (a.depth > 1 && a.busy[slot]) RNA_HIP(e, hipStreamWaitEvent(search_stream, a.done[slot], 0));   // (RNA_ASTAR_NOWAIT only; the same stream anyway)
+  if (g_trace.on && a.depth > 1) {
+    if (!g_stage.a[slot]) { (void)hipEventCreate(&g_stage.a[slot]); (void)hipEventCreate(&g_stage.c[slot]); }
+    (void)hipEventRecord(g_stage.a[slot], search_stream);
+    g_stage.t_enq[slot] = std::chrono::steady_clock::now();
+  }
   {
     int rc = tsa_launch(e, slot, e->stream, search_stream, a.depth > 1 ? a.ev_init : nullptr, q_dev, n, paths_dev, max_len, res_dev);
     if (rc != RNA_OK) return rc;
   }
+  if (g_trace.on && a.depth > 1) { (void)hipEventRecord(g_stage.c[slot], search_stream); g_stage.armed[slot] = true; }
+  g_trace.lap(2);
   if (a.depth > 1) {
     RNA_HIP(e, hipEventRecord(a.done[slot], search_stream));
     a.busy[slot] = true;
@@ -254,6 +329,8 @@ int launch_chunk(rna_engine* e, const rna_astar_query* q_dev, int n, int32_t* pa
   a.last_n = n;
   a.last_slot = slot;
   if (slot_out) *slot_out = slot;
+  g_trace.lap(3);
+  if (a.depth > 1) g_trace.n += 1;
   return RNA_OK;
 }
 
@@ -283,6 +360,8 @@ int astar_settle(rna_engine* e) {
 int astar_release(rna_engine* e) {
   AstarDevice& a = e->astar;
   (void)sync_all(e);
+  stage_trace_dump();
+  g_trace.dump();
 #ifdef RNA_TSA_STATS
   tsa_stats_dump();
 #endif
