@@ -174,8 +174,17 @@ __global__ void graph_astar_kernel(GraphK G, const double* __restrict__ start_ta
 // RRT
 // ------------------------------------------------------------------------------------------------
 constexpr int RRT_ITER = 2000;          // rrt_planner.cpp:6
+#ifndef RNA_RRT_WIDE
+#define RNA_RRT_WIDE 0   // 1: every wavefront carries TWO registers of look-ahead draws (124 instead of 62) and twelve wavefronts evaluate a
+                         // round's samples -- the lever rounds 4-5 named for config 4's share.  Built in round 6, exact (the three GPU RRT
+                         // tests: config 4's 512 queries bit for bit), and SLOWER: 57.5 ms against 41.5 (profiles/r06_rrt_wide_window.txt).
+                         // A round covers 10.8 samples instead of 8.7 (+25 %: the rounds that accept a sample waste the rest either way),
+                         // but it takes 10.0 us instead of 5.7: the sample bookkeeping over pairs of 62-bit limbs 0.78 -> 1.84 us on every
+                         // wavefront, and wave 0 waits 4.4 us instead of 1.4 for the slowest of twelve wavefronts that share the SIMDs of
+                         // one CU three deep.  With eight wavefronts and the wide window 53.6 ms, with sixteen 76.4.  Off.
+#endif
 #ifndef RNA_RRT_SPEC
-#define RNA_RRT_SPEC 8
+#define RNA_RRT_SPEC (RNA_RRT_WIDE ? 12 : 8)
 #endif
 constexpr int RRT_SPEC = RNA_RRT_SPEC;  // wavefronts per query = samples evaluated speculatively per round
 static_assert(RRT_SPEC >= 1 && RRT_SPEC <= 16, "one workgroup per query");   // (a round covers the samples whose draws lie inside the 62-draw window: at least 10 random ones, fewer wavefronts than samples just wait)
@@ -246,6 +255,70 @@ __device__ __forceinline__ void rng_refill(WaveRng& r, int lane) {  // keep >= 3
     rng_chain(r, r.chain >> 31);
   }
 }
+
+#if RNA_RRT_WIDE
+// ---- the same stream with a 124-draw window (round 6) ----
+// d0 holds draws 0..61 of the window (one per lane), d1 draws 62..123; `last` the newest block of 31.  Masks over the window are
+// pairs of 62-bit limbs: bit i < 62 of `lo` = draw i, bit i of `hi` = draw 62 + i (hi may carry two bits more: where the chain of
+// sample starts leaves the window).
+struct M2 { unsigned long long lo, hi; };
+constexpr unsigned long long W_LIVE = (1ull << 62) - 1ull;
+__device__ __forceinline__ M2 m2(unsigned long long lo, unsigned long long hi) { M2 r; r.lo = lo; r.hi = hi; return r; }
+__device__ __forceinline__ M2 m2_and(M2 a, M2 b) { return m2(a.lo & b.lo, a.hi & b.hi); }
+__device__ __forceinline__ M2 m2_andn(M2 a, M2 b) { return m2(a.lo & ~b.lo, a.hi & ~b.hi); }
+__device__ __forceinline__ M2 m2_or(M2 a, M2 b) { return m2(a.lo | b.lo, a.hi | b.hi); }
+__device__ __forceinline__ bool m2_any(M2 a) { return (a.lo | a.hi) != 0ull; }
+__device__ __forceinline__ bool m2_eq(M2 a, M2 b) { return a.lo == b.lo && a.hi == b.hi; }
+__device__ __forceinline__ int m2_pop(M2 a) { return __popcll(a.lo) + __popcll(a.hi); }
+__device__ __forceinline__ M2 m2_shl(M2 a, int k) {   // k = 1 or 3; the sources are inside the window (62-bit limbs)
+  return m2((a.lo << k) & W_LIVE, (a.hi << k) | (a.lo >> (62 - k)));
+}
+__device__ __forceinline__ M2 m2_shr31(M2 a) { return m2(((a.lo >> 31) | (a.hi << 31)) & W_LIVE, a.hi >> 31); }
+__device__ __forceinline__ M2 m2_below(int i) {   // bits of the draws before draw i (0 <= i <= 126)
+  return i <= 62 ? m2(i == 62 ? W_LIVE : (1ull << i) - 1ull, 0ull) : m2(W_LIVE, (1ull << (i - 62)) - 1ull);
+}
+__device__ __forceinline__ bool m2_bit(M2 a, int i) { return ((i < 62 ? a.lo >> i : a.hi >> (i - 62)) & 1ull) != 0ull; }
+__device__ __forceinline__ M2 m2_lowest(M2 a) { return a.lo ? m2(a.lo & (0ull - a.lo), 0ull) : m2(0ull, a.hi & (0ull - a.hi)); }
+__device__ __forceinline__ M2 m2_drop_lowest(M2 a) { return a.lo ? m2(a.lo & (a.lo - 1ull), a.hi) : m2(0ull, a.hi & (a.hi - 1ull)); }
+__device__ __forceinline__ int m2_first(M2 a) { return a.lo ? __ffsll((long long)a.lo) - 1 : 62 + __ffsll((long long)a.hi) - 1; }   // (a != 0)
+__device__ __forceinline__ int m2_last(M2 a) { return a.hi ? 62 + 63 - __clzll((long long)a.hi) : 63 - __clzll((long long)a.lo); }   // (a != 0)
+
+struct WaveRngW { unsigned d0, d1, last; int pos; M2 three, chain; };
+
+__device__ __forceinline__ void rngw_chain(WaveRngW& r, M2 from) {
+  r.three = m2(__ballot((int)(r.d0 >> 1) % 10 > 3) & W_LIVE, __ballot((int)(r.d1 >> 1) % 10 > 3) & W_LIVE);
+  M2 c = from, prev;
+  do {
+    prev = c;
+    const M2 src = m2(c.lo & W_LIVE, c.hi & W_LIVE);
+    c = m2_or(c, m2_or(m2_shl(m2_andn(src, r.three), 1), m2_shl(m2_and(src, r.three), 3)));
+  } while (!m2_eq(c, prev));
+  r.chain = c;
+}
+__device__ void rngw_seed(WaveRngW& r, unsigned seed, int lane) {
+  WaveRng n;
+  rng_seed(n, seed, lane);   // d = blocks 0 and 1, last = block 1
+  const unsigned y2 = rng_block(n.last, lane), y3 = rng_block(y2, lane);
+  const unsigned up = (unsigned)__shfl((int)y3, lane >= 31 ? lane - 31 : lane);
+  r.d0 = n.d;
+  r.d1 = lane < 31 ? y2 : up;
+  r.last = y3;
+  r.pos = 0;
+  rngw_chain(r, m2(1ull, 0ull));
+}
+__device__ __forceinline__ void rngw_refill(WaveRngW& r, int lane) {   // keep >= 93 unread draws behind pos
+  while (r.pos >= 31) {
+    const unsigned y = rng_block(r.last, lane);
+    const int from = lane < 31 ? lane + 31 : lane - 31;
+    const unsigned a_hi = (unsigned)__shfl((int)r.d0, from), b_lo = (unsigned)__shfl((int)r.d1, from), y_lo = (unsigned)__shfl((int)y, lane >= 31 ? lane - 31 : lane);
+    r.d0 = lane < 31 ? a_hi : b_lo;    // draws 31..61 of d0, then draws 0..30 of d1
+    r.d1 = lane < 31 ? b_lo : y_lo;    // draws 31..61 of d1, then the new block
+    r.last = y;
+    r.pos -= 31;
+    rngw_chain(r, m2_shr31(r.chain));
+  }
+}
+#endif
 
 // GlobalPlanner::ifBlocked (map_global_planner.h:39-54) through CircleIterator (CircleIterator.cpp:16-93):
 // wave-cooperative, returns the same value in every lane.
@@ -369,7 +442,7 @@ struct RrtSlot { double wx, wy; int near, blocked; };
 
 // 4 wavefronts per SIMD (<= 128 VGPRs): two 8-wavefront workgroups per CU, 512 queries resident on the chip
 #ifndef RNA_RRT_WAVES_PER_EU
-#define RNA_RRT_WAVES_PER_EU 4
+#define RNA_RRT_WAVES_PER_EU (RNA_RRT_WIDE ? 6 : 4)   // (wide: two 12-wavefront workgroups per CU need six wavefronts per SIMD, i.e. <= 80 VGPRs)
 #endif
 __global__ void __launch_bounds__(64 * RRT_SPEC) __attribute__((amdgpu_waves_per_eu(RNA_RRT_WAVES_PER_EU, RNA_RRT_WAVES_PER_EU)))
 rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __restrict__ queries, int n,
@@ -381,8 +454,13 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
   const int q = blockIdx.x;
   const rna_rrt_query qu = queries[q];
   int* tp = tree_parent + (size_t)q * RRT_ITER;
+#if RNA_RRT_WIDE
+  WaveRngW rs;
+  rngw_seed(rs, qu.seed, lane);
+#else
   WaveRng rs;
   rng_seed(rs, qu.seed, lane);
+#endif
 
   const double strideStep = 0.4;   // rrt_planner.h:23 ; targetTendency_ is int(0.5) == 0 (rrt_planner.h:24,32)
   const bool target_inside = position_within_map(g, qu.target[0], qu.target[1]);
@@ -413,12 +491,43 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
       if (samples >= qu.max_samples) { aborted = true; break; }
       const int valid = qu.max_samples - samples;
       RRT_T(t0);
+#if RNA_RRT_WIDE
+      rngw_refill(rs, lane);
+#else
       rng_refill(rs, lane);
+#endif
       // sample(), rrt_planner.cpp:61-68: one draw decides goal or random, a random sample takes two more.
       // A goal sample's outcome depends on the tree alone, and an unblocked one is accepted on the spot, so
       // once one has been found blocked every later goal sample is known blocked until the tree grows: those
       // take no wavefront.  The round therefore covers samples in draw order until it holds RRT_SPEC that need
       // evaluating (or the 62-draw window ends) -- on the bench maps 40 % of the samples are goal samples.
+#if RNA_RRT_WIDE
+      // (the same bookkeeping over the 124-draw window: masks are pairs of 62-bit limbs, see M2)
+      const int res0 = (int)(rs.d0 >> 1), res1 = (int)(rs.d1 >> 1);
+      const M2 three = rs.three;
+      const bool goal_known = goal_blocked_at == n_tree;
+      // sample starts from pos on whose draws lie inside the window (a random sample needs three draws: it starts at 121 at the latest)
+      M2 startmask = m2_and(m2_andn(m2(rs.chain.lo & W_LIVE, rs.chain.hi & W_LIVE), m2_below(rs.pos)), m2(W_LIVE, (W_LIVE & ~three.hi) | (three.hi & (W_LIVE >> 2))));
+      const M2 goals = m2_andn(startmask, three);
+      M2 slotmask = m2_and(startmask, three);
+      if (!goal_known) slotmask = m2_or(slotmask, m2_lowest(goals));
+      M2 over = slotmask;                          // samples past the RRT_SPEC-th one that needs a wavefront wait
+#pragma unroll
+      for (int k = 0; k < RRT_SPEC; ++k) over = m2_drop_lowest(over);
+      if (m2_any(over)) startmask = m2_and(startmask, m2_below(m2_first(over)));
+      if (m2_pop(startmask) > valid) {             // ... and so do samples past the budget
+        M2 m = startmask;
+        for (int k = 0; k < valid; ++k) m = m2_drop_lowest(m);
+        startmask = m2_and(startmask, m2_below(m2_first(m)));
+      }
+      slotmask = m2_and(slotmask, startmask);
+      const int goal_lane = (!goal_known && m2_any(m2_and(goals, startmask))) ? m2_first(goals) : -1;
+      const int nslot = m2_pop(slotmask);
+      const int last_start = m2_last(startmask);
+      const int p_end = last_start + (m2_bit(three, last_start) ? 3 : 1);
+#define RRT_IS_RANDOM(i) m2_bit(three, (i))
+#define RRT_DRAW(i) ((i) < 62 ? __builtin_amdgcn_readlane(res0, (i)) : __builtin_amdgcn_readlane(res1, (i) - 62))
+#else
       const int res = (int)(rs.d >> 1);
       const unsigned long long three = rs.three;
       const bool goal_known = goal_blocked_at == n_tree;
@@ -440,14 +549,23 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
       const int nslot = __popcll(slotmask);
       const int last_start = 63 - __clzll((long long)startmask);
       const int p_end = last_start + (((three >> last_start) & 1ull) ? 3 : 1);
+#define RRT_IS_RANDOM(i) (((three >> (i)) & 1ull) != 0ull)
+#define RRT_DRAW(i) __builtin_amdgcn_readlane(res, (i))
+#endif
       RrtSlot* const out = slot[round & 1u];
       if (wave < nslot) {
+#if RNA_RRT_WIDE
+        M2 m = slotmask;
+        for (int k = 0; k < wave; ++k) m = m2_drop_lowest(m);
+        const int mine = __builtin_amdgcn_readfirstlane(m2_first(m));
+#else
         unsigned long long m = slotmask;
         for (int k = 0; k < wave; ++k) m &= m - 1;
         const int mine = __ffsll((long long)m) - 1;
+#endif
         double rx, ry;
-        if ((three >> mine) & 1ull) {
-          const int r1 = __builtin_amdgcn_readlane(res, mine + 1), r2 = __builtin_amdgcn_readlane(res, mine + 2);
+        if (RRT_IS_RANDOM(mine)) {
+          const int r1 = RRT_DRAW(mine + 1), r2 = RRT_DRAW(mine + 2);
           const int ridx[2] = {r1 % g.size[0], r2 % g.size[1]};
           double pp[2];
           position_from_index(g, ridx, pp);
@@ -537,7 +655,7 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
         RRT_T(t4);
         RRT_ACC(3, t3, t4);
         if (lane == 0) out[wave] = RrtSlot{wx, wy, near, blocked ? 1 : 0};
-#ifdef RNA_RRT_DEBUG_SAMPLE
+#if defined(RNA_RRT_DEBUG_SAMPLE) && !RNA_RRT_WIDE
         {
           const int sno = samples + __popcll(startmask & ((2ull << mine) - 1ull));
           if (lane == 0 && sno == RNA_RRT_DEBUG_SAMPLE)
@@ -553,6 +671,31 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
       ++round;
       // outcome per sample, one sample start per lane: a random sample reads its slot, a goal sample the slot of
       // the round's evaluated goal sample (or is known blocked); the first open one in draw order is accepted
+#if RNA_RRT_WIDE
+      // outcome per sample: lane l speaks for the starts at draw l and at draw 62 + l
+      const int goal_slot = goal_lane >= 0 ? m2_pop(m2_and(slotmask, m2_below(goal_lane))) : 0;
+      bool open_a = false, open_b = false;
+      {
+        const int ia = lane, ib = 62 + lane;
+        const bool st_a = lane < 62 && m2_bit(startmask, ia), st_b = lane < 62 && m2_bit(startmask, ib);
+        const bool rn_a = m2_bit(three, ia), rn_b = lane < 62 && m2_bit(three, ib);
+        if (st_a && (rn_a || goal_lane >= 0)) open_a = out[rn_a ? m2_pop(m2_and(slotmask, m2_below(ia))) : goal_slot].blocked == 0;
+        if (st_b && (rn_b || goal_lane >= 0)) open_b = out[rn_b ? m2_pop(m2_and(slotmask, m2_below(ib))) : goal_slot].blocked == 0;
+      }
+      const M2 open = m2(__ballot(open_a), __ballot(open_b));
+      if (m2_any(open)) {
+        const int wl = m2_first(open);
+        const bool wr = m2_bit(three, wl);
+        samples += m2_pop(m2_and(startmask, m2_below(wl + 1)));
+        rs.pos = wl + (wr ? 3 : 1);
+        const RrtSlot w = out[wr ? m2_pop(m2_and(slotmask, m2_below(wl))) : goal_slot];
+        nx = w.wx; ny = w.wy; nparent = w.near;
+        break;
+      }
+      samples += m2_pop(startmask);
+      rs.pos = p_end;
+      if (goal_lane >= 0) goal_blocked_at = n_tree;
+#else
       const unsigned long long below = (1ull << lane) - 1ull;
       const int goal_slot = goal_lane >= 0 ? __popcll(slotmask & ((1ull << goal_lane) - 1ull)) : 0;
       const bool is_start = (startmask >> lane) & 1ull, is_random = (three >> lane) & 1ull;
@@ -574,6 +717,9 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
       samples += __popcll(startmask);
       rs.pos = p_end;
       if (goal_lane >= 0) goal_blocked_at = n_tree;
+#endif
+#undef RRT_IS_RANDOM
+#undef RRT_DRAW
     }
   }
 
