@@ -57,21 +57,107 @@ RNA_HD int k_safety_dist(float sd0, float sd1, int speed) {  // vfh.cpp:194-205
   return val < 0 ? 0 : val;
 }
 RNA_HD float k_delta_angle(float a1, float a2) {  // vfh.cpp:673-686
-  float diff = a2 - a1;
-  if (diff > 180) diff -= 360;
-  else if (diff < -180) diff += 360;
-  return diff;
+  const float diff = a2 - a1;
+  // (both corrections are computed and one value is picked: as an if / else-if the device compiler keeps two nested
+  // branches with their exec-mask bookkeeping at every one of the kernel's twenty call sites)
+  const float down = diff - 360, up = diff + 360;
+  return diff > 180 ? down : (diff < -180 ? up : diff);
 }
 // glibc 2.35 hypotf() is (float)sqrt((double)x*x + (double)y*y); restated so host tables and the
 // device agree bit for bit (checked against libm in tests/test_host_tables.py)
 RNA_HD float k_hypotf(float x, float y) { return (float)sqrt((double)x * (double)x + (double)y * (double)y); }
 
 // angles::normalize_angle_positive (ROS `angles` package)
+// fmod is exact, and for y <= |x| < 2y its value is |x| - y with the sign of x, itself exact (Sterbenz): with |a| < 4 pi --
+// any yaw within two turns -- both fmod calls are a compare and a subtraction, and the library's loop is the rare path.
+__device__ __forceinline__ double fmod_two_pi(double x) {
+  const double y = 2.0 * M_PI, ax = fabs(x);
+  if (ax < y) return x;
+  if (ax < 2.0 * y) return copysign(ax - y, x);
+  return fmod(x, y);
+}
 __device__ __forceinline__ double normalize_angle_positive(double a) {
-  return fmod(fmod(a, 2.0 * M_PI) + 2.0 * M_PI, 2.0 * M_PI);
+  return fmod_two_pi(fmod_two_pi(a) + 2.0 * M_PI);
 }
 
-__global__ void __launch_bounds__(VFH_THREADS)
+// wrap_index (gridmath.hpp) for the values the kernel meets -- an index of the map plus or minus the buffer's start, in
+// [-size, 2 size) -- without its two integer divisions; anything else takes the original.
+__device__ __forceinline__ int wrap_near(int v, int size) {
+  const int w = v < 0 ? v + size : (v >= size ? v - size : v);
+  return (unsigned)w < (unsigned)size ? w : wrap_index(v, size);
+}
+
+// ONE axis of submap_information (gridmath.hpp: getSubmapInformation, gmc/src/GridMapMath.cpp:246-296, followed by
+// GridMap::setGeometry(SubmapGeometry), gmc/src/GridMap.cpp:51-75), operation by operation in the same order.  What the
+// kernel needs of it: does the submap exist, the unwrapped index of its top-left cell, its size, and the position of that
+// cell's centre (`off`: pos + (len/2 - res/2) of the SUBMAP, the origin of GridMapIterator's positions).
+// setGeometry's size = round(len / res) with len = sz * res is sz itself: RN(RN(sz res) / res) = sz (1 + d1)(1 + d2),
+// |d| <= 2^-53, is within 2^-51 sz of sz, less than 1/2 for any size a map can have, so the division and the round are
+// not evaluated; its len = size * res is then the same product again.
+struct SubmapAxis { int ok, tl_u, size; double off; };
+__device__ __forceinline__ SubmapAxis submap_axis(const Geom& g, int a, double p, double req_len) {
+  SubmapAxis o;
+  o.ok = 0; o.tl_u = 0; o.size = 0; o.off = 0.0;
+  const double len = g.len[a], pos = g.pos[a], res = g.res;
+  const int size = g.size[a], start = g.start[a];
+  const bool unmoved = g.start[0] == 0 && g.start[1] == 0;
+  auto limit = [&](double x) {   // limit_position_to_range
+    const double vto = 0.5 * len;
+    double shifted = (x - pos) + vto;
+    double eps = 10.0 * DBL_EPSILON;
+    if (fabs(x) > 1.0) eps *= fabs(x);
+    if (shifted <= 0) shifted = eps;
+    else if (shifted >= len) shifted = len - eps;
+    return (shifted + pos) - vto;
+  };
+  auto unwrapped_index_of = [&](double x, int& u_out) -> bool {   // index_from_position, then unwrap_index of its result
+    const double t = -((x - pos) - 0.5 * len);
+    if (!(t >= 0.0 && t < len)) return false;
+    const int u = -(int)(((x - 0.5 * len) - pos) / res);
+    if (unmoved) {
+      if ((unsigned)u >= (unsigned)size) return false;
+      u_out = u;
+    } else {
+      u_out = wrap_near(wrap_near(u + start, size) - start, size);
+    }
+    return true;
+  };
+  int tl_u, br_u;
+  if (!unwrapped_index_of(limit(p - (-0.5 * req_len)), tl_u)) return o;
+  if (!unwrapped_index_of(limit(p + (-0.5 * req_len)), br_u)) return o;
+  double corner = (pos + (0.5 * len - 0.5 * res)) + res * (double)(-tl_u);   // position_from_index(top_left)
+  corner = corner - (-(0.5 * res));
+  const int sz = br_u - tl_u + 1;
+  const double len_s = (double)sz * res;
+  const double pos_s = corner - 0.5 * len_s;
+  const double t = -((p - pos_s) - 0.5 * len_s);   // the requested position has to lie inside the submap
+  if (!(t >= 0.0 && t < len_s)) return o;
+  o.ok = 1; o.tl_u = tl_u; o.size = sz;
+  o.off = pos_s + (0.5 * len_s - 0.5 * res);
+  return o;
+}
+
+// Wavefronts per SIMD the register allocation aims at: seven (72 registers, nothing spilled; left alone the compiler takes 80 =
+// six).  At 16 384 poses the kernel is bound by instruction issue and the seventh wavefront fills the gaps of the others' waits:
+// 96.2 -> 93.0 us, and nothing changes below 4 096 poses (profiles/r06_vfh_rework_ab.txt; eight spill and lose it again).
+#ifndef RNA_VFH_WAVES
+#define RNA_VFH_WAVES 7
+#endif
+#define VFH_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RNA_VFH_WAVES, RNA_VFH_WAVES)))
+#ifdef RNA_VFH_SKIPS
+// developer build (scripts/pmc_vfh_sq.sh): phases switched off by RNA_VFH_SKIP's bits, to read the instruction counters of the
+// rest.  1 the obstacle cells' trigonometry, 2 the window's cell loads, 4 the cell magnitudes, 8 the sector sums, 16 the
+// masked histogram's cell walk, 32 Select_Direction.  Results are wrong by design.
+__device__ int d_vfh_skip;
+#define VFH_SKIP(bit) (__builtin_amdgcn_readfirstlane(d_vfh_skip) & (bit))
+// RNA_VFH_EXIT=n: every thread leaves at the n-th mark (the counters of the kernel's prefix, on live data)
+__device__ int d_vfh_exit;
+#define VFH_EXIT(n) if (__builtin_amdgcn_readfirstlane(d_vfh_exit) == (n)) return
+#else
+#define VFH_SKIP(bit) 0
+#define VFH_EXIT(n)
+#endif
+__global__ void __launch_bounds__(VFH_THREADS) VFH_WAVES_ATTR
 vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose* __restrict__ poses,
                 const double* __restrict__ ext_ranges, rna_vfh_out* __restrict__ out,
                 float* __restrict__ origin_out, float* __restrict__ hist_out) {
@@ -85,8 +171,10 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
   unsigned* const nz = reinterpret_cast<unsigned*>(vfh_dyn + ((K.NQ + 31) & ~31));
   __shared__ float s_hist[MAX_H];
   __shared__ unsigned s_phi_right, s_phi_left;
-  __shared__ int s_emergency, s_nocc;
-  __shared__ int occ[VFH_OCC_CAP];   // submap cells that hold an obstacle
+  __shared__ int s_emergency, s_nocc, s_cant;
+  __shared__ int occ[VFH_OCC_CAP];   // submap cells that hold an obstacle: (j << 16) | i
+  __shared__ int s_ax_ok[2], s_ax_tl[2], s_ax_size[2];   // the submap's geometry, one axis from each wavefront
+  __shared__ double s_ax_off[2];
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -107,8 +195,8 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
     st_picked = K.picked[b];
     st_last_picked = K.last_picked[b];
     st_max_speed_picked = K.max_speed_picked[b];
-    st_blocked_radius = K.blocked_radius[b];
   }
+  st_blocked_radius = K.blocked_radius[b];   // (both: wavefront 1 answers Cant_Turn_To_Goal)
   // (round 5: every load whose address is known here goes out here -- the kernel is a chain of phases, each of which used to
   // start with a trip to L2 of its own: the robot's last speed before the cell magnitudes, its last binary histogram inside
   // the histogram step)
@@ -122,24 +210,29 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
                         : (unsigned long long)__double_as_longlong(5000.0);
   for (int i = tid; i < K.NW; i += VFH_THREADS) nz[i] = 0;
   if (tid == 0) { s_phi_right = 0u; s_phi_left = __float_as_uint(180.0f); s_emergency = 0; s_nocc = 0; }
+  VFH_EXIT(1);   // loads of the state, ranges preset
+  // The 1.5 m submap's geometry is the same for all 128 threads and all f64 (six divisions when both axes are done by
+  // everyone: 312 of the kernel's 1 608 vector instructions per wavefront, profiles/r06_vfh_phase_counters.txt).  The axes
+  // share nothing but the verdict: wavefront 0 takes x, wavefront 1 takes y, and they meet at the barrier the preset needs.
+  if (!ext_ranges) {
+    const int a = wave0 ? 0 : 1;
+    const SubmapAxis ax = submap_axis(g, a, a == 0 ? pose.x : pose.y, 1.5);
+    if ((tid & 63) == 0) { s_ax_ok[a] = ax.ok; s_ax_tl[a] = ax.tl_u; s_ax_size[a] = ax.size; s_ax_off[a] = ax.off; }
+  }
   __syncthreads();
 
+  VFH_EXIT(2);   // + the submap's geometry
   if (!ext_ranges) {
-    const double rp[2] = {pose.x, pose.y};
-    const double rl[2] = {1.5, 1.5};
-    SubmapInfo sm;
-    if (submap_information(g, rp, rl, sm)) {  // getSubMap failure leaves every range at 5000
-      int tl_u[2];
-      unwrap_index(g, sm.top_left, tl_u);
-      const int sr = sm.size[0], sc = sm.size[1];
-      const double offx = sm.pos[0] + (0.5 * sm.len[0] - 0.5 * g.res);
-      const double offy = sm.pos[1] + (0.5 * sm.len[1] - 0.5 * g.res);
-      // One obstacle cell costs an f64 atan2, two fmod and a sqrt (~2 us), a free one a load and two compares, and 2 % of
+    if (s_ax_ok[0] && s_ax_ok[1]) {  // getSubMap failure leaves every range at 5000
+      const int tl_u[2] = {s_ax_tl[0], s_ax_tl[1]};
+      const int sr = s_ax_size[0], sc = s_ax_size[1];
+      const double offx = s_ax_off[0], offy = s_ax_off[1];
+      // One obstacle cell costs an f64 atan2, a division and a sqrt (~2 us), a free one a load and two compares, and 2 % of
       // the cells are obstacles: they are collected first and then shared out one per lane, so the wavefronts run the
       // trigonometry once instead of once per loop iteration that happens to hold an obstacle (6-8 us -> 3-4 us).
       // atomicMin makes the result independent of the order.
-      auto obstacle = [&](int lin) {
-        const int i = lin % sr, j = lin / sr;  // GridMapIterator order; lanes run along Index(0)
+      auto obstacle = [&](int i, int j) {   // cell (i, j) of the submap: GridMapIterator's Index(0), Index(1)
+        if (VFH_SKIP(1)) return;
         const double px = offx + g.res * (double)(-i);
         const double py = offy + g.res * (double)(-j);
         const double angle = atan2(py - pose.y, px - pose.x);
@@ -152,41 +245,72 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
         atomicMin(&rng[fl * 2], bits);
         atomicMin(&rng[ce * 2], bits);
       };
-      // eight cells per thread and trip, all eight reads issued before the first is looked at: the 31 x 31 window is ONE trip
-      // to L2 instead of eight one after the other (the loop's `continue`s kept the compiler from batching them: 5 of the
-      // phase's 6-8 us)
-      const int ncell_sm = sr * sc;
-      for (int base = 0; base < ncell_sm; base += 8 * VFH_THREADS) {
-        float val[8];
+      // getBufferIndexFromIndex (gridmath.hpp buffer_index), then the matrix.  A cell of the submap has an unwrapped index in
+      // [0, size) and the buffer's start lies in [0, size) (launch_step checks it): wrap_index of their sum is one compare,
+      // and on a map that never moved (start 0) the same code never takes it -- one path, no divisions, no branches.
+      const int base0 = tl_u[0] + g.start[0], base1 = tl_u[1] + g.start[1];
+      auto cell_address = [&](int i, int j) -> const float* {
+        int b0 = base0 + i, b1 = base1 + j;
+        b0 -= b0 >= g.size[0] ? g.size[0] : 0;
+        b1 -= b1 >= g.size[1] ? g.size[1] : 0;
+        return master + ((size_t)b1 * g.size[0] + (size_t)b0);
+      };
+      // Eight cells per thread and trip, all eight reads issued before the first is looked at: the 31 x 31 window is ONE trip
+      // to L2 (round 5).  Round 6: a thread keeps its column and steps through the rows -- lanes run along Index(0), a row of
+      // the window is one coalesced read, and no cell's (i, j) needs a division (lin % sr, lin / sr cost 15 instructions a
+      // cell: with the addressing 357 of the 1 608).  A thread outside the window reads the window's last row / column
+      // and drops the value: eight loads without a branch between them.  The order of the cells is free: atomicMin.
+      const bool listed = sr <= VFH_THREADS && sc < 32768 && sr > 0 && sc > 0;   // (not: a resolution below 1.2 cm, rows longer than the workgroup)
+      if (listed) {
+        const int cwl = sr <= 32 ? 5 : sr <= 64 ? 6 : 7;       // columns of the thread grid: the power of two that holds a row
+        const int i = tid & ((1 << cwl) - 1), j0 = tid >> cwl, rpp = VFH_THREADS >> cwl;
+        const int ic = i < sr ? i : sr - 1;
+        for (int jb = 0; jb < sc && !VFH_SKIP(2); jb += 8 * rpp) {
+          float val[8];
 #pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8) {
-          const int lin = base + k8 * VFH_THREADS + tid;
-          val[k8] = 0.0f;
-          if (lin < ncell_sm) {
-            const int i = lin % sr, j = lin / sr;
-            const int u[2] = {tl_u[0] + i, tl_u[1] + j};
-            int bi[2];
-            buffer_index(g, u, bi);
-            val[k8] = master[(size_t)bi[1] * g.size[0] + bi[0]];
+          for (int k8 = 0; k8 < 8; ++k8) {
+            const int j = jb + k8 * rpp + j0;
+            val[k8] = *cell_address(ic, j < sc ? j : sc - 1);
           }
-        }
+          // the thread's obstacle cells of this trip as a mask, ONE reservation in the list for all of them (most threads
+          // have none: 2 % of the cells are obstacles)
+          unsigned found = 0u;
 #pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8) {
-          const int lin = base + k8 * VFH_THREADS + tid;
-          const float value = val[k8];
-          if (lin >= ncell_sm || value != value || value <= 3) continue;
-          const int k = atomicAdd(&s_nocc, 1);
-          if (k < VFH_OCC_CAP) occ[k] = lin;
-          else obstacle(lin);   // a submap with more obstacle cells than the list holds: the rest in place
+          for (int k8 = 0; k8 < 8; ++k8)   // (NaN compares false, as the reference's `value != value ||` makes it)
+            found |= (val[k8] > 3 && jb + k8 * rpp + j0 < sc ? 1u : 0u) << k8;
+          if (i < sr && found) {
+            int k = atomicAdd(&s_nocc, __popc(found));
+            while (found) {
+              const int k8 = __ffs(found) - 1;
+              found &= found - 1;
+              if (k < VFH_OCC_CAP) occ[k] = ((jb + k8 * rpp + j0) << 16) | i;
+              ++k;
+            }
+          }
         }
       }
       __syncthreads();
-      const int nocc = s_nocc < VFH_OCC_CAP ? s_nocc : VFH_OCC_CAP;
-      for (int k = tid; k < nocc; k += VFH_THREADS) obstacle(occ[k]);
+      VFH_EXIT(3);   // + the window's cells
+      // the listed obstacle cells, one per lane; a window the list does not hold (more than 1 024 obstacle cells, or not
+      // listed at all) is walked cell by cell instead -- a cell met twice changes nothing (atomicMin)
+      const bool use_list = listed && s_nocc <= VFH_OCC_CAP;
+      const int n_todo = use_list ? s_nocc : sr * sc;
+      for (int k = tid; k < n_todo; k += VFH_THREADS) {
+        int i, j;
+        if (use_list) {
+          i = occ[k] & 0xffff; j = occ[k] >> 16;
+        } else {
+          i = k % sr; j = k / sr;
+          const float value = *cell_address(i, j);
+          if (value != value || value <= 3) continue;
+        }
+        obstacle(i, j);
+      }
     }
   }
   __syncthreads();
   VFH_STAMP();
+  VFH_EXIT(4);   // + the obstacle cells' ranges
 
   // ---------------- Update_VFH prologue (vfh.cpp:490-515) ----------------
   const float desired_angle = pose.goal_direction;
@@ -199,7 +323,7 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
 
   // ---------------- Calculate_Cells_Mag (vfh.cpp:986-1049) ----------------
   const float r_safe = K.robot_radius + (float)k_safety_dist(K.sd0, K.sd1, speed);
-  for (int q0 = 0; q0 < K.NQ; q0 += 4 * VFH_THREADS) {   // (four cells per thread and trip, the table reads first)
+  for (int q0 = 0; q0 < K.NQ && !VFH_SKIP(4); q0 += 4 * VFH_THREADS) {   // (four cells per thread and trip, the table reads first)
     float cd4[4], bm4[4];
     int ri4[4];
 #pragma unroll
@@ -228,6 +352,7 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
   }
   __syncthreads();
   VFH_STAMP();
+  VFH_EXIT(5);   // + cell magnitudes
   const bool emergency = s_emergency != 0;
 
   float* origin = K.origin + (size_t)b * K.H;
@@ -244,7 +369,7 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
     if (tid < K.H) {
       const unsigned* mb = K.memb + ((size_t)speed_index * K.H + tid) * K.NW;
       float sum = 0.0f;
-      for (int w0 = 0; w0 < K.NW; w0 += 8) {   // (the sector's membership words eight at a time: one trip to L2 per eight)
+      for (int w0 = 0; w0 < K.NW && !VFH_SKIP(8); w0 += 8) {   // (the sector's membership words eight at a time: one trip to L2 per eight)
         unsigned mbw[8];
 #pragma unroll
         for (int k8 = 0; k8 < 8; ++k8) mbw[k8] = w0 + k8 < K.NW ? mb[w0 + k8] : 0u;
@@ -260,6 +385,7 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
         }
       }
       origin[tid] = sum;
+      VFH_EXIT(6);   // + sector sums (leaves inside a divergent region: wave 1's upper lanes go on to the next mark)
       // ---------------- Build_Binary_Polar_Histogram (vfh.cpp:1102-1121, 214-231) ----------------
       const float hi = (float)(K.bh0 - (speed * (K.bh0 - K.bh1) / 1000.0));
       const float lo = (float)(K.bl0 - (speed * (K.bl0 - K.bl1) / 1000.0));
@@ -279,14 +405,17 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
     {
       const unsigned* inr = K.in_circle + ((size_t)tspeed * 2 + 0) * K.NW;
       const unsigned* inl = K.in_circle + ((size_t)tspeed * 2 + 1) * K.NW;
-      for (int q = tid; q < K.NQF; q += VFH_THREADS) {
-        if (mag[q] == 0.0f) continue;
+      for (int q = tid; q < K.NQF && !VFH_SKIP(16); q += VFH_THREADS) {
+        // (the cell's direction and its two circle words are read whether or not the cell is occupied: three loads that
+        // leave together, instead of one trip to L2 behind each test)
         const float dir = K.cell_dir[q];
+        const unsigned in_r = inr[q >> 5], in_l = inl[q >> 5];
+        if (mag[q] == 0.0f) continue;
         const unsigned bit = 1u << (q & 31);
         if (k_delta_angle(dir, 90.0f) > 0) {
-          if ((inr[q >> 5] & bit) && dir >= 0.0f && dir < 90.0f) atomicMax(&s_phi_right, __float_as_uint(dir));
+          if ((in_r & bit) && dir >= 0.0f && dir < 90.0f) atomicMax(&s_phi_right, __float_as_uint(dir));
         } else {
-          if ((inl[q >> 5] & bit) && dir <= 180.0f) atomicMin(&s_phi_left, __float_as_uint(dir));
+          if ((in_l & bit) && dir <= 180.0f) atomicMin(&s_phi_left, __float_as_uint(dir));
         }
       }
     }
@@ -295,18 +424,18 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
       const float phi_right = __uint_as_float(s_phi_right), phi_left = __uint_as_float(s_phi_left);
       const float angle = (float)(tid * K.sector_angle);
       const float h = s_hist[tid];
-      float nh;
-      if ((h == 0) && (((k_delta_angle(angle, phi_right) <= 0) && (k_delta_angle(angle, 90.0f) >= 0)) ||
-                       ((k_delta_angle(angle, phi_left) >= 0) && (k_delta_angle(angle, 90.0f) <= 0))))
-        nh = 0.0f;
-      else
-        nh = 1.0f;
+      // (the reference's short-circuit expression, every term evaluated: none has a side effect)
+      const float d_right = k_delta_angle(angle, phi_right), d_left = k_delta_angle(angle, phi_left);
+      const float d_ahead = k_delta_angle(angle, 90.0f);
+      const bool open = (h == 0) & (((d_right <= 0) & (d_ahead >= 0)) | ((d_left >= 0) & (d_ahead <= 0)));
+      const float nh = open ? 0.0f : 1.0f;
       s_hist[tid] = nh;
       hist[tid] = nh;
     }
   }
   __syncthreads();
   VFH_STAMP();
+  VFH_EXIT(7);   // + binary and masked histograms
 
   // ---------------- serial tail on one lane ----------------
   // the masked histogram as two 64-bit lane masks (H <= 128), so the valley search below tests bits in registers
@@ -316,11 +445,26 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
     hbits_lo = __ballot(tid < K.H && s_hist[tid] == 1);
     hbits_hi = __ballot(tid + 64 < K.H && s_hist[(tid + 64) & (MAX_H - 1)] == 1);
   }
+  float picked = st_picked;
+  float last_picked = st_last_picked;
+  int max_speed_for_picked = st_max_speed_picked;
+  const float blocked_radius = emergency ? st_blocked_radius : bcr_tspeed;   // (an emergency stop leaves the last step's)
+  if (!wave0) {
+    // Cant_Turn_To_Goal (vfh.cpp:612-654) needs the goal and the blocked circle, not the picked direction: the second
+    // wavefront, which has nothing else to do in the tail, answers it while the first selects the direction (an f64 cos
+    // and sin and two hypotf: 0.55 us of the 2.5 us tail, and 178 instructions off the first wavefront's path).
+    const float goal_x = (float)(dist_to_goal * cos(desired_angle * M_PI / 180));
+    const float goal_y = (float)(dist_to_goal * sin(desired_angle * M_PI / 180));
+    bool cant = false;
+    float dc = k_hypotf(goal_x - blocked_radius, goal_y);
+    if (dc + goal_tol < blocked_radius) cant = true;
+    if (!cant) {
+      dc = k_hypotf(-goal_x - blocked_radius, goal_y);
+      if (dc + goal_tol < blocked_radius) cant = true;
+    }
+    if ((tid & 63) == 0) s_cant = cant ? 1 : 0;
+  }
   if (wave0) {   // every lane of the first wavefront computes the same values; lane 0 stores them
-    float picked = st_picked;
-    float last_picked = st_last_picked;
-    int max_speed_for_picked = st_max_speed_picked;
-    float blocked_radius = st_blocked_radius;
     const int H = K.H, SA = K.sector_angle;
     auto hist_at = [&](int i) -> float { return ((i < 64 ? hbits_lo >> i : hbits_hi >> (i - 64)) & 1ull) ? 1.0f : 0.0f; };
 
@@ -329,7 +473,6 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
       max_speed_for_picked = 0;
       last_picked = picked;
     } else {
-      blocked_radius = bcr_tspeed;
       // ---------------- Select_Direction (vfh.cpp:755-870) ----------------
       // The reference walks the ring of sectors once from the first blocked sector of the front half, opens a valley
       // at every 1 -> 0 step, closes it at the next 0 -> 1 step, and weighs the valley's candidate angles as they come;
@@ -343,7 +486,7 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
       int ncand = 0;
       float best_angle = 90.0f;
       int best_speed = max_speed_for_picked;
-      if (front == 0ull) {
+      if (front == 0ull || VFH_SKIP(32)) {
         picked = desired_angle;
         last_picked = picked;
         max_speed_for_picked = K.current_max_speed;
@@ -445,24 +588,17 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
     }
 
     VFH_STAMP();   // (developer build: lane 0's stamps 4.. subdivide the tail)
+    VFH_EXIT(8);   // + Select_Direction
+  }
+  __syncthreads();
+  if (wave0) {
     // ---------------- speed (vfh.cpp:571-599) ----------------
     int speed_incr;
     if ((pose.dt > 0.3) || (pose.dt < 0)) speed_incr = 10;
     else speed_incr = (int)(K.max_accel * pose.dt);
-
-    {  // Cant_Turn_To_Goal (vfh.cpp:612-654)
-      const float goal_x = (float)(dist_to_goal * cos(desired_angle * M_PI / 180));
-      const float goal_y = (float)(dist_to_goal * sin(desired_angle * M_PI / 180));
-      bool cant = false;
-      float dc = k_hypotf(goal_x - blocked_radius, goal_y);
-      if (dc + goal_tol < blocked_radius) cant = true;
-      if (!cant) {
-        dc = k_hypotf(-goal_x - blocked_radius, goal_y);
-        if (dc + goal_tol < blocked_radius) cant = true;
-      }
-      if (cant) speed_incr = -speed_incr;
-    }
+    if (s_cant) speed_incr = -speed_incr;
     VFH_STAMP();
+    VFH_EXIT(9);   // + Cant_Turn_To_Goal
     int chosen_speed = last_speed + speed_incr;
     if (max_speed_for_picked < chosen_speed) chosen_speed = max_speed_for_picked;
 
@@ -695,9 +831,16 @@ int launch_step(rna_engine* e, const rna_pose* poses_dev, const double* ranges_d
     st = e->vfh_stream;
   }
   {
+    // (the kernel wraps a window cell's buffer index with one compare: the start index rna_move leaves is in [0, size))
+    for (int a = 0; a < 2; ++a)
+      if (e->geom.start[a] < 0 || e->geom.start[a] >= e->geom.size[a]) return fail(e, RNA_EINVAL, "vfh: buffer start index outside the map");
     KernelTimer kt(e, RNA_K_VFH_STEP, st);
     const VfhK K = make_k(e);
     const size_t lds = (size_t)(((K.NQ + 31) & ~31) + K.NW) * sizeof(float);   // mag | nz
+#ifdef RNA_VFH_SKIPS
+    { const char* sk = getenv("RNA_VFH_SKIP"); const int v = sk ? atoi(sk) : 0; RNA_HIP(e, hipMemcpyToSymbol(HIP_SYMBOL(d_vfh_skip), &v, sizeof v)); }
+    { const char* sk = getenv("RNA_VFH_EXIT"); const int v = sk ? atoi(sk) : 0; RNA_HIP(e, hipMemcpyToSymbol(HIP_SYMBOL(d_vfh_exit), &v, sizeof v)); }
+#endif
     hipLaunchKernelGGL(vfh_step_kernel, dim3(n), dim3(VFH_THREADS), lds, st, K, e->geom,
                        e->layer[RNA_LAYER_MASTER], poses_dev, ranges_dev, out_dev, origin_dev, hist_dev);
     RNA_HIP(e, hipGetLastError());

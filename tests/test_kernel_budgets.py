@@ -15,13 +15,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ros_navigation_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
-TILE_FLAGS = ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]   # FLAGS_astar_tile of ros_navigation_amd/csrc/Makefile
+TILE_FLAGS = ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]   # FLAGS_astar_tile and FLAGS_vfh of ros_navigation_amd/csrc/Makefile
 LDS_PER_CU = 160 * 1024
 VGPRS_PER_SIMD = 512
 
 
 def resources(src):
-    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", *(TILE_FLAGS if src == "astar_tile.hip" else []), "-c",
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", *(TILE_FLAGS if src in ("astar_tile.hip", "vfh.hip") else []), "-c",
                           os.path.join(CSRC, src), "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
