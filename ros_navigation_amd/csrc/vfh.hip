@@ -137,11 +137,11 @@ __device__ __forceinline__ SubmapAxis submap_axis(const Geom& g, int a, double p
   return o;
 }
 
-// Wavefronts per SIMD the register allocation aims at: seven (72 registers, nothing spilled; left alone the compiler takes 80 =
-// six).  At 16 384 poses the kernel is bound by instruction issue and the seventh wavefront fills the gaps of the others' waits:
-// 96.2 -> 93.0 us, and nothing changes below 4 096 poses (profiles/r06_vfh_rework_ab.txt; eight spill and lose it again).
+// Wavefronts per SIMD the register allocation aims at: six (80 registers, nothing spilled).  At 16 384 poses the kernel is bound
+// by instruction issue and a sixth wavefront fills the gaps of the others' waits (five: +5 %); seven (72 registers) spill three
+// and cost 1.5 us at 1 024 poses (profiles/r06_vfh_rework_ab.txt).
 #ifndef RNA_VFH_WAVES
-#define RNA_VFH_WAVES 7
+#define RNA_VFH_WAVES 6
 #endif
 #define VFH_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RNA_VFH_WAVES, RNA_VFH_WAVES)))
 #ifdef RNA_VFH_SKIPS
@@ -203,6 +203,37 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
   const int last_speed = K.last_chosen_speed[b];
   float st_last_binary = 0.0f;
   if (tid < K.H) st_last_binary = K.last_binary[(size_t)b * K.H + tid];
+
+  // ---------------- Update_VFH prologue (vfh.cpp:490-515) ----------------
+  const float desired_angle = pose.goal_direction;
+  const float dist_to_goal = pose.goal_distance;
+  const float goal_tol = pose.goal_tolerance;
+  int speed = pose.current_speed < 0 ? 0 : pose.current_speed;
+  if (speed < last_speed) speed = last_speed;
+  const int tspeed = speed > K.max_speed ? K.max_speed : speed;  // table index (reference: OOB read)
+  const float bcr_tspeed = K.bcr[tspeed];   // (for the tail: on its way while the histograms are built)
+
+  // The cell tables Calculate_Cells_Mag reads: distance, range index, base magnitude, direction, the two blocked-circle words.
+  // (They depend on the thread and the speed alone, and asking for them a phase early -- with the window's map cells -- was
+  // tried: 24 registers held through the obstacle cells' trigonometry cost more than the trip saved, 13.7 -> 14.1 us for one
+  // pose at five wavefronts per SIMD, 83.7 -> 92 us for 16 384; profiles/r06_vfh_rework_ab.txt.)
+  float cd4[4], bm4[4], dir4[4];
+  int ri4[4];
+  unsigned inr4[4], inl4[4];
+  const unsigned* inr = K.in_circle + ((size_t)tspeed * 2 + 0) * K.NW;
+  const unsigned* inl = K.in_circle + ((size_t)tspeed * 2 + 1) * K.NW;
+  auto load_cell_tables = [&](int q0) {
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int q = q0 + k4 * VFH_THREADS + tid;
+      cd4[k4] = 0.0f; bm4[k4] = 0.0f; ri4[k4] = 0; dir4[k4] = 0.0f; inr4[k4] = 0u; inl4[k4] = 0u;
+      if (q < K.NQF) {   // (unsigned indices: a scalar base and ONE 32-bit offset register serve the four cell tables)
+        const unsigned uq = (unsigned)q, uw = uq >> 5;
+        cd4[k4] = K.cell_dist[uq]; ri4[k4] = K.range_idx[uq]; bm4[k4] = K.cell_base_mag[uq];
+        dir4[k4] = K.cell_dir[uq]; inr4[k4] = inr[uw]; inl4[k4] = inl[uw];
+      }
+    }
+  };
 
   // ---------------- ranges (steerer.cpp:147-191) ----------------
   for (int i = tid; i < 361; i += VFH_THREADS)
@@ -312,26 +343,22 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
   VFH_STAMP();
   VFH_EXIT(4);   // + the obstacle cells' ranges
 
-  // ---------------- Update_VFH prologue (vfh.cpp:490-515) ----------------
-  const float desired_angle = pose.goal_direction;
-  const float dist_to_goal = pose.goal_distance;
-  const float goal_tol = pose.goal_tolerance;
-  int speed = pose.current_speed < 0 ? 0 : pose.current_speed;
-  if (speed < last_speed) speed = last_speed;
-  const int tspeed = speed > K.max_speed ? K.max_speed : speed;  // table index (reference: OOB read)
-  const float bcr_tspeed = K.bcr[tspeed];   // (for the tail: on its way while the histograms are built)
+  int speed_index = (int)floorf(((float)speed / (float)K.current_max_speed) * K.T);  // vfh.cpp:175-186
+  if (speed_index >= K.T) speed_index = K.T - 1;
 
   // ---------------- Calculate_Cells_Mag (vfh.cpp:986-1049) ----------------
+  // with the occupied front cells' part of Build_Masked_Polar_Histogram (vfh.cpp:1131-1213): the reference walks the occupied
+  // front cells sequentially, raising phi_right / lowering phi_left.  Front cells have directions in (0,180): a cell updates
+  // phi_right iff it lies right of straight-ahead (Delta(dir,90) > 0), inside the right blocked circle and dir >= phi_right,
+  // so the final phi_right is the MAX direction of those cells (and symmetrically phi_left the MIN on the left side) --
+  // independent of the visiting order, and so the thread that finds a cell occupied here can say it right away (its
+  // direction and circle words come with the trip that brings the cell's distance: the walk used to be a pass of its own
+  // over the magnitudes, with a trip to L2 of its own).  Circle membership is a host table.  After an emergency stop the
+  // two angles are not read.
   const float r_safe = K.robot_radius + (float)k_safety_dist(K.sd0, K.sd1, speed);
+  const int q_centre = K.CY * K.W + K.CX;   // (x == CX && y == CY of q = y W + x, without the division)
   for (int q0 = 0; q0 < K.NQ && !VFH_SKIP(4); q0 += 4 * VFH_THREADS) {   // (four cells per thread and trip, the table reads first)
-    float cd4[4], bm4[4];
-    int ri4[4];
-#pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
-      const int q = q0 + k4 * VFH_THREADS + tid;
-      cd4[k4] = 0.0f; bm4[k4] = 0.0f; ri4[k4] = 0;
-      if (q < K.NQF) { cd4[k4] = K.cell_dist[q]; ri4[k4] = K.range_idx[q]; bm4[k4] = K.cell_base_mag[q]; }
-    }
+    load_cell_tables(q0);
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
       const int q = q0 + k4 * VFH_THREADS + tid;
@@ -341,14 +368,36 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
         const float cd = cd4[k4];
         const double range = __longlong_as_double((long long)rng[ri4[k4]]);
         if ((cd + K.cell_width / 2.0) > range) {
-          const int x = q % K.W, y = q / K.W;
-          if (cd < r_safe && !(x == K.CX && y == K.CY)) s_emergency = 1;
+          if (cd < r_safe && q != q_centre) s_emergency = 1;
           m = bm4[k4];
         }
       }
       mag[q] = m;
-      if (m != 0.0f) atomicOr(&nz[q >> 5], 1u << (q & 31));
+      if (m != 0.0f) {
+        atomicOr(&nz[q >> 5], 1u << (q & 31));
+        if (!VFH_SKIP(16)) {
+          const float dir = dir4[k4];
+          const unsigned bit = 1u << (q & 31);
+          if (k_delta_angle(dir, 90.0f) > 0) {
+            if ((inr4[k4] & bit) && dir >= 0.0f && dir < 90.0f) atomicMax(&s_phi_right, __float_as_uint(dir));
+          } else {
+            if ((inl4[k4] & bit) && dir <= 180.0f) atomicMin(&s_phi_left, __float_as_uint(dir));
+          }
+        }
+      }
     }
+  }
+  // The sector's membership words (Build_Primary_Polar_Histogram below) depend on the speed alone: all sixteen leave here,
+  // before the barrier, in one trip (they used to be fetched eight at a time after it: two trips to L2 at the head of the
+  // histogram step).  Sixteen reads whatever NW is, without a test between them: the words past NW belong to the next
+  // sector -- the table ends with sixteen spare words -- and the sums below stop at NW.  (A window of more than 512 cells
+  // keeps the old loop.)
+  const bool memb_in_regs = K.NW <= 16;
+  unsigned mbw[16];
+  {
+    const unsigned* mb = K.memb + ((size_t)speed_index * K.H + (tid < K.H ? tid : 0)) * K.NW;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mbw[k] = mb[k];
   }
   __syncthreads();
   VFH_STAMP();
@@ -364,23 +413,42 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
     if (tid < K.H) origin[tid] = 1.0f;
   } else {
     // ---------------- Build_Primary_Polar_Histogram (vfh.cpp:1057-1095) ----------------
-    int speed_index = (int)floorf(((float)speed / (float)K.current_max_speed) * K.T);  // vfh.cpp:175-186
-    if (speed_index >= K.T) speed_index = K.T - 1;
     if (tid < K.H) {
-      const unsigned* mb = K.memb + ((size_t)speed_index * K.H + tid) * K.NW;
       float sum = 0.0f;
-      for (int w0 = 0; w0 < K.NW && !VFH_SKIP(8); w0 += 8) {   // (the sector's membership words eight at a time: one trip to L2 per eight)
-        unsigned mbw[8];
+      if (memb_in_regs) {
 #pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8) mbw[k8] = w0 + k8 < K.NW ? mb[w0 + k8] : 0u;
-#pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8) {
-          const int w = w0 + k8;
-          unsigned bits = w < K.NW ? (mbw[k8] & nz[w]) : 0u;
-          while (bits) {  // ascending q == the reference's (y outer, x inner) order
-            const int bit = __ffs(bits) - 1;
+        for (int w = 0; w < 16; ++w) {
+          if (w >= K.NW || VFH_SKIP(8)) break;
+          unsigned bits = mbw[w] & nz[w];
+          // ascending q == the reference's (y outer, x inner) order.  Two cells a turn: both magnitudes are asked for
+          // before the first is added (the LDS round trip was the turn's length); a turn with one cell left adds 0.0f,
+          // which leaves a sum that started at +0 as it is.
+          while (bits) {
+            const int bit0 = __ffs(bits) - 1;
             bits &= bits - 1;
-            sum += mag[w * 32 + bit];
+            const bool two = bits != 0u;
+            const int bit1 = two ? __ffs(bits) - 1 : bit0;
+            bits &= bits - 1;   // (0 & 0xffffffff stays 0)
+            const float m0 = mag[w * 32 + bit0], m1 = mag[w * 32 + bit1];
+            sum += m0;
+            sum += two ? m1 : 0.0f;
+          }
+        }
+      } else {
+        const unsigned* mb = K.memb + ((size_t)speed_index * K.H + tid) * K.NW;
+        for (int w0 = 0; w0 < K.NW && !VFH_SKIP(8); w0 += 8) {   // (the sector's membership words eight at a time: one trip to L2 per eight)
+          unsigned mb8[8];
+#pragma unroll
+          for (int k8 = 0; k8 < 8; ++k8) mb8[k8] = w0 + k8 < K.NW ? mb[w0 + k8] : 0u;
+#pragma unroll
+          for (int k8 = 0; k8 < 8; ++k8) {
+            const int w = w0 + k8;
+            unsigned bits = w < K.NW ? (mb8[k8] & nz[w]) : 0u;
+            while (bits) {
+              const int bit = __ffs(bits) - 1;
+              bits &= bits - 1;
+              sum += mag[w * 32 + bit];
+            }
           }
         }
       }
@@ -396,29 +464,7 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
       last_binary[tid] = h;
       s_hist[tid] = h;
     }
-    // ---------------- Build_Masked_Polar_Histogram (vfh.cpp:1131-1213) ----------------
-    // The reference walks the occupied front cells sequentially, raising phi_right / lowering
-    // phi_left.  Front cells have directions in (0,180): a cell updates phi_right iff it lies right
-    // of straight-ahead (Delta(dir,90) > 0), inside the right blocked circle and dir >= phi_right,
-    // so the final phi_right is the MAX direction of those cells (and symmetrically phi_left the
-    // MIN on the left side) -- independent of the visiting order.  Circle membership is a host table.
-    {
-      const unsigned* inr = K.in_circle + ((size_t)tspeed * 2 + 0) * K.NW;
-      const unsigned* inl = K.in_circle + ((size_t)tspeed * 2 + 1) * K.NW;
-      for (int q = tid; q < K.NQF && !VFH_SKIP(16); q += VFH_THREADS) {
-        // (the cell's direction and its two circle words are read whether or not the cell is occupied: three loads that
-        // leave together, instead of one trip to L2 behind each test)
-        const float dir = K.cell_dir[q];
-        const unsigned in_r = inr[q >> 5], in_l = inl[q >> 5];
-        if (mag[q] == 0.0f) continue;
-        const unsigned bit = 1u << (q & 31);
-        if (k_delta_angle(dir, 90.0f) > 0) {
-          if ((in_r & bit) && dir >= 0.0f && dir < 90.0f) atomicMax(&s_phi_right, __float_as_uint(dir));
-        } else {
-          if ((in_l & bit) && dir <= 180.0f) atomicMin(&s_phi_left, __float_as_uint(dir));
-        }
-      }
-    }
+    // ---------------- Build_Masked_Polar_Histogram (vfh.cpp:1131-1213): phi_left / phi_right were found with the magnitudes ----------------
     __syncthreads();
     if (tid < K.H) {
       const float phi_right = __uint_as_float(s_phi_right), phi_left = __uint_as_float(s_phi_left);
@@ -497,42 +543,31 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
         const int sp_wide = cms < K.max_speed_wide ? cms : K.max_speed_wide;
         // the ring as a 128-bit value (bits >= H are zero)
         const unsigned long long r_lo = hbits_lo, r_hi = hbits_hi;
-        auto shr128 = [](unsigned long long lo, unsigned long long hi, int n, unsigned long long& olo, unsigned long long& ohi) {
-          if (n == 0) { olo = lo; ohi = hi; }
-          else if (n < 64) { olo = (lo >> n) | (hi << (64 - n)); ohi = hi >> n; }
-          else if (n == 64) { olo = hi; ohi = 0ull; }
-          else if (n < 128) { olo = hi >> (n - 64); ohi = 0ull; }
-          else { olo = 0ull; ohi = 0ull; }
-        };
-        auto shl128 = [](unsigned long long lo, unsigned long long hi, int n, unsigned long long& olo, unsigned long long& ohi) {
-          if (n == 0) { olo = lo; ohi = hi; }
-          else if (n < 64) { ohi = (hi << n) | (lo >> (64 - n)); olo = lo << n; }
-          else if (n == 64) { ohi = lo; olo = 0ull; }
-          else if (n < 128) { ohi = lo << (n - 64); olo = 0ull; }
-          else { olo = 0ull; ohi = 0ull; }
-        };
         float my_w = 10000000.0f;    // Select_Candidate_Angle's starting minimum: a candidate has to beat it
         int my_ord = 0x7fffffff;     // (position of the valley in the walk) * 4 + candidate number
         float my_a = 90.0f;
         int my_sp = 0, my_n = 0;
+#pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
           const int sct = tid + 64 * pass;
           if (sct >= H) continue;
           const int prev = sct == 0 ? H - 1 : sct - 1;
           if (!(hist_at(sct) == 0 && hist_at(prev) == 1)) continue;   // not the first sector of a valley
-          // first blocked sector after sct, going round: the ring rotated right by sct + 1
-          const int n = sct + 1;
-          unsigned long long alo, ahi, blo, bhi;
-          shr128(r_lo, r_hi, n, alo, ahi);
-          shl128(r_lo, r_hi, H - n, blo, bhi);
-          unsigned long long q_lo = alo | blo, q_hi = ahi | bhi;
-          if (H < 64) { q_lo &= (1ull << H) - 1ull; q_hi = 0ull; }
-          else if (H < 128) q_hi &= (1ull << (H - 64)) - 1ull;
-          const int q = q_lo ? __builtin_ctzll(q_lo) : 64 + __builtin_ctzll(q_hi);   // (the ring holds a 1: sector `start`)
-          int last = sct + q;                    // the valley's last free sector = (im - 1) of the closing step
-          if (last >= H) last -= H;
+          // first blocked sector after sct, going round (the ring holds a 1: sector `start`, in its lower word): the lowest set
+          // bit above sct, or else the lowest of all.  `pass` is a constant of the unrolled loop: one 64-bit shift and two
+          // bit searches (round 6; the ring used to be rotated to the lane's position as a 128-bit value, two five-way
+          // branches on the lane's shift count).
+          int next;
+          if (pass == 0) {
+            const unsigned long long above = sct >= 63 ? 0ull : (r_lo & (~0ull << (sct + 1)));
+            next = above ? __builtin_ctzll(above) : (r_hi ? 64 + __builtin_ctzll(r_hi) : __builtin_ctzll(r_lo));
+          } else {
+            const unsigned long long above = sct >= 127 ? 0ull : (r_hi & (~0ull << (sct - 63)));
+            next = above ? 64 + __builtin_ctzll(above) : (r_lo ? __builtin_ctzll(r_lo) : 64 + __builtin_ctzll(r_hi));
+          }
+          const int last = next == 0 ? H - 1 : next - 1;   // the valley's last free sector = (im - 1) of the closing step
           const int b1 = sct * SA;
-          int b2 = last * SA;                    // (im - 1) * SA, + 360 when im == 0: the same number, H * SA == 360
+          const int b2 = last * SA;                    // (im - 1) * SA, + 360 when im == 0: the same number, H * SA == 360
           const float angle = k_delta_angle((float)b1, (float)b2);
           if (fabsf(angle) < 10) continue;
           int pos = sct - start;                 // the walk reaches this valley after `pos` steps
@@ -559,21 +594,25 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
               consider(desired_angle, sp_wide);
           }
         }
-        // the wavefront's minimum by (weight, order); a candidate only counts if it beats the starting minimum
-        float w = my_w;
-        int ord = my_ord;
-        for (int o = 32; o >= 1; o >>= 1) {
-          const float ow = __shfl_xor(w, o);
-          const int oo = __shfl_xor(ord, o);
-          if (ow < w || (ow == w && oo < ord)) { w = ow; ord = oo; }
-        }
-        const unsigned long long winner = __ballot(my_ord != 0x7fffffff && my_ord == ord && my_w == w);
-        for (int o = 32; o >= 1; o >>= 1) my_n += __shfl_xor(my_n, o);
-        ncand = my_n;
-        if (winner) {
-          const int wl = __builtin_ctzll(winner);
-          best_angle = __shfl(my_a, wl);
-          best_speed = __shfl(my_sp, wl);
+        // the wavefront's minimum by (weight, order); a candidate only counts if it beats the starting minimum.  A ring has a
+        // handful of valleys: the lanes that hold a candidate are read one after the other (v_readlane, a scalar loop of two
+        // or three turns) -- the butterfly of 18 ds_bpermute round trips this replaces was a third of the step's 1.5 us.
+        {
+          unsigned long long holders = __ballot(my_ord != 0x7fffffff);
+          float w = 10000000.0f;
+          int ord = 0x7fffffff;
+          while (holders) {
+            const int l = __builtin_ctzll(holders);
+            holders &= holders - 1ull;
+            const float cw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_w), l));
+            const int co = __builtin_amdgcn_readlane(my_ord, l);
+            if (cw < w || (cw == w && co < ord)) {
+              w = cw; ord = co;
+              best_angle = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_a), l));
+              best_speed = __builtin_amdgcn_readlane(my_sp, l);
+            }
+          }
+          ncand = __ballot(my_n != 0) != 0ull ? 1 : 0;   // (only "was any candidate looked at" is asked below)
         }
         if (ncand == 0) {
           picked = last_picked;
@@ -712,7 +751,7 @@ bool build_tables(const rna_vfh_params& p, HostTables& t) {
   t.cell_base_mag.assign(t.NQ, 0.f);
   t.cell_dir.assign(t.NQ, 0.f);
   t.range_idx.assign(t.NQ, 0);
-  t.memb.assign((size_t)T * H * t.NW, 0u);
+  t.memb.assign((size_t)T * H * t.NW + 16, 0u);   // (+16: the kernel reads sixteen words from a row's start whatever NW is)
   t.in_circle.assign((size_t)(MAX_SPEED + 1) * 2 * t.NW, 0u);
 
   for (int x = 0; x < W; x++) {
