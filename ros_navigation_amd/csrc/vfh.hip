@@ -395,7 +395,7 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
   const bool memb_in_regs = K.NW <= 16;
   unsigned mbw[16];
   {
-    const unsigned* mb = K.memb + ((size_t)speed_index * K.H + (tid < K.H ? tid : 0)) * K.NW;
+    const unsigned* mb = K.memb + ((size_t)speed_index * K.H + (tid < K.H ? tid : K.H - 1)) * K.NW;
 #pragma unroll
     for (int k = 0; k < 16; ++k) mbw[k] = mb[k];
   }
@@ -413,13 +413,20 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
     if (tid < K.H) origin[tid] = 1.0f;
   } else {
     // ---------------- Build_Primary_Polar_Histogram (vfh.cpp:1057-1095) ----------------
-    if (tid < K.H) {
-      float sum = 0.0f;
-      if (memb_in_regs) {
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-          if (w >= K.NW || VFH_SKIP(8)) break;
-          unsigned bits = mbw[w] & nz[w];
+    float sum = 0.0f;
+    if (memb_in_regs) {
+      // The window's non-zero words: ONE read, lane l holds word l, and the loop takes word w from lane w with v_readlane -- the
+      // same for every sector, so a scalar, and a word without an occupied cell is skipped by a scalar branch (reading nz[w]
+      // in the loop was an LDS round trip at the head of each of the fifteen turns).  EVERY lane runs the loop, so that the
+      // lane v_readlane asks is awake: the second wavefront holds eight sectors, its other lanes repeat the last one's sum
+      // (`mbw` above was read for sector H - 1 there) and drop it.
+      {
+        const int wl = tid & 63;
+        const unsigned nzv = nz[wl < K.NW ? wl : 0];
+        for (int w = 0; w < K.NW && !VFH_SKIP(8); ++w) {   // (mbw[w]: a register picked by the loop counter, s_set_gpr_idx)
+          const unsigned nzw = __builtin_amdgcn_readlane(nzv, w);
+          if (nzw == 0u) continue;
+          unsigned bits = mbw[w] & nzw;
           // ascending q == the reference's (y outer, x inner) order.  Two cells a turn: both magnitudes are asked for
           // before the first is added (the LDS round trip was the turn's length); a turn with one cell left adds 0.0f,
           // which leaves a sum that started at +0 as it is.
@@ -434,7 +441,10 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
             sum += two ? m1 : 0.0f;
           }
         }
-      } else {
+      }
+    }
+    if (tid < K.H) {
+      if (!memb_in_regs) {
         const unsigned* mb = K.memb + ((size_t)speed_index * K.H + tid) * K.NW;
         for (int w0 = 0; w0 < K.NW && !VFH_SKIP(8); w0 += 8) {   // (the sector's membership words eight at a time: one trip to L2 per eight)
           unsigned mb8[8];
@@ -678,6 +688,8 @@ vfh_step_kernel(VfhK K, Geom g, const float* __restrict__ master, const rna_pose
     printf("[vfh stats] us: ranges %.2f cells_mag %.2f histograms %.2f tail: select %.2f cant_turn %.2f rest %.2f\n", (ts_[1] - ts_[0]) * 0.01,
            (ts_[2] - ts_[1]) * 0.01, (ts_[3] - ts_[2]) * 0.01, (ts_[4] - ts_[3]) * 0.01, (ts_[5] - ts_[4]) * 0.01, (ts_[6] - ts_[5]) * 0.01);
 #endif
+  // (the caller's copies of the two histograms.  Writing them where the values are made, from registers, instead of reading
+  // back here what the same thread stored above, was tried: +0.6 us at 1 024 poses, +4 % at 16 384 -- r06_vfh_rework_ab.txt)
   if (tid < K.H) {
     if (origin_out) origin_out[(size_t)b * K.H + tid] = origin[tid];
     if (hist_out) hist_out[(size_t)b * K.H + tid] = hist[tid];
