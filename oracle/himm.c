@@ -86,8 +86,13 @@ int og_ranges_from_submap(const og_geom* g, const float* master, const double ro
 
   const double len[2] = { 1.5, 1.5 };
   og_geom sg;
-  float sub[64 * 64];
-  if (!og_get_submap(g, master, robot_pos, len, &sg, sub, 64 * 64)) return 0;
+  /* (the copy of the window: sized by the resolution.  A fixed 64 x 64 buffer stood here until round 6 and made every window of
+   * a map finer than 2.4 cm a "getSubmap failure" of the oracle's own, which the reference does not have) */
+  const int side = (int)(1.5 / g->res) + 3;
+  const int cap = side * side;
+  float* sub = (float*)malloc((size_t)cap * sizeof(float));
+  if (!sub) return 0;
+  if (!og_get_submap(g, master, robot_pos, len, &sg, sub, cap)) { free(sub); return 0; }
 
   int n = sg.size[0] * sg.size[1];
   for (int lin = 0; lin < n; ++lin) {
@@ -108,5 +113,6 @@ int og_ranges_from_submap(const og_geom* g, const float* master, const double ro
     if (ranges[fl * 2][0] > distance) ranges[fl * 2][0] = distance;
     if (ranges[ce * 2][0] > distance) ranges[ce * 2][0] = distance;
   }
+  free(sub);
   return 1;
 }

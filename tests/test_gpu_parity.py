@@ -257,6 +257,46 @@ def test_vfh_step_dense_walls_edges_and_w60(R):
     e.close()
 
 
+@pytest.mark.parametrize("res,density,sector_angle,moved", [
+    (0.025, 0.45, 5, False),    # 61 x 61 window, 64-column thread grid; ~1 600 obstacle cells in a window: the list overflows
+    (0.025, 0.10, 10, True),    # 36 sectors (less than a wavefront), on a moved buffer
+    (0.01, 0.20, 5, False),     # 151 x 151 window: rows longer than the workgroup, the cell-by-cell walk
+    (0.1, 0.30, 15, True),      # 16 x 16 window, 24 sectors, moved buffer
+])
+def test_vfh_step_other_resolutions_and_sector_counts(R, res, density, sector_angle, moved):
+    """vfh_step_kernel's paths the Steerer's own numbers (5 cm cells: a 31 x 31 window, 72 sectors) do not reach: the window
+    walk's 64- and 128-column thread grids, the obstacle list's overflow (more than 1 024 obstacle cells in a window -> the
+    window is walked cell by cell), windows with rows longer than the workgroup, histograms with fewer sectors than a
+    wavefront has lanes, each also on a moved buffer.  getSubmap + getRangesFromSubmap (gmc/src/GridMap.cpp:287-339,
+    mc/src/steerer.cpp:147-191) and Update_VFH against the oracle, bit for bit."""
+    L = 6.0 if res < 0.1 else 12.0
+    e = R.Engine(L, L, res)
+    g = O.make_geom(L, L, res)
+    master = R.synth.obstacles_rect(e.rows, e.cols, density=density, seed=13, side=(2, 9))
+    e.upload(R.capi.LAYER_MASTER, master)
+    ref = master.copy()
+    dx, dy = 0.0, 0.0
+    if moved:
+        dx, dy = 0.73, -0.41
+        ptrs = (C.POINTER(C.c_float) * 1)(O.fptr(ref))
+        regs = (O.Region * 4)()
+        mv = C.c_int(0)
+        O.lib().og_move(C.byref(g), ptrs, 1, O.d2(dx, dy), regs, C.byref(mv))
+        assert e.move(dx, dy) and tuple(e.geometry().start_index) == tuple(g.start) != (0, 0)
+        e.upload(R.capi.LAYER_MASTER, ref)     # (the strips the move cleared stay cleared in both)
+    p = O.default_vfh_params()
+    p.sector_angle = sector_angle
+    rp = R.capi.default_vfh_params()
+    for f, _ in rp._fields_:
+        setattr(rp, f, getattr(p, f))
+    poses = R.synth.poses(40, L, L, seed=17, margin=0.3)
+    poses["x"] += dx
+    poses["y"] += dy
+    e.vfh_init(len(poses), rp)
+    check_vfh_vs_oracle(R, e, g, ref, poses, steps=3, params=p)
+    e.close()
+
+
 @pytest.mark.parametrize("pi", [0, 1])
 def test_vfh_update_matches_reference_golden(R, pi):
     """Update_VFH on caller-provided scans against vectors produced by the reference's own vfh.cpp."""
