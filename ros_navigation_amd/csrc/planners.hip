@@ -431,6 +431,101 @@ __device__ unsigned long long g_rrt_stat[8];
 #define RRT_ACC(slot, a, b)
 #endif
 
+// One sample against the current tree: findNearNode, the steering step of extendTree, ifBlocked at the new point.  Wave-cooperative
+// (all 64 lanes), the same values in every lane.
+struct RrtEval { double wx, wy; int near; bool blocked; };
+#ifdef RNA_RRT_STATS
+#define RRT_STAT_PARAM , unsigned long long* rrt_acc, unsigned long long t1
+#define RRT_STAT_ARG , rrt_acc, t1
+#else
+#define RRT_STAT_PARAM
+#define RRT_STAT_ARG
+#endif
+__device__ __forceinline__ RrtEval rrt_evaluate(const Geom& g, const float* __restrict__ master, const double2* tn, int n_tree,
+                                                double rx, double ry, int lane RRT_STAT_PARAM) {
+  const double strideStep = 0.4;   // rrt_planner.h:23
+  // findNearNode, rrt_planner.cpp:70-89 : strict < on hypot() keeps the lowest index among equals.
+  // hypot costs ~10x a squared distance, so the scan runs on squared distances first; hypot (glibc's, error
+  // < 1 ulp, i.e. 2^-52 relative) can only reorder nodes whose squared distances agree to within
+  // 2^-48, and exactly those are re-examined with glibc_hypot in the reference's order.
+  // One pass: every lane keeps its nearest node by squared distance (lowest index among equals) and
+  // its second-smallest squared distance.  After the wave reduction, hypot is evaluated for at most one
+  // node per lane; only if some lane holds TWO nodes inside the 2^-46 band (practically never) the
+  // band is rescanned in full.
+  double l1 = 1.0e300, l2 = 1.0e300;
+  int i1 = 0x7fffffff;
+  for (int i0 = lane; i0 < n_tree; i0 += 256) {   // four nodes per lane and trip: the LDS reads go out together
+    double2 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = tn[min(i0 + 64 * u, RRT_ITER - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 64 * u;
+      const double dx = rx - t[u].x, dy = ry - t[u].y;
+      const double d2 = i < n_tree ? dx * dx + dy * dy : 1.0e300;
+      if (d2 < l1) { l2 = l1; l1 = d2; i1 = i; }
+      else if (d2 < l2) l2 = d2;
+    }
+  }
+  double m2 = l1;
+  int imin = i1;
+  wave_min_pair(m2, imin);                       // nearest by squared distance, lowest index among equals
+  const double band = m2 + m2 * 0x1p-46 + 1.0e-300;
+  double best = 9999.0;
+  int best_i = 0x7fffffff;
+  if (__ballot(l2 <= band || (l1 <= band && i1 != imin)) == 0ull) {
+    // the usual case: no other node within the band, the answer is imin (if it beats the reference's 9999 start)
+    // hypot < 9999 needs no hypot when the squared distance is far below 9999^2
+    if (imin != 0x7fffffff) {
+      const double2 t = tn[imin];
+      if (m2 < 9.0e7 || glibc_hypot(rx - t.x, ry - t.y) < best) best_i = imin;
+    }
+  } else {
+    for (int i = lane; i < n_tree; i += 64) {
+      const double2 t = tn[i];
+      const double dx = rx - t.x, dy = ry - t.y;
+      if (dx * dx + dy * dy <= band) {
+        const double d = glibc_hypot(dx, dy);
+        if (d < best) { best = d; best_i = i; }
+      }
+    }
+    wave_min_pair(best, best_i);
+  }
+  const int near = (best_i == 0x7fffffff) ? 0 : best_i;
+  RRT_T(t2);
+  RRT_ACC(1, t1, t2);
+  const double npx = tn[near].x, npy = tn[near].y;
+  double wx, wy;
+  // hypot < 0.4 is decided by the squared distance except within rounding of 0.16
+  const double ddx = npx - rx, ddy = npy - ry, dd2 = ddx * ddx + ddy * ddy;
+  const bool within = dd2 < 0.1599 ? true : (dd2 > 0.1601 ? false : glibc_hypot(ddx, ddy) < strideStep);
+  if (within) { wx = rx; wy = ry; }
+  else {
+#ifdef RNA_RRT_LIBM_STEER
+    const double a = atan2(ry - npy, rx - npx);   // as written in the reference (rrt_planner.cpp:45-47), with the device's libm
+    wx = npx + strideStep * cos(a);
+    wy = npy + strideStep * sin(a);
+#else
+    // cos(atan2(dy, dx)) = dx / hypot(dx, dy): one square root and two divisions, all IEEE-rounded, instead of three
+    // double-precision libm calls -- which are what held the kernel at 127 VGPRs (78 without them: twelve
+    // wavefronts per query instead of eight fit the chip).  Against glibc's atan2 / cos / sin the offset differs in
+    // its last bits either way (the device libm's does too, DESIGN.md 4 "What stays open"): the sum with the node's
+    // coordinate then rounds differently for a few per cent of the nodes, by one ulp, which only matters at the
+    // last-bit ties scripts/fuzz_rrt.py classifies.
+    const double sdx = rx - npx, sdy = ry - npy;
+    const double sh = sqrt(sdx * sdx + sdy * sdy);
+    wx = npx + strideStep * (sdx / sh);
+    wy = npy + strideStep * (sdy / sh);
+#endif
+  }
+  RRT_T(t3);
+  RRT_ACC(2, t2, t3);
+  const bool blocked = wave_if_blocked(g, master, wx, wy, lane);
+  RRT_T(t4);
+  RRT_ACC(3, t3, t4);
+  return RrtEval{wx, wy, near, blocked};
+}
+
 // One query per workgroup, RRT_SPEC wavefronts.  extendTree (rrt_planner.cpp:26-59) draws samples until one is
 // not blocked; the draws do not depend on the outcomes and the tree only changes when a sample is accepted, so
 // the next RRT_SPEC samples are evaluated against the current tree at once, one per wavefront, and the first
@@ -438,6 +533,11 @@ __device__ unsigned long long g_rrt_stat[8];
 // wavefront carries the rand() stream and takes the same decisions, so one barrier per round is all the
 // synchronisation there is.  (On the bench maps 94 % of the samples are blocked; with the goal samples answered
 // from the last evaluation, see below, a round consumes 8.7 samples on average and 13 on a stuck tree.)
+// Round 6 also ran up to four rounds back to back before ONE barrier on trees that had stopped accepting (the later rounds' samples
+// are known once the earlier ones are assumed blocked; on an accept the stream is put back).  Exact -- the GPU tests and 8 704
+// fuzzed queries -- and slower, 46.7 ms against 41.4 for config 4's share: what the timers call "barrier wait" is not the cost of
+// the barrier but the spread between the wavefronts of a round, and it adds up over the rounds of a group all the same
+// (0.82 us a round, 3.24 us a group of four: profiles/r06_rrt_rounds_ahead.txt).  Not kept.
 struct RrtSlot { double wx, wy; int near, blocked; };
 
 // 4 wavefronts per SIMD (<= 128 VGPRs): two 8-wavefront workgroups per CU, 512 queries resident on the chip
@@ -462,7 +562,7 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
   rng_seed(rs, qu.seed, lane);
 #endif
 
-  const double strideStep = 0.4;   // rrt_planner.h:23 ; targetTendency_ is int(0.5) == 0 (rrt_planner.h:24,32)
+  // (strideStep 0.4, rrt_planner.h:23, lives in rrt_evaluate; targetTendency_ is int(0.5) == 0, rrt_planner.h:24,32)
   const bool target_inside = position_within_map(g, qu.target[0], qu.target[1]);
   const double pbx = g.pos[0] + g.len[0] / 2, pby = g.pos[1] + g.len[1] / 2;
   const double mbx = g.pos[0] - g.len[0] / 2, mby = g.pos[1] - g.len[1] / 2;
@@ -575,92 +675,17 @@ rrt_kernel(Geom g, const float* __restrict__ master, const rna_rrt_query* __rest
         }
         RRT_T(t1);
         RRT_ACC(0, t0, t1);
-        // findNearNode, rrt_planner.cpp:70-89 : strict < on hypot() keeps the lowest index among equals.
-        // hypot costs ~10x a squared distance, so the scan runs on squared distances first; hypot (glibc's, error
-        // < 1 ulp, i.e. 2^-52 relative) can only reorder nodes whose squared distances agree to within
-        // 2^-48, and exactly those are re-examined with glibc_hypot in the reference's order.
-        // One pass: every lane keeps its nearest node by squared distance (lowest index among equals) and
-        // its second-smallest squared distance.  After the wave reduction, hypot is evaluated for at most one
-        // node per lane; only if some lane holds TWO nodes inside the 2^-46 band (practically never) the
-        // band is rescanned in full.
-        double l1 = 1.0e300, l2 = 1.0e300;
-        int i1 = 0x7fffffff;
-        for (int i0 = lane; i0 < n_tree; i0 += 256) {   // four nodes per lane and trip: the LDS reads go out together
-          double2 t[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) t[u] = tn[min(i0 + 64 * u, RRT_ITER - 1)];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int i = i0 + 64 * u;
-            const double dx = rx - t[u].x, dy = ry - t[u].y;
-            const double d2 = i < n_tree ? dx * dx + dy * dy : 1.0e300;
-            if (d2 < l1) { l2 = l1; l1 = d2; i1 = i; }
-            else if (d2 < l2) l2 = d2;
-          }
-        }
-        double m2 = l1;
-        int imin = i1;
-        wave_min_pair(m2, imin);                       // nearest by squared distance, lowest index among equals
-        const double band = m2 + m2 * 0x1p-46 + 1.0e-300;
-        double best = 9999.0;
-        int best_i = 0x7fffffff;
-        if (__ballot(l2 <= band || (l1 <= band && i1 != imin)) == 0ull) {
-          // the usual case: no other node within the band, the answer is imin (if it beats the reference's 9999 start)
-          // hypot < 9999 needs no hypot when the squared distance is far below 9999^2
-          if (imin != 0x7fffffff) {
-            const double2 t = tn[imin];
-            if (m2 < 9.0e7 || glibc_hypot(rx - t.x, ry - t.y) < best) best_i = imin;
-          }
-        } else {
-          for (int i = lane; i < n_tree; i += 64) {
-            const double2 t = tn[i];
-            const double dx = rx - t.x, dy = ry - t.y;
-            if (dx * dx + dy * dy <= band) {
-              const double d = glibc_hypot(dx, dy);
-              if (d < best) { best = d; best_i = i; }
-            }
-          }
-          wave_min_pair(best, best_i);
-        }
-        const int near = (best_i == 0x7fffffff) ? 0 : best_i;
-        RRT_T(t2);
-        RRT_ACC(1, t1, t2);
-        const double npx = tn[near].x, npy = tn[near].y;
-        double wx, wy;
-        // hypot < 0.4 is decided by the squared distance except within rounding of 0.16
-        const double ddx = npx - rx, ddy = npy - ry, dd2 = ddx * ddx + ddy * ddy;
-        const bool within = dd2 < 0.1599 ? true : (dd2 > 0.1601 ? false : glibc_hypot(ddx, ddy) < strideStep);
-        if (within) { wx = rx; wy = ry; }
-        else {
-#ifdef RNA_RRT_LIBM_STEER
-          const double a = atan2(ry - npy, rx - npx);   // as written in the reference (rrt_planner.cpp:45-47), with the device's libm
-          wx = npx + strideStep * cos(a);
-          wy = npy + strideStep * sin(a);
-#else
-          // cos(atan2(dy, dx)) = dx / hypot(dx, dy): one square root and two divisions, all IEEE-rounded, instead of three
-          // double-precision libm calls -- which are what held the kernel at 127 VGPRs (78 without them: twelve
-          // wavefronts per query instead of eight fit the chip).  Against glibc's atan2 / cos / sin the offset differs in
-          // its last bits either way (the device libm's does too, DESIGN.md 4 "What stays open"): the sum with the node's
-          // coordinate then rounds differently for a few per cent of the nodes, by one ulp, which only matters at the
-          // last-bit ties scripts/fuzz_rrt.py classifies.
-          const double sdx = rx - npx, sdy = ry - npy;
-          const double sh = sqrt(sdx * sdx + sdy * sdy);
-          wx = npx + strideStep * (sdx / sh);
-          wy = npy + strideStep * (sdy / sh);
-#endif
-        }
-        RRT_T(t3);
-        RRT_ACC(2, t2, t3);
-        const bool blocked = wave_if_blocked(g, master, wx, wy, lane);
-        RRT_T(t4);
-        RRT_ACC(3, t3, t4);
+        const RrtEval ev = rrt_evaluate(g, master, tn, n_tree, rx, ry, lane RRT_STAT_ARG);
+        const double wx = ev.wx, wy = ev.wy;
+        const int near = ev.near;
+        const bool blocked = ev.blocked;
         if (lane == 0) out[wave] = RrtSlot{wx, wy, near, blocked ? 1 : 0};
 #if defined(RNA_RRT_DEBUG_SAMPLE) && !RNA_RRT_WIDE
         {
           const int sno = samples + __popcll(startmask & ((2ull << mine) - 1ull));
           if (lane == 0 && sno == RNA_RRT_DEBUG_SAMPLE)
-            printf("[rrt dbg] q %d sample %d rnd (%.17g, %.17g) near %d (%.17g, %.17g) n_tree %d new (%.17g, %.17g) blocked %d m2 %.17g\n",
-                   q, sno, rx, ry, near, npx, npy, n_tree, wx, wy, (int)blocked, m2);
+            printf("[rrt dbg] q %d sample %d rnd (%.17g, %.17g) near %d n_tree %d new (%.17g, %.17g) blocked %d\n",
+                   q, sno, rx, ry, near, n_tree, wx, wy, (int)blocked);
         }
 #endif
       }

@@ -27,3 +27,20 @@ ab = res["status"] == -1
 print("aborted queries: tree sizes", sorted(res["tree_size"][ab].tolist()))
 big = np.argsort(-res["samples"])[:24]
 print("the 24 queries with most samples: (samples, nodes, status)", [(int(res["samples"][k]), int(res["tree_size"][k]), int(res["status"][k])) for k in big])
+if os.environ.get("RRT_ONLY_ABORTED"):
+    # the longest chains by themselves: the batch's time is theirs (each alone on a CU)
+    sel = np.flatnonzero(ab)
+    q2 = q[sel].copy()
+    print("--- the %d aborted queries alone" % len(sel), file=sys.stderr); sys.stderr.flush()
+    e.profile_reset()
+    r2, _ = e.rrt(q2)
+    ms2 = e.profile_get()["rrt"][0]
+    print("aborted alone: %.1f ms for %d samples each -> %.3f us per sample; tree sizes %s" % (ms2, int(r2["samples"].max()), ms2 * 1e3 / r2["samples"].max(), sorted(r2["tree_size"].tolist())))
+    for ts in (1, None):
+        k = [i for i in sel if (res["tree_size"][i] == 1) == (ts == 1)]
+        if not k: continue
+        print("--- aborted with tree %s" % ("of one node" if ts == 1 else "of more nodes"), file=sys.stderr); sys.stderr.flush()
+        e.profile_reset()
+        r3, _ = e.rrt(q[k].copy())
+        ms3 = e.profile_get()["rrt"][0]
+        print("  %d queries, trees %s: %.1f ms -> %.3f us per sample" % (len(k), sorted(r3["tree_size"].tolist()), ms3, ms3 * 1e3 / r3["samples"].max()))
