@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- replan cycles/sec (HIMM + VFH+ + A*) on a 4096 x 4096 grid, BASELINE.json's metric.
 
-One "step" = one TURN of the A* pipeline (--pipeline map updates, default 16), i.e. 16 passes of
+One "step" = one TURN of the A* pipeline (--pipeline map updates, default 20), i.e. 20 passes of
     HIMM ray batch (64 robot origins x 1563 rays) on the laser layer + fused compose-master
     -> VFH+ step for 256 robot poses -> grid A* for 256 (start, goal) queries
-all resident in HBM: 16 x 256 = 4096 replan cycles per step.  The searches of 16 consecutive passes are in
+all resident in HBM: 20 x 256 = 5120 replan cycles per step.  The searches of 20 consecutive passes are in
 flight at once (each on its own pipeline stage), so a single pass is not a unit whose time can be
-measured by itself: a step hands every stage one batch, and the driver's 20 steps then time 320
+measured by itself: a step hands every stage one batch, and the driver's 20 steps then time 400
 passes of steady state instead of 20 passes through a pipeline that is empty at both ends.
 A "replan cycle" is one (pose -> VFH command, start/goal -> A* path) pair served against the map
 that has received its HIMM batch; the ray batch is amortised over the 256 cycles of its pass
@@ -33,10 +33,10 @@ import time
 
 # pipelined A* batches run on several HIP streams; give the runtime enough hardware queues
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-DEFAULT_PIPELINE = 18   # A* batches in flight on one GPU (the committed counter files under profiles/ belong to it).  Round 6, default
-                        # bench / the driver's 20-step run: 16 -> 162.0 / 158.0 k, 18 -> 162.5 / 160.1 k, 20 -> 163.5 / 161.1 k cycles/s
-                        # (profiles/r06_sweep_depth.txt); from 22 on a process's streams run out of hardware queues (129 k), so
-                        # 18 it is: four stages away from the cliff
+DEFAULT_PIPELINE = 20   # A* batches in flight on one GPU (the committed counter files under profiles/ belong to it).  Round 6, default
+                        # bench / the driver's 20-step run: 16 -> 162.0 / 158.0 k, 18 -> 162.5 / 161.5 k, 20 -> 164.0 / 162.5 k cycles/s
+                        # (profiles/r06_sweep_depth.txt, r06_sweep_depth_final.txt: three runs each on two boxes, 20 ahead of 18 in every
+                        # one); from 22 on a process's streams run out of hardware queues (129 k) and the engine takes 20 at most
 # ... and next to an RCCL communicator, whose streams take hardware queues of their own: the rate falls off from 21 stages on
 # without one and from 18 on with one (profiles/r04_sweep_depth_rccl.txt); 14 and 16 measure the same there
 DEFAULT_PIPELINE_RCCL = 14
@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--queue-capacity", type=int, default=0)
     ap.add_argument("--max-path", type=int, default=32768)
     ap.add_argument("--pipeline", type=int, default=0,
-                    help="A* batches in flight (rna_astar_set_pipeline_depth); 0 = 18 on one GPU, 14 next to an RCCL communicator.  "
+                    help="A* batches in flight (rna_astar_set_pipeline_depth); 0 = 20 on one GPU, 14 next to an RCCL communicator.  "
                          "Four search workgroups share a CU, so ~900 queries "
                          "run at once and the batches' tails differ (round 4, default steps / the driver's 20: 13: 148.9k / 146.5k, "
                          "16: 151.1k / 147.9k cycles/s -- profiles/r04_sweep_depth_13_16.txt; round 6: profiles/r06_sweep_depth.txt; 20 is the engine's maximum, and more than two stages need "

@@ -691,7 +691,7 @@ def test_bench_loop_at_full_size_matches_oracle_every_step(R):
     import bench
     hip = _Hip()
     n, nq, rot, depth, max_len = 4096, 256, 4, bench.DEFAULT_PIPELINE, 32768
-    steps = -(-3 * depth // rot) * rot   # every stage three times (at least), a whole number of turns of the rotating input sets: 56 for 18 stages
+    steps = -(-3 * depth // rot) * rot   # every stage three times (at least), a whole number of turns of the rotating input sets: 60 for 20 stages
     part = steps // rot          # visits of one query set; each checks every part-th query
     assert steps % rot == 0 and steps >= 3 * depth and depth >= 13
     L = n * 0.05
