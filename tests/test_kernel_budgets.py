@@ -88,3 +88,17 @@ def test_the_rasteriser_fits_a_cu_that_has_lost_one_search_workgroup():
     assert raster["LDS"] <= 16 * 1024, raster
     assert 3 * bench_search_lds + raster["LDS"] <= LDS_PER_CU, (bench_search_lds, raster["LDS"])
     assert alloc(raster["VGPRs"]) * 8 <= VGPRS_PER_SIMD and raster["ScratchSize"] == 0, raster     # 8 wavefronts per SIMD
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_six_vfh_wavefronts_fit_a_simd_without_a_spill():
+    """vfh_step_kernel is bound by instruction issue at thousands of poses: what round 6 measured (78 us for 16 384 poses, DESIGN.md 5
+    "Round 6" 6) was measured at six wavefronts per SIMD with nothing in scratch -- five cost 5 %, seven spill.  One workgroup
+    (two wavefronts) per pose: its static LDS plus the Steerer window's dynamic share (480 magnitudes + 15 words) leaves the wave slots,
+    not the LDS, as the limit of a CU."""
+    vfh = resources("vfh.hip")
+    step = next(v for k, v in vfh.items() if "vfh_step_kernel" in k)
+    assert step["ScratchSize"] == 0, step
+    assert alloc(step["VGPRs"]) * 6 <= VGPRS_PER_SIMD, step
+    dynamic = (((480 + 31) // 32) * 32 + 15) * 4
+    assert 12 * (step["LDS"] + dynamic) <= LDS_PER_CU, (step["LDS"], dynamic)     # 24 wavefronts = 6 per SIMD are 12 workgroups
