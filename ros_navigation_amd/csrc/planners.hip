@@ -365,10 +365,14 @@ __device__ bool wave_if_blocked(const Geom& g, const float* __restrict__ master,
   // three cells per lane and trip (the 0.3 m disc at 0.05 m resolution spans <= 169 cells): the map reads of one
   // trip are issued together, so the test costs one memory round trip instead of three
   for (int k0 = lane; k0 < total; k0 += 192) {
+    // (round 6: a cell's map read needs its index alone -- it leaves BEFORE the cell's centre is tested against the disc, and the
+    // double-precision arithmetic of that test runs while the read is on its way instead of in front of it; a cell of the
+    // bounding box outside the disc is read and not looked at)
     size_t at[3];
-    bool in[3];
+    bool ok[3];
+    int w0s[3], w1s[3];
 #pragma unroll
-    for (int u3 = 0; u3 < 3; ++u3) {   // pure arithmetic first ...
+    for (int u3 = 0; u3 < 3; ++u3) {   // index arithmetic first ...
       const int k = k0 + 64 * u3;
       int row = (int)((float)k * rcp_ni);      // k / ni without the integer divide (k < 2^23), corrected below
       int col = k - row * ni;
@@ -377,21 +381,25 @@ __device__ bool wave_if_blocked(const Geom& g, const float* __restrict__ master,
       int bi[2];
       buffer_index(g, u, bi);
       // position_from_index(bi) unwraps bi again: that is u itself, wrapped into the map
-      const int w0 = (unsigned)u[0] < (unsigned)g.size[0] ? u[0] : wrap_index(u[0], g.size[0]);
-      const int w1 = (unsigned)u[1] < (unsigned)g.size[1] ? u[1] : wrap_index(u[1], g.size[1]);
-      const double x = ox + g.res * (double)(-w0);
-      const double y = oy + g.res * (double)(-w1);
-      const double dx = x - px, dy = y - py;
+      w0s[u3] = (unsigned)u[0] < (unsigned)g.size[0] ? u[0] : wrap_index(u[0], g.size[0]);
+      w1s[u3] = (unsigned)u[1] < (unsigned)g.size[1] ? u[1] : wrap_index(u[1], g.size[1]);
       // an index past the map (unmoved map, corner on the far edge) is read out of bounds by the reference: skipped here
-      in[u3] = (k < total) & (dx * dx + dy * dy <= r2) & ((unsigned)bi[0] < (unsigned)g.size[0]) & ((unsigned)bi[1] < (unsigned)g.size[1]);
-      at[u3] = in[u3] ? (size_t)bi[1] * g.size[0] + bi[0] : 0;
+      ok[u3] = (k < total) & ((unsigned)bi[0] < (unsigned)g.size[0]) & ((unsigned)bi[1] < (unsigned)g.size[1]);
+      at[u3] = ok[u3] ? (size_t)bi[1] * g.size[0] + bi[0] : 0;
     }
     float val[3];
 #pragma unroll
     for (int u3 = 0; u3 < 3; ++u3) val[u3] = master[at[u3]];   // ... then the three reads together (cell 0 for lanes without one)
 #pragma unroll
+    for (int u3 = 0; u3 < 3; ++u3) {   // ... and the disc test while they travel
+      const double x = ox + g.res * (double)(-w0s[u3]);
+      const double y = oy + g.res * (double)(-w1s[u3]);
+      const double dx = x - px, dy = y - py;
+      ok[u3] = ok[u3] & (dx * dx + dy * dy <= r2);
+    }
+#pragma unroll
     for (int u3 = 0; u3 < 3; ++u3)
-      if (in[u3] && !(val[u3] != val[u3]) && val[u3] > 0.0f) hit = true;
+      if (ok[u3] && !(val[u3] != val[u3]) && val[u3] > 0.0f) hit = true;
   }
   return __ballot(hit) != 0ULL;
 }
@@ -405,7 +413,8 @@ __device__ __forceinline__ void dpp_min_step(unsigned& lo, unsigned& hi, int& id
   const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xF, false);
   const int oidx = __builtin_amdgcn_update_dpp(idx, idx, CTRL, ROW_MASK, 0xF, false);
   const unsigned long long a = ((unsigned long long)ohi << 32) | olo, b = ((unsigned long long)hi << 32) | lo;
-  if (a < b || (a == b && oidx < idx)) { lo = olo; hi = ohi; idx = oidx; }
+  const bool take = (a < b) | ((a == b) & (oidx < idx));   // (selects: as an `if` each of the six steps kept an exec-masked branch)
+  lo = take ? olo : lo; hi = take ? ohi : hi; idx = take ? oidx : idx;
 }
 __device__ __forceinline__ void wave_min_pair(double& v, int& idx) {
   const unsigned long long bits = (unsigned long long)__double_as_longlong(v);   // v >= 0: bit order == value order
