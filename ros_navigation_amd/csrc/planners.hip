@@ -376,7 +376,10 @@ __device__ bool wave_if_blocked(const Geom& g, const float* __restrict__ master,
       const int k = k0 + 64 * u3;
       int row = (int)((float)k * rcp_ni);      // k / ni without the integer divide (k < 2^23), corrected below
       int col = k - row * ni;
-      if (col < 0) { row--; col += ni; } else if (col >= ni) { row++; col -= ni; }
+      {  // (selects)
+        const int fix = col < 0 ? -1 : (col >= ni ? 1 : 0);
+        row += fix; col -= fix * ni;
+      }
       const int u[2] = {su0 + col, su1 + row};
       int bi[2];
       buffer_index(g, u, bi);
@@ -472,8 +475,11 @@ __device__ __forceinline__ RrtEval rrt_evaluate(const Geom& g, const float* __re
       const int i = i0 + 64 * u;
       const double dx = rx - t[u].x, dy = ry - t[u].y;
       const double d2 = i < n_tree ? dx * dx + dy * dy : 1.0e300;
-      if (d2 < l1) { l2 = l1; l1 = d2; i1 = i; }
-      else if (d2 < l2) l2 = d2;
+      // (selects, not an if / else-if: four exec-masked branch pairs per trip of the scan otherwise)
+      const bool nearer = d2 < l1, second = d2 < l2;
+      l2 = nearer ? l1 : (second ? d2 : l2);
+      i1 = nearer ? i : i1;
+      l1 = nearer ? d2 : l1;
     }
   }
   double m2 = l1;

@@ -44,3 +44,9 @@ if os.environ.get("RRT_ONLY_ABORTED"):
         r3, _ = e.rrt(q[k].copy())
         ms3 = e.profile_get()["rrt"][0]
         print("  %d queries, trees %s: %.1f ms -> %.3f us per sample" % (len(k), sorted(r3["tree_size"].tolist()), ms3, ms3 * 1e3 / r3["samples"].max()))
+if os.environ.get("RRT_LONGEST_ALONE"):
+    # the queries with most samples, each by itself on the chip: which chain is the batch's length?
+    for k in np.argsort(-res["samples"])[:int(os.environ["RRT_LONGEST_ALONE"])]:
+        e.profile_reset()
+        r1, _ = e.rrt(q[k:k + 1].copy())
+        print("  query %3d alone: %5.1f ms  samples %6d nodes %4d status %2d" % (k, e.profile_get()["rrt"][0], int(r1["samples"][0]), int(r1["tree_size"][0]), int(r1["status"][0])))
