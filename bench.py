@@ -36,7 +36,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 DEFAULT_PIPELINE = 20   # A* batches in flight on one GPU (the committed counter files under profiles/ belong to it).  Round 6, default
                         # bench / the driver's 20-step run: 16 -> 162.0 / 158.0 k, 18 -> 162.5 / 161.5 k, 20 -> 164.0 / 162.5 k cycles/s
                         # (profiles/r06_sweep_depth.txt, r06_sweep_depth_final.txt: three runs each on two boxes, 20 ahead of 18 in every
-                        # one); from 22 on a process's streams run out of hardware queues (129 k) and the engine takes 20 at most
+                        # one); from 22 on the rate falls to 135 k whatever GPU_MAX_HW_QUEUES is (the process holds 25 queues then: r06_sweep_depth_hw_queues.txt) and
+                        # the engine takes 20 at most
 # ... and next to an RCCL communicator, whose streams take hardware queues of their own: the rate falls off from 21 stages on
 # without one and from 18 on with one (profiles/r04_sweep_depth_rccl.txt); 14 and 16 measure the same there
 DEFAULT_PIPELINE_RCCL = 14

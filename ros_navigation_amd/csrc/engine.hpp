@@ -66,7 +66,12 @@ struct AstarDevice {
   int threads = 512;               // workgroup size of the search kernel (256 / 512 / 1024)
   // Pipelined batches: `depth` independent sets of search fields + queues, each with its own HIP
   // stream, so the tail of batch k (few long queries) overlaps the head of batch k+1.
-  static constexpr int MAX_DEPTH = 20;   // (a process's streams run out of hardware queues from 22 stages on: profiles/r04_sweep_depth_16_22_engine_max_24.txt)
+#ifndef RNA_ASTAR_MAX_DEPTH
+#define RNA_ASTAR_MAX_DEPTH 20   // (developer builds may raise it: scripts/r06_depth_hwq.sh)
+#endif
+  // From 22 stages on the rate falls by a fifth, with GPU_MAX_HW_QUEUES = 8 and = 24 alike (profiles/r04_sweep_depth_16_22_engine_max_24.txt,
+  // r06_sweep_depth_hw_queues.txt): the process then holds 25 queues (the stages' streams, the engine stream, the side stream, the null stream).
+  static constexpr int MAX_DEPTH = RNA_ASTAR_MAX_DEPTH;
   int depth = 4;
   int32_t* g[MAX_DEPTH] = {};      // frontier kernel: [max_queries][field_stride] search fields (g << 8) | mask;
                                    // tile kernel: the stage's page pool (pages, then pending bitmaps), see astar_tile.hip
